@@ -1,0 +1,191 @@
+/* knpemi_hip.h -- C ABI of libknpemi_hip.so, the MI355X (gfx950) implementation of the
+ * per-time-step hot path of adajel/knp-emi-fenics-x.
+ *
+ * The reference has no FFI of its own: its hot path is reached through Python calls into
+ * DOLFINx/PETSc/numbalsoda.  Each entry point below names the reference call it replaces
+ * (paths relative to the reference repository root).  Conventions:
+ *   - every function returns 0 on success and a negative KNPEMI_E* code on failure; nothing
+ *     throws across the boundary; knpemi_last_error() returns the message of the last failure
+ *     on the calling thread;
+ *   - the caller owns every host buffer; the library owns all device memory behind the
+ *     opaque handle and frees it in knpemi_destroy();
+ *   - a handle is not thread-safe; handles on different devices are independent;
+ *   - kernels are enqueued on the handle's HIP stream; getters that copy to the host and
+ *     knpemi_sync() block until that stream is idle.
+ *   - all floating point data is IEEE binary64, all indices are int32.
+ */
+#ifndef KNPEMI_HIP_H
+#define KNPEMI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KNPEMI_OK 0
+#define KNPEMI_EINVAL (-1)   /* bad argument / unsupported configuration */
+#define KNPEMI_EHIP (-2)     /* HIP runtime error (no device, launch failure, ...) */
+#define KNPEMI_ENOMEM (-3)
+#define KNPEMI_EODE (-4)     /* LSODA reported failure on at least one membrane dof
+                                (`assert success`, src/knpemi/odeSolver.py:121) */
+
+/* cell kinds (CG-1 on each): triangle / tetrahedron = P1, hexahedron = Q1
+ * (src/knpemi/emiWeakForm.py:66, examples/idealized_geometries/make_mesh_2D.py:53-55,
+ *  make_mesh_3D.py:100-102) */
+#define KNPEMI_TRIANGLE 0
+#define KNPEMI_TETRAHEDRON 1
+#define KNPEMI_HEXAHEDRON 2
+
+/* membrane models shipped as device code (the reference's numba cfunc plug-ins):
+ *   HH_SI  examples/idealized_geometries/mm_hh.py:139-227          (4 states, 22 parameters)
+ *   HH_MV  examples/local_astrocyte_depolarization/mm_hh.py:130-201 (4 states, 22 parameters)
+ *   GLIAL  examples/local_astrocyte_depolarization/mm_glial.py:133-205 (1 state, 23 parameters) */
+#define KNPEMI_MODEL_HH_SI 0
+#define KNPEMI_MODEL_HH_MV 1
+#define KNPEMI_MODEL_GLIAL 2
+
+#define KNPEMI_MAX_IONS 3
+#define KNPEMI_MAX_SUB 8
+#define KNPEMI_MAX_MODELS 4   /* membrane models per cellular sub-domain */
+
+/* Fields addressable with knpemi_set_field / knpemi_get_field.  `sub` is the sub-domain index
+ * (0 = ECS), `idx` the ion index k or, for I_CH, model*KNPEMI_MAX_IONS + k.  Lengths are the
+ * number of vertices of the sub-mesh (bulk fields) or of membrane dofs of Q_sub (PHI_M, I_CH):
+ * exactly `Function.x.array` of the reference objects named on the right. */
+#define KNPEMI_F_PHI 0      /* phi[tag]                      emiWeakForm.py:68   */
+#define KNPEMI_F_C 1        /* c[tag][k], k < K-1            knpWeakForm.py:65   */
+#define KNPEMI_F_C_PREV 2   /* c_prev[tag][k], k < K-1       knpWeakForm.py:67   */
+#define KNPEMI_F_C_ELIM 3   /* ion_list[-1]['c_tag']         knpWeakForm.py:77   */
+#define KNPEMI_F_PHI_M 4    /* phi_M_prev[tag]               emiWeakForm.py:78   */
+#define KNPEMI_F_I_CH 5     /* mem_model['I_ch_k'][ion]      utils.py:137-141    */
+#define KNPEMI_F_SOURCE 6   /* ion['f_source'] (ECS only)    knpWeakForm.py:164-166 */
+
+/* matrices / vectors */
+#define KNPEMI_A_EMI 0      /* a  of emi_system   emiWeakForm.py:138-167 */
+#define KNPEMI_P_EMI 1      /* p  of emi_system   emiWeakForm.py:169-198 */
+#define KNPEMI_A_KNP 2      /* a (= p) of knp_system  knpWeakForm.py:123-143,319 */
+#define KNPEMI_B_EMI 0      /* L of emi_system    emiWeakForm.py:201-241 */
+#define KNPEMI_B_KNP 1      /* L of knp_system    knpWeakForm.py:146-216 */
+
+/* assemble flags */
+#define KNPEMI_WANT_P 1       /* also fill P_EMI (fused with A_EMI, one pass) */
+#define KNPEMI_NO_SPLITTING 2 /* splitting_scheme=False (emiWeakForm.py:234-236, knpWeakForm.py:201-206) */
+
+typedef struct knpemi_handle knpemi_handle;
+
+/* Flattened topology of the mixed-dimensional problem.  Replaces what the reference builds with
+ * scifem.extract_submesh (run_3D.py:156-158), dolfinx function spaces (emiWeakForm.py:63-79) and
+ * scifem.compute_interface_data (emiWeakForm.py:39-42).  All per-sub arrays have n_sub entries;
+ * entry 0 is the ECS.  Vertices on a membrane exist once in the ECS sub-mesh and once in the
+ * cell's sub-mesh.  Facet vertex a of facet f is the same physical point in facet_e, facet_i
+ * and facet_q ("+" = ECS side, "-" = cell side; emiWeakForm.py:25-26). */
+typedef struct {
+  int32_t gdim;                      /* 2 or 3 */
+  int32_t cell_kind;                 /* KNPEMI_TRIANGLE | TETRAHEDRON | HEXAHEDRON */
+  int32_t n_sub;                     /* sub-domains, ECS first */
+  int32_t n_ions;                    /* K; the last ion is eliminated (run_3D.py:255-256) */
+  const int32_t* n_vert;             /* [n_sub] vertices (owned + ghost) of each sub-mesh */
+  const int32_t* n_cell;             /* [n_sub] */
+  const double* const* x;            /* [n_sub] -> n_vert*gdim, row-major */
+  const int32_t* const* cells;       /* [n_sub] -> n_cell*nv sub-mesh vertex ids */
+  const int32_t* n_q;                /* [n_sub] membrane dofs of Q_sub (0 for the ECS) */
+  const int32_t* n_facet;            /* [n_sub] membrane facets of the cell (0 for the ECS) */
+  const int32_t* const* facet_e;     /* [n_sub] -> n_facet*nf ECS sub-mesh vertex ids */
+  const int32_t* const* facet_i;     /* [n_sub] -> n_facet*nf cell sub-mesh vertex ids */
+  const int32_t* const* facet_q;     /* [n_sub] -> n_facet*nf dofs of Q_sub */
+  const int32_t* const* facet_model; /* [n_sub] -> n_facet index of the membrane model whose
+                                        tag the facet carries (mm['ode'].tag), -1 = none */
+  const int32_t* const* q_to_e;      /* [n_sub] -> n_q ECS vertex of each Q dof (utils.py:150-207) */
+  const int32_t* const* q_to_i;      /* [n_sub] -> n_q cell vertex of each Q dof */
+  const int32_t* n_models;           /* [n_sub] membrane models of the cell (len(mem_models)) */
+} knpemi_problem_desc;
+
+/* Physical parameters: the `physical_params` / `ion_list` dictionaries (run_3D.py:180-256). */
+typedef struct {
+  double dt, F, psi, C_M;                               /* C_phi = C_M / dt (run_3D.py:189) */
+  double z[KNPEMI_MAX_IONS];                            /* ion['z'] */
+  double D[KNPEMI_MAX_SUB][KNPEMI_MAX_IONS];            /* ion['D'][tag] */
+  double rho_z;                                         /* rho['z'] (utils.py:249) */
+  double rho[KNPEMI_MAX_SUB];                           /* rho[tag] */
+} knpemi_params;
+
+const char* knpemi_last_error(void);
+int knpemi_device_count(void);
+
+/* Build the device problem: uploads the topology, derives vertex->cell adjacency, CSR patterns
+ * and row-relative scatter slots.  Replaces LinearProblem construction (pdeSolver.py:46-66,
+ * 121-139: sparsity pattern + FFCx JIT). */
+int knpemi_create(const knpemi_problem_desc* desc, int device, knpemi_handle** out);
+void knpemi_destroy(knpemi_handle* h);
+int knpemi_set_params(knpemi_handle* h, const knpemi_params* p);
+int knpemi_sync(knpemi_handle* h);
+
+/* Function I/O (`Function.x.array[:] = ...` / reading it back). */
+int knpemi_set_field(knpemi_handle* h, int field, int sub, int idx, const double* host, size_t n);
+int knpemi_get_field(knpemi_handle* h, int field, int sub, int idx, double* host, size_t n);
+
+/* Assembly: the matrix/vector assembly inside problem_emi.solve() / problem_knp.solve()
+ * (run_3D.py:355-356 -> dolfinx assemble_matrix/assemble_vector over FFCx kernels). */
+int knpemi_assemble_emi(knpemi_handle* h, int flags);
+int knpemi_assemble_knp(knpemi_handle* h, int flags);
+
+/* CSR access.  A_EMI/P_EMI: square, unknown order [phi_0, phi_1, ...] (pdeSolver.py:42).
+ * A_KNP: block diagonal, unknown order [c[0][0], c[0][1], c[1][0], ...] (pdeSolver.py:117). */
+int knpemi_csr_dims(knpemi_handle* h, int which, int64_t* n_rows, int64_t* nnz);
+int knpemi_get_csr_pattern(knpemi_handle* h, int which, int32_t* rowptr, int32_t* colind);
+int knpemi_get_csr_values(knpemi_handle* h, int which, double* vals);
+int knpemi_get_rhs(knpemi_handle* h, int which, double* b);
+/* Device-resident views for on-GPU consumers (solvers, RCCL halo exchange through torch). */
+int knpemi_device_csr(knpemi_handle* h, int which, const int32_t** rowptr, const int32_t** colind,
+                      const double** vals);
+int knpemi_device_rhs(knpemi_handle* h, int which, const double** b);
+/* Write a solver result back into the bulk fields: x has the unknown order of the system
+ * (`which` = KNPEMI_B_EMI -> phi, KNPEMI_B_KNP -> c).  on_device != 0: x is a device pointer. */
+int knpemi_set_solution(knpemi_handle* h, int which, const double* x, int on_device);
+int knpemi_get_solution(knpemi_handle* h, int which, double* x);
+
+/* Membrane ODEs: MembraneModel (src/knpemi/odeSolver.py:6-188).  `states`/`params` are the
+ * row-major [n_q][n_states|n_params] tables `MembraneModel.states/.parameters`. */
+int knpemi_ode_bind(knpemi_handle* h, int sub, int model, int model_id, int n_states, int n_params);
+int knpemi_ode_set_tables(knpemi_handle* h, int sub, int model, const double* states,
+                          const double* params);
+int knpemi_ode_get_tables(knpemi_handle* h, int sub, int model, double* states, double* params);
+/* stimulus_mask[n_q] (may be NULL = everywhere) and (param index, value) pairs written into the
+ * masked rows before every step (odeSolver.py:98-112). */
+int knpemi_ode_set_stimulus(knpemi_handle* h, int sub, int model, const uint8_t* stimulus_mask,
+                            int n_pairs, const int32_t* param_idx, const double* values);
+/* One fused launch of update_ode_variables (utils.py:210-235: with KNPEMI_ODE_SET_TRACES the
+ * concentration traces go into the "<ion>_e"/"<ion>_i" parameter columns, with KNPEMI_ODE_SET_V
+ * V <- phi_M_prev, i.e. the k > 0 branch of utils.py:233), MembraneModel.step_lsoda
+ * (odeSolver.py:92-127) and the copy-back of run_3D.py:104-109 (phi_M_prev <- V, I_ch_k <-
+ * currents).  ion_param[3*K] = parameter indices of "<ion>_e", "<ion>_i", "I_ch_<ion>" for each
+ * ion (ode.parameter_indices), v_index = ode.state_indices('V'). */
+#define KNPEMI_ODE_SET_V 1
+#define KNPEMI_ODE_SET_TRACES 2
+int knpemi_ode_step(knpemi_handle* h, int sub, int model, double t0, double dt, double rtol,
+                    double atol, int flags, const int32_t* ion_param, int v_index);
+/* Number of RHS evaluations / internal steps of the last knpemi_ode_step (sum over dofs). */
+int knpemi_ode_stats(knpemi_handle* h, int sub, int model, int64_t* n_rhs, int64_t* n_steps,
+                     int32_t* n_failed);
+
+/* End-of-step update: update_pde_variables (utils.py:238-295): c_prev <- c, eliminated ion from
+ * electroneutrality, phi_M_prev <- tr(phi_i) - tr(phi_e). */
+int knpemi_update_pde(knpemi_handle* h);
+
+/* Nodal trace of an (ECS, cell) pair of bulk functions onto Q_sub: interpolate_to_membrane
+ * (utils.py:150-207).  u_e has n_vert[0] entries, u_i n_vert[sub]; q_e, q_i receive n_q[sub]. */
+int knpemi_trace(knpemi_handle* h, int sub, const double* u_e, const double* u_i, double* q_e,
+                 double* q_i);
+
+/* Stream-event timing of a region on the handle's stream (bench.py / rocprof cross-check). */
+int knpemi_timer_start(knpemi_handle* h);
+int knpemi_timer_stop_ms(knpemi_handle* h, double* ms);
+/* HIP stream (hipStream_t) the handle enqueues on, for external event timing / ordering. */
+void* knpemi_stream(knpemi_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KNPEMI_HIP_H */

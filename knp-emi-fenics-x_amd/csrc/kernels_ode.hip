@@ -1,0 +1,123 @@
+// Membrane ODE sweep on gfx950: one thread per membrane dof, LSODA entirely in private memory.
+//
+// One launch fuses what the reference does in three Python stages per membrane model and step
+// (examples/idealized_geometries/run_3D.py:80-111):
+//   1. update_ode_variables (src/knpemi/utils.py:210-235): nodal traces of the K concentrations on
+//      both sides of the membrane -> parameter columns "<ion>_e"/"<ion>_i"; V <- phi_M_prev (k > 0);
+//   2. MembraneModel.step_lsoda (src/knpemi/odeSolver.py:92-127): optional stimulus write, LSODA over
+//      [t, t + dt] with rtol 1e-8 / atol 1e-10, state row <- solution at t + dt;
+//   3. copy-back (run_3D.py:104-109): phi_M_prev <- V, I_ch_k <- parameter columns "I_ch_<ion>".
+// The currents handed to the PDEs are, as in the reference, whatever the last RHS call made by LSODA
+// stored in the parameter row; lsoda_core.h reproduces ODEPACK's call
+// sequence, so this is the same evaluation point.
+//
+// Tables are stored transposed on the device ([column][dof]) so that neighbouring threads read
+// neighbouring addresses; the ODE work itself is latency/compute bound (fp64 exp/log, divergent
+// step control), not HBM bound.
+#include "knpemi_internal.h"
+#include "membrane_models.h"
+
+namespace {
+
+struct OdeArgs {
+  int nq, q0, n_stim, flags, v_index, model_slot, NQtot;
+  int ion_param[3 * KN_MAXK];
+  int stim_idx[8];
+  double stim_val[8];
+  double t0, dt, rtol, atol;
+  double* states;
+  double* params;
+  const uint8_t* mask;
+  unsigned long long* stats;
+};
+
+template <class M>
+__global__ __launch_bounds__(64) void ode_step_kernel(KnDev D, OdeArgs a, const LsodaCoef* __restrict__ cf) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= a.nq) return;
+  const int qg = a.q0 + q;
+  double p[M::NP];
+  double y[M::NS];
+#pragma unroll
+  for (int j = 0; j < M::NP; ++j) p[j] = a.params[(size_t)j * a.nq + q];
+#pragma unroll
+  for (int j = 0; j < M::NS; ++j) y[j] = a.states[(size_t)j * a.nq + q];
+  // 1. concentration traces (record components 4..6 hold c_0, c_1, c_eliminated)
+  const double* re = D.VR + (size_t)D.q2e[qg] * KN_REC + 4;
+  const double* ri = D.VR + (size_t)D.q2i[qg] * KN_REC + 4;
+  if (a.flags & KNPEMI_ODE_SET_TRACES)
+    for (int k = 0; k < KN_MAXK; ++k) {
+      p[a.ion_param[3 * k]] = re[k];
+      p[a.ion_param[3 * k + 1]] = ri[k];
+    }
+  if (a.flags & KNPEMI_ODE_SET_V) y[a.v_index] = D.phiM[qg];
+  // 2. stimulus + LSODA
+  if (a.n_stim > 0 && (!a.mask || a.mask[q]))
+    for (int i = 0; i < a.n_stim; ++i) p[a.stim_idx[i]] = a.stim_val[i];
+  Lsoda<M::NS, M> s;
+  const int rc = s.integrate(cf, y, a.t0, a.t0 + a.dt, a.rtol, a.atol, p, 10000);
+  // 3. write back (the whole parameter row is in/out, like the numpy view in odeSolver.py:108)
+#pragma unroll
+  for (int j = 0; j < M::NP; ++j) a.params[(size_t)j * a.nq + q] = p[j];
+#pragma unroll
+  for (int j = 0; j < M::NS; ++j) a.states[(size_t)j * a.nq + q] = y[j];
+  D.phiM[qg] = y[a.v_index];
+  for (int k = 0; k < KN_MAXK; ++k)
+    D.Ich[((size_t)a.model_slot * KN_MAXK + k) * a.NQtot + qg] = p[a.ion_param[3 * k + 2]];
+  atomicAdd(&a.stats[0], (unsigned long long)s.nfe);
+  atomicAdd(&a.stats[1], (unsigned long long)s.nst);
+  if (rc != 0) atomicAdd(&a.stats[2], 1ull);
+}
+
+}  // namespace
+
+static int ensure_coef(knpemi_handle* h, const LsodaCoef** out) {
+  if (!h->d_lsoda_coef) {
+    LsodaCoef c;
+    lsoda_fill_coef(&c);
+    void* d = nullptr;
+    KN_HIP(hipMalloc(&d, sizeof(LsodaCoef)));
+    h->allocs.push_back(d);
+    KN_HIP(hipMemcpy(d, &c, sizeof(LsodaCoef), hipMemcpyHostToDevice));
+    h->d_lsoda_coef = d;
+  }
+  *out = static_cast<const LsodaCoef*>(h->d_lsoda_coef);
+  return KNPEMI_OK;
+}
+
+int kn_launch_ode_step(knpemi_handle* h, int slot, double t0, double dt, double rtol, double atol,
+                       int flags, const int32_t* ion_param, int v_index) {
+  KnOdeModel& m = h->ode[slot];
+  if (m.nq == 0) return KNPEMI_OK;
+  const LsodaCoef* cf = nullptr;
+  int rc = ensure_coef(h, &cf);
+  if (rc) return rc;
+  OdeArgs a;
+  a.nq = m.nq; a.q0 = h->qoff[m.sub]; a.n_stim = m.n_stim; a.flags = flags; a.v_index = v_index;
+  a.model_slot = slot; a.NQtot = h->dev.NQtot;
+  for (int i = 0; i < 3 * KN_MAXK; ++i) a.ion_param[i] = ion_param[i];
+  for (int i = 0; i < 8; ++i) { a.stim_idx[i] = m.stim_idx[i]; a.stim_val[i] = m.stim_val[i]; }
+  a.t0 = t0; a.dt = dt; a.rtol = rtol; a.atol = atol;
+  a.states = m.d_states; a.params = m.d_params; a.mask = m.d_mask; a.stats = m.d_stats;
+  KN_HIP(hipMemsetAsync(m.d_stats, 0, 3 * sizeof(unsigned long long), h->stream));
+  // 64-thread workgroups: the sweep has only n_q (10^3..10^5) threads, so spread the waves over as
+  // many CUs as possible instead of stacking four of them on one.
+  dim3 grid((m.nq + 63) / 64), block(64);
+  switch (m.model_id) {
+    case KNPEMI_MODEL_HH_SI:
+      hipLaunchKernelGGL((ode_step_kernel<ModelHHSI>), grid, block, 0, h->stream, h->dev, a, cf);
+      break;
+    case KNPEMI_MODEL_HH_MV:
+      hipLaunchKernelGGL((ode_step_kernel<ModelHHMV>), grid, block, 0, h->stream, h->dev, a, cf);
+      break;
+    default:
+      hipLaunchKernelGGL((ode_step_kernel<ModelGlial>), grid, block, 0, h->stream, h->dev, a, cf);
+      break;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    kn_set_error(std::string("ode_step_kernel: ") + hipGetErrorString(e));
+    return KNPEMI_EHIP;
+  }
+  return KNPEMI_OK;
+}

@@ -1,0 +1,863 @@
+// Host side of libknpemi_hip.so: problem builder (adjacency, CSR patterns, scatter slots),
+// device memory management, field I/O and the exported C ABI (include/knpemi_hip.h).
+//
+// The reference builds the equivalent data inside DOLFINx when `LinearProblem` is constructed
+// (src/knpemi/pdeSolver.py:46-66,121-139: sparsity patterns, dof maps, entity maps) and inside
+// scifem.compute_interface_data (src/knpemi/emiWeakForm.py:39-42).
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "knpemi_internal.h"
+
+static thread_local std::string g_err;
+void kn_set_error(const std::string& msg) { g_err = msg; }
+
+extern "C" const char* knpemi_last_error(void) { return g_err.c_str(); }
+
+extern "C" int knpemi_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+namespace {
+
+template <class T>
+int dev_upload(knpemi_handle* h, const std::vector<T>& v, const T** out) {
+  void* p = nullptr;
+  size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  KN_HIP(hipMalloc(&p, bytes));
+  h->allocs.push_back(p);
+  if (!v.empty()) KN_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = static_cast<const T*>(p);
+  return 0;
+}
+
+template <class T>
+int dev_zeros(knpemi_handle* h, size_t n, T** out) {
+  void* p = nullptr;
+  size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+  KN_HIP(hipMalloc(&p, bytes));
+  h->allocs.push_back(p);
+  KN_HIP(hipMemset(p, 0, bytes));
+  *out = static_cast<T*>(p);
+  return 0;
+}
+
+int fail(int code, const std::string& msg) {
+  kn_set_error(msg);
+  return code;
+}
+
+// Degree-6 rules on the membrane facet (UFL estimates degree 6 for the
+// rational KNP coupling integrand; Basix would pick Gauss-Jacobi with 4 points per direction on
+// intervals/quadrilaterals and the 12-point Xiao-Gimbutas rule on triangles).  Layout: nq weights
+// (reference-cell measure included), nq*NF shape values, and for quadrilaterals nq*NF*2 shape
+// derivatives.  Returns nq.
+int kn_gamma_quadrature(int NF, std::vector<double>* out) {
+  static const double gx[4] = {0.5 - 0.5 * 0.8611363115940526, 0.5 - 0.5 * 0.3399810435848563,
+                               0.5 + 0.5 * 0.3399810435848563, 0.5 + 0.5 * 0.8611363115940526};
+  static const double gw[4] = {0.5 * 0.3478548451374538, 0.5 * 0.6521451548625461,
+                               0.5 * 0.6521451548625461, 0.5 * 0.3478548451374538};
+  std::vector<double>& q = *out;
+  q.clear();
+  if (NF == 2) {
+    for (int i = 0; i < 4; ++i) q.push_back(gw[i]);
+    for (int i = 0; i < 4; ++i) { q.push_back(1.0 - gx[i]); q.push_back(gx[i]); }
+    return 4;
+  }
+  if (NF == 3) {
+    // 12-point degree-6 symmetric rule (Dunavant), polished to full double precision
+    const double w1 = 0.1167862757263793660252896, b1 = 0.2492867451709104212916386;
+    const double w2 = 0.05084490637020681692093681, b2 = 0.0630890144915022283403316;
+    const double w3 = 0.08285107561837357519355346, b3 = 0.05314504984481694735324967,
+                 c3 = 0.3103524510337844054166077;
+    const double a1 = 1.0 - 2.0 * b1, a2 = 1.0 - 2.0 * b2, a3 = 1.0 - b3 - c3;
+    const double P[12][4] = {
+        {w1, a1, b1, b1}, {w1, b1, a1, b1}, {w1, b1, b1, a1},
+        {w2, a2, b2, b2}, {w2, b2, a2, b2}, {w2, b2, b2, a2},
+        {w3, a3, b3, c3}, {w3, a3, c3, b3}, {w3, b3, a3, c3},
+        {w3, b3, c3, a3}, {w3, c3, a3, b3}, {w3, c3, b3, a3}};
+    for (int i = 0; i < 12; ++i) q.push_back(0.5 * P[i][0]);
+    for (int i = 0; i < 12; ++i) for (int b = 0; b < 3; ++b) q.push_back(P[i][1 + b]);
+    return 12;
+  }
+  // quadrilateral: 4 x 4 Gauss, vertices in lexicographic order
+  for (int j = 0; j < 4; ++j) for (int i = 0; i < 4; ++i) q.push_back(gw[i] * gw[j]);
+  for (int j = 0; j < 4; ++j) for (int i = 0; i < 4; ++i) {
+    const double x = gx[i], y = gx[j];
+    q.push_back((1 - x) * (1 - y)); q.push_back(x * (1 - y)); q.push_back((1 - x) * y); q.push_back(x * y);
+  }
+  for (int j = 0; j < 4; ++j) for (int i = 0; i < 4; ++i) {
+    const double x = gx[i], y = gx[j];
+    const double d[4][2] = {{-(1 - y), -(1 - x)}, {(1 - y), -x}, {-y, (1 - x)}, {y, x}};
+    for (int b = 0; b < 4; ++b) { q.push_back(d[b][0]); q.push_back(d[b][1]); }
+  }
+  return 16;
+}
+
+}  // namespace
+
+extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_handle** out) {
+  if (!d || !out) return fail(KNPEMI_EINVAL, "knpemi_create: null argument");
+  *out = nullptr;
+  if (d->n_ions != KN_MAXK)
+    return fail(KNPEMI_EINVAL, "knpemi_create: exactly 3 ionic species (2 solved + 1 eliminated) "
+                               "are supported, as in every reference driver (run_3D.py:256)");
+  if (d->n_sub < 1 || d->n_sub > KN_MAXSUB) return fail(KNPEMI_EINVAL, "knpemi_create: bad n_sub");
+  int NV, NF;
+  if (d->cell_kind == KNPEMI_TRIANGLE && d->gdim == 2) { NV = 3; NF = 2; }
+  else if (d->cell_kind == KNPEMI_TETRAHEDRON && d->gdim == 3) { NV = 4; NF = 3; }
+  else if (d->cell_kind == KNPEMI_HEXAHEDRON && d->gdim == 3) { NV = 8; NF = 4; }
+  else return fail(KNPEMI_EINVAL, "knpemi_create: cell_kind/gdim combination not supported");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(KNPEMI_EHIP, "knpemi_create: no HIP device visible (the hot path has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(KNPEMI_EINVAL, "knpemi_create: bad device index");
+  KN_HIP(hipSetDevice(device));
+
+  auto* h = new knpemi_handle();
+  std::unique_ptr<knpemi_handle, void (*)(knpemi_handle*)> guard(h, knpemi_destroy);
+  h->device = device;
+  KN_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  KN_HIP(hipEventCreate(&h->ev0));
+  KN_HIP(hipEventCreate(&h->ev1));
+  h->gdim = d->gdim; h->cell_kind = d->cell_kind; h->NV = NV; h->NF = NF;
+  h->n_sub = d->n_sub; h->K = d->n_ions;
+  const int S = d->n_sub, K = d->n_ions;
+  h->n_vert.assign(d->n_vert, d->n_vert + S);
+  h->n_cell.assign(d->n_cell, d->n_cell + S);
+  h->n_q.assign(S, 0); h->n_facet.assign(S, 0); h->n_models.assign(S, 0);
+  for (int s = 1; s < S; ++s) {
+    h->n_q[s] = d->n_q ? d->n_q[s] : 0;
+    h->n_facet[s] = d->n_facet ? d->n_facet[s] : 0;
+    h->n_models[s] = d->n_models ? d->n_models[s] : 0;
+    if (h->n_models[s] > KNPEMI_MAX_MODELS) return fail(KNPEMI_EINVAL, "too many membrane models");
+  }
+  auto prefix = [&](const std::vector<int>& n) {
+    std::vector<int> o(S + 1, 0);
+    for (int s = 0; s < S; ++s) o[s + 1] = o[s] + n[s];
+    return o;
+  };
+  h->voff = prefix(h->n_vert); h->coff = prefix(h->n_cell); h->qoff = prefix(h->n_q);
+  h->foff = prefix(h->n_facet); h->moff = prefix(h->n_models);
+  const int Ntot = h->voff[S], nctot = h->coff[S], NQtot = h->qoff[S], nftot = h->foff[S];
+  h->ode.resize(h->moff[S]);
+
+  // ---- global cells, vertex records -----------------------------------------------------------
+  std::vector<int> cells((size_t)nctot * NV);
+  std::vector<double> VR((size_t)Ntot * KN_REC, 0.0);
+  for (int s = 0; s < S; ++s) {
+    for (int64_t i = 0; i < (int64_t)h->n_cell[s] * NV; ++i) {
+      int v = d->cells[s][i];
+      if (v < 0 || v >= h->n_vert[s]) return fail(KNPEMI_EINVAL, "cell vertex id out of range");
+      cells[(size_t)h->coff[s] * NV + i] = v + h->voff[s];
+    }
+    for (int v = 0; v < h->n_vert[s]; ++v)
+      for (int c = 0; c < d->gdim; ++c)
+        VR[(size_t)(h->voff[s] + v) * KN_REC + c] = d->x[s][(size_t)v * d->gdim + c];
+  }
+
+  // ---- vertex -> cell adjacency (counting sort) ---------------------------------------------------
+  std::vector<int64_t> v2c_ptr(Ntot + 1, 0);
+  for (size_t i = 0; i < cells.size(); ++i) v2c_ptr[cells[i] + 1]++;
+  for (int g = 0; g < Ntot; ++g) v2c_ptr[g + 1] += v2c_ptr[g];
+  std::vector<int> v2c(cells.size());
+  {
+    std::vector<int64_t> fill(v2c_ptr.begin(), v2c_ptr.end() - 1);
+    for (int c = 0; c < nctot; ++c)
+      for (int li = 0; li < NV; ++li) v2c[fill[cells[(size_t)c * NV + li]]++] = c * 8 + li;
+  }
+
+  // ---- Laplacian pattern -------------------------------------------------------------------------
+  std::vector<int>& rowptrL = h->h_rowptrL; std::vector<int>& colindL = h->h_colindL;
+  rowptrL.assign(Ntot + 1, 0);
+  colindL.reserve((size_t)Ntot * (NV == 8 ? 27 : (NV == 4 ? 15 : 7)));
+  {
+    std::vector<int> tmp;
+    for (int g = 0; g < Ntot; ++g) {
+      tmp.clear();
+      tmp.push_back(g);
+      for (int64_t p = v2c_ptr[g]; p < v2c_ptr[g + 1]; ++p) {
+        const int* cv = &cells[(size_t)(v2c[p] >> 3) * NV];
+        tmp.insert(tmp.end(), cv, cv + NV);
+      }
+      std::sort(tmp.begin(), tmp.end());
+      tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+      colindL.insert(colindL.end(), tmp.begin(), tmp.end());
+      if (colindL.size() > (size_t)INT32_MAX) return fail(KNPEMI_EINVAL, "matrix too large for int32 CSR");
+      rowptrL[g + 1] = (int)colindL.size();
+    }
+  }
+
+  // ---- membrane facets in global ids, coupling columns ------------------------------------------
+  std::vector<int> fe((size_t)nftot * NF), fi((size_t)nftot * NF), fq((size_t)nftot * NF), fmodel(nftot, -1);
+  std::vector<int> q2e(NQtot), q2i(NQtot);
+  std::vector<std::pair<int, int>> coup;  // (row, col)
+  std::vector<std::pair<int, int>> ment;  // (row, facet*8 + a)
+  for (int s = 1; s < S; ++s) {
+    for (int q = 0; q < h->n_q[s]; ++q) {
+      q2e[h->qoff[s] + q] = d->q_to_e[s][q] + h->voff[0];
+      q2i[h->qoff[s] + q] = d->q_to_i[s][q] + h->voff[s];
+    }
+    for (int f = 0; f < h->n_facet[s]; ++f) {
+      int fg = h->foff[s] + f;
+      int m = d->facet_model ? d->facet_model[s][f] : -1;
+      if (m >= h->n_models[s]) return fail(KNPEMI_EINVAL, "facet_model out of range");
+      fmodel[fg] = m < 0 ? -1 : h->moff[s] + m;
+      for (int a = 0; a < NF; ++a) {
+        int e = d->facet_e[s][(size_t)f * NF + a], i = d->facet_i[s][(size_t)f * NF + a];
+        int q = d->facet_q[s][(size_t)f * NF + a];
+        if (e < 0 || e >= h->n_vert[0] || i < 0 || i >= h->n_vert[s] || q < 0 || q >= h->n_q[s])
+          return fail(KNPEMI_EINVAL, "membrane facet index out of range");
+        fe[(size_t)fg * NF + a] = e + h->voff[0];
+        fi[(size_t)fg * NF + a] = i + h->voff[s];
+        fq[(size_t)fg * NF + a] = q + h->qoff[s];
+      }
+      for (int a = 0; a < NF; ++a) {
+        ment.emplace_back(fe[(size_t)fg * NF + a], fg * 8 + a);
+        ment.emplace_back(fi[(size_t)fg * NF + a], fg * 8 + a);
+        for (int b = 0; b < NF; ++b) {
+          coup.emplace_back(fe[(size_t)fg * NF + a], fi[(size_t)fg * NF + b]);
+          coup.emplace_back(fi[(size_t)fg * NF + a], fe[(size_t)fg * NF + b]);
+        }
+      }
+    }
+  }
+  std::sort(coup.begin(), coup.end());
+  coup.erase(std::unique(coup.begin(), coup.end()), coup.end());
+  std::stable_sort(ment.begin(), ment.end(),
+                   [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+
+  // ---- EMI pattern: ECS rows [laplacian | coupling], cell rows [coupling | laplacian] --------------
+  std::vector<int>& rowptr = h->h_rowptr; std::vector<int>& colind = h->h_colind;
+  rowptr.assign(Ntot + 1, 0);
+  colind.reserve(colindL.size() + coup.size());
+  std::vector<uint8_t> lapoff(Ntot, 0);
+  {
+    size_t cp = 0;
+    for (int g = 0; g < Ntot; ++g) {
+      size_t c0 = cp;
+      while (cp < coup.size() && coup[cp].first == g) ++cp;
+      int nco = (int)(cp - c0);
+      const bool ecs = g < h->voff[1];
+      if (!ecs) for (size_t c = c0; c < cp; ++c) colind.push_back(coup[c].second);
+      colind.insert(colind.end(), colindL.begin() + rowptrL[g], colindL.begin() + rowptrL[g + 1]);
+      if (ecs) for (size_t c = c0; c < cp; ++c) colind.push_back(coup[c].second);
+      if (colind.size() > (size_t)INT32_MAX) return fail(KNPEMI_EINVAL, "matrix too large for int32 CSR");
+      rowptr[g + 1] = (int)colind.size();
+      if (rowptr[g + 1] - rowptr[g] > 255) return fail(KNPEMI_EINVAL, "matrix row longer than 255 entries");
+      lapoff[g] = (uint8_t)(ecs ? 0 : nco);
+    }
+  }
+
+  // ---- row blocks (never straddle a sub-domain) and sliced ELL of (row, cell) pairs ----------------
+  std::vector<int> blk_row0, blk_nrows, blk_sub;
+  for (int s = 0; s < S; ++s)
+    for (int r0 = h->voff[s]; r0 < h->voff[s + 1]; r0 += KN_ROWS_PER_BLOCK) {
+      blk_row0.push_back(r0);
+      blk_nrows.push_back(std::min(KN_ROWS_PER_BLOCK, h->voff[s + 1] - r0));
+      blk_sub.push_back(s);
+    }
+  const int nblocks = (int)blk_row0.size();
+  const int SPB = KN_ROWS_PER_BLOCK / KN_SLICE;  // slices per block
+  const int SW = NV == 8 ? 2 : 1;
+  std::vector<int64_t> sl_ptr((size_t)nblocks * SPB + 1, 0);
+  for (int b = 0; b < nblocks; ++b)
+    for (int w = 0; w < SPB; ++w) {
+      int64_t mx = 0;
+      int ga = blk_row0[b] + w * KN_SLICE, gb = std::min(blk_row0[b] + blk_nrows[b], ga + KN_SLICE);
+      for (int g = ga; g < gb; ++g) mx = std::max(mx, v2c_ptr[g + 1] - v2c_ptr[g]);
+      sl_ptr[(size_t)b * SPB + w + 1] = sl_ptr[(size_t)b * SPB + w] + mx * KN_SLICE;
+    }
+  std::vector<int> pair_cell((size_t)sl_ptr.back(), -1);
+  std::vector<uint32_t> pair_slots((size_t)sl_ptr.back() * SW, 0);
+  for (int b = 0; b < nblocks; ++b)
+    for (int t = 0; t < blk_nrows[b]; ++t) {
+      const int g = blk_row0[b] + t, w = t / KN_SLICE, lane = t % KN_SLICE;
+      const int* rb = &colindL[rowptrL[g]];
+      const int* re = &colindL[rowptrL[g + 1]];
+      for (int64_t p = v2c_ptr[g]; p < v2c_ptr[g + 1]; ++p) {
+        size_t ent = (size_t)sl_ptr[(size_t)b * SPB + w] + (size_t)(p - v2c_ptr[g]) * KN_SLICE + lane;
+        pair_cell[ent] = v2c[p];
+        const int* cv = &cells[(size_t)(v2c[p] >> 3) * NV];
+        for (int j = 0; j < NV; ++j) {
+          uint32_t slot = (uint32_t)(std::lower_bound(rb, re, cv[j]) - rb);
+          pair_slots[ent * SW + (j >> 2)] |= slot << (8 * (j & 3));
+        }
+      }
+    }
+
+  // ---- membrane rows ----------------------------------------------------------------------------------
+  std::vector<int> gam_idx(Ntot, -1), mptr(1, 0), mentry, mrow;
+  std::vector<uint64_t> mslots;
+  for (size_t i = 0; i < ment.size();) {
+    int g = ment[i].first;
+    gam_idx[g] = (int)mrow.size();
+    mrow.push_back(g);
+    bool ecs = g < h->voff[1];
+    const int* rb = &colind[rowptr[g]];
+    const int* re = &colind[rowptr[g + 1]];
+    for (; i < ment.size() && ment[i].first == g; ++i) {
+      int fg = ment[i].second >> 3;
+      uint64_t sl = 0;
+      for (int b = 0; b < NF; ++b) {
+        int own = ecs ? fe[(size_t)fg * NF + b] : fi[(size_t)fg * NF + b];
+        int oth = ecs ? fi[(size_t)fg * NF + b] : fe[(size_t)fg * NF + b];
+        uint64_t so = (uint64_t)(std::lower_bound(rb, re, own) - rb);
+        uint64_t st = (uint64_t)(std::lower_bound(rb, re, oth) - rb);
+        sl |= so << (8 * b);
+        sl |= st << (8 * (4 + b));
+      }
+      mentry.push_back(ment[i].second);
+      mslots.push_back(sl);
+    }
+    mptr.push_back((int)mentry.size());
+  }
+
+  // ---- LDS segment sizes ----------------------------------------------------------------------------------
+  for (int b = 0; b < nblocks; ++b) {
+    int g0 = blk_row0[b], g1 = g0 + blk_nrows[b];
+    h->lds_doubles_emi = std::max(h->lds_doubles_emi, rowptr[g1] - rowptr[g0]);
+    h->lds_doubles_knp = std::max(h->lds_doubles_knp, rowptrL[g1] - rowptrL[g0]);
+  }
+
+  // ---- upload --------------------------------------------------------------------------------------------
+  KnDev& D = h->dev;
+  D.Ntot = Ntot; D.nctot = nctot; D.NQtot = NQtot; D.nftot = nftot; D.nblocks = nblocks;
+  D.M = (int)mrow.size();
+  D.nnz = (int64_t)colind.size(); D.nnzL = (int64_t)colindL.size();
+  int rc;
+  const double* vr_c = nullptr;
+  if ((rc = dev_upload(h, VR, &vr_c))) return rc;
+  D.VR = const_cast<double*>(vr_c);
+  if ((rc = dev_upload(h, cells, &D.cells))) return rc;
+  if ((rc = dev_upload(h, blk_row0, &D.blk_row0))) return rc;
+  if ((rc = dev_upload(h, blk_nrows, &D.blk_nrows))) return rc;
+  if ((rc = dev_upload(h, blk_sub, &D.blk_sub))) return rc;
+  if ((rc = dev_upload(h, sl_ptr, &D.sl_ptr))) return rc;
+  if ((rc = dev_upload(h, pair_cell, &D.pair_cell))) return rc;
+  if ((rc = dev_upload(h, pair_slots, &D.pair_slots))) return rc;
+  if ((rc = dev_upload(h, rowptr, &D.rowptr))) return rc;
+  if ((rc = dev_upload(h, colind, &D.colind))) return rc;
+  if ((rc = dev_upload(h, lapoff, &D.lapoff))) return rc;
+  if ((rc = dev_upload(h, rowptrL, &D.rowptrL))) return rc;
+  if ((rc = dev_upload(h, colindL, &D.colindL))) return rc;
+  if ((rc = dev_upload(h, gam_idx, &D.gam_idx))) return rc;
+  if ((rc = dev_upload(h, mptr, &D.mptr))) return rc;
+  if ((rc = dev_upload(h, mentry, &D.mentry))) return rc;
+  if ((rc = dev_upload(h, mslots, &D.mslots))) return rc;
+  if ((rc = dev_upload(h, mrow, &D.mrow))) return rc;
+  if ((rc = dev_upload(h, fe, &D.fe))) return rc;
+  if ((rc = dev_upload(h, fi, &D.fi))) return rc;
+  if ((rc = dev_upload(h, fq, &D.fq))) return rc;
+  if ((rc = dev_upload(h, fmodel, &D.fmodel))) return rc;
+  if ((rc = dev_upload(h, q2e, &D.q2e))) return rc;
+  if ((rc = dev_upload(h, q2i, &D.q2i))) return rc;
+  if ((rc = dev_zeros(h, (size_t)(K - 1) * Ntot, &D.csol))) return rc;
+  D.fsrc = nullptr;
+  if ((rc = dev_zeros(h, (size_t)D.nnz, &D.A_emi))) return rc;
+  if ((rc = dev_zeros(h, (size_t)D.nnz, &D.P_emi))) return rc;
+  if ((rc = dev_zeros(h, (size_t)Ntot, &D.b_emi))) return rc;
+  if ((rc = dev_zeros(h, (size_t)(K - 1) * D.nnzL, &D.A_knp))) return rc;
+  if ((rc = dev_zeros(h, (size_t)(K - 1) * Ntot, &D.b_knp))) return rc;
+  if ((rc = dev_zeros(h, (size_t)NQtot, &D.phiM))) return rc;
+  if ((rc = dev_zeros(h, (size_t)std::max(1, h->moff[S]) * K * std::max(1, NQtot), &D.Ich))) return rc;
+  h->stage_len = (size_t)std::max(Ntot, 1) * (K - 1) + 2 * (size_t)std::max(NQtot, 1);
+  if ((rc = dev_zeros(h, h->stage_len, &h->d_stage))) return rc;
+
+  {
+    std::vector<double> qt;
+    D.nq_gamma = kn_gamma_quadrature(NF, &qt);
+    if ((rc = dev_upload(h, qt, &D.qtab))) return rc;
+  }
+
+  KnConsts& C = h->consts;
+  C.n_sub = S; C.K = K;
+  for (int s = 0; s <= S; ++s) { C.voff[s] = h->voff[s]; C.qoff[s] = h->qoff[s]; }
+  for (int s = S + 1; s <= KN_MAXSUB; ++s) { C.voff[s] = h->voff[S]; C.qoff[s] = h->qoff[S]; }
+  C.splitting = 1;
+
+  *out = guard.release();
+  return KNPEMI_OK;
+}
+
+extern "C" void knpemi_destroy(knpemi_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" int knpemi_set_params(knpemi_handle* h, const knpemi_params* p) {
+  if (!h || !p) return fail(KNPEMI_EINVAL, "knpemi_set_params: null argument");
+  if (!(p->dt > 0) || !(p->C_M > 0) || p->z[h->K - 1] == 0.0)
+    return fail(KNPEMI_EINVAL, "knpemi_set_params: dt, C_M must be positive and z_K non-zero");
+  KnConsts& C = h->consts;
+  C.dt = p->dt; C.inv_dt = 1.0 / p->dt; C.F = p->F; C.psi = p->psi; C.C_M = p->C_M;
+  C.C_phi = p->C_M / p->dt;
+  const int K = h->K;
+  for (int k = 0; k < K; ++k) {
+    C.z[k] = p->z[k];
+    C.elim_coef[k] = -(1.0 / p->z[K - 1]) * p->z[k];
+  }
+  for (int s = 0; s < h->n_sub; ++s) {
+    KnSubConst& sc = C.sc[s];
+    for (int k = 0; k < K; ++k) {
+      const double z = p->z[k], Dk = p->D[s][k];
+      sc.kap[k] = p->F * z * z * Dk * p->psi;
+      sc.sig[k] = p->F * z * Dk;
+      sc.D[k] = Dk;
+      sc.zpsiD[k] = z * p->psi * Dk;
+      sc.az2D[k] = Dk * z * z;
+    }
+    sc.rho_term = -(1.0 / p->z[K - 1]) * p->rho_z * p->rho[s];
+  }
+  KN_HIP(hipSetDevice(h->device));
+  if (!h->d_consts) {
+    void* p2 = nullptr;
+    KN_HIP(hipMalloc(&p2, sizeof(KnConsts)));
+    h->allocs.push_back(p2);
+    h->d_consts = static_cast<KnConsts*>(p2);
+  }
+  KN_HIP(hipStreamSynchronize(h->stream));
+  KN_HIP(hipMemcpy(h->d_consts, &h->consts, sizeof(KnConsts), hipMemcpyHostToDevice));
+  h->have_params = 1;
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_sync(knpemi_handle* h) {
+  if (!h) return fail(KNPEMI_EINVAL, "null handle");
+  KN_HIP(hipStreamSynchronize(h->stream));
+  return KNPEMI_OK;
+}
+
+extern "C" void* knpemi_stream(knpemi_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+// ---------------------------------------------------------------------------------------------------
+// field I/O
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct FieldLoc { double* base; int stride; size_t n; };
+
+int locate(knpemi_handle* h, int field, int sub, int idx, FieldLoc* loc) {
+  if (sub < 0 || sub >= h->n_sub) return fail(KNPEMI_EINVAL, "field: bad sub-domain index");
+  const int K = h->K;
+  KnDev& D = h->dev;
+  const size_t v0 = h->voff[sub], nv = h->n_vert[sub], q0 = h->qoff[sub], nq = h->n_q[sub];
+  switch (field) {
+    case KNPEMI_F_PHI: *loc = {D.VR + v0 * KN_REC + 7, KN_REC, nv}; return 0;
+    case KNPEMI_F_C_PREV:
+      if (idx < 0 || idx >= K - 1) return fail(KNPEMI_EINVAL, "field: bad ion index");
+      *loc = {D.VR + v0 * KN_REC + 4 + idx, KN_REC, nv}; return 0;
+    case KNPEMI_F_C_ELIM: *loc = {D.VR + v0 * KN_REC + 4 + (K - 1), KN_REC, nv}; return 0;
+    case KNPEMI_F_C:
+      if (idx < 0 || idx >= K - 1) return fail(KNPEMI_EINVAL, "field: bad ion index");
+      *loc = {D.csol + (size_t)idx * D.Ntot + v0, 1, nv}; return 0;
+    case KNPEMI_F_PHI_M:
+      if (sub == 0) return fail(KNPEMI_EINVAL, "field: the ECS has no membrane space");
+      *loc = {D.phiM + q0, 1, nq}; return 0;
+    case KNPEMI_F_I_CH: {
+      int m = idx / KN_MAXK, k = idx % KN_MAXK;
+      if (sub == 0 || m < 0 || m >= h->n_models[sub] || k >= K)
+        return fail(KNPEMI_EINVAL, "field: bad I_ch index");
+      *loc = {D.Ich + ((size_t)(h->moff[sub] + m) * K + k) * std::max(1, D.NQtot) + q0, 1, nq};
+      return 0;
+    }
+    case KNPEMI_F_SOURCE:
+      if (sub != 0 || idx < 0 || idx >= K - 1) return fail(KNPEMI_EINVAL, "field: f_source lives on the ECS");
+      if (!D.fsrc) {
+        int rc = dev_zeros(h, (size_t)(K - 1) * h->n_vert[0], &D.fsrc);
+        if (rc) return rc;
+      }
+      *loc = {D.fsrc + (size_t)idx * h->n_vert[0], 1, nv}; return 0;
+  }
+  return fail(KNPEMI_EINVAL, "field: unknown field id");
+}
+}  // namespace
+
+extern "C" int knpemi_set_field(knpemi_handle* h, int field, int sub, int idx, const double* host, size_t n) {
+  if (!h || !host) return fail(KNPEMI_EINVAL, "knpemi_set_field: null argument");
+  FieldLoc L;
+  int rc = locate(h, field, sub, idx, &L);
+  if (rc) return rc;
+  if (n != L.n) return fail(KNPEMI_EINVAL, "knpemi_set_field: length does not match the function space");
+  if (n == 0) return KNPEMI_OK;
+  KN_HIP(hipSetDevice(h->device));
+  if (L.stride == 1) {
+    KN_HIP(hipMemcpyAsync(L.base, host, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    KN_HIP(hipStreamSynchronize(h->stream));
+    return KNPEMI_OK;
+  }
+  KN_HIP(hipMemcpyAsync(h->d_stage, host, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  rc = kn_launch_field_scatter(h, h->d_stage, L.base, (int)n, L.stride);
+  if (rc) return rc;
+  KN_HIP(hipStreamSynchronize(h->stream));
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_get_field(knpemi_handle* h, int field, int sub, int idx, double* host, size_t n) {
+  if (!h || !host) return fail(KNPEMI_EINVAL, "knpemi_get_field: null argument");
+  FieldLoc L;
+  int rc = locate(h, field, sub, idx, &L);
+  if (rc) return rc;
+  if (n != L.n) return fail(KNPEMI_EINVAL, "knpemi_get_field: length does not match the function space");
+  if (n == 0) return KNPEMI_OK;
+  KN_HIP(hipSetDevice(h->device));
+  const double* src = L.base;
+  if (L.stride != 1) {
+    rc = kn_launch_field_gather(h, L.base, L.stride, h->d_stage, (int)n);
+    if (rc) return rc;
+    src = h->d_stage;
+  }
+  KN_HIP(hipMemcpyAsync(host, src, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_trace(knpemi_handle* h, int sub, const double* u_e, const double* u_i, double* q_e,
+                            double* q_i) {
+  if (!h || !u_e || !u_i || !q_e || !q_i) return fail(KNPEMI_EINVAL, "knpemi_trace: null argument");
+  if (sub < 1 || sub >= h->n_sub) return fail(KNPEMI_EINVAL, "knpemi_trace: sub must be a cellular sub-domain");
+  const int nq = h->n_q[sub], ne = h->n_vert[0], ni = h->n_vert[sub];
+  if (nq == 0) return KNPEMI_OK;
+  if ((size_t)ne + ni + 2 * (size_t)nq > h->stage_len) return fail(KNPEMI_EINVAL, "knpemi_trace: staging buffer too small");
+  KN_HIP(hipSetDevice(h->device));
+  double* de = h->d_stage;
+  double* di = de + ne;
+  double* qe = di + ni;
+  double* qi = qe + nq;
+  KN_HIP(hipMemcpyAsync(de, u_e, (size_t)ne * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  KN_HIP(hipMemcpyAsync(di, u_i, (size_t)ni * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  int rc = kn_launch_trace(h, de, di, sub, qe, qi);
+  if (rc) return rc;
+  KN_HIP(hipMemcpyAsync(q_e, qe, (size_t)nq * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  KN_HIP(hipMemcpyAsync(q_i, qi, (size_t)nq * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  return KNPEMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// assembly + CSR access
+// ---------------------------------------------------------------------------------------------------
+extern "C" int knpemi_assemble_emi(knpemi_handle* h, int flags) {
+  if (!h) return fail(KNPEMI_EINVAL, "null handle");
+  if (!h->have_params) return fail(KNPEMI_EINVAL, "knpemi_assemble_emi: knpemi_set_params not called");
+  KN_HIP(hipSetDevice(h->device));
+  return kn_launch_emi_rows(h, flags);
+}
+
+extern "C" int knpemi_assemble_knp(knpemi_handle* h, int flags) {
+  if (!h) return fail(KNPEMI_EINVAL, "null handle");
+  if (!h->have_params) return fail(KNPEMI_EINVAL, "knpemi_assemble_knp: knpemi_set_params not called");
+  KN_HIP(hipSetDevice(h->device));
+  int rc = kn_launch_knp_rows(h, flags);
+  if (rc) return rc;
+  return kn_launch_knp_membrane(h, flags);
+}
+
+extern "C" int knpemi_csr_dims(knpemi_handle* h, int which, int64_t* n_rows, int64_t* nnz) {
+  if (!h || !n_rows || !nnz) return fail(KNPEMI_EINVAL, "knpemi_csr_dims: null argument");
+  if (which == KNPEMI_A_EMI || which == KNPEMI_P_EMI) { *n_rows = h->dev.Ntot; *nnz = h->dev.nnz; }
+  else if (which == KNPEMI_A_KNP) { *n_rows = (int64_t)(h->K - 1) * h->dev.Ntot; *nnz = (h->K - 1) * h->dev.nnzL; }
+  else return fail(KNPEMI_EINVAL, "knpemi_csr_dims: unknown matrix");
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_get_csr_pattern(knpemi_handle* h, int which, int32_t* rowptr, int32_t* colind) {
+  if (!h || !rowptr || !colind) return fail(KNPEMI_EINVAL, "knpemi_get_csr_pattern: null argument");
+  if (which == KNPEMI_A_EMI || which == KNPEMI_P_EMI) {
+    std::memcpy(rowptr, h->h_rowptr.data(), h->h_rowptr.size() * sizeof(int));
+    std::memcpy(colind, h->h_colind.data(), h->h_colind.size() * sizeof(int));
+    return KNPEMI_OK;
+  }
+  if (which != KNPEMI_A_KNP) return fail(KNPEMI_EINVAL, "knpemi_get_csr_pattern: unknown matrix");
+  // block (sub, ion): rows/cols shifted to [c[0][0], c[0][1], c[1][0], ...] (pdeSolver.py:117)
+  const int KS = h->K - 1;
+  int64_t row = 0, pos = 0;
+  rowptr[0] = 0;
+  for (int s = 0; s < h->n_sub; ++s) {
+    const int v0 = h->voff[s], nv = h->n_vert[s];
+    for (int k = 0; k < KS; ++k) {
+      const int64_t shift = (int64_t)KS * v0 + (int64_t)k * nv - v0;
+      for (int v = 0; v < nv; ++v) {
+        for (int p = h->h_rowptrL[v0 + v]; p < h->h_rowptrL[v0 + v + 1]; ++p)
+          colind[pos++] = (int32_t)(h->h_colindL[p] + shift);
+        rowptr[++row] = (int32_t)pos;
+      }
+    }
+  }
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_device_csr(knpemi_handle* h, int which, const int32_t** rowptr,
+                                 const int32_t** colind, const double** vals) {
+  if (!h) return fail(KNPEMI_EINVAL, "null handle");
+  if (which == KNPEMI_A_EMI || which == KNPEMI_P_EMI) {
+    if (rowptr) *rowptr = h->dev.rowptr;
+    if (colind) *colind = h->dev.colind;
+    if (vals) *vals = which == KNPEMI_A_EMI ? h->dev.A_emi : h->dev.P_emi;
+    return KNPEMI_OK;
+  }
+  if (which == KNPEMI_A_KNP) {  // values only: block b = (sub, ion) occupies a contiguous range
+    if (rowptr) *rowptr = h->dev.rowptrL;
+    if (colind) *colind = h->dev.colindL;
+    if (vals) *vals = h->dev.A_knp;
+    return KNPEMI_OK;
+  }
+  return fail(KNPEMI_EINVAL, "knpemi_device_csr: unknown matrix");
+}
+
+extern "C" int knpemi_get_csr_values(knpemi_handle* h, int which, double* vals) {
+  if (!h || !vals) return fail(KNPEMI_EINVAL, "knpemi_get_csr_values: null argument");
+  const double* src; size_t n;
+  if (which == KNPEMI_A_EMI) { src = h->dev.A_emi; n = h->dev.nnz; }
+  else if (which == KNPEMI_P_EMI) { src = h->dev.P_emi; n = h->dev.nnz; }
+  else if (which == KNPEMI_A_KNP) { src = h->dev.A_knp; n = (size_t)(h->K - 1) * h->dev.nnzL; }
+  else return fail(KNPEMI_EINVAL, "knpemi_get_csr_values: unknown matrix");
+  KN_HIP(hipSetDevice(h->device));
+  KN_HIP(hipMemcpyAsync(vals, src, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_device_rhs(knpemi_handle* h, int which, const double** b) {
+  if (!h || !b) return fail(KNPEMI_EINVAL, "null argument");
+  if (which == KNPEMI_B_EMI) *b = h->dev.b_emi;
+  else if (which == KNPEMI_B_KNP) *b = h->dev.b_knp;
+  else return fail(KNPEMI_EINVAL, "knpemi_device_rhs: unknown vector");
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_get_rhs(knpemi_handle* h, int which, double* b) {
+  if (!h || !b) return fail(KNPEMI_EINVAL, "knpemi_get_rhs: null argument");
+  const double* src; size_t n;
+  if (which == KNPEMI_B_EMI) { src = h->dev.b_emi; n = h->dev.Ntot; }
+  else if (which == KNPEMI_B_KNP) { src = h->dev.b_knp; n = (size_t)(h->K - 1) * h->dev.Ntot; }
+  else return fail(KNPEMI_EINVAL, "knpemi_get_rhs: unknown vector");
+  KN_HIP(hipSetDevice(h->device));
+  KN_HIP(hipMemcpyAsync(b, src, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_set_solution(knpemi_handle* h, int which, const double* x, int on_device) {
+  if (!h || !x) return fail(KNPEMI_EINVAL, "knpemi_set_solution: null argument");
+  KN_HIP(hipSetDevice(h->device));
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  KnDev& D = h->dev;
+  if (which == KNPEMI_B_EMI) {
+    const double* src = x;
+    if (!on_device) {
+      KN_HIP(hipMemcpyAsync(h->d_stage, x, (size_t)D.Ntot * sizeof(double), kind, h->stream));
+      src = h->d_stage;
+    }
+    int rc = kn_launch_field_scatter(h, src, D.VR + 7, D.Ntot, KN_REC);
+    if (rc) return rc;
+  } else if (which == KNPEMI_B_KNP) {
+    const int KS = h->K - 1;
+    for (int s = 0; s < h->n_sub; ++s)
+      for (int k = 0; k < KS; ++k) {
+        const size_t nv = h->n_vert[s];
+        if (!nv) continue;
+        KN_HIP(hipMemcpyAsync(D.csol + (size_t)k * D.Ntot + h->voff[s],
+                              x + (size_t)KS * h->voff[s] + (size_t)k * nv, nv * sizeof(double), kind, h->stream));
+      }
+  } else return fail(KNPEMI_EINVAL, "knpemi_set_solution: unknown system");
+  if (!on_device) KN_HIP(hipStreamSynchronize(h->stream));
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_get_solution(knpemi_handle* h, int which, double* x) {
+  if (!h || !x) return fail(KNPEMI_EINVAL, "knpemi_get_solution: null argument");
+  KN_HIP(hipSetDevice(h->device));
+  KnDev& D = h->dev;
+  if (which == KNPEMI_B_EMI) {
+    int rc = kn_launch_field_gather(h, D.VR + 7, KN_REC, h->d_stage, D.Ntot);
+    if (rc) return rc;
+    KN_HIP(hipMemcpyAsync(x, h->d_stage, (size_t)D.Ntot * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  } else if (which == KNPEMI_B_KNP) {
+    const int KS = h->K - 1;
+    for (int s = 0; s < h->n_sub; ++s)
+      for (int k = 0; k < KS; ++k) {
+        const size_t nv = h->n_vert[s];
+        if (!nv) continue;
+        KN_HIP(hipMemcpyAsync(x + (size_t)KS * h->voff[s] + (size_t)k * nv,
+                              D.csol + (size_t)k * D.Ntot + h->voff[s], nv * sizeof(double),
+                              hipMemcpyDeviceToHost, h->stream));
+      }
+  } else return fail(KNPEMI_EINVAL, "knpemi_get_solution: unknown system");
+  KN_HIP(hipStreamSynchronize(h->stream));
+  return KNPEMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// membrane ODE tables
+// ---------------------------------------------------------------------------------------------------
+namespace {
+int ode_slot(knpemi_handle* h, int sub, int model, int need_bound) {
+  if (!h || sub < 1 || sub >= h->n_sub || model < 0 || model >= h->n_models[sub]) {
+    kn_set_error("membrane model index out of range");
+    return -1;
+  }
+  int slot = h->moff[sub] + model;
+  if (need_bound && !h->ode[slot].bound) {
+    kn_set_error("membrane model not bound (knpemi_ode_bind)");
+    return -1;
+  }
+  return slot;
+}
+}  // namespace
+
+extern "C" int knpemi_ode_bind(knpemi_handle* h, int sub, int model, int model_id, int n_states, int n_params) {
+  int slot = ode_slot(h, sub, model, 0);
+  if (slot < 0) return KNPEMI_EINVAL;
+  static const int ns_of[3] = {4, 4, 1}, np_of[3] = {22, 22, 23};
+  if (model_id < 0 || model_id > 2) return fail(KNPEMI_EINVAL, "knpemi_ode_bind: unknown model id");
+  if (n_states != ns_of[model_id] || n_params != np_of[model_id])
+    return fail(KNPEMI_EINVAL, "knpemi_ode_bind: state/parameter count does not match the model");
+  KN_HIP(hipSetDevice(h->device));
+  KnOdeModel& m = h->ode[slot];
+  if (m.bound) return fail(KNPEMI_EINVAL, "knpemi_ode_bind: model already bound");
+  m.sub = sub; m.model_id = model_id; m.n_states = n_states; m.n_params = n_params;
+  m.nq = h->n_q[sub];
+  int rc;
+  if ((rc = dev_zeros(h, (size_t)n_states * m.nq, &m.d_states))) return rc;
+  if ((rc = dev_zeros(h, (size_t)n_params * m.nq, &m.d_params))) return rc;
+  if ((rc = dev_zeros(h, 3, &m.d_stats))) return rc;
+  m.bound = 1;
+  return KNPEMI_OK;
+}
+
+static void transpose(const double* src, double* dst, int rows, int cols) {
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) dst[(size_t)c * rows + r] = src[(size_t)r * cols + c];
+}
+
+extern "C" int knpemi_ode_set_tables(knpemi_handle* h, int sub, int model, const double* states, const double* params) {
+  int slot = ode_slot(h, sub, model, 1);
+  if (slot < 0) return KNPEMI_EINVAL;
+  KnOdeModel& m = h->ode[slot];
+  KN_HIP(hipSetDevice(h->device));
+  std::vector<double> t;
+  if (states) {
+    t.resize((size_t)m.nq * m.n_states);
+    transpose(states, t.data(), m.nq, m.n_states);
+    KN_HIP(hipMemcpyAsync(m.d_states, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    KN_HIP(hipStreamSynchronize(h->stream));
+  }
+  if (params) {
+    t.resize((size_t)m.nq * m.n_params);
+    transpose(params, t.data(), m.nq, m.n_params);
+    KN_HIP(hipMemcpyAsync(m.d_params, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    KN_HIP(hipStreamSynchronize(h->stream));
+  }
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_ode_get_tables(knpemi_handle* h, int sub, int model, double* states, double* params) {
+  int slot = ode_slot(h, sub, model, 1);
+  if (slot < 0) return KNPEMI_EINVAL;
+  KnOdeModel& m = h->ode[slot];
+  KN_HIP(hipSetDevice(h->device));
+  std::vector<double> t;
+  if (states) {
+    t.resize((size_t)m.nq * m.n_states);
+    KN_HIP(hipMemcpyAsync(t.data(), m.d_states, t.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    KN_HIP(hipStreamSynchronize(h->stream));
+    transpose(t.data(), states, m.n_states, m.nq);
+  }
+  if (params) {
+    t.resize((size_t)m.nq * m.n_params);
+    KN_HIP(hipMemcpyAsync(t.data(), m.d_params, t.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    KN_HIP(hipStreamSynchronize(h->stream));
+    transpose(t.data(), params, m.n_params, m.nq);
+  }
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_ode_set_stimulus(knpemi_handle* h, int sub, int model, const uint8_t* mask,
+                                       int n_pairs, const int32_t* param_idx, const double* values) {
+  int slot = ode_slot(h, sub, model, 1);
+  if (slot < 0) return KNPEMI_EINVAL;
+  KnOdeModel& m = h->ode[slot];
+  if (n_pairs < 0 || n_pairs > 8) return fail(KNPEMI_EINVAL, "knpemi_ode_set_stimulus: at most 8 stimulus entries");
+  KN_HIP(hipSetDevice(h->device));
+  for (int i = 0; i < n_pairs; ++i) {
+    if (param_idx[i] < 0 || param_idx[i] >= m.n_params)
+      return fail(KNPEMI_EINVAL, "knpemi_ode_set_stimulus: parameter index out of range");
+    m.stim_idx[i] = param_idx[i];
+    m.stim_val[i] = values[i];
+  }
+  m.n_stim = n_pairs;
+  if (mask) {
+    if (!m.d_mask) {
+      int rc = dev_zeros(h, (size_t)m.nq, &m.d_mask);
+      if (rc) return rc;
+    }
+    KN_HIP(hipMemcpyAsync(m.d_mask, mask, (size_t)m.nq, hipMemcpyHostToDevice, h->stream));
+    KN_HIP(hipStreamSynchronize(h->stream));
+  } else if (m.d_mask) {
+    KN_HIP(hipMemsetAsync(m.d_mask, 1, (size_t)m.nq, h->stream));
+  }
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_ode_step(knpemi_handle* h, int sub, int model, double t0, double dt, double rtol,
+                               double atol, int flags, const int32_t* ion_param, int v_index) {
+  int slot = ode_slot(h, sub, model, 1);
+  if (slot < 0) return KNPEMI_EINVAL;
+  if (!ion_param) return fail(KNPEMI_EINVAL, "knpemi_ode_step: ion_param is required");
+  KnOdeModel& m = h->ode[slot];
+  for (int i = 0; i < 3 * h->K; ++i)
+    if (ion_param[i] < 0 || ion_param[i] >= m.n_params)
+      return fail(KNPEMI_EINVAL, "knpemi_ode_step: parameter index out of range");
+  if (v_index < 0 || v_index >= m.n_states) return fail(KNPEMI_EINVAL, "knpemi_ode_step: bad V index");
+  if (!(dt > 0) || !(rtol >= 0) || !(atol >= 0) || (rtol == 0 && atol == 0))
+    return fail(KNPEMI_EINVAL, "knpemi_ode_step: bad dt / tolerances");
+  KN_HIP(hipSetDevice(h->device));
+  return kn_launch_ode_step(h, slot, t0, dt, rtol, atol, flags, ion_param, v_index);
+}
+
+extern "C" int knpemi_ode_stats(knpemi_handle* h, int sub, int model, int64_t* n_rhs, int64_t* n_steps, int32_t* n_failed) {
+  int slot = ode_slot(h, sub, model, 1);
+  if (slot < 0) return KNPEMI_EINVAL;
+  unsigned long long st[3];
+  KN_HIP(hipSetDevice(h->device));
+  KN_HIP(hipMemcpyAsync(st, h->ode[slot].d_stats, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  if (n_rhs) *n_rhs = (int64_t)st[0];
+  if (n_steps) *n_steps = (int64_t)st[1];
+  if (n_failed) *n_failed = (int32_t)st[2];
+  if (st[2]) return fail(KNPEMI_EODE, "LSODA failed on at least one membrane dof (odeSolver.py:121 `assert success`)");
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_update_pde(knpemi_handle* h) {
+  if (!h) return fail(KNPEMI_EINVAL, "null handle");
+  if (!h->have_params) return fail(KNPEMI_EINVAL, "knpemi_update_pde: knpemi_set_params not called");
+  KN_HIP(hipSetDevice(h->device));
+  return kn_launch_update_pde(h);
+}
+
+extern "C" int knpemi_timer_start(knpemi_handle* h) {
+  if (!h) return fail(KNPEMI_EINVAL, "null handle");
+  KN_HIP(hipEventRecord(h->ev0, h->stream));
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_timer_stop_ms(knpemi_handle* h, double* ms) {
+  if (!h || !ms) return fail(KNPEMI_EINVAL, "null argument");
+  KN_HIP(hipEventRecord(h->ev1, h->stream));
+  KN_HIP(hipEventSynchronize(h->ev1));
+  float f = 0.f;
+  KN_HIP(hipEventElapsedTime(&f, h->ev0, h->ev1));
+  *ms = f;
+  return KNPEMI_OK;
+}

@@ -1,0 +1,132 @@
+// Internal data structures shared by the host-side builder/API and the gfx950 kernels.
+// Not part of the C ABI (see include/knpemi_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/knpemi_hip.h"
+
+#define KN_MAXK KNPEMI_MAX_IONS
+#define KN_MAXSUB KNPEMI_MAX_SUB
+#define KN_REC 8          // doubles per vertex record: x y z _ | c0 c1 c_elim phi
+#define KN_ROWS_PER_BLOCK 256
+#define KN_SLICE 64       // rows per sliced-ELL slice == wavefront width on gfx950
+
+// Per-sub-domain constants folded on the host from knpemi_params (double arithmetic identical
+// to what the kernels would do per cell).
+struct KnSubConst {
+  double kap[KN_MAXK];   // F * psi * z_k^2 * D_k^s      (emiWeakForm.py:103)
+  double sig[KN_MAXK];   // F * z_k * D_k^s              (emiWeakForm.py:217)
+  double D[KN_MAXK];     // D_k^s
+  double zpsiD[KN_MAXK]; // z_k * psi * D_k^s            (knpWeakForm.py:141)
+  double az2D[KN_MAXK];  // D_k^s z_k^2                  (knpWeakForm.py:97)
+  double rho_term;       // -(1/z_K) * rho_z * rho^s     (utils.py:249)
+};
+
+struct KnConsts {
+  int n_sub, K;
+  int voff[KN_MAXSUB + 1];   // global vertex offset of each sub-domain
+  int qoff[KN_MAXSUB + 1];   // global Q-dof offset
+  KnSubConst sc[KN_MAXSUB];
+  double dt, inv_dt, F, psi, C_M, C_phi;
+  double z[KN_MAXK];
+  double elim_coef[KN_MAXK]; // -(z_k / z_K)            (utils.py:258)
+  int splitting;
+};
+
+// Device views (raw pointers; owned by knpemi_handle).
+struct KnDev {
+  int Ntot, nctot, NQtot, nftot;
+  int nblocks;                // row blocks; a block never straddles two sub-domains
+  const int* blk_row0;        // [nblocks] first global row of the block
+  const int* blk_nrows;       // [nblocks] rows in the block (<= KN_ROWS_PER_BLOCK)
+  const int* blk_sub;         // [nblocks] sub-domain of the block
+  double* VR;                 // [Ntot][KN_REC]
+  double* csol;               // [K-1][Ntot]  solver output c (block order handled by offsets)
+  double* fsrc;               // [K-1][N_0] optional ECS source term (NULL when unused)
+  const int* cells;           // [nctot][NV] global vertex ids
+  // sliced ELL of (row, incident cell) pairs
+  const int64_t* sl_ptr;      // [4*nblocks+1] entry offsets (multiples of KN_SLICE); slice
+                              // 4*b + w holds rows blk_row0[b] + 64*w .. of block b
+  const int* pair_cell;       // cell*8 + local index, -1 = padding
+  const uint32_t* pair_slots; // NV<=4: 4 x uint8 slots; hex: two consecutive words per entry
+  // EMI CSR (monolithic) and Laplacian-pattern CSR (KNP blocks share it per sub-domain)
+  const int* rowptr; const int* colind; const uint8_t* lapoff;
+  const int* rowptrL; const int* colindL;
+  double* A_emi; double* P_emi; double* b_emi;
+  double* A_knp; double* b_knp;          // block order (sub, ion)
+  int64_t nnz, nnzL;
+  // membrane
+  const int* gam_idx;         // [Ntot] membrane-row index or -1
+  const int* mptr;            // [M+1]
+  const int* mentry;          // facet*8 + local vertex a
+  const uint64_t* mslots;     // bytes 0..3 own-side slot of col b, bytes 4..7 other-side slot
+  const int* mrow;            // [M] global row of each membrane row
+  const int* fe; const int* fi; const int* fq;   // [nftot][NF] global ids
+  const int* fmodel;          // [nftot] global model slot or -1
+  const int* q2e; const int* q2i;                // [NQtot] global vertex ids
+  double* phiM;               // [NQtot]
+  double* Ich;                // [n_model_slots][K][stride NQtot] (indexed by global q)
+  int M;
+  // membrane quadrature tables (degree 6): weights and shape values
+  const double* qtab;         // [nq] weights, then [nq][NF] shape values, then (quads) [nq][NF][2] derivatives
+  int nq_gamma;
+};
+
+struct KnOdeModel {
+  int bound = 0, sub = 0, model_id = -1, n_states = 0, n_params = 0, nq = 0;
+  double* d_states = nullptr;   // [n_states][nq]
+  double* d_params = nullptr;   // [n_params][nq]
+  uint8_t* d_mask = nullptr;    // [nq] or NULL
+  int n_stim = 0;
+  int stim_idx[8];
+  double stim_val[8];
+  unsigned long long* d_stats = nullptr; // [3]: rhs evals, steps, failures
+};
+
+struct knpemi_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int gdim = 0, cell_kind = 0, NV = 0, NF = 0, n_sub = 0, K = 0;
+  std::vector<int> n_vert, n_cell, n_q, n_facet, n_models;
+  std::vector<int> voff, coff, qoff, foff, moff;
+  KnConsts consts{};
+  KnConsts* d_consts = nullptr;        // device copy read by the kernels
+  const void* d_lsoda_coef = nullptr;  // LsodaCoef tables (kernels_ode.hip)
+  KnDev dev{};
+  int have_params = 0;
+  int lds_doubles_emi = 0, lds_doubles_knp = 0; // per-block LDS segment sizes (doubles)
+  std::vector<void*> allocs;  // everything hipMalloc'ed
+  std::vector<KnOdeModel> ode; // [moff[n_sub]]
+  // host copies of patterns for export
+  std::vector<int> h_rowptr, h_colind, h_rowptrL, h_colindL;
+  double* d_stage = nullptr; size_t stage_len = 0;   // staging buffer for strided field I/O
+};
+
+// error plumbing ------------------------------------------------------------------------------
+void kn_set_error(const std::string& msg);
+#define KN_HIP(call)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      kn_set_error(std::string(#call) + ": " + hipGetErrorString(e_));                   \
+      return KNPEMI_EHIP;                                                                \
+    }                                                                                    \
+  } while (0)
+
+// kernel launchers (kernels_*.hip) ------------------------------------------------------------
+int kn_launch_emi_rows(knpemi_handle* h, int flags);
+int kn_launch_knp_rows(knpemi_handle* h, int flags);
+int kn_launch_knp_membrane(knpemi_handle* h, int flags);
+int kn_launch_ode_step(knpemi_handle* h, int slot, double t0, double dt, double rtol, double atol,
+                       int flags, const int32_t* ion_param, int v_index);
+int kn_launch_update_pde(knpemi_handle* h);
+int kn_launch_field_scatter(knpemi_handle* h, const double* src, double* dst, int n, int dst_stride);
+int kn_launch_field_gather(knpemi_handle* h, const double* src, int src_stride, double* dst, int n);
+int kn_launch_trace(knpemi_handle* h, const double* ue, const double* ui, int sub, double* qe, double* qi);

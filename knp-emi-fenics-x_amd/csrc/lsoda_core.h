@@ -1,0 +1,705 @@
+// LSODA (Livermore Solver for ODEs with Automatic method switching) for tiny systems, written so
+// that one GPU thread integrates one membrane dof entirely out of its own private memory.
+//
+// The reference calls numbalsoda's C++ LSODA once per membrane dof and step
+// (src/knpemi/odeSolver.py:116-120: `lsoda(addr, state, [t, t+dt], data=params, rtol=1e-8,
+// atol=1e-10)`).  numbalsoda is un-vendored and un-pinned (pyproject.toml:13-18); what is
+// restated here is the published ODEPACK algorithm it implements (Hindmarsh 1983; Petzold 1983):
+// variable-order, variable-step Adams (orders 1..12, functional iteration) and BDF (orders 1..5,
+// chord iteration with a finite-difference Jacobian) in Nordsieck form with automatic stiffness
+// detection, istate = 1 / itask = 1 semantics (fresh start at every call, overshoot tout and
+// interpolate back).
+//
+// Compiles for the device (hipcc) and for the host (g++, used only by tests/ to check this very
+// code against scipy's ODEPACK LSODA on the CPU -- it is not a CPU fallback of the product).
+#pragma once
+
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define KN_HD __host__ __device__ __forceinline__
+#define KN_HDN __host__ __device__ __noinline__
+#else
+#define KN_HD inline
+#define KN_HDN
+#endif
+
+#define KN_ETA 2.2204460492503131e-16
+
+// Method coefficients (ODEPACK CFODE), 1-based like the original: elco[meth-1][nq][i],
+// tesco[meth-1][nq][k]; cm1/cm2 = tesco[.][2] * elco[.][nq+1] used by the method switch.
+struct LsodaCoef {
+  double elco[2][13][14];
+  double tesco[2][13][4];
+  double cm1[13];
+  double cm2[6];
+};
+
+// Host-side construction of the coefficient tables (exact restatement of CFODE).
+inline void lsoda_fill_coef(LsodaCoef* c) {
+  for (int m = 0; m < 2; ++m)
+    for (int q = 0; q < 13; ++q) {
+      for (int i = 0; i < 14; ++i) c->elco[m][q][i] = 0.0;
+      for (int i = 0; i < 4; ++i) c->tesco[m][q][i] = 0.0;
+    }
+  double pc[13];
+  {  // Adams
+    double(*elco)[14] = c->elco[0];
+    double(*tesco)[4] = c->tesco[0];
+    elco[1][1] = 1.0; elco[1][2] = 1.0;
+    tesco[1][1] = 0.0; tesco[1][2] = 2.0; tesco[2][1] = 1.0; tesco[12][3] = 0.0;
+    pc[1] = 1.0;
+    double rqfac = 1.0;
+    for (int nq = 2; nq <= 12; ++nq) {
+      const double rq1fac = rqfac;
+      rqfac = rqfac / (double)nq;
+      const int nqm1 = nq - 1, nqp1 = nq + 1;
+      const double fnqm1 = (double)nqm1;
+      pc[nq] = 0.0;
+      for (int i = nq; i >= 2; --i) pc[i] = pc[i - 1] + fnqm1 * pc[i];
+      pc[1] = fnqm1 * pc[1];
+      double pint = pc[1], xpin = pc[1] / 2.0, tsign = 1.0;
+      for (int i = 2; i <= nq; ++i) {
+        tsign = -tsign;
+        pint += tsign * pc[i] / (double)i;
+        xpin += tsign * pc[i] / (double)(i + 1);
+      }
+      elco[nq][1] = pint * rq1fac;
+      elco[nq][2] = 1.0;
+      for (int i = 2; i <= nq; ++i) elco[nq][i + 1] = rq1fac * pc[i] / (double)i;
+      const double agamq = rqfac * xpin, ragq = 1.0 / agamq;
+      tesco[nq][2] = ragq;
+      if (nq < 12) tesco[nqp1][1] = ragq * rqfac / (double)nqp1;
+      tesco[nqm1][3] = ragq;
+    }
+  }
+  {  // BDF
+    double(*elco)[14] = c->elco[1];
+    double(*tesco)[4] = c->tesco[1];
+    pc[1] = 1.0;
+    double rq1fac = 1.0;
+    for (int nq = 1; nq <= 5; ++nq) {
+      const double fnq = (double)nq;
+      const int nqp1 = nq + 1;
+      pc[nqp1] = 0.0;
+      for (int i = nq + 1; i >= 2; --i) pc[i] = pc[i - 1] + fnq * pc[i];
+      pc[1] *= fnq;
+      for (int i = 1; i <= nqp1; ++i) elco[nq][i] = pc[i] / pc[2];
+      elco[nq][2] = 1.0;
+      tesco[nq][1] = rq1fac;
+      tesco[nq][2] = (double)nqp1 / elco[nq][1];
+      tesco[nq][3] = (double)(nq + 2) / elco[nq][1];
+      rq1fac /= fnq;
+    }
+  }
+  c->cm1[0] = 0.0;
+  c->cm2[0] = 0.0;
+  for (int i = 1; i <= 12; ++i) c->cm1[i] = c->tesco[0][i][2] * c->elco[0][i][i + 1];
+  for (int i = 1; i <= 5; ++i) c->cm2[i] = c->tesco[1][i][2] * c->elco[1][i][i + 1];
+}
+
+// N = number of states (1..8); F provides `static void rhs(double t, const double* y, double* dy,
+// double* p)` where p is the (in/out) parameter row, exactly the numba cfunc signature
+// `rhs_numba(t, states, values, parameters)` of the reference's membrane modules.
+template <int N, class F>
+struct Lsoda {
+  static constexpr int MXORDN = 12, MXORDS = 5, MAXCOR = 3, MSBP = 20, MXNCF = 10;
+
+  const LsodaCoef* cf;
+  double* p;  // parameter row (side-effect target of the RHS)
+  double rtol, atol;
+  double yh[15][N];  // Nordsieck array yh[1..13]; row 14 only bounds a dead branch of methodswitch
+  double wm[N][N];
+  int ipvt[N];
+  double ewt[N], savf[N], acor[N], y[N];
+  double el[14];
+  double h, hu, tn, hold, rc, crate, conit, el0, rmax, pdest, pdlast, pdnorm, ratio, tsw;
+  int nq, l, meth, mused, miter, ialth, ipup, jcur, jstart, kflag, icount, irflag, nslp, nst, nfe,
+      nje, lmax, maxord, nqu, ierpj;
+
+  KN_HD double sm1(int i) const {
+    switch (i) {
+      case 1: return 0.5; case 2: return 0.575; case 3: return 0.55; case 4: return 0.45;
+      case 5: return 0.35; case 6: return 0.25; case 7: return 0.2; case 8: return 0.15;
+      case 9: return 0.1; case 10: return 0.075; case 11: return 0.05; case 12: return 0.025;
+      default: return 0.0;
+    }
+  }
+  KN_HD double elco(int q, int i) const { return cf->elco[meth - 1][q][i]; }
+  KN_HD double tesco(int q, int i) const { return cf->tesco[meth - 1][q][i]; }
+
+  KN_HD double vmnorm(const double* v) const {
+    double vm = 0.0;
+    for (int i = 0; i < N; ++i) vm = fmax(vm, fabs(v[i]) * ewt[i]);
+    return vm;
+  }
+
+  KN_HD bool ewset(const double* yc) {
+    for (int i = 0; i < N; ++i) {
+      const double e = rtol * fabs(yc[i]) + atol;
+      if (!(e > 0.0)) return false;
+      ewt[i] = 1.0 / e;
+    }
+    return true;
+  }
+
+  KN_HD void resetcoeff() {
+    for (int i = 1; i <= l; ++i) el[i] = elco(nq, i);
+    rc = rc * el[1] / el0;
+    el0 = el[1];
+    conit = 0.5 / (double)(nq + 2);
+  }
+
+  KN_HD void scaleh(double* rh, double* pdh) {
+    *rh = fmin(*rh, rmax);
+    // hmxi = 0 (no maximum step): rh / max(1, |h| * hmxi * rh) == rh
+    if (meth == 1) {
+      irflag = 0;
+      *pdh = fmax(fabs(h) * pdlast, 0.000001);
+      if ((*rh * *pdh * 1.00001) >= sm1(nq)) {
+        *rh = sm1(nq) / *pdh;
+        irflag = 1;
+      }
+    }
+    double r = 1.0;
+    for (int j = 2; j <= l; ++j) {
+      r *= *rh;
+      for (int i = 0; i < N; ++i) yh[j][i] *= r;
+    }
+    h *= *rh;
+    rc *= *rh;
+    ialth = l;
+  }
+
+  KN_HD void retract(double told) {
+    tn = told;
+    for (int j = nq; j >= 1; --j)
+      for (int i1 = j; i1 <= nq; ++i1)
+        for (int i = 0; i < N; ++i) yh[i1][i] -= yh[i1 + 1][i];
+  }
+
+  KN_HD void corfailure(double told, double* rh, int* ncf, int* corflag) {
+    (*ncf)++;
+    rmax = 2.0;
+    retract(told);
+    if (fabs(h) <= 0.0 || *ncf == MXNCF) {  // hmin = 0
+      *corflag = 2;
+      return;
+    }
+    *corflag = 1;
+    *rh = 0.25;
+    ipup = miter;
+  }
+
+  // Finite-difference Jacobian, P = I - h*el0*J, LU factorisation (PRJA with miter = 2).
+  KN_HDN void prja(double t) {
+    nje++;
+    ierpj = 0;
+    jcur = 1;
+    const double hl0 = h * el0;
+    double fac = vmnorm(savf);
+    double r0 = 1000.0 * fabs(h) * KN_ETA * (double)N * fac;
+    if (r0 == 0.0) r0 = 1.0;
+    const double sqrteta = 1.4901161193847656e-08;
+    for (int j = 0; j < N; ++j) {
+      const double yj = y[j];
+      const double r = fmax(sqrteta * fabs(yj), r0 / ewt[j]);
+      y[j] += r;
+      fac = -hl0 / r;
+      F::rhs(t, y, acor, p);
+      for (int i = 0; i < N; ++i) wm[i][j] = (acor[i] - savf[i]) * fac;
+      y[j] = yj;
+    }
+    nfe += N;
+    double an = 0.0;  // fnorm: weighted max-row-sum norm of (-h*el0*J)
+    for (int i = 0; i < N; ++i) {
+      double sum = 0.0;
+      for (int j = 0; j < N; ++j) sum += fabs(wm[i][j]) / ewt[j];
+      an = fmax(an, sum * ewt[i]);
+    }
+    pdnorm = an / fabs(hl0);
+    for (int i = 0; i < N; ++i) wm[i][i] += 1.0;
+    // dgefa: Gaussian elimination with partial pivoting (LINPACK column-oriented variant)
+    for (int k = 0; k < N - 1; ++k) {
+      int piv = k;
+      double mx = fabs(wm[k][k]);
+      for (int i = k + 1; i < N; ++i)
+        if (fabs(wm[i][k]) > mx) { mx = fabs(wm[i][k]); piv = i; }
+      ipvt[k] = piv;
+      if (wm[piv][k] == 0.0) { ierpj = 1; continue; }
+      if (piv != k) { const double t2 = wm[piv][k]; wm[piv][k] = wm[k][k]; wm[k][k] = t2; }
+      const double tinv = -1.0 / wm[k][k];
+      for (int i = k + 1; i < N; ++i) wm[i][k] *= tinv;
+      for (int j = k + 1; j < N; ++j) {
+        double t2 = wm[piv][j];
+        if (piv != k) { wm[piv][j] = wm[k][j]; wm[k][j] = t2; }
+        for (int i = k + 1; i < N; ++i) wm[i][j] += t2 * wm[i][k];
+      }
+    }
+    ipvt[N - 1] = N - 1;
+    if (wm[N - 1][N - 1] == 0.0) ierpj = 1;
+  }
+
+  KN_HD void solsy(double* b) {  // dgesl, job = 0
+    for (int k = 0; k < N - 1; ++k) {
+      const int piv = ipvt[k];
+      const double t2 = b[piv];
+      if (piv != k) { b[piv] = b[k]; b[k] = t2; }
+      for (int i = k + 1; i < N; ++i) b[i] += t2 * wm[i][k];
+    }
+    for (int k = N - 1; k >= 0; --k) {
+      b[k] /= wm[k][k];
+      const double t2 = -b[k];
+      for (int i = 0; i < k; ++i) b[i] += t2 * wm[i][k];
+    }
+  }
+
+  KN_HDN void correction(double pnorm, double* del, double* delp, double told, int* ncf, double* rh,
+                         int* m, int* corflag) {
+    double rate = 0.0;
+    *m = 0;
+    *corflag = 0;
+    *del = 0.0;
+    for (int i = 0; i < N; ++i) y[i] = yh[1][i];
+    F::rhs(tn, y, savf, p);
+    nfe++;
+    while (true) {
+      if (*m == 0) {
+        if (ipup > 0) {
+          prja(tn);
+          ipup = 0;
+          rc = 1.0;
+          nslp = nst;
+          crate = 0.7;
+          if (ierpj != 0) { corfailure(told, rh, ncf, corflag); return; }
+        }
+        for (int i = 0; i < N; ++i) acor[i] = 0.0;
+      }
+      if (miter == 0) {
+        for (int i = 0; i < N; ++i) {
+          savf[i] = h * savf[i] - yh[2][i];
+          y[i] = savf[i] - acor[i];
+        }
+        *del = vmnorm(y);
+        for (int i = 0; i < N; ++i) {
+          y[i] = yh[1][i] + el[1] * savf[i];
+          acor[i] = savf[i];
+        }
+      } else {
+        for (int i = 0; i < N; ++i) y[i] = h * savf[i] - (yh[2][i] + acor[i]);
+        solsy(y);
+        *del = vmnorm(y);
+        for (int i = 0; i < N; ++i) {
+          acor[i] += y[i];
+          y[i] = yh[1][i] + el[1] * acor[i];
+        }
+      }
+      if (*del <= 100.0 * pnorm * KN_ETA) break;
+      if (*m != 0 || meth != 1) {
+        if (*m != 0) {
+          double rm = 1024.0;
+          if (*del <= (1024.0 * *delp)) rm = *del / *delp;
+          rate = fmax(rate, rm);
+          crate = fmax(0.2 * crate, rm);
+        }
+        const double dcon = *del * fmin(1.0, 1.5 * crate) / (tesco(nq, 2) * conit);
+        if (dcon <= 1.0) {
+          pdest = fmax(pdest, rate / fabs(h * el[1]));
+          if (pdest != 0.0) pdlast = pdest;
+          break;
+        }
+      }
+      (*m)++;
+      if (*m == MAXCOR || (*m >= 2 && *del > 2.0 * *delp)) {
+        if (miter == 0 || jcur == 1) { corfailure(told, rh, ncf, corflag); return; }
+        ipup = miter;
+        *m = 0;
+        rate = 0.0;
+        *del = 0.0;
+        for (int i = 0; i < N; ++i) y[i] = yh[1][i];
+        F::rhs(tn, y, savf, p);
+        nfe++;
+      } else {
+        *delp = *del;
+        F::rhs(tn, y, savf, p);
+        nfe++;
+      }
+    }
+  }
+
+  KN_HDN void methodswitch(double dsm, double pnorm, double* pdh, double* rh) {
+    int nqm1, nqm2;
+    double rh1, rh2, rh1it, exm2, dm2, exm1, dm1, alpha, exsm;
+    if (meth == 1) {
+      if (nq > 5) return;
+      if (dsm <= (100.0 * pnorm * KN_ETA) || pdest == 0.0) {
+        if (irflag == 0) return;
+        rh2 = 2.0;
+        nqm2 = nq < MXORDS ? nq : MXORDS;
+      } else {
+        exsm = 1.0 / (double)l;
+        rh1 = 1.0 / (1.2 * pow(dsm, exsm) + 0.0000012);
+        rh1it = 2.0 * rh1;
+        *pdh = pdlast * fabs(h);
+        if ((*pdh * rh1) > 0.00001) rh1it = sm1(nq) / *pdh;
+        rh1 = fmin(rh1, rh1it);
+        if (nq > MXORDS) {
+          nqm2 = MXORDS;
+          const int lm2 = MXORDS + 1;
+          exm2 = 1.0 / (double)lm2;
+          dm2 = vmnorm(yh[lm2 + 1]) / cf->cm2[MXORDS];
+          rh2 = 1.0 / (1.2 * pow(dm2, exm2) + 0.0000012);
+        } else {
+          dm2 = dsm * (cf->cm1[nq] / cf->cm2[nq]);
+          rh2 = 1.0 / (1.2 * pow(dm2, exsm) + 0.0000012);
+          nqm2 = nq;
+        }
+        if (rh2 < ratio * rh1) return;
+      }
+      *rh = rh2;
+      icount = 20;
+      meth = 2;
+      miter = 2;
+      pdlast = 0.0;
+      nq = nqm2;
+      l = nq + 1;
+      return;
+    }
+    exsm = 1.0 / (double)l;
+    if (MXORDN < nq) {
+      nqm1 = MXORDN;
+      const int lm1 = MXORDN + 1;
+      exm1 = 1.0 / (double)lm1;
+      dm1 = vmnorm(yh[lm1 + 1]) / cf->cm1[MXORDN];
+      rh1 = 1.0 / (1.2 * pow(dm1, exm1) + 0.0000012);
+    } else {
+      dm1 = dsm * (cf->cm2[nq] / cf->cm1[nq]);
+      rh1 = 1.0 / (1.2 * pow(dm1, exsm) + 0.0000012);
+      nqm1 = nq;
+      exm1 = exsm;
+    }
+    rh1it = 2.0 * rh1;
+    *pdh = pdnorm * fabs(h);
+    if ((*pdh * rh1) > 0.00001) rh1it = sm1(nqm1) / *pdh;
+    rh1 = fmin(rh1, rh1it);
+    rh2 = 1.0 / (1.2 * pow(dsm, exsm) + 0.0000012);
+    if ((rh1 * ratio) < (5.0 * rh2)) return;
+    alpha = fmax(0.001, rh1);
+    dm1 *= pow(alpha, exm1);
+    if (dm1 <= 1000.0 * KN_ETA * pnorm) return;
+    *rh = rh1;
+    icount = 20;
+    meth = 1;
+    miter = 0;
+    pdlast = 0.0;
+    nq = nqm1;
+    l = nq + 1;
+  }
+
+  KN_HDN void orderswitch(double* rhup, double dsm, double* pdh, double* rh, int* orderflag) {
+    int newq;
+    *orderflag = 0;
+    const double exsm = 1.0 / (double)l;
+    double rhsm = 1.0 / (1.2 * pow(dsm, exsm) + 0.0000012);
+    double rhdn = 0.0;
+    if (nq != 1) {
+      const double ddn = vmnorm(yh[l]) / tesco(nq, 1);
+      const double exdn = 1.0 / (double)nq;
+      rhdn = 1.0 / (1.3 * pow(ddn, exdn) + 0.0000013);
+    }
+    if (meth == 1) {
+      *pdh = fmax(fabs(h) * pdlast, 0.000001);
+      if (l < lmax) *rhup = fmin(*rhup, sm1(l) / *pdh);
+      rhsm = fmin(rhsm, sm1(nq) / *pdh);
+      if (nq > 1) rhdn = fmin(rhdn, sm1(nq - 1) / *pdh);
+      pdest = 0.0;
+    }
+    if (rhsm >= *rhup) {
+      if (rhsm >= rhdn) {
+        newq = nq;
+        *rh = rhsm;
+      } else {
+        newq = nq - 1;
+        *rh = rhdn;
+        if (kflag < 0 && *rh > 1.0) *rh = 1.0;
+      }
+    } else {
+      if (*rhup <= rhdn) {
+        newq = nq - 1;
+        *rh = rhdn;
+        if (kflag < 0 && *rh > 1.0) *rh = 1.0;
+      } else {
+        *rh = *rhup;
+        if (*rh >= 1.1) {
+          const double r = el[l] / (double)l;
+          nq = l;
+          l = nq + 1;
+          for (int i = 0; i < N; ++i) yh[l][i] = acor[i] * r;
+          *orderflag = 2;
+          return;
+        }
+        ialth = 3;
+        return;
+      }
+    }
+    if (meth == 1) {
+      if ((*rh * *pdh * 1.00001) < sm1(newq))
+        if (kflag == 0 && *rh < 1.1) { ialth = 3; return; }
+    } else {
+      if (kflag == 0 && *rh < 1.1) { ialth = 3; return; }
+    }
+    if (kflag <= -2) *rh = fmin(*rh, 0.2);
+    if (newq == nq) { *orderflag = 1; return; }
+    nq = newq;
+    l = nq + 1;
+    *orderflag = 2;
+  }
+
+  KN_HD void endstoda() {
+    const double r = 1.0 / tesco(nqu, 2);
+    for (int i = 0; i < N; ++i) acor[i] *= r;
+    hold = h;
+    jstart = 1;
+  }
+
+  // One internal step (DSTODA).
+  KN_HDN void stoda() {
+    int corflag, orderflag, m, ncf;
+    double del, delp, dsm, dup, exup, r, rh, rhup, told, pdh, pnorm;
+    kflag = 0;
+    told = tn;
+    ncf = 0;
+    ierpj = 0;
+    jcur = 0;
+    delp = 0.0;
+    pdh = 0.0;
+    rh = 1.0;
+    if (jstart == 0) {
+      lmax = maxord + 1;
+      nq = 1;
+      l = 2;
+      ialth = 2;
+      rmax = 10000.0;
+      rc = 0.0;
+      el0 = 1.0;
+      crate = 0.7;
+      hold = h;
+      nslp = 0;
+      ipup = miter;
+      icount = 20;
+      irflag = 0;
+      pdest = 0.0;
+      pdlast = 0.0;
+      ratio = 5.0;
+      resetcoeff();
+    }
+    if (jstart == -1) {
+      ipup = miter;
+      lmax = maxord + 1;
+      if (ialth == 1) ialth = 2;
+      if (meth != mused) {
+        ialth = l;
+        resetcoeff();
+      }
+      if (h != hold) {
+        rh = h / hold;
+        h = hold;
+        scaleh(&rh, &pdh);
+      }
+    }
+    if (jstart > 0 && h != hold) {
+      rh = h / hold;
+      h = hold;
+      scaleh(&rh, &pdh);
+    }
+    while (true) {
+      while (true) {
+        if (fabs(rc - 1.0) > 0.3) ipup = miter;
+        if (nst >= nslp + MSBP) ipup = miter;
+        tn += h;
+        for (int j = nq; j >= 1; --j)
+          for (int i1 = j; i1 <= nq; ++i1)
+            for (int i = 0; i < N; ++i) yh[i1][i] += yh[i1 + 1][i];
+        pnorm = vmnorm(yh[1]);
+        correction(pnorm, &del, &delp, told, &ncf, &rh, &m, &corflag);
+        if (corflag == 0) break;
+        if (corflag == 1) {
+          rh = fmax(rh, 0.0);
+          scaleh(&rh, &pdh);
+          continue;
+        }
+        kflag = -2;
+        hold = h;
+        jstart = 1;
+        return;
+      }
+      jcur = 0;
+      if (m == 0) dsm = del / tesco(nq, 2);
+      else dsm = vmnorm(acor) / tesco(nq, 2);
+      if (dsm <= 1.0) {
+        kflag = 0;
+        nst++;
+        hu = h;
+        nqu = nq;
+        mused = meth;
+        for (int j = 1; j <= l; ++j) {
+          r = el[j];
+          for (int i = 0; i < N; ++i) yh[j][i] += r * acor[i];
+        }
+        icount--;
+        if (icount < 0) {
+          methodswitch(dsm, pnorm, &pdh, &rh);
+          if (meth != mused) {
+            rh = fmax(rh, 0.0);
+            scaleh(&rh, &pdh);
+            rmax = 10.0;
+            // endstoda() uses the coefficients of the method that took the step
+            const double rr = 1.0 / cf->tesco[mused - 1][nqu][2];
+            for (int i = 0; i < N; ++i) acor[i] *= rr;
+            hold = h;
+            jstart = 1;
+            break;
+          }
+        }
+        ialth--;
+        if (ialth == 0) {
+          rhup = 0.0;
+          if (l != lmax) {
+            for (int i = 0; i < N; ++i) savf[i] = acor[i] - yh[lmax][i];
+            dup = vmnorm(savf) / tesco(nq, 3);
+            exup = 1.0 / (double)(l + 1);
+            rhup = 1.0 / (1.4 * pow(dup, exup) + 0.0000014);
+          }
+          orderswitch(&rhup, dsm, &pdh, &rh, &orderflag);
+          if (orderflag == 0) { endstoda(); break; }
+          if (orderflag == 1) {
+            rh = fmax(rh, 0.0);
+            scaleh(&rh, &pdh);
+            rmax = 10.0;
+            endstoda();
+            break;
+          }
+          resetcoeff();
+          rh = fmax(rh, 0.0);
+          scaleh(&rh, &pdh);
+          rmax = 10.0;
+          endstoda();
+          break;
+        }
+        if (ialth > 1 || l == lmax) { endstoda(); break; }
+        for (int i = 0; i < N; ++i) yh[lmax][i] = acor[i];
+        endstoda();
+        break;
+      }
+      // error test failed
+      kflag--;
+      retract(told);
+      rmax = 2.0;
+      if (fabs(h) <= 0.0) {
+        kflag = -1;
+        hold = h;
+        jstart = 1;
+        break;
+      }
+      if (kflag > -3) {
+        rhup = 0.0;
+        orderswitch(&rhup, dsm, &pdh, &rh, &orderflag);
+        if (orderflag == 1 || orderflag == 0) {
+          if (orderflag == 0) rh = fmin(rh, 0.2);
+          rh = fmax(rh, 0.0);
+          scaleh(&rh, &pdh);
+        }
+        if (orderflag == 2) {
+          resetcoeff();
+          rh = fmax(rh, 0.0);
+          scaleh(&rh, &pdh);
+        }
+        continue;
+      }
+      if (kflag == -10) {
+        kflag = -1;
+        hold = h;
+        jstart = 1;
+        break;
+      }
+      rh = 0.1;
+      h *= rh;
+      for (int i = 0; i < N; ++i) y[i] = yh[1][i];
+      F::rhs(tn, y, savf, p);
+      nfe++;
+      for (int i = 0; i < N; ++i) yh[2][i] = h * savf[i];
+      ipup = miter;
+      ialth = 5;
+      if (nq == 1) continue;
+      nq = 1;
+      l = 2;
+      resetcoeff();
+    }
+  }
+
+  // Integrate y0 from t0 to tout (istate = 1, itask = 1).  Returns 0 on success, a negative
+  // ODEPACK-style code otherwise.  On success y0 holds y(tout).
+  KN_HDN int integrate(const LsodaCoef* coef, double* y0, double t0, double tout, double rtol_,
+                       double atol_, double* params, int mxstep) {
+    cf = coef;
+    p = params;
+    rtol = rtol_;
+    atol = atol_;
+    for (int j = 0; j < 15; ++j)
+      for (int i = 0; i < N; ++i) yh[j][i] = 0.0;
+    tn = t0;
+    tsw = t0;
+    maxord = MXORDN;
+    jstart = 0;
+    nst = 0; nje = 0; nslp = 0;
+    hu = 0.0; nqu = 0; mused = 0; miter = 0; meth = 1;
+    nq = 1; l = 2;
+    for (int i = 0; i < N; ++i) y[i] = y0[i];
+    F::rhs(t0, y, yh[2], p);
+    nfe = 1;
+    for (int i = 0; i < N; ++i) yh[1][i] = y[i];
+    if (!ewset(y)) return -6;
+    // initial step size (DLSODA block c)
+    const double tdist = fabs(tout - t0);
+    const double w0 = fmax(fabs(t0), fabs(tout));
+    if (tdist < 2.0 * KN_ETA * w0) return -3;
+    double tol = rtol;
+    if (tol <= 0.0) {
+      for (int i = 0; i < N; ++i) {
+        const double ayi = fabs(y[i]);
+        if (ayi != 0.0) tol = fmax(tol, atol / ayi);
+      }
+    }
+    tol = fmax(tol, 100.0 * KN_ETA);
+    tol = fmin(tol, 0.001);
+    double sum = vmnorm(yh[2]);
+    sum = 1.0 / (tol * w0 * w0) + tol * sum * sum;
+    double h0 = 1.0 / sqrt(sum);
+    h0 = fmin(h0, tdist);
+    h0 = (tout - t0) >= 0.0 ? h0 : -h0;
+    h = h0;
+    for (int i = 0; i < N; ++i) yh[2][i] *= h0;
+    while (true) {
+      if (nst > 0) {
+        if (!ewset(yh[1])) return -6;
+      }
+      if (nst >= mxstep) return -1;
+      double tolsf = KN_ETA * vmnorm(yh[1]);
+      if (tolsf > 0.01) return -2;
+      stoda();
+      if (kflag != 0) return kflag == -1 ? -4 : -5;
+      if (meth != mused) {
+        tsw = tn;
+        maxord = meth == 2 ? MXORDS : MXORDN;
+        jstart = -1;
+      }
+      if ((tn - tout) * h < 0.0) continue;
+      // intdy, k = 0
+      const double s = (tout - tn) / h;
+      for (int i = 0; i < N; ++i) y0[i] = yh[l][i];
+      for (int jj = l - 1; jj >= 1; --jj)
+        for (int i = 0; i < N; ++i) y0[i] = yh[jj][i] + s * y0[i];
+      return 0;
+    }
+  }
+};

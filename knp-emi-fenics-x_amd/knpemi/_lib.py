@@ -1,0 +1,131 @@
+"""ctypes binding of libknpemi_hip.so (C ABI: include/knpemi_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is
+visible when a device problem is created, the hot path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libknpemi_hip.so")
+
+OK, EINVAL, EHIP, ENOMEM, EODE = 0, -1, -2, -3, -4
+TRIANGLE, TETRAHEDRON, HEXAHEDRON = 0, 1, 2
+MODEL_HH_SI, MODEL_HH_MV, MODEL_GLIAL = 0, 1, 2
+MAX_IONS, MAX_SUB, MAX_MODELS = 3, 8, 4
+F_PHI, F_C, F_C_PREV, F_C_ELIM, F_PHI_M, F_I_CH, F_SOURCE = range(7)
+A_EMI, P_EMI, A_KNP = 0, 1, 2
+B_EMI, B_KNP = 0, 1
+WANT_P, NO_SPLITTING = 1, 2
+ODE_SET_V, ODE_SET_TRACES = 1, 2
+
+c_int_p = C.POINTER(C.c_int32)
+c_dbl_p = C.POINTER(C.c_double)
+c_u8_p = C.POINTER(C.c_uint8)
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [
+        ("gdim", C.c_int32), ("cell_kind", C.c_int32), ("n_sub", C.c_int32), ("n_ions", C.c_int32),
+        ("n_vert", c_int_p), ("n_cell", c_int_p),
+        ("x", C.POINTER(c_dbl_p)), ("cells", C.POINTER(c_int_p)),
+        ("n_q", c_int_p), ("n_facet", c_int_p),
+        ("facet_e", C.POINTER(c_int_p)), ("facet_i", C.POINTER(c_int_p)),
+        ("facet_q", C.POINTER(c_int_p)), ("facet_model", C.POINTER(c_int_p)),
+        ("q_to_e", C.POINTER(c_int_p)), ("q_to_i", C.POINTER(c_int_p)),
+        ("n_models", c_int_p),
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("dt", C.c_double), ("F", C.c_double), ("psi", C.c_double), ("C_M", C.c_double),
+        ("z", C.c_double * MAX_IONS),
+        ("D", (C.c_double * MAX_IONS) * MAX_SUB),
+        ("rho_z", C.c_double),
+        ("rho", C.c_double * MAX_SUB),
+    ]
+
+
+class KnpemiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libknpemi_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/knpemi_hip.h declares
+SIGNATURES = {
+    "knpemi_last_error": (C.c_char_p, []),
+    "knpemi_device_count": (C.c_int, []),
+    "knpemi_create": (C.c_int, [C.POINTER(ProblemDesc), C.c_int, C.POINTER(C.c_void_p)]),
+    "knpemi_destroy": (None, [C.c_void_p]),
+    "knpemi_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
+    "knpemi_sync": (C.c_int, [C.c_void_p]),
+    "knpemi_set_field": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_dbl_p, C.c_size_t]),
+    "knpemi_get_field": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_dbl_p, C.c_size_t]),
+    "knpemi_assemble_emi": (C.c_int, [C.c_void_p, C.c_int]),
+    "knpemi_assemble_knp": (C.c_int, [C.c_void_p, C.c_int]),
+    "knpemi_csr_dims": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "knpemi_get_csr_pattern": (C.c_int, [C.c_void_p, C.c_int, c_int_p, c_int_p]),
+    "knpemi_get_csr_values": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p]),
+    "knpemi_get_rhs": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p]),
+    "knpemi_device_csr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_void_p)]),
+    "knpemi_device_rhs": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "knpemi_set_solution": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "knpemi_get_solution": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p]),
+    "knpemi_ode_bind": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "knpemi_ode_set_tables": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dbl_p, c_dbl_p]),
+    "knpemi_ode_get_tables": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dbl_p, c_dbl_p]),
+    "knpemi_ode_set_stimulus": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_u8_p, C.c_int, c_int_p, c_dbl_p]),
+    "knpemi_ode_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                  C.c_double, C.c_int, c_int_p, C.c_int]),
+    "knpemi_ode_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "knpemi_update_pde": (C.c_int, [C.c_void_p]),
+    "knpemi_trace": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p]),
+    "knpemi_timer_start": (C.c_int, [C.c_void_p]),
+    "knpemi_timer_stop_ms": (C.c_int, [C.c_void_p, c_dbl_p]),
+    "knpemi_stream": (C.c_void_p, [C.c_void_p]),
+}
+
+
+def load():
+    """Load libknpemi_hip.so (built in-tree by `__graft_entry__.build()` / csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C knp-emi-fenics-x_amd/csrc). "
+            "The knpemi hot path has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != OK:
+        msg = load().knpemi_last_error()
+        raise KnpemiError(rc, msg.decode() if msg else "unknown error")
+
+
+def dptr(a):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(c_dbl_p)
+
+
+def iptr(a):
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(c_int_p)

@@ -74,16 +74,33 @@ def functionspace(mesh, element=("CG", 1)):
 
 
 class Vector:
-    """`Function.x`: `.array` plus `scatter_forward()` (owner -> ghost update)."""
+    """`Function.x`: `.array` plus `scatter_forward()` (owner -> ghost update).
+
+    Every access to `.array` bumps `version` (the caller may write through the
+    returned view), which is how the device layer knows when a host array has
+    to be uploaded again; the device layer itself reads/writes `_a` directly.
+    """
 
     def __init__(self, n, mesh):
-        self.array = np.zeros(n, dtype=np.float64)
+        self._a = np.zeros(n, dtype=np.float64)
         self._mesh = mesh
+        self.version = 0
+
+    @property
+    def array(self):
+        self.version += 1
+        return self._a
+
+    @array.setter
+    def array(self, value):
+        self.version += 1
+        self._a[:] = value
 
     def scatter_forward(self):
         halo = getattr(self._mesh, "halo", None)
         if halo is not None:
-            halo.forward_host(self.array)
+            self.version += 1
+            halo.forward_host(self._a)
 
 
 class Function:

@@ -328,6 +328,9 @@ def extract_submesh(mesh, tags, values):
     lookup[pverts] = np.arange(pverts.shape[0], dtype=np.int32)
     ctype = mesh.cell_type if tags.dim == mesh.tdim else mesh.facet_type
     sub = Mesh(mesh.x[pverts], lookup[ev], ctype, mesh.comm)
+    sub.parent_vertices = pverts      # sub-mesh vertex -> parent vertex
+    sub.parent_entities = ents        # sub-mesh cell -> parent entity (cell or facet)
+    sub.parent = mesh
     emap = EntityMap(ents, mesh.num_entities(tags.dim))
     vmap = EntityMap(pverts, mesh.num_vertices)
     return sub, emap, vmap, None, None

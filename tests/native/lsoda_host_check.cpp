@@ -1,0 +1,41 @@
+// Test-only host build of the PRODUCT integrator (csrc/lsoda_core.h + membrane_models.h) so that
+// `pytest -m "not gpu"` can check it against scipy's ODEPACK LSODA on the CPU.  Not shipped, not a
+// fallback: the product's ODE sweep only exists as the HIP kernel in csrc/kernels_ode.hip.
+#include "../../knp-emi-fenics-x_amd/csrc/membrane_models.h"
+
+static LsodaCoef g_cf;
+static bool g_init = false;
+
+template <class M>
+static int run(double* y, double* p, double t0, double t1, double rtol, double atol, int* stats) {
+  Lsoda<M::NS, M> s;
+  int rc = s.integrate(&g_cf, y, t0, t1, rtol, atol, p, 10000);
+  // product semantic: currents evaluated at the returned state at t1
+  double dy[M::NS];
+  M::rhs(t1, y, dy, p);
+  if (stats) { stats[0] = s.nfe; stats[1] = s.nst; stats[2] = s.nje; stats[3] = s.mused; stats[4] = s.nqu; }
+  return rc;
+}
+
+extern "C" int lsoda_host(int model, double* y, double* p, double t0, double t1, double rtol,
+                          double atol, int* stats) {
+  if (!g_init) { lsoda_fill_coef(&g_cf); g_init = true; }
+  if (model == 0) return run<ModelHHSI>(y, p, t0, t1, rtol, atol, stats);
+  if (model == 1) return run<ModelHHMV>(y, p, t0, t1, rtol, atol, stats);
+  if (model == 2) return run<ModelGlial>(y, p, t0, t1, rtol, atol, stats);
+  return -100;
+}
+
+extern "C" void lsoda_host_rhs(int model, double t, const double* y, double* dy, double* p) {
+  if (model == 0) ModelHHSI::rhs(t, y, dy, p);
+  else if (model == 1) ModelHHMV::rhs(t, y, dy, p);
+  else ModelGlial::rhs(t, y, dy, p);
+}
+
+extern "C" void lsoda_host_coef(double* elco, double* tesco) {
+  LsodaCoef c; lsoda_fill_coef(&c);
+  for (int m = 0; m < 2; ++m) for (int q = 0; q < 13; ++q) {
+    for (int i = 0; i < 14; ++i) elco[(m * 13 + q) * 14 + i] = c.elco[m][q][i];
+    for (int i = 0; i < 4; ++i) tesco[(m * 13 + q) * 4 + i] = c.tesco[m][q][i];
+  }
+}
