@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- assembled dofs/s of the KNP-EMI per-time-step hot path on MI355X.
+
+One "step" = one pass of the hot path over one synthetic field state, device-resident
+(SURVEY.md section 8d / BASELINE.md section 2): fused ODE launch (trace refresh + LSODA sweep +
+copy-back), EMI assembly (A, P, b in one pass), KNP assembly (A once, b incl. the membrane
+kernel), end-of-step update.  Krylov solves and file output are excluded.  At N > 1 the mesh is
+N times longer (weak scaling, x-slabs) and every step also exchanges the ghost-dof halos.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import contextlib
+import ctypes as C
+import io
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "knp-emi-fenics-x_amd"), os.path.join(ROOT, "examples", "idealized_geometries")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+
+WORKLOADS = {
+    # name: (mesh kind, resolution factor) -- geometry of make_mesh_3D.py, 6 tets per hexahedron
+    "config2": ("tet", 1),     # BASELINE.json configs[1]: 124 416 tets, 79 251 dofs/step
+    "config2h": ("hex", 2),    # reference-faithful Q1 hexahedra, 165 888 cells
+    "config3": ("tet", 2),     # 995 328 tets on ONE GPU (the 8-GPU mesh of configs[2])
+    "r3": ("tet", 3),          # 7.96 M tets
+    "2d": ("2d", 3),
+}
+
+
+def algorithmic_bytes(s, dp):
+    """compulsory bytes per launch, every array counted once."""
+    import numpy as np
+    from knpemi import _lib as L
+    nv = s.mesh.cells.shape[1]
+    gdim = s.mesh.gdim
+    nc = int(dp.n_cell.sum())
+    N = int(dp.n_vert.sum())
+    nF = int(dp.n_facet.sum())
+    nf = dp.flat["facet_e"][1].shape[1] if nF else 0
+    NQ = int(dp.n_q.sum())
+    nnz = dp._pattern(L.A_EMI)[1]
+    nnzL = dp._pattern(L.A_KNP)[1] // 2
+    idx = nc * (4 * nv + 4 * nv * nv)          # dofmap + scatter-slot map
+    geo = 8 * gdim * N
+    gam_idx = nF * (16 + 4 * (2 * nf) ** 2 + 2 * nf * 4)
+    out = {
+        # A and P (two matrices, one pass), b_emi, 3 coefficient fields, membrane coupling + Robin RHS
+        "emi_rows_kernel": idx + geo + 8 * N * 3 + 2 * 8 * nnz + 8 * N + gam_idx + 8 * NQ + 8 * 2 * NQ,
+        # two ion blocks, phi + 2 c_prev coefficients, 2 RHS vectors
+        "knp_rows_kernel": idx + geo + 8 * N * 3 + 2 * 8 * nnzL + 2 * 8 * N,
+        # pairs + dofs, ~12 gathered coefficient fields on the membrane, RMW of 2 RHS entries per side
+        "knp_membrane_kernel": nF * (16 + 2 * nf * 4) + 8 * NQ * 12 + 2 * 8 * 2 * NQ * 2,
+        "update_pde_kernel": 8 * N * (2 * 2 + 3) + 8 * NQ * 3,
+    }
+    for m in s.mem_models:
+        ns, npar = m['ode'].states.shape[1], m['ode'].parameters.shape[1]
+        out["ode_step_kernel"] = out.get("ode_step_kernel", 0) + 2 * 8 * NQ * (ns + npar) + 8 * NQ * 6 + 8 * NQ * 4
+    return out
+
+
+def cpu_baseline(s, n_steps):
+    """Oracle (numpy/scipy restatement, 1 core) timed on this host on a bounded sample:
+    full EMI + KNP assembly and update, LSODA sweep on every 8th membrane dof (scaled up)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import adapters
+    o, P, params, ions = adapters.oracle_problem(s)
+    c_all, phi, phiM, mm = adapters.oracle_fields(s)
+    ode = s.mem_models[0]['ode']
+    ix = o.MODELS[ode.ode.MODEL_ID]["pidx"]
+    st, pa = ode.states.copy(), ode.parameters.copy()
+    mask = np.fromiter(map(s.stim_params['stimulus_locator'], ode.dof_locations), dtype=bool)
+    stim = {ix[k]: v for k, v in s.stim_params['stimulus'].items()}
+    rows = list(range(0, ode.nodes, 8))
+    rho = {'z': -1, **{t: 0.0 for t in s.subdomain_list}}
+    t_asm = t_ode = 0.0
+    for k in range(n_steps):
+        t0 = time.perf_counter()
+        for name, kk in (("K", 0), ("Cl", 1), ("Na", 2)):
+            te, ti = P.trace(1, c_all[0][kk], c_all[1][kk])
+            pa[:, ix[f"{name}_e"]] = te
+            pa[:, ix[f"{name}_i"]] = ti
+        o.ode_sweep(ode.ode.MODEL_ID, st, pa, k * s.dt, s.dt, mask, stim, rows=rows)
+        t1 = time.perf_counter()
+        o.assemble_emi(P, params, ions, c_all, phiM, mm)
+        o.assemble_knp(P, params, ions, c_all, phi, phiM, mm, s.dt)
+        c_new = {t: [c_all[t][0].copy(), c_all[t][1].copy()] for t in c_all}
+        o.update_pde_variables(P, ions, rho, c_new, c_all, phi, phiM)
+        t2 = time.perf_counter()
+        t_ode += (t1 - t0) * ode.nodes / len(rows)
+        t_asm += t2 - t1
+    return (t_asm + t_ode) / n_steps, t_asm / n_steps, t_ode / n_steps, len(rows)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-steps", type=int, default=3, help="oracle steps timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--knp-twice", action="store_true",
+                    help="assemble A_knp twice per step as the reference does (p = a, knpWeakForm.py:319)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from knpemi import _lib as L
+    from knpemi.stepper import DeviceStepper
+    from setup_problem import Setup
+
+    kind, r = WORKLOADS[args.workload]
+    quiet = io.StringIO()
+    with contextlib.redirect_stdout(quiet):
+        if world > 1:
+            from knpemi.fem.partition import make_slab_problem
+            s = make_slab_problem(kind, r, rank, world, g_syn=10.0)
+        else:
+            s = Setup(kind, r, g_syn=10.0)
+    s.perturb(seed=12345 + rank)
+    # synthetic "solution" state: c = c_prev, so the end-of-step update keeps the fields stationary
+    for tag in s.subdomain_list:
+        for k in range(2):
+            s.c[tag][k].x.array[:] = s.c_prev[tag][k].x._a
+        s.ion_list[-1][f'c_{tag}'].x.array[:] = -(1.0 / s.ion_list[-1]['z']) * sum(
+            ion['z'] * f.x._a for ion, f in zip(s.ion_list[:-1], s.c_prev[tag]))
+    # potentials: rest potential across the membrane plus a smooth perturbation
+    L_x = s.mesh.x[:, 0].max() if world == 1 else s.global_length
+    for tag in s.subdomain_list:
+        x = s.subdomain_list[tag]['mesh_sub'].x
+        s.phi[tag].x.array[:] = (-0.0744 if tag > 0 else 0.0) + 1e-3 * np.sin(2 * np.pi * x[:, 0] / L_x)
+
+    stepper = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp),
+                            s.c, s.c_prev, s.phi, s.phi_M_prev, assemble_knp_twice=args.knp_twice)
+    dp = stepper.dp
+    for mm in s.mem_models:
+        stepper.add_membrane_model(mm['ode'], s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
+    halo = getattr(s, "halo", None)
+    if halo is not None:
+        halo.attach(dp)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    lib = dp.lib
+    # warm-up: bracket every kernel to find the dominant one
+    L.check(lib.knpemi_profile(dp.h, 0x1F))
+    for _ in range(args.warmup):
+        stepper.step(halo)
+    sync()
+    per_kernel = {}
+    for kid, name in enumerate(L.KERNEL_NAMES):
+        n, ms = C.c_int64(), C.c_double()
+        L.check(lib.knpemi_profile_read(dp.h, kid, C.byref(n), C.byref(ms)))
+        if n.value:
+            per_kernel[name] = ms.value / n.value * 1e3   # us per launch
+    asm = {k: v for k, v in per_kernel.items() if k != "ode_step_kernel"}
+    dominant = max(asm, key=asm.get) if asm else "emi_rows_kernel"
+    dom_id = L.KERNEL_NAMES.index(dominant)
+    # timed region: only the dominant assembly kernel stays bracketed by HIP events
+    L.check(lib.knpemi_profile(dp.h, 1 << dom_id))
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stepper.step(halo)
+    sync()
+    elapsed = time.perf_counter() - t0
+    n, ms = C.c_int64(), C.c_double()
+    L.check(lib.knpemi_profile_read(dp.h, dom_id, C.byref(n), C.byref(ms)))
+    dom_us = ms.value / max(n.value, 1) * 1e3
+    L.check(lib.knpemi_profile(dp.h, 0))
+    if stepper.ode_failures():
+        raise SystemExit("LSODA failed on the device")
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    owned = getattr(s, "owned_dofs", None)
+    dofs_local = 3 * (owned if owned is not None else int(dp.n_vert.sum()))
+    if dist is not None:
+        tot = torch.tensor([dofs_local], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tot)
+        dofs_total = int(tot.item())
+    else:
+        dofs_total = dofs_local
+    ms_per_step = elapsed / args.steps * 1e3
+    value = dofs_total / (elapsed / args.steps)
+
+    if rank == 0:
+        bytes_alg = algorithmic_bytes(s, dp)
+        achieved = bytes_alg[dominant] / (dom_us * 1e-6) / 1e9
+        out = {
+            "metric": "assembled dofs/s (volume + membrane-facet assembly + membrane ODE sweep) per timestep; "
+                      "3D idealized mesh, fp64",
+            "value": value, "unit": "dofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: make_mesh_3D geometry r={r}, {kind}, "
+                                   f"{int(dp.n_cell.sum())} cells/GPU, {int(dp.n_vert.sum())} sub-mesh vertices/GPU, "
+                                   f"{int(dp.n_q.sum())} membrane ODE dofs/GPU, 3 ions (K, Cl, Na eliminated), HH, "
+                                   f"g_syn=10 for x<20um, dt=1e-4",
+                       "dofs_per_step": dofs_total, "A_knp_assemblies_per_step": 2 if args.knp_twice else 1,
+                       "partition": "x-slabs" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_alg[dominant], "avg_launch_us": dom_us},
+            "kernels_us": per_kernel,
+        }
+        if args.cpu_steps > 0 and world == 1:
+            with contextlib.redirect_stdout(quiet):
+                t_step, t_asm, t_ode, nrows = cpu_baseline(s, args.cpu_steps)
+            out["cpu_baseline"] = {
+                "value": dofs_total / t_step, "unit": "dofs/s", "cores": 1, "kind": "port",
+                "sample": f"{args.cpu_steps} steps of the numpy/scipy oracle on the same mesh: full EMI+KNP assembly and "
+                          f"update ({t_asm:.2f} s/step), LSODA sweep on {nrows} of {s.mem_models[0]['ode'].nodes} "
+                          f"membrane dofs scaled to all ({t_ode:.2f} s/step)"}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -179,6 +179,18 @@ int knpemi_update_pde(knpemi_handle* h);
 int knpemi_trace(knpemi_handle* h, int sub, const double* u_e, const double* u_i, double* q_e,
                  double* q_i);
 
+/* Per-kernel HIP-event profiling on the handle's stream: every launch of a kernel whose bit is set
+ * in `kernel_mask` is bracketed by an event pair; knpemi_profile_read() synchronises, returns the
+ * number of bracketed launches and their summed duration, and resets the accumulator. */
+#define KNPEMI_K_ODE 0           /* ode_step_kernel      */
+#define KNPEMI_K_EMI_ROWS 1      /* emi_rows_kernel      */
+#define KNPEMI_K_KNP_ROWS 2      /* knp_rows_kernel      */
+#define KNPEMI_K_KNP_MEMBRANE 3  /* knp_membrane_kernel  */
+#define KNPEMI_K_UPDATE 4        /* update_pde_kernel    */
+#define KNPEMI_N_KERNELS 5
+int knpemi_profile(knpemi_handle* h, uint32_t kernel_mask);
+int knpemi_profile_read(knpemi_handle* h, int kernel, int64_t* launches, double* total_ms);
+
 /* Stream-event timing of a region on the handle's stream (bench.py / rocprof cross-check). */
 int knpemi_timer_start(knpemi_handle* h);
 int knpemi_timer_stop_ms(knpemi_handle* h, double* ms);

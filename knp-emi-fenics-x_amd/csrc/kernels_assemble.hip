@@ -641,6 +641,11 @@ int kn_launch_emi_rows(knpemi_handle* h, int flags) {
   const int want_p = (flags & KNPEMI_WANT_P) ? 1 : 0, split = (flags & KNPEMI_NO_SPLITTING) ? 0 : 1;
   dim3 grid(D.nblocks), block(KN_ROWS_PER_BLOCK);
   int rc;
+  if (h->cell_kind == KNPEMI_TRIANGLE) rc = set_lds_limit(emi_rows_kernel<2, 3>, lds);
+  else if (h->cell_kind == KNPEMI_TETRAHEDRON) rc = set_lds_limit(emi_rows_kernel<3, 4>, lds);
+  else rc = set_lds_limit(emi_rows_kernel<3, 8>, lds);
+  if (rc) return rc;
+  KnProfScope prof(h, KNPEMI_K_EMI_ROWS);
   if (h->cell_kind == KNPEMI_TRIANGLE) {
     if ((rc = set_lds_limit(emi_rows_kernel<2, 3>, lds))) return rc;
     hipLaunchKernelGGL((emi_rows_kernel<2, 3>), grid, block, lds, h->stream, D, h->d_consts, lds_n, want_p, split);
@@ -663,6 +668,7 @@ int kn_launch_knp_rows(knpemi_handle* h, int flags) {
   if (lds > 160 * 1024) { kn_set_error("KNP row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   dim3 grid(D.nblocks), block(KN_ROWS_PER_BLOCK);
   int rc;
+  KnProfScope prof(h, KNPEMI_K_KNP_ROWS);
   if (h->cell_kind == KNPEMI_TRIANGLE) {
     if ((rc = set_lds_limit(knp_rows_kernel<2, 3>, lds))) return rc;
     hipLaunchKernelGGL((knp_rows_kernel<2, 3>), grid, block, lds, h->stream, D, h->d_consts, lds_n);
@@ -683,6 +689,7 @@ int kn_launch_knp_membrane(knpemi_handle* h, int flags) {
   const int NF = h->NF;
   const size_t lds = (size_t)D.nq_gamma * (1 + NF + (NF == 4 ? 2 * NF : 0)) * sizeof(double);
   dim3 grid((D.M + 255) / 256), block(256);
+  KnProfScope prof(h, KNPEMI_K_KNP_MEMBRANE);
   if (NF == 2) hipLaunchKernelGGL((knp_membrane_kernel<2>), grid, block, lds, h->stream, D, h->d_consts, split);
   else if (NF == 3) hipLaunchKernelGGL((knp_membrane_kernel<3>), grid, block, lds, h->stream, D, h->d_consts, split);
   else hipLaunchKernelGGL((knp_membrane_kernel<4>), grid, block, lds, h->stream, D, h->d_consts, split);
@@ -693,6 +700,7 @@ int kn_launch_update_pde(knpemi_handle* h) {
   const KnDev& D = h->dev;
   const int n = std::max(D.Ntot, D.NQtot);
   if (n == 0) return KNPEMI_OK;
+  KnProfScope prof(h, KNPEMI_K_UPDATE);
   hipLaunchKernelGGL(update_pde_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, D, h->d_consts);
   return check_launch("update_pde_kernel");
 }

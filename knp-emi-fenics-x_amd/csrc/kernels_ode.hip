@@ -103,6 +103,7 @@ int kn_launch_ode_step(knpemi_handle* h, int slot, double t0, double dt, double 
   // 64-thread workgroups: the sweep has only n_q (10^3..10^5) threads, so spread the waves over as
   // many CUs as possible instead of stacking four of them on one.
   dim3 grid((m.nq + 63) / 64), block(64);
+  KnProfScope prof(h, KNPEMI_K_ODE);
   switch (m.model_id) {
     case KNPEMI_MODEL_HH_SI:
       hipLaunchKernelGGL((ode_step_kernel<ModelHHSI>), grid, block, 0, h->stream, h->dev, a, cf);

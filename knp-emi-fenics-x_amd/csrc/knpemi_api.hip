@@ -389,6 +389,7 @@ extern "C" void knpemi_destroy(knpemi_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : h->allocs) (void)hipFree(p);
+  for (auto& v : h->prof_ev) for (hipEvent_t e : v) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -844,6 +845,32 @@ extern "C" int knpemi_update_pde(knpemi_handle* h) {
   if (!h->have_params) return fail(KNPEMI_EINVAL, "knpemi_update_pde: knpemi_set_params not called");
   KN_HIP(hipSetDevice(h->device));
   return kn_launch_update_pde(h);
+}
+
+extern "C" int knpemi_profile(knpemi_handle* h, uint32_t kernel_mask) {
+  if (!h) return fail(KNPEMI_EINVAL, "null handle");
+  KN_HIP(hipSetDevice(h->device));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  h->prof_mask = kernel_mask;
+  for (int k = 0; k < KNPEMI_N_KERNELS; ++k) h->prof_used[k] = 0;
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_profile_read(knpemi_handle* h, int kernel, int64_t* launches, double* total_ms) {
+  if (!h || kernel < 0 || kernel >= KNPEMI_N_KERNELS || !launches || !total_ms)
+    return fail(KNPEMI_EINVAL, "knpemi_profile_read: bad argument");
+  KN_HIP(hipSetDevice(h->device));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  double sum = 0.0;
+  for (size_t i = 0; i + 1 < h->prof_used[kernel]; i += 2) {
+    float f = 0.f;
+    KN_HIP(hipEventElapsedTime(&f, h->prof_ev[kernel][i], h->prof_ev[kernel][i + 1]));
+    sum += f;
+  }
+  *launches = (int64_t)(h->prof_used[kernel] / 2);
+  *total_ms = sum;
+  h->prof_used[kernel] = 0;
+  return KNPEMI_OK;
 }
 
 extern "C" int knpemi_timer_start(knpemi_handle* h) {

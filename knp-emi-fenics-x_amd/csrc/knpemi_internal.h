@@ -107,6 +107,30 @@ struct knpemi_handle {
   // host copies of patterns for export
   std::vector<int> h_rowptr, h_colind, h_rowptrL, h_colindL;
   double* d_stage = nullptr; size_t stage_len = 0;   // staging buffer for strided field I/O
+  // per-kernel event profiling (knpemi_profile)
+  uint32_t prof_mask = 0;
+  std::vector<hipEvent_t> prof_ev[KNPEMI_N_KERNELS];  // begin/end pairs
+  size_t prof_used[KNPEMI_N_KERNELS] = {0, 0, 0, 0, 0};
+};
+
+// RAII bracket around one kernel launch; no-op unless the kernel's bit is set in prof_mask.
+struct KnProfScope {
+  knpemi_handle* h; int k; bool on;
+  KnProfScope(knpemi_handle* h_, int k_) : h(h_), k(k_), on((h_->prof_mask >> k_) & 1u) {
+    if (!on) return;
+    auto& v = h->prof_ev[k];
+    if (h->prof_used[k] + 2 > v.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+      v.push_back(a); v.push_back(b);
+    }
+    (void)hipEventRecord(v[h->prof_used[k]], h->stream);
+  }
+  ~KnProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(h->prof_ev[k][h->prof_used[k] + 1], h->stream);
+    h->prof_used[k] += 2;
+  }
 };
 
 // error plumbing ------------------------------------------------------------------------------

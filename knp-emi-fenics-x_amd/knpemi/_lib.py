@@ -22,6 +22,8 @@ A_EMI, P_EMI, A_KNP = 0, 1, 2
 B_EMI, B_KNP = 0, 1
 WANT_P, NO_SPLITTING = 1, 2
 ODE_SET_V, ODE_SET_TRACES = 1, 2
+K_ODE, K_EMI_ROWS, K_KNP_ROWS, K_KNP_MEMBRANE, K_UPDATE = range(5)
+KERNEL_NAMES = ["ode_step_kernel", "emi_rows_kernel", "knp_rows_kernel", "knp_membrane_kernel", "update_pde_kernel"]
 
 c_int_p = C.POINTER(C.c_int32)
 c_dbl_p = C.POINTER(C.c_double)
@@ -90,6 +92,8 @@ SIGNATURES = {
                                    C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "knpemi_update_pde": (C.c_int, [C.c_void_p]),
     "knpemi_trace": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p]),
+    "knpemi_profile": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "knpemi_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), c_dbl_p]),
     "knpemi_timer_start": (C.c_int, [C.c_void_p]),
     "knpemi_timer_stop_ms": (C.c_int, [C.c_void_p, c_dbl_p]),
     "knpemi_stream": (C.c_void_p, [C.c_void_p]),

@@ -1,0 +1,134 @@
+"""Device-resident time stepping of the hot path.
+
+The reference API keeps every field in host numpy arrays (`Function.x.array`), so its drop-in
+(`pdeSolver.LinearProblem.solve`, `MembraneModel.step_lsoda`) mirrors data across PCIe at every
+call.  `DeviceStepper` runs the same sequence of one time step of `run_3D.py:345-368`
+
+    solve_odes  ->  assemble EMI (A, P, b)  ->  [solve]  ->  assemble KNP (A, b)  ->  [solve]
+                ->  update_pde_variables
+
+with all fields, tables and operators resident in HBM, calling the C ABI directly.  The linear
+solves are not part of the hot path; a caller plugs them in through
+`solve_emi` / `solve_knp` callbacks that receive the device problem (device CSR pointers are
+available from `knpemi_device_csr`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class DeviceStepper:
+    def __init__(self, forms_emi, forms_knp, c, c_prev, phi, phi_M_prev, solve_emi=None, solve_knp=None,
+                 assemble_knp_twice=False):
+        a = forms_emi[0]
+        self.dp = a.dp
+        self.a = a
+        self.lib = self.dp.lib
+        self.c, self.c_prev, self.phi, self.phi_M_prev = c, c_prev, phi, phi_M_prev
+        self.solve_emi, self.solve_knp = solve_emi, solve_knp
+        self.assemble_knp_twice = assemble_knp_twice
+        self.k = 0
+        self.models = []   # (MembraneModel, stimulus, locator)
+        dp = self.dp
+        dp.set_params(a.physical_params, a.ion_list, a.dt)
+        self.dt = float(a.dt)
+        self.flags_emi = L.WANT_P | (0 if a.splitting_scheme else L.NO_SPLITTING)
+        self.flags_knp = 0 if a.splitting_scheme else L.NO_SPLITTING
+        self.upload()
+
+    # -- host <-> device ------------------------------------------------------------------
+    def upload(self):
+        """Push every Function and ODE table to the device (start of a run)."""
+        dp, a = self.dp, self.a
+        n_solved = len(a.ion_list) - 1
+        for tag, sd in a.subdomain_list.items():
+            s = dp.sub_index[tag]
+            dp.push(L.F_PHI, s, 0, self.phi[tag])
+            for k in range(n_solved):
+                dp.push(L.F_C_PREV, s, k, self.c_prev[tag][k])
+                dp.push(L.F_C, s, k, self.c[tag][k])
+            dp.push(L.F_C_ELIM, s, 0, a.ion_list[-1][f'c_{tag}'])
+            if tag > 0:
+                dp.push(L.F_PHI_M, s, 0, self.phi_M_prev[tag])
+                for j, mm in enumerate(sd.get('mem_models', [])):
+                    for k, ion in enumerate(a.ion_list):
+                        dp.push(L.F_I_CH, s, j * L.MAX_IONS + k, mm['I_ch_k'][ion['name']])
+
+    def add_membrane_model(self, ode_model, stimulus=None, stimulus_locator=None):
+        """Register a bound MembraneModel: uploads its tables and stimulus once."""
+        dp = self.dp
+        stimulus = stimulus or {}
+        if stimulus_locator is None:
+            mask = np.ones(ode_model.nodes, np.uint8)
+        else:
+            mask = np.fromiter(map(stimulus_locator, ode_model.dof_locations), dtype=bool).astype(np.uint8)
+        sidx = np.array([ode_model.ode.parameter_indices(k) for k in stimulus], np.int32)
+        sval = np.array([float(v) for v in stimulus.values()], np.float64)
+        L.check(self.lib.knpemi_ode_set_stimulus(
+            dp.h, ode_model._sub, ode_model._model, mask.ctypes.data_as(L.c_u8_p), len(sidx),
+            L.iptr(sidx) if len(sidx) else None, L.dptr(sval) if len(sval) else None))
+        st = np.ascontiguousarray(ode_model.states)
+        pa = np.ascontiguousarray(ode_model.parameters)
+        L.check(self.lib.knpemi_ode_set_tables(dp.h, ode_model._sub, ode_model._model, L.dptr(st), L.dptr(pa)))
+        self.models.append(ode_model)
+
+    def download(self):
+        """Pull fields and ODE tables back into the host objects (end of a run / output)."""
+        dp, a = self.dp, self.a
+        n_solved = len(a.ion_list) - 1
+        for tag, sd in a.subdomain_list.items():
+            s = dp.sub_index[tag]
+            dp.pull(L.F_PHI, s, 0, self.phi[tag])
+            for k in range(n_solved):
+                dp.pull(L.F_C_PREV, s, k, self.c_prev[tag][k])
+                dp.pull(L.F_C, s, k, self.c[tag][k])
+            dp.pull(L.F_C_ELIM, s, 0, a.ion_list[-1][f'c_{tag}'])
+            if tag > 0:
+                dp.pull(L.F_PHI_M, s, 0, self.phi_M_prev[tag])
+                for j, mm in enumerate(sd.get('mem_models', [])):
+                    for k, ion in enumerate(a.ion_list):
+                        dp.pull(L.F_I_CH, s, j * L.MAX_IONS + k, mm['I_ch_k'][ion['name']])
+        for m in self.models:
+            st = np.ascontiguousarray(m.states)
+            pa = np.ascontiguousarray(m.parameters)
+            L.check(self.lib.knpemi_ode_get_tables(dp.h, m._sub, m._model, L.dptr(st), L.dptr(pa)))
+            m.states[...] = st
+            m.parameters[...] = pa
+
+    # -- one time step, everything enqueued on the handle's stream ---------------------------
+    def step(self, halo=None):
+        dp, lib = self.dp, self.lib
+        flags = L.ODE_SET_TRACES | (L.ODE_SET_V if self.k > 0 else 0)
+        for m in self.models:
+            L.check(lib.knpemi_ode_step(dp.h, m._sub, m._model, float(m.time), self.dt, m.rtol, m.atol,
+                                        flags, L.iptr(m._ion_param), int(m.V_index)))
+            m.time = m.time + self.dt
+        if halo is not None:
+            halo.exchange_membrane()
+        L.check(lib.knpemi_assemble_emi(dp.h, self.flags_emi))
+        if self.solve_emi is not None:
+            self.solve_emi(dp)
+            if halo is not None:
+                halo.exchange_bulk()
+        L.check(lib.knpemi_assemble_knp(dp.h, self.flags_knp))
+        if self.assemble_knp_twice:   # the reference assembles p = a a second time (knpWeakForm.py:319)
+            L.check(lib.knpemi_assemble_knp(dp.h, self.flags_knp))
+        if self.solve_knp is not None:
+            self.solve_knp(dp)
+        L.check(lib.knpemi_update_pde(dp.h))
+        if halo is not None:
+            halo.exchange_bulk()
+        self.k += 1
+
+    def ode_failures(self):
+        n = 0
+        for m in self.models:
+            nf = C.c_int32()
+            nr, ns = C.c_int64(), C.c_int64()
+            self.lib.knpemi_ode_stats(self.dp.h, m._sub, m._model, C.byref(nr), C.byref(ns), C.byref(nf))
+            n += nf.value
+        return n
