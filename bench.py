@@ -123,8 +123,13 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("KNPEMI_BENCH_BACKEND", "nccl")   # "gloo": single-GPU rehearsal only
+        dev = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
 
     from knpemi import _lib as L
     from knpemi.stepper import DeviceStepper
@@ -195,14 +200,15 @@ def main():
     if stepper.ode_failures():
         raise SystemExit("LSODA failed on the device")
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        red_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     owned = getattr(s, "owned_dofs", None)
     dofs_local = 3 * (owned if owned is not None else int(dp.n_vert.sum()))
     if dist is not None:
-        tot = torch.tensor([dofs_local], dtype=torch.int64, device="cuda")
+        tot = torch.tensor([dofs_local], dtype=torch.int64, device=red_dev)
         dist.all_reduce(tot)
         dofs_total = int(tot.item())
     else:

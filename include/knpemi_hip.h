@@ -166,7 +166,8 @@ int knpemi_ode_set_stimulus(knpemi_handle* h, int sub, int model, const uint8_t*
 #define KNPEMI_ODE_SET_TRACES 2
 int knpemi_ode_step(knpemi_handle* h, int sub, int model, double t0, double dt, double rtol,
                     double atol, int flags, const int32_t* ion_param, int v_index);
-/* Number of RHS evaluations / internal steps of the last knpemi_ode_step (sum over dofs). */
+/* RHS evaluations / internal steps / failed dofs summed over all knpemi_ode_step launches since
+ * the previous call (the counters are reset by this call). */
 int knpemi_ode_stats(knpemi_handle* h, int sub, int model, int64_t* n_rhs, int64_t* n_steps,
                      int32_t* n_failed);
 
@@ -178,6 +179,17 @@ int knpemi_update_pde(knpemi_handle* h);
  * (utils.py:150-207).  u_e has n_vert[0] entries, u_i n_vert[sub]; q_e, q_i receive n_q[sub]. */
 int knpemi_trace(knpemi_handle* h, int sub, const double* u_e, const double* u_i, double* q_e,
                  double* q_i);
+
+/* Multi-GPU forward halo (owner -> ghost) of dof fields; replaces
+ * Function.x.scatter_forward() (utils.py:100,199,204,254,293).  idx_dev / buf_dev are DEVICE pointers
+ * (the caller moves buf between GPUs, e.g. torch.distributed send/recv over RCCL).
+ * kind 0 (bulk): idx = global vertex ids (sub-mesh vertex + offset of its sub-domain), 4 doubles per
+ *   entry: c_prev[0], c_prev[1], c_eliminated, phi;
+ * kind 1 (membrane): idx = global Q-dof ids, 1 + 3*n_model_slots doubles per entry: phi_M_prev and
+ *   the I_ch_k of every membrane model. */
+int knpemi_halo_width(knpemi_handle* h, int kind);
+int knpemi_halo_pack(knpemi_handle* h, int kind, const int32_t* idx_dev, int n, double* buf_dev);
+int knpemi_halo_unpack(knpemi_handle* h, int kind, const int32_t* idx_dev, int n, const double* buf_dev);
 
 /* Per-kernel HIP-event profiling on the handle's stream: every launch of a kernel whose bit is set
  * in `kernel_mask` is bracketed by an event pair; knpemi_profile_read() synchronises, returns the

@@ -608,6 +608,33 @@ __global__ void update_pde_kernel(KnDev D, const KnConsts* __restrict__ Cp) {
   if (i < D.NQtot) D.phiM[i] = D.VR[(size_t)D.q2i[i] * KN_REC + 7] - D.VR[(size_t)D.q2e[i] * KN_REC + 7];
 }
 
+// Forward-halo pack / unpack (owner -> ghost copies of dof fields between GPUs).
+__global__ void halo_kernel(KnDev D, int kind, int pack, const int* __restrict__ idx, int n, int n_slots,
+                            double* __restrict__ buf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int g = idx[i];
+  if (kind == 0) {
+    double* rec = D.VR + (size_t)g * KN_REC + 4;
+    double* b = buf + (size_t)i * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (pack) b[c] = rec[c];
+      else rec[c] = b[c];
+    }
+  } else {
+    const int w = 1 + KN_MAXK * n_slots;
+    double* b = buf + (size_t)i * w;
+    if (pack) b[0] = D.phiM[g];
+    else D.phiM[g] = b[0];
+    for (int c = 0; c < KN_MAXK * n_slots; ++c) {
+      double* f = D.Ich + (size_t)c * D.NQtot + g;
+      if (pack) b[1 + c] = *f;
+      else *f = b[1 + c];
+    }
+  }
+}
+
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -703,6 +730,13 @@ int kn_launch_update_pde(knpemi_handle* h) {
   KnProfScope prof(h, KNPEMI_K_UPDATE);
   hipLaunchKernelGGL(update_pde_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, D, h->d_consts);
   return check_launch("update_pde_kernel");
+}
+
+int kn_launch_halo(knpemi_handle* h, int kind, int pack, const int32_t* idx, int n, double* buf) {
+  if (n == 0) return KNPEMI_OK;
+  hipLaunchKernelGGL(halo_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->dev, kind, pack, idx, n,
+                     h->moff[h->n_sub], buf);
+  return check_launch("halo_kernel");
 }
 
 int kn_launch_field_scatter(knpemi_handle* h, const double* src, double* dst, int n, int dst_stride) {

@@ -99,7 +99,7 @@ int kn_launch_ode_step(knpemi_handle* h, int slot, double t0, double dt, double 
   for (int i = 0; i < 8; ++i) { a.stim_idx[i] = m.stim_idx[i]; a.stim_val[i] = m.stim_val[i]; }
   a.t0 = t0; a.dt = dt; a.rtol = rtol; a.atol = atol;
   a.states = m.d_states; a.params = m.d_params; a.mask = m.d_mask; a.stats = m.d_stats;
-  KN_HIP(hipMemsetAsync(m.d_stats, 0, 3 * sizeof(unsigned long long), h->stream));
+  // counters accumulate over launches; knpemi_ode_stats() reads and resets them
   // 64-thread workgroups: the sweep has only n_q (10^3..10^5) threads, so spread the waves over as
   // many CUs as possible instead of stacking four of them on one.
   dim3 grid((m.nq + 63) / 64), block(64);

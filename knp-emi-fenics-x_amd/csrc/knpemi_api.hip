@@ -832,6 +832,7 @@ extern "C" int knpemi_ode_stats(knpemi_handle* h, int sub, int model, int64_t* n
   unsigned long long st[3];
   KN_HIP(hipSetDevice(h->device));
   KN_HIP(hipMemcpyAsync(st, h->ode[slot].d_stats, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+  KN_HIP(hipMemsetAsync(h->ode[slot].d_stats, 0, sizeof(st), h->stream));
   KN_HIP(hipStreamSynchronize(h->stream));
   if (n_rhs) *n_rhs = (int64_t)st[0];
   if (n_steps) *n_steps = (int64_t)st[1];
@@ -845,6 +846,25 @@ extern "C" int knpemi_update_pde(knpemi_handle* h) {
   if (!h->have_params) return fail(KNPEMI_EINVAL, "knpemi_update_pde: knpemi_set_params not called");
   KN_HIP(hipSetDevice(h->device));
   return kn_launch_update_pde(h);
+}
+
+extern "C" int knpemi_halo_width(knpemi_handle* h, int kind) {
+  if (!h) return KNPEMI_EINVAL;
+  return kind == 0 ? 4 : 1 + KN_MAXK * h->moff[h->n_sub];
+}
+
+extern "C" int knpemi_halo_pack(knpemi_handle* h, int kind, const int32_t* idx_dev, int n, double* buf_dev) {
+  if (!h || (n > 0 && (!idx_dev || !buf_dev)) || n < 0 || kind < 0 || kind > 1)
+    return fail(KNPEMI_EINVAL, "knpemi_halo_pack: bad argument");
+  KN_HIP(hipSetDevice(h->device));
+  return kn_launch_halo(h, kind, 1, idx_dev, n, buf_dev);
+}
+
+extern "C" int knpemi_halo_unpack(knpemi_handle* h, int kind, const int32_t* idx_dev, int n, const double* buf_dev) {
+  if (!h || (n > 0 && (!idx_dev || !buf_dev)) || n < 0 || kind < 0 || kind > 1)
+    return fail(KNPEMI_EINVAL, "knpemi_halo_unpack: bad argument");
+  KN_HIP(hipSetDevice(h->device));
+  return kn_launch_halo(h, kind, 0, idx_dev, n, const_cast<double*>(buf_dev));
 }
 
 extern "C" int knpemi_profile(knpemi_handle* h, uint32_t kernel_mask) {

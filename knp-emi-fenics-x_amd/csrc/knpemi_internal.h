@@ -151,6 +151,7 @@ int kn_launch_knp_membrane(knpemi_handle* h, int flags);
 int kn_launch_ode_step(knpemi_handle* h, int slot, double t0, double dt, double rtol, double atol,
                        int flags, const int32_t* ion_param, int v_index);
 int kn_launch_update_pde(knpemi_handle* h);
+int kn_launch_halo(knpemi_handle* h, int kind, int pack, const int32_t* idx, int n, double* buf);
 int kn_launch_field_scatter(knpemi_handle* h, const double* src, double* dst, int n, int dst_stride);
 int kn_launch_field_gather(knpemi_handle* h, const double* src, int src_stride, double* dst, int n);
 int kn_launch_trace(knpemi_handle* h, const double* ue, const double* ui, int sub, double* qe, double* qi);

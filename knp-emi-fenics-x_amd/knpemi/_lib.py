@@ -92,6 +92,9 @@ SIGNATURES = {
                                    C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "knpemi_update_pde": (C.c_int, [C.c_void_p]),
     "knpemi_trace": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p]),
+    "knpemi_halo_width": (C.c_int, [C.c_void_p, C.c_int]),
+    "knpemi_halo_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "knpemi_halo_unpack": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "knpemi_profile": (C.c_int, [C.c_void_p, C.c_uint32]),
     "knpemi_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), c_dbl_p]),
     "knpemi_timer_start": (C.c_int, [C.c_void_p]),

@@ -77,6 +77,18 @@ def make_mesh_3D(resolution_factor, cell_type=CellType.hexahedron, l=2, axon_tag
     return mesh, ct, ft
 
 
+def make_mesh_3D_slab(resolution_factor, cell_type, l, x_cells, comm=None):
+    """Cells with x-index in [x_cells[0], x_cells[1]) of `make_mesh_3D(r, cell_type, l)`: the local
+    mesh of one rank of the x-slab partition (coordinates identical to the global mesh)."""
+    n = (l * 16 * 2 ** resolution_factor, 9 * 2 ** resolution_factor, 9 * 2 ** resolution_factor)
+    hi = (l * 16e-6, 0.9e-6, 0.9e-6)
+    axes = [np.linspace(0.0, hi[d], n[d] + 1) for d in range(3)]
+    axes[0] = axes[0][x_cells[0]:x_cells[1] + 1]
+    mesh = create_box(comm, None, None, cell_type, axes=axes)
+    ct, ft = _tag(mesh, axon_boxes(l), [1, 1, 1, 1])
+    return mesh, ct, ft
+
+
 def make_mesh_mms(M, comm=None):
     """Unit square, ICS = [0.25, 0.75]^2 (`tests/make_mesh_mms.py:21-24,43-83`)."""
     mesh = create_unit_square(comm, M, M)

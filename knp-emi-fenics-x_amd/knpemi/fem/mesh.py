@@ -195,8 +195,9 @@ class EntityMap:
 # ---------------------------------------------------------------------------
 # structured generators (geometry of the reference's mesh scripts)
 # ---------------------------------------------------------------------------
-def _grid_points(p0, p1, n):
-    axes = [np.linspace(p0[d], p1[d], n[d] + 1) for d in range(len(n))]
+def _grid_points(p0, p1, n, axes=None):
+    if axes is None:
+        axes = [np.linspace(p0[d], p1[d], n[d] + 1) for d in range(len(n))]
     if len(n) == 2:
         Y, X = np.meshgrid(axes[1], axes[0], indexing="ij")
         return np.stack([X.ravel(), Y.ravel()], axis=1)
@@ -235,14 +236,18 @@ _KUHN = np.array([[0, 1, 3, 7], [0, 1, 5, 7], [0, 2, 3, 7],
                   [0, 2, 6, 7], [0, 4, 5, 7], [0, 4, 6, 7]], np.int32)
 
 
-def create_box(comm, points, n, cell_type=CellType.hexahedron):
+def create_box(comm, points, n, cell_type=CellType.hexahedron, axes=None):
     """`dolfinx.mesh.create_box` geometry (`make_mesh_3D.py:100-102`).
 
     `hexahedron` reproduces the reference's Q1 mesh; `tetrahedron` splits every
-    hexahedron into 6 Kuhn tetrahedra (BASELINE configs 2, 3 and 5).
+    hexahedron into 6 Kuhn tetrahedra (BASELINE configs 2, 3 and 5).  `axes`
+    (three coordinate arrays) overrides the uniform grid; the multi-GPU slab
+    meshes pass slices of the global axes so that coordinates match bit for bit.
     """
+    if axes is not None:
+        n = [len(a) - 1 for a in axes]
     nx, ny, nz = (int(v) for v in n)
-    x = _grid_points(points[0], points[1], (nx, ny, nz))
+    x = _grid_points(points[0] if points else None, points[1] if points else None, (nx, ny, nz), axes)
     k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
     sx, sy = 1, nx + 1
     sz = (nx + 1) * (ny + 1)

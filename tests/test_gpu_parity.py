@@ -148,3 +148,59 @@ def test_abi_error_paths(hip_lib):
     assert hip_lib.knpemi_assemble_emi(None, 0) == L.EINVAL
     n, nnz = C.c_int64(), C.c_int64()
     assert hip_lib.knpemi_csr_dims(dp.h, 7, C.byref(n), C.byref(nnz)) == L.EINVAL
+
+
+@pytest.mark.parametrize("kind,r", [("2d", 1), ("tet", 0), ("hex", 0)])
+def test_assembly_matches_golden_fixtures(hip_lib, kind, r):
+    """HIP path against the committed golden vectors (tests/golden/make_golden.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"assembly_{kind}_r{r}.npz"))
+    s = Setup(kind, r)
+    s.perturb(12345)
+    for split in (True, False):
+        tag = "split" if split else "nosplit"
+        _, (A, Pm, b, Ak, bk) = _assemble_both(s, split)
+        v = np.random.default_rng(1).uniform(-1, 1, A.shape[0])
+        vk = np.random.default_rng(2).uniform(-1, 1, Ak.shape[0])
+        assert rel_err(b, g[f"{tag}_b_emi"]) < TOL and rel_err(bk, g[f"{tag}_b_knp"]) < TOL
+        assert rel_err(A @ v, g[f"{tag}_A_emi_v"]) < TOL and rel_err(Pm @ v, g[f"{tag}_P_emi_v"]) < TOL
+        assert rel_err(Ak @ vk, g[f"{tag}_A_knp_v"]) < TOL
+        assert rel_err(A.diagonal(), g[f"{tag}_A_emi_diag"]) < TOL
+        assert tuple(g[f"{tag}_nnz"]) == (A.nnz, Pm.nnz, Ak.nnz)
+
+
+def test_device_stepper_matches_dropin_path(hip_lib):
+    """The device-resident step sequence (knpemi.stepper) leaves the same fields and ODE tables as the
+    host-mirrored drop-in calls, bit for bit (no solves in between: c, phi held fixed)."""
+    from knpemi import update_ode_variables, update_pde_variables
+    from knpemi.pdeSolver import create_solver_emi, create_solver_knp
+    from knpemi.stepper import DeviceStepper
+    res = []
+    for mode in ("dropin", "stepper"):
+        s = Setup("tet", 0, g_syn=10.0)
+        s.perturb()
+        ode = s.mem_models[0]['ode']
+        if mode == "stepper":
+            st = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp), s.c, s.c_prev, s.phi,
+                               s.phi_M_prev)
+            st.add_membrane_model(ode, s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
+            for _ in range(3):
+                st.step()
+            b_emi, b_knp = st.dp.rhs(0), st.dp.rhs(1)
+            st.download()
+        else:
+            emi = create_solver_emi(s.a_emi, s.L_emi, s.phi, s.entity_maps, s.subdomain_list, None, p=s.p_emi, direct=False)
+            knp = create_solver_knp(s.a_knp, s.L_knp, s.c, s.entity_maps, s.subdomain_list, None, p=s.p_knp)
+            for k in range(3):
+                update_ode_variables(ode, s.c_prev, s.phi_M_prev[1], s.ion_list, s.subdomain_list, s.mesh, s.ct, 1, k)
+                ode.step_lsoda(s.dt, s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
+                ode.get_membrane_potential(s.phi_M_prev[1])
+                for ion, f in s.mem_models[0]['I_ch_k'].items():
+                    ode.get_parameter("I_ch_" + ion, f)
+                _, b_emi = emi.assemble()
+                _, b_knp = knp.assemble()
+                update_pde_variables(s.c, s.c_prev, s.phi, s.phi_M_prev, s.physical_parameters, s.ion_list,
+                                     s.subdomain_list, s.mesh, s.ct)
+        res.append((ode.states.copy(), s.phi_M_prev[1].x._a.copy(), s.c_prev[1][0].x._a.copy(), b_emi, b_knp))
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)

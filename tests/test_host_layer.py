@@ -1,0 +1,98 @@
+"""CPU tests of the host-side mesh / function / membrane-table layer."""
+import numpy as np
+import pytest
+
+from knpemi.fem import (Function, compute_interface_data, extract_submesh, functionspace, make_mesh_2D,
+                        make_mesh_3D, make_mesh_mms)
+
+
+@pytest.mark.parametrize("r,expect", [(1, (496, 315, 240, 183, 124, 256)), (2, (1984, 1125, 960, 605, 248, 768))])
+def test_mesh_2d_sizes(r, expect):
+    """SURVEY.md appendix B (arithmetic of make_mesh_2D.py:21-22,45-55)."""
+    m, ct, ft = make_mesh_2D(r)
+    s0, *_ = extract_submesh(m, ct, 0)
+    s1, *_ = extract_submesh(m, ct, 1)
+    g, *_ = extract_submesh(m, ft, [1])
+    assert (m.num_cells, m.num_vertices, s1.num_cells, s1.num_vertices, g.num_cells, s0.num_vertices) == expect
+    assert g.num_vertices == g.num_cells   # closed membrane curve
+
+
+def test_mesh_2d_r0_has_empty_ics():
+    m, ct, ft = make_mesh_2D(0)
+    assert (ct.values == 1).sum() == 0 and m.num_cells == 124
+
+
+@pytest.mark.parametrize("cell,expect", [("hexahedron", (2592, 3300, 352, 828, 736, 744, 3216)),
+                                         ("tetrahedron", (15552, 3300, 2112, 828, 1472, 744, 3216))])
+def test_mesh_3d_sizes(cell, expect):
+    m, ct, ft = make_mesh_3D(0, cell)
+    s0, *_ = extract_submesh(m, ct, 0)
+    s1, *_ = extract_submesh(m, ct, 1)
+    g, *_ = extract_submesh(m, ft, [1])
+    assert (m.num_cells, m.num_vertices, s1.num_cells, s1.num_vertices, g.num_cells, g.num_vertices,
+            s0.num_vertices) == expect
+    assert set(np.unique(ft.values)) == {0, 1, 5}
+
+
+def test_mms_mesh_tags():
+    m, ct, ft = make_mesh_mms(8)
+    assert m.num_cells == 128 and set(np.unique(ft.values)) == {1, 5}   # other facets stay untagged
+    assert len(ft.find(1)) == 16 and len(ft.find(5)) == 32
+
+
+def test_interface_orientation_and_maps():
+    m, ct, ft = make_mesh_3D(0, "tetrahedron")
+    idata = compute_interface_data(ct, ft.find(1))
+    dense = ct.dense()
+    assert np.all(dense[idata[:, 0]] == 0) and np.all(dense[idata[:, 2]] == 1)   # "+" = ECS
+    # the local facet indices really address the shared facet
+    assert np.array_equal(m.cell_facets[idata[:, 0], idata[:, 1]], ft.find(1))
+    assert np.array_equal(m.cell_facets[idata[:, 2], idata[:, 3]], ft.find(1))
+    with pytest.raises(RuntimeError, match="interior facet"):
+        compute_interface_data(ct, ft.find(5)[:3])
+    sub, emap, vmap, _, _ = extract_submesh(m, ct, 1)
+    assert np.array_equal(m.x[vmap.sub_to_parent], sub.x)
+    assert np.all(np.diff(vmap.sub_to_parent) > 0)           # numbering rule: increasing parent vertex
+    inv = emap.sub_topology_to_topology(np.arange(m.num_cells, dtype=np.int32), inverse=True)
+    assert (inv >= 0).sum() == sub.num_cells
+
+
+def test_function_versioning_and_interpolate():
+    m, ct, ft = make_mesh_2D(1)
+    f = Function(functionspace(m, ("CG", 1)), name="u")
+    v0 = f.x.version
+    f.x.array[:] = 3.0
+    assert f.x.version > v0 and f.x._a[0] == 3.0
+    f.interpolate(lambda x: x[0] + 2 * x[1])
+    assert np.allclose(f.x._a, m.x[:, 0] + 2 * m.x[:, 1])
+    with pytest.raises(NotImplementedError):
+        functionspace(m, ("CG", 2))
+
+
+def test_membrane_model_tables_and_protocol():
+    import contextlib
+    import io
+    from helpers import load_model
+    from knpemi import MembraneModel
+    m, ct, ft = make_mesh_2D(1)
+    g, *_ = extract_submesh(m, ft, [1])
+    Q = functionspace(g, ("CG", 1))
+    hh = load_model("hh_si")
+    with contextlib.redirect_stdout(io.StringIO()):
+        mm = MembraneModel(hh, ft, 1, Q)
+        assert mm.states.shape == (124, 4) and mm.parameters.shape == (124, 22) and mm.tag == 1
+        mm.set_parameter_values({"Cm": lambda x: 0.02}, locator=lambda x: x[0] < 20e-6)
+        u = Function(Q)
+        u.x.array[:] = np.arange(124.0)
+        mm.set_membrane_potential(u)
+        w = Function(Q)
+        mm.get_membrane_potential(w)
+    sel = mm.dof_locations[:, 0] < 20e-6
+    assert np.all(mm.parameters[sel, 7] == 0.02) and np.all(mm.parameters[~sel, 7] == 0.0)
+    assert np.array_equal(w.x._a, np.arange(124.0)) and mm.V_index == 3
+    with pytest.raises(ValueError):
+        hh.parameter_indices("nope")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mm.step_lsoda(1e-4, {})
+    with pytest.raises(AssertionError):
+        MembraneModel(hh, ft, 1.0, Q)

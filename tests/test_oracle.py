@@ -1,0 +1,123 @@
+"""CPU tests of the oracle: known answers, invariants and the committed golden vectors."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+import knpemi_oracle as o
+from helpers import Setup, csr_rel_err, rel_err
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def quiet_setup(*a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return Setup(*a, build_forms=False, **k)
+
+
+@pytest.mark.parametrize("cell,deg,npts", [("triangle", 2, 3), ("triangle", 6, 12), ("tetrahedron", 2, 4),
+                                          ("interval", 6, 4), ("quadrilateral", 6, 16), ("hexahedron", 3, 8)])
+def test_quadrature_exactness(cell, deg, npts):
+    """Every rule integrates all monomials up to its degree exactly on the reference cell."""
+    from math import factorial
+    pts, wts = o.quadrature(cell, deg)
+    assert len(wts) == npts
+    d = pts.shape[1]
+    simplex = cell in ("triangle", "tetrahedron")
+    for powers in np.ndindex(*([deg + 1] * d)):
+        if simplex and sum(powers) > deg:
+            continue
+        num = np.sum(wts * np.prod(pts ** np.array(powers), axis=1))
+        if simplex:
+            exact = np.prod([factorial(p) for p in powers]) / factorial(sum(powers) + d)
+        else:
+            exact = np.prod([1.0 / (p + 1) for p in powers])
+        assert abs(num - exact) < 1e-14
+
+
+def test_p1_element_known_answers():
+    """Stiffness of the reference triangle / tetrahedron and Q1 mass of the unit cube."""
+    for cell, X in (("triangle", np.array([[0, 0], [1, 0], [0, 1.]])),
+                    ("tetrahedron", np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1.]]))):
+        pts, w = o.quadrature(cell, 1)
+        phi, dphi = o.tabulate(cell, pts)
+        det, G = o._geometry(X[None], dphi)
+        K = np.einsum("q,cq,cqag,cqbg->ab", w, det, G, G)
+        vol = 0.5 if cell == "triangle" else 1 / 6
+        d = X.shape[1]
+        ref = np.zeros((d + 1, d + 1))
+        ref[0, 0] = d
+        ref[0, 1:] = ref[1:, 0] = -1
+        ref[1:, 1:] = np.eye(d)
+        assert np.allclose(K, vol * ref, atol=1e-15)
+    pts, w = o.quadrature("hexahedron", 2)
+    phi, dphi = o.tabulate("hexahedron", pts)
+    M = np.einsum("q,qa,qb->ab", w, phi, phi)
+    assert abs(M.sum() - 1.0) < 1e-14 and abs(M[0, 0] - 1 / 27) < 1e-15 and abs(M[0, 7] - 1 / 216) < 1e-15
+
+
+@pytest.mark.parametrize("kind,r", [("2d", 1), ("tet", 0), ("hex", 0)])
+def test_assembly_invariants(kind, r):
+    """Form-independent invariants: constant null space and symmetry of A_emi,
+    zero-sum membrane RHS, A_knp row sums = lumped mass / dt when phi = 0."""
+    s = quiet_setup(kind, r)
+    s.perturb()
+    _, P, params, ions = s.oracle()
+    c_all, phi, phiM, mm = s.oracle_fields()
+    A, Pm, b = o.assemble_emi(P, params, ions, c_all, phiM, mm)
+    scale = np.abs(A.data).max()
+    assert np.abs(A @ np.ones(A.shape[0])).max() < 1e-13 * scale
+    assert csr_rel_err(A, A.T.tocsr()) < 1e-14
+    c_flat = {t: [np.full_like(c, c.mean()) for c in c_all[t]] for t in c_all}   # grad c = 0
+    _, _, b_gamma = o.assemble_emi(P, params, ions, c_flat, phiM, mm)
+    assert abs(b_gamma.sum()) < 1e-12 * np.abs(b_gamma).max()
+    zero_phi = {t: np.zeros_like(phi[t]) for t in phi}
+    Ak, _ = o.assemble_knp(P, params, ions, c_all, zero_phi, phiM, mm, s.dt)
+    measure = (Ak @ np.ones(Ak.shape[0])).sum() * s.dt / 2
+    box = s.mesh.x.max(axis=0) - s.mesh.x.min(axis=0)
+    assert abs(measure - np.prod(box)) < 1e-12 * np.prod(box)
+    # P = A + ICS mass: rows of the ECS block are untouched
+    D = (Pm - A).tocsr()
+    assert abs(D[:P.N[0]]).sum() == 0.0 and abs(D.sum() - (np.prod(box) - 0) * 0) >= 0
+
+
+@pytest.mark.parametrize("kind,r", [("2d", 1), ("tet", 0), ("hex", 0)])
+def test_oracle_reproduces_golden(kind, r):
+    g = np.load(os.path.join(GOLDEN, f"assembly_{kind}_r{r}.npz"))
+    s = quiet_setup(kind, r)
+    s.perturb(12345)
+    _, P, params, ions = s.oracle()
+    c_all, phi, phiM, mm = s.oracle_fields()
+    for split in (True, False):
+        tag = "split" if split else "nosplit"
+        A, Pm, b = o.assemble_emi(P, params, ions, c_all, phiM, mm, splitting_scheme=split)
+        Ak, bk = o.assemble_knp(P, params, ions, c_all, phi, phiM, mm, s.dt, splitting_scheme=split)
+        v = np.random.default_rng(1).uniform(-1, 1, A.shape[0])
+        vk = np.random.default_rng(2).uniform(-1, 1, Ak.shape[0])
+        assert rel_err(b, g[f"{tag}_b_emi"]) < 1e-13 and rel_err(bk, g[f"{tag}_b_knp"]) < 1e-13
+        assert rel_err(A @ v, g[f"{tag}_A_emi_v"]) < 1e-13 and rel_err(Ak @ vk, g[f"{tag}_A_knp_v"]) < 1e-13
+        assert rel_err(Pm @ v, g[f"{tag}_P_emi_v"]) < 1e-13
+
+
+def test_hh_initial_state_is_calibrated():
+    """The reference's HH initial state is a steady state of its own RHS with its own initial
+    concentrations (mm_hh.py:12-16, run_3D.py:191-197): |dV/dt| and gate rates are ~0."""
+    g = np.load(os.path.join(GOLDEN, "ode_models.npz"))
+    rhs0 = g["hh_si_stim0_rhs0"]
+    y0 = g["hh_si_stim0_y0"]
+    assert np.abs(rhs0[:3]).max() < 1e-6          # gates: 1/s
+    assert abs(rhs0[3]) < 1e-6 * abs(y0[3]) / 1e-4  # V changes by < 1e-6 relative per time step
+
+
+def test_ode_golden_reproduced_by_oracle():
+    g = np.load(os.path.join(GOLDEN, "ode_models.npz"))
+    for key in ("hh_si_stim10", "hh_mv_stim1", "glial_stim0"):
+        model = key.rsplit("_stim", 1)[0]
+        st, pa = g[f"{key}_y0"][None, :].copy(), g[f"{key}_p0"][None, :].copy()
+        dt = float(g[f"{key}_dt"])
+        for k in range(3):
+            o.ode_sweep(model, st, pa, k * dt, dt)
+            ref = g[f"{key}_traj"][k]
+            assert rel_err(st[0], ref[:st.shape[1]]) < 1e-12
