@@ -31,37 +31,51 @@ struct OdeArgs {
   unsigned long long* stats;
 };
 
+constexpr int ODE_BLOCK = 64;
+
 template <class M>
-__global__ __launch_bounds__(64) void ode_step_kernel(KnDev D, OdeArgs a, const LsodaCoef* __restrict__ cf) {
+__global__ __launch_bounds__(ODE_BLOCK) void ode_step_kernel(KnDev D, OdeArgs a, const LsodaCoef* __restrict__ cf) {
+  using Integrator = Lsoda<M::NS, M, ODE_BLOCK>;
+  // LSODA's dynamically indexed state (Nordsieck history, coefficients, iteration matrix) lives in LDS,
+  // one column per lane; the rest of the integrator state stays in registers.
+  __shared__ double work[Integrator::WORK * ODE_BLOCK];
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= a.nq) return;
   const int qg = a.q0 + q;
-  double p[M::NP];
+  const StridedRow<0> p{a.params + q, (size_t)a.nq};   // this dof's parameter row in the transposed table
   double y[M::NS];
 #pragma unroll
-  for (int j = 0; j < M::NP; ++j) p[j] = a.params[(size_t)j * a.nq + q];
-#pragma unroll
   for (int j = 0; j < M::NS; ++j) y[j] = a.states[(size_t)j * a.nq + q];
-  // 1. concentration traces (record components 4..6 hold c_0, c_1, c_eliminated)
-  const double* re = D.VR + (size_t)D.q2e[qg] * KN_REC + 4;
-  const double* ri = D.VR + (size_t)D.q2i[qg] * KN_REC + 4;
-  if (a.flags & KNPEMI_ODE_SET_TRACES)
+  // 1. concentration traces (record components 4..6 hold c_0, c_1, c_eliminated) -> parameter columns
+  if (a.flags & KNPEMI_ODE_SET_TRACES) {
+    const double* re = D.VR + (size_t)D.q2e[qg] * KN_REC + 4;
+    const double* ri = D.VR + (size_t)D.q2i[qg] * KN_REC + 4;
     for (int k = 0; k < KN_MAXK; ++k) {
       p[a.ion_param[3 * k]] = re[k];
       p[a.ion_param[3 * k + 1]] = ri[k];
     }
-  if (a.flags & KNPEMI_ODE_SET_V) y[a.v_index] = D.phiM[qg];
-  // 2. stimulus + LSODA
+  }
+  if (a.flags & KNPEMI_ODE_SET_V) {
+    const double v = D.phiM[qg];
+#pragma unroll
+    for (int j = 0; j < M::NS; ++j) y[j] = (j == a.v_index) ? v : y[j];
+  }
+  // 2. stimulus + LSODA (the parameter row is read once by prepare(); only the currents change)
   if (a.n_stim > 0 && (!a.mask || a.mask[q]))
     for (int i = 0; i < a.n_stim; ++i) p[a.stim_idx[i]] = a.stim_val[i];
-  Lsoda<M::NS, M> s;
-  const int rc = s.integrate(cf, y, a.t0, a.t0 + a.dt, a.rtol, a.atol, p, 10000);
-  // 3. write back (the whole parameter row is in/out, like the numpy view in odeSolver.py:108)
+  Integrator s;
+  s.f.prepare(p);
+  const int rc = s.integrate(cf, work + threadIdx.x, y, a.t0, a.t0 + a.dt, a.rtol, a.atol, 10000);
+  // 3. write back: currents into the parameter row (the reference's RHS side effect), state row,
+  //    phi_M_prev <- V and the I_ch_k fields
+  s.f.finish(p);
+  double v_out = y[0];
 #pragma unroll
-  for (int j = 0; j < M::NP; ++j) a.params[(size_t)j * a.nq + q] = p[j];
-#pragma unroll
-  for (int j = 0; j < M::NS; ++j) a.states[(size_t)j * a.nq + q] = y[j];
-  D.phiM[qg] = y[a.v_index];
+  for (int j = 0; j < M::NS; ++j) {
+    a.states[(size_t)j * a.nq + q] = y[j];
+    v_out = (j == a.v_index) ? y[j] : v_out;
+  }
+  D.phiM[qg] = v_out;
   for (int k = 0; k < KN_MAXK; ++k)
     D.Ich[((size_t)a.model_slot * KN_MAXK + k) * a.NQtot + qg] = p[a.ion_param[3 * k + 2]];
   atomicAdd(&a.stats[0], (unsigned long long)s.nfe);
@@ -102,7 +116,7 @@ int kn_launch_ode_step(knpemi_handle* h, int slot, double t0, double dt, double 
   // counters accumulate over launches; knpemi_ode_stats() reads and resets them
   // 64-thread workgroups: the sweep has only n_q (10^3..10^5) threads, so spread the waves over as
   // many CUs as possible instead of stacking four of them on one.
-  dim3 grid((m.nq + 63) / 64), block(64);
+  dim3 grid((m.nq + ODE_BLOCK - 1) / ODE_BLOCK), block(ODE_BLOCK);
   KnProfScope prof(h, KNPEMI_K_ODE);
   switch (m.model_id) {
     case KNPEMI_MODEL_HH_SI:

@@ -40,7 +40,9 @@ int dev_zeros(knpemi_handle* h, size_t n, T** out) {
   size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
   KN_HIP(hipMalloc(&p, bytes));
   h->allocs.push_back(p);
-  KN_HIP(hipMemset(p, 0, bytes));
+  // zero on the handle's own (non-blocking) stream: a null-stream hipMemset is not ordered with it
+  KN_HIP(hipMemsetAsync(p, 0, bytes, h->stream));
+  KN_HIP(hipStreamSynchronize(h->stream));
   *out = static_cast<T*>(p);
   return 0;
 }

@@ -18,7 +18,7 @@
 
 #if defined(__HIPCC__)
 #define KN_HD __host__ __device__ __forceinline__
-#define KN_HDN __host__ __device__ __noinline__
+#define KN_HDN __host__ __device__ __forceinline__
 #else
 #define KN_HD inline
 #define KN_HDN
@@ -101,18 +101,25 @@ inline void lsoda_fill_coef(LsodaCoef* c) {
 // N = number of states (1..8); F provides `static void rhs(double t, const double* y, double* dy,
 // double* p)` where p is the (in/out) parameter row, exactly the numba cfunc signature
 // `rhs_numba(t, states, values, parameters)` of the reference's membrane modules.
-template <int N, class F>
+// STRIDE: distance (in doubles) between consecutive elements of the dynamically indexed work arrays
+// (Nordsieck history, method coefficients, iteration matrix).  The host build uses 1 (a private
+// array); the HIP kernel points `work` at LDS with STRIDE = workgroup size so that lane l owns the
+// column l: conflict-free, and an order of magnitude lower latency than scratch memory.
+template <int N, class F, int STRIDE = 1>
 struct Lsoda {
   static constexpr int MXORDN = 12, MXORDS = 5, MAXCOR = 3, MSBP = 20, MXNCF = 10;
+  static constexpr int WORK = 15 * N + 14 + N * N;   // doubles of work storage per integrator
 
   const LsodaCoef* cf;
-  double* p;  // parameter row (side-effect target of the RHS)
+  F f;        // model functor: caches the parameter row, keeps the side-effect currents
   double rtol, atol;
-  double yh[15][N];  // Nordsieck array yh[1..13]; row 14 only bounds a dead branch of methodswitch
-  double wm[N][N];
+  double* work;
+  // YH(1..13, N): Nordsieck array (row 14 only bounds a dead branch of methodswitch)
+  KN_HD double& YH(int j, int i) { return work[(j * N + i) * STRIDE]; }
+  KN_HD double& EL(int i) { return work[(15 * N + i) * STRIDE]; }
+  KN_HD double& WM(int i, int j) { return work[(15 * N + 14 + i * N + j) * STRIDE]; }
   int ipvt[N];
   double ewt[N], savf[N], acor[N], y[N];
-  double el[14];
   double h, hu, tn, hold, rc, crate, conit, el0, rmax, pdest, pdlast, pdnorm, ratio, tsw;
   int nq, l, meth, mused, miter, ialth, ipup, jcur, jstart, kflag, icount, irflag, nslp, nst, nfe,
       nje, lmax, maxord, nqu, ierpj;
@@ -130,12 +137,18 @@ struct Lsoda {
 
   KN_HD double vmnorm(const double* v) const {
     double vm = 0.0;
-    for (int i = 0; i < N; ++i) vm = fmax(vm, fabs(v[i]) * ewt[i]);
+    _Pragma("unroll") for (int i = 0; i < N; ++i) vm = fmax(vm, fabs(v[i]) * ewt[i]);
+    return vm;
+  }
+
+  KN_HD double vmnorm_yh(int j) {
+    double vm = 0.0;
+    _Pragma("unroll") for (int i = 0; i < N; ++i) vm = fmax(vm, fabs(YH(j, i)) * ewt[i]);
     return vm;
   }
 
   KN_HD bool ewset(const double* yc) {
-    for (int i = 0; i < N; ++i) {
+    _Pragma("unroll") for (int i = 0; i < N; ++i) {
       const double e = rtol * fabs(yc[i]) + atol;
       if (!(e > 0.0)) return false;
       ewt[i] = 1.0 / e;
@@ -144,9 +157,9 @@ struct Lsoda {
   }
 
   KN_HD void resetcoeff() {
-    for (int i = 1; i <= l; ++i) el[i] = elco(nq, i);
-    rc = rc * el[1] / el0;
-    el0 = el[1];
+    for (int i = 1; i <= l; ++i) EL(i) = elco(nq, i);
+    rc = rc * EL(1) / el0;
+    el0 = EL(1);
     conit = 0.5 / (double)(nq + 2);
   }
 
@@ -164,7 +177,7 @@ struct Lsoda {
     double r = 1.0;
     for (int j = 2; j <= l; ++j) {
       r *= *rh;
-      for (int i = 0; i < N; ++i) yh[j][i] *= r;
+      _Pragma("unroll") for (int i = 0; i < N; ++i) YH(j, i) *= r;
     }
     h *= *rh;
     rc *= *rh;
@@ -175,7 +188,7 @@ struct Lsoda {
     tn = told;
     for (int j = nq; j >= 1; --j)
       for (int i1 = j; i1 <= nq; ++i1)
-        for (int i = 0; i < N; ++i) yh[i1][i] -= yh[i1 + 1][i];
+        _Pragma("unroll") for (int i = 0; i < N; ++i) YH(i1, i) -= YH(i1 + 1, i);
   }
 
   KN_HD void corfailure(double told, double* rh, int* ncf, int* corflag) {
@@ -201,56 +214,67 @@ struct Lsoda {
     double r0 = 1000.0 * fabs(h) * KN_ETA * (double)N * fac;
     if (r0 == 0.0) r0 = 1.0;
     const double sqrteta = 1.4901161193847656e-08;
+#pragma unroll
     for (int j = 0; j < N; ++j) {
       const double yj = y[j];
       const double r = fmax(sqrteta * fabs(yj), r0 / ewt[j]);
       y[j] += r;
       fac = -hl0 / r;
-      F::rhs(t, y, acor, p);
-      for (int i = 0; i < N; ++i) wm[i][j] = (acor[i] - savf[i]) * fac;
+      f.rhs(t, y, acor);
+      _Pragma("unroll") for (int i = 0; i < N; ++i) WM(i, j) = (acor[i] - savf[i]) * fac;
       y[j] = yj;
     }
     nfe += N;
     double an = 0.0;  // fnorm: weighted max-row-sum norm of (-h*el0*J)
-    for (int i = 0; i < N; ++i) {
+    _Pragma("unroll") for (int i = 0; i < N; ++i) {
       double sum = 0.0;
-      for (int j = 0; j < N; ++j) sum += fabs(wm[i][j]) / ewt[j];
+      for (int j = 0; j < N; ++j) sum += fabs(WM(i, j)) / ewt[j];
       an = fmax(an, sum * ewt[i]);
     }
     pdnorm = an / fabs(hl0);
-    for (int i = 0; i < N; ++i) wm[i][i] += 1.0;
+    _Pragma("unroll") for (int i = 0; i < N; ++i) WM(i, i) += 1.0;
     // dgefa: Gaussian elimination with partial pivoting (LINPACK column-oriented variant)
+#pragma unroll
     for (int k = 0; k < N - 1; ++k) {
       int piv = k;
-      double mx = fabs(wm[k][k]);
+      double mx = fabs(WM(k, k));
       for (int i = k + 1; i < N; ++i)
-        if (fabs(wm[i][k]) > mx) { mx = fabs(wm[i][k]); piv = i; }
+        if (fabs(WM(i, k)) > mx) { mx = fabs(WM(i, k)); piv = i; }
       ipvt[k] = piv;
-      if (wm[piv][k] == 0.0) { ierpj = 1; continue; }
-      if (piv != k) { const double t2 = wm[piv][k]; wm[piv][k] = wm[k][k]; wm[k][k] = t2; }
-      const double tinv = -1.0 / wm[k][k];
-      for (int i = k + 1; i < N; ++i) wm[i][k] *= tinv;
+      if (WM(piv, k) == 0.0) { ierpj = 1; continue; }
+      if (piv != k) { const double t2 = WM(piv, k); WM(piv, k) = WM(k, k); WM(k, k) = t2; }
+      const double tinv = -1.0 / WM(k, k);
+      for (int i = k + 1; i < N; ++i) WM(i, k) *= tinv;
       for (int j = k + 1; j < N; ++j) {
-        double t2 = wm[piv][j];
-        if (piv != k) { wm[piv][j] = wm[k][j]; wm[k][j] = t2; }
-        for (int i = k + 1; i < N; ++i) wm[i][j] += t2 * wm[i][k];
+        double t2 = WM(piv, j);
+        if (piv != k) { WM(piv, j) = WM(k, j); WM(k, j) = t2; }
+        for (int i = k + 1; i < N; ++i) WM(i, j) += t2 * WM(i, k);
       }
     }
-    ipvt[N - 1] = N - 1;
-    if (wm[N - 1][N - 1] == 0.0) ierpj = 1;
+    ipvt[N - 1] = N - 1;  // (ipvt is only indexed with unrolled constants)
+    if (WM(N - 1, N - 1) == 0.0) ierpj = 1;
   }
 
-  KN_HD void solsy(double* b) {  // dgesl, job = 0
+  KN_HD void solsy(double* b) {  // dgesl, job = 0 (selects instead of b[piv]: b stays in registers)
+#pragma unroll
     for (int k = 0; k < N - 1; ++k) {
       const int piv = ipvt[k];
-      const double t2 = b[piv];
-      if (piv != k) { b[piv] = b[k]; b[k] = t2; }
-      for (int i = k + 1; i < N; ++i) b[i] += t2 * wm[i][k];
+      double t2 = b[k];
+#pragma unroll
+      for (int i = k + 1; i < N; ++i) t2 = (i == piv) ? b[i] : t2;
+      const double bk = b[k];
+#pragma unroll
+      for (int i = k + 1; i < N; ++i) b[i] = (i == piv) ? bk : b[i];
+      b[k] = t2;
+#pragma unroll
+      for (int i = k + 1; i < N; ++i) b[i] += t2 * WM(i, k);
     }
+#pragma unroll
     for (int k = N - 1; k >= 0; --k) {
-      b[k] /= wm[k][k];
+      b[k] /= WM(k, k);
       const double t2 = -b[k];
-      for (int i = 0; i < k; ++i) b[i] += t2 * wm[i][k];
+#pragma unroll
+      for (int i = 0; i < k; ++i) b[i] += t2 * WM(i, k);
     }
   }
 
@@ -260,8 +284,8 @@ struct Lsoda {
     *m = 0;
     *corflag = 0;
     *del = 0.0;
-    for (int i = 0; i < N; ++i) y[i] = yh[1][i];
-    F::rhs(tn, y, savf, p);
+    _Pragma("unroll") for (int i = 0; i < N; ++i) y[i] = YH(1, i);
+    f.rhs(tn, y, savf);
     nfe++;
     while (true) {
       if (*m == 0) {
@@ -273,25 +297,25 @@ struct Lsoda {
           crate = 0.7;
           if (ierpj != 0) { corfailure(told, rh, ncf, corflag); return; }
         }
-        for (int i = 0; i < N; ++i) acor[i] = 0.0;
+        _Pragma("unroll") for (int i = 0; i < N; ++i) acor[i] = 0.0;
       }
       if (miter == 0) {
-        for (int i = 0; i < N; ++i) {
-          savf[i] = h * savf[i] - yh[2][i];
+        _Pragma("unroll") for (int i = 0; i < N; ++i) {
+          savf[i] = h * savf[i] - YH(2, i);
           y[i] = savf[i] - acor[i];
         }
         *del = vmnorm(y);
-        for (int i = 0; i < N; ++i) {
-          y[i] = yh[1][i] + el[1] * savf[i];
+        _Pragma("unroll") for (int i = 0; i < N; ++i) {
+          y[i] = YH(1, i) + EL(1) * savf[i];
           acor[i] = savf[i];
         }
       } else {
-        for (int i = 0; i < N; ++i) y[i] = h * savf[i] - (yh[2][i] + acor[i]);
+        _Pragma("unroll") for (int i = 0; i < N; ++i) y[i] = h * savf[i] - (YH(2, i) + acor[i]);
         solsy(y);
         *del = vmnorm(y);
-        for (int i = 0; i < N; ++i) {
+        _Pragma("unroll") for (int i = 0; i < N; ++i) {
           acor[i] += y[i];
-          y[i] = yh[1][i] + el[1] * acor[i];
+          y[i] = YH(1, i) + EL(1) * acor[i];
         }
       }
       if (*del <= 100.0 * pnorm * KN_ETA) break;
@@ -304,7 +328,7 @@ struct Lsoda {
         }
         const double dcon = *del * fmin(1.0, 1.5 * crate) / (tesco(nq, 2) * conit);
         if (dcon <= 1.0) {
-          pdest = fmax(pdest, rate / fabs(h * el[1]));
+          pdest = fmax(pdest, rate / fabs(h * EL(1)));
           if (pdest != 0.0) pdlast = pdest;
           break;
         }
@@ -316,12 +340,12 @@ struct Lsoda {
         *m = 0;
         rate = 0.0;
         *del = 0.0;
-        for (int i = 0; i < N; ++i) y[i] = yh[1][i];
-        F::rhs(tn, y, savf, p);
+        _Pragma("unroll") for (int i = 0; i < N; ++i) y[i] = YH(1, i);
+        f.rhs(tn, y, savf);
         nfe++;
       } else {
         *delp = *del;
-        F::rhs(tn, y, savf, p);
+        f.rhs(tn, y, savf);
         nfe++;
       }
     }
@@ -347,7 +371,7 @@ struct Lsoda {
           nqm2 = MXORDS;
           const int lm2 = MXORDS + 1;
           exm2 = 1.0 / (double)lm2;
-          dm2 = vmnorm(yh[lm2 + 1]) / cf->cm2[MXORDS];
+          dm2 = vmnorm_yh(lm2 + 1) / cf->cm2[MXORDS];
           rh2 = 1.0 / (1.2 * pow(dm2, exm2) + 0.0000012);
         } else {
           dm2 = dsm * (cf->cm1[nq] / cf->cm2[nq]);
@@ -370,7 +394,7 @@ struct Lsoda {
       nqm1 = MXORDN;
       const int lm1 = MXORDN + 1;
       exm1 = 1.0 / (double)lm1;
-      dm1 = vmnorm(yh[lm1 + 1]) / cf->cm1[MXORDN];
+      dm1 = vmnorm_yh(lm1 + 1) / cf->cm1[MXORDN];
       rh1 = 1.0 / (1.2 * pow(dm1, exm1) + 0.0000012);
     } else {
       dm1 = dsm * (cf->cm2[nq] / cf->cm1[nq]);
@@ -403,7 +427,7 @@ struct Lsoda {
     double rhsm = 1.0 / (1.2 * pow(dsm, exsm) + 0.0000012);
     double rhdn = 0.0;
     if (nq != 1) {
-      const double ddn = vmnorm(yh[l]) / tesco(nq, 1);
+      const double ddn = vmnorm_yh(l) / tesco(nq, 1);
       const double exdn = 1.0 / (double)nq;
       rhdn = 1.0 / (1.3 * pow(ddn, exdn) + 0.0000013);
     }
@@ -431,10 +455,10 @@ struct Lsoda {
       } else {
         *rh = *rhup;
         if (*rh >= 1.1) {
-          const double r = el[l] / (double)l;
+          const double r = EL(l) / (double)l;
           nq = l;
           l = nq + 1;
-          for (int i = 0; i < N; ++i) yh[l][i] = acor[i] * r;
+          _Pragma("unroll") for (int i = 0; i < N; ++i) YH(l, i) = acor[i] * r;
           *orderflag = 2;
           return;
         }
@@ -457,7 +481,7 @@ struct Lsoda {
 
   KN_HD void endstoda() {
     const double r = 1.0 / tesco(nqu, 2);
-    for (int i = 0; i < N; ++i) acor[i] *= r;
+    _Pragma("unroll") for (int i = 0; i < N; ++i) acor[i] *= r;
     hold = h;
     jstart = 1;
   }
@@ -519,8 +543,8 @@ struct Lsoda {
         tn += h;
         for (int j = nq; j >= 1; --j)
           for (int i1 = j; i1 <= nq; ++i1)
-            for (int i = 0; i < N; ++i) yh[i1][i] += yh[i1 + 1][i];
-        pnorm = vmnorm(yh[1]);
+            _Pragma("unroll") for (int i = 0; i < N; ++i) YH(i1, i) += YH(i1 + 1, i);
+        pnorm = vmnorm_yh(1);
         correction(pnorm, &del, &delp, told, &ncf, &rh, &m, &corflag);
         if (corflag == 0) break;
         if (corflag == 1) {
@@ -543,8 +567,8 @@ struct Lsoda {
         nqu = nq;
         mused = meth;
         for (int j = 1; j <= l; ++j) {
-          r = el[j];
-          for (int i = 0; i < N; ++i) yh[j][i] += r * acor[i];
+          r = EL(j);
+          _Pragma("unroll") for (int i = 0; i < N; ++i) YH(j, i) += r * acor[i];
         }
         icount--;
         if (icount < 0) {
@@ -555,7 +579,7 @@ struct Lsoda {
             rmax = 10.0;
             // endstoda() uses the coefficients of the method that took the step
             const double rr = 1.0 / cf->tesco[mused - 1][nqu][2];
-            for (int i = 0; i < N; ++i) acor[i] *= rr;
+            _Pragma("unroll") for (int i = 0; i < N; ++i) acor[i] *= rr;
             hold = h;
             jstart = 1;
             break;
@@ -565,7 +589,7 @@ struct Lsoda {
         if (ialth == 0) {
           rhup = 0.0;
           if (l != lmax) {
-            for (int i = 0; i < N; ++i) savf[i] = acor[i] - yh[lmax][i];
+            _Pragma("unroll") for (int i = 0; i < N; ++i) savf[i] = acor[i] - YH(lmax, i);
             dup = vmnorm(savf) / tesco(nq, 3);
             exup = 1.0 / (double)(l + 1);
             rhup = 1.0 / (1.4 * pow(dup, exup) + 0.0000014);
@@ -587,7 +611,7 @@ struct Lsoda {
           break;
         }
         if (ialth > 1 || l == lmax) { endstoda(); break; }
-        for (int i = 0; i < N; ++i) yh[lmax][i] = acor[i];
+        _Pragma("unroll") for (int i = 0; i < N; ++i) YH(lmax, i) = acor[i];
         endstoda();
         break;
       }
@@ -624,10 +648,10 @@ struct Lsoda {
       }
       rh = 0.1;
       h *= rh;
-      for (int i = 0; i < N; ++i) y[i] = yh[1][i];
-      F::rhs(tn, y, savf, p);
+      _Pragma("unroll") for (int i = 0; i < N; ++i) y[i] = YH(1, i);
+      f.rhs(tn, y, savf);
       nfe++;
-      for (int i = 0; i < N; ++i) yh[2][i] = h * savf[i];
+      _Pragma("unroll") for (int i = 0; i < N; ++i) YH(2, i) = h * savf[i];
       ipup = miter;
       ialth = 5;
       if (nq == 1) continue;
@@ -639,14 +663,14 @@ struct Lsoda {
 
   // Integrate y0 from t0 to tout (istate = 1, itask = 1).  Returns 0 on success, a negative
   // ODEPACK-style code otherwise.  On success y0 holds y(tout).
-  KN_HDN int integrate(const LsodaCoef* coef, double* y0, double t0, double tout, double rtol_,
-                       double atol_, double* params, int mxstep) {
+  KN_HDN int integrate(const LsodaCoef* coef, double* work_, double* y0, double t0, double tout,
+                       double rtol_, double atol_, int mxstep) {
     cf = coef;
-    p = params;
+    work = work_;
     rtol = rtol_;
     atol = atol_;
     for (int j = 0; j < 15; ++j)
-      for (int i = 0; i < N; ++i) yh[j][i] = 0.0;
+      _Pragma("unroll") for (int i = 0; i < N; ++i) YH(j, i) = 0.0;
     tn = t0;
     tsw = t0;
     maxord = MXORDN;
@@ -654,10 +678,10 @@ struct Lsoda {
     nst = 0; nje = 0; nslp = 0;
     hu = 0.0; nqu = 0; mused = 0; miter = 0; meth = 1;
     nq = 1; l = 2;
-    for (int i = 0; i < N; ++i) y[i] = y0[i];
-    F::rhs(t0, y, yh[2], p);
+    _Pragma("unroll") for (int i = 0; i < N; ++i) y[i] = y0[i];
+    f.rhs(t0, y, savf);
     nfe = 1;
-    for (int i = 0; i < N; ++i) yh[1][i] = y[i];
+    _Pragma("unroll") for (int i = 0; i < N; ++i) { YH(1, i) = y[i]; YH(2, i) = savf[i]; }
     if (!ewset(y)) return -6;
     // initial step size (DLSODA block c)
     const double tdist = fabs(tout - t0);
@@ -665,26 +689,27 @@ struct Lsoda {
     if (tdist < 2.0 * KN_ETA * w0) return -3;
     double tol = rtol;
     if (tol <= 0.0) {
-      for (int i = 0; i < N; ++i) {
+      _Pragma("unroll") for (int i = 0; i < N; ++i) {
         const double ayi = fabs(y[i]);
         if (ayi != 0.0) tol = fmax(tol, atol / ayi);
       }
     }
     tol = fmax(tol, 100.0 * KN_ETA);
     tol = fmin(tol, 0.001);
-    double sum = vmnorm(yh[2]);
+    double sum = vmnorm_yh(2);
     sum = 1.0 / (tol * w0 * w0) + tol * sum * sum;
     double h0 = 1.0 / sqrt(sum);
     h0 = fmin(h0, tdist);
     h0 = (tout - t0) >= 0.0 ? h0 : -h0;
     h = h0;
-    for (int i = 0; i < N; ++i) yh[2][i] *= h0;
+    _Pragma("unroll") for (int i = 0; i < N; ++i) YH(2, i) *= h0;
     while (true) {
       if (nst > 0) {
-        if (!ewset(yh[1])) return -6;
+        _Pragma("unroll") for (int i = 0; i < N; ++i) y[i] = YH(1, i);
+        if (!ewset(y)) return -6;
       }
       if (nst >= mxstep) return -1;
-      double tolsf = KN_ETA * vmnorm(yh[1]);
+      double tolsf = KN_ETA * vmnorm_yh(1);
       if (tolsf > 0.01) return -2;
       stoda();
       if (kflag != 0) return kflag == -1 ? -4 : -5;
@@ -696,9 +721,9 @@ struct Lsoda {
       if ((tn - tout) * h < 0.0) continue;
       // intdy, k = 0
       const double s = (tout - tn) / h;
-      for (int i = 0; i < N; ++i) y0[i] = yh[l][i];
+      _Pragma("unroll") for (int i = 0; i < N; ++i) y0[i] = YH(l, i);
       for (int jj = l - 1; jj >= 1; --jj)
-        for (int i = 0; i < N; ++i) y0[i] = yh[jj][i] + s * y0[i];
+        _Pragma("unroll") for (int i = 0; i < N; ++i) y0[i] = YH(jj, i) + s * y0[i];
       return 0;
     }
   }

@@ -13,14 +13,34 @@
 
 #include "lsoda_core.h"
 
+// Each model is a functor.  `prepare(p)` reads the parameter row once (any indexable row: a plain
+// array on the host, a strided view of the transposed device table in the kernel) and caches what the
+// RHS needs, including the sub-expressions that depend on parameters only (Nernst potentials, pump
+// current); `rhs` is the cfunc body and keeps the side-effect currents in members; `finish(p)` stores
+// them into the parameter row, which is what the reference's in-place writes amount to after the
+// last call.
+template <int S>
+struct StridedRow {   // p[j] of dof q in a [column][dof] table: base + j * S
+  double* b;
+  size_t stride;
+  KN_HD double& operator[](int j) const { return b[(size_t)j * stride]; }
+};
 struct ModelHHSI {
   static constexpr int NS = 4, NP = 22;
-  KN_HD static void rhs(double t, const double* y, double* dy, double* p) {
-    const double m = y[0], h = y[1], n = y[2], V = y[3];
+  double E_Na, E_K, i_pump, gNa, gK, glNa, glK, Cm, stim;
+  mutable double I_Na, I_K;
+  template <class Row>
+  KN_HD void prepare(const Row& p) {
+    gNa = p[0]; gK = p[1]; glNa = p[2]; glK = p[3]; Cm = p[7]; stim = p[8];
     const double psi = p[21], zK = p[19];
     // both Nernst potentials use z_K, as the reference does (mm_hh.py:169-170)
-    const double E_Na = 1.0 / psi * 1.0 / zK * log(p[11] / p[12]);
-    const double E_K = 1.0 / psi * 1.0 / zK * log(p[9] / p[10]);
+    E_Na = 1.0 / psi * 1.0 / zK * log(p[11] / p[12]);
+    E_K = 1.0 / psi * 1.0 / zK * log(p[9] / p[10]);
+    const double a1 = 1 + p[4] / p[9], a2 = 1 + p[5] / p[12];
+    i_pump = p[6] / ((a1 * a1) * (a2 * a2 * a2));
+  }
+  KN_HD void rhs(double t, const double* y, double* dy) const {
+    const double m = y[0], h = y[1], n = y[2], V = y[3];
     const double u = 1.0e3 * (V + 65.0e-3);
     const double am = 0.1e3 * (25. - u) / (exp((25. - u) / 10.) - 1);
     const double bm = 4.e3 * exp(-u / 18.);
@@ -31,26 +51,33 @@ struct ModelHHSI {
     dy[0] = (1 - m) * am - m * bm;
     dy[1] = (1 - h) * ah - h * bh;
     dy[2] = (1 - n) * an - n * bn;
-    const double i_stim = p[8] * exp(-fmod(t, 0.03) / 0.002) * (t < 125e-3 ? 1.0 : 0.0);
-    const double a1 = 1 + p[4] / p[9], a2 = 1 + p[5] / p[12];
-    const double i_pump = p[6] / ((a1 * a1) * (a2 * a2 * a2));
-    const double i_Na = (p[2] + p[0] * h * (m * m * m) + i_stim) * (V - E_Na) + 3 * i_pump;
+    const double i_stim = stim * exp(-fmod(t, 0.03) / 0.002) * (t < 125e-3 ? 1.0 : 0.0);
+    const double i_Na = (glNa + gNa * h * (m * m * m) + i_stim) * (V - E_Na) + 3 * i_pump;
     const double n2 = n * n;
-    const double i_K = (p[3] + p[1] * (n2 * n2)) * (V - E_K) - 2 * i_pump;
-    p[15] = i_Na;
-    p[16] = i_K;
-    p[17] = 0.0;
-    dy[3] = (-i_K - i_Na) / p[7];
+    const double i_K = (glK + gK * (n2 * n2)) * (V - E_K) - 2 * i_pump;
+    I_Na = i_Na;
+    I_K = i_K;
+    dy[3] = (-i_K - i_Na) / Cm;
   }
+  template <class Row>
+  KN_HD void finish(const Row& p) const { p[15] = I_Na; p[16] = I_K; p[17] = 0.0; }
 };
 
 struct ModelHHMV {
   static constexpr int NS = 4, NP = 22;
-  KN_HD static void rhs(double t, const double* y, double* dy, double* p) {
-    const double m = y[0], h = y[1], n = y[2], V = y[3];
+  double E_Na, E_K, i_pump, gNa, gK, glNa, glK, Cm, stim;
+  mutable double I_Na, I_K;
+  template <class Row>
+  KN_HD void prepare(const Row& p) {
+    gNa = p[0]; gK = p[1]; glNa = p[2]; glK = p[3]; Cm = p[7]; stim = p[8];
     const double psi = p[21], zK = p[19];
-    const double E_Na = 1.0 / psi * 1.0 / zK * log(p[11] / p[12]);
-    const double E_K = 1.0 / psi * 1.0 / zK * log(p[9] / p[10]);
+    E_Na = 1.0 / psi * 1.0 / zK * log(p[11] / p[12]);
+    E_K = 1.0 / psi * 1.0 / zK * log(p[9] / p[10]);
+    const double a1 = 1 + p[4] / p[9], a2 = 1 + p[5] / p[12];
+    i_pump = p[6] / ((a1 * a1) * (a2 * a2 * a2));
+  }
+  KN_HD void rhs(double t, const double* y, double* dy) const {
+    const double m = y[0], h = y[1], n = y[2], V = y[3];
     const double u = V + 65.0;
     const double am = 0.1 * (25. - u) / (exp((25. - u) / 10.) - 1);
     const double bm = 4. * exp(-u / 18.);
@@ -61,45 +88,53 @@ struct ModelHHMV {
     dy[0] = (1 - m) * am - m * bm;
     dy[1] = (1 - h) * ah - h * bh;
     dy[2] = (1 - n) * an - n * bn;
-    const double i_stim = p[8] * exp(-fmod(t, 30.0) / 2.0) * (t < 125 ? 1.0 : 0.0);
-    const double a1 = 1 + p[4] / p[9], a2 = 1 + p[5] / p[12];
-    const double i_pump = p[6] / ((a1 * a1) * (a2 * a2 * a2));
-    const double i_Na = (p[2] + p[0] * h * (m * m * m) + i_stim) * (V - E_Na) + 3 * i_pump;
+    const double i_stim = stim * exp(-fmod(t, 30.0) / 2.0) * (t < 125 ? 1.0 : 0.0);
+    const double i_Na = (glNa + gNa * h * (m * m * m) + i_stim) * (V - E_Na) + 3 * i_pump;
     const double n2 = n * n;
-    const double i_K = (p[3] + p[1] * (n2 * n2)) * (V - E_K) - 2 * i_pump;
-    p[15] = i_Na;
-    p[16] = i_K;
-    p[17] = 0.0;
-    dy[3] = (-i_K - i_Na) / p[7];
+    const double i_K = (glK + gK * (n2 * n2)) * (V - E_K) - 2 * i_pump;
+    I_Na = i_Na;
+    I_K = i_K;
+    dy[3] = (-i_K - i_Na) / Cm;
   }
+  template <class Row>
+  KN_HD void finish(const Row& p) const { p[15] = I_Na; p[16] = I_K; p[17] = 0.0; }
 };
 
 struct ModelGlial {
   static constexpr int NS = 1, NP = 23;
-  KN_HD static void rhs(double t, const double* y, double* dy, double* p) {
-    (void)t;
-    const double V = y[0];
+  double E_Na, E_K, E_Cl, i_pump, gfac, glCl, glNa, glK, Cm;   // gfac = sqrt(K_e/K_e_init) * A * B
+  mutable double I_Na, I_K, I_Cl;
+  template <class Row>
+  KN_HD void prepare(const Row& p) {
+    glCl = p[0]; glNa = p[1]; glK = p[2]; Cm = p[3];
     const double psi = p[22], zK = p[20], zCl = p[21];
-    const double E_Na = 1.0 / psi * 1.0 / zK * log(p[15] / p[16]);
-    const double E_K = 1.0 / psi * 1.0 / zK * log(p[13] / p[14]);
-    const double E_Cl = 1.0 / psi * 1.0 / zCl * log(p[17] / p[18]);
+    E_Na = 1.0 / psi * 1.0 / zK * log(p[15] / p[16]);
+    E_K = 1.0 / psi * 1.0 / zK * log(p[13] / p[14]);
+    E_Cl = 1.0 / psi * 1.0 / zCl * log(p[17] / p[18]);
     const double temperature = 307e3, R = 8.315e3, F = 96500e3;  // hard-coded in mm_glial.py:168-170
     const double na15 = p[16] * sqrt(p[16]), mna15 = p[9] * sqrt(p[9]);
-    const double i_pump = p[10] * (p[13] / (p[13] + p[8])) * (na15 / (na15 + mna15));
+    i_pump = p[10] * (p[13] / (p[13] + p[8])) * (na15 / (na15 + mna15));
     const double E_K_init = R * temperature / F * log(p[11] / p[12]);
-    const double dphi = V - E_K;
     const double A = 1 + exp(18.5 / 42.4);
     const double B = 1 + exp(-(118.6 + E_K_init) / 44.1);
+    gfac = sqrt(p[13] / p[11]) * (A * B);
+  }
+  KN_HD void rhs(double t, const double* y, double* dy) const {
+    (void)t;
+    const double V = y[0];
+    const double dphi = V - E_K;
     const double C = 1 + exp((dphi + 18.5) / 42.4);
     const double D = 1 + exp(-(118.6 + V) / 44.1);
-    const double g_Kir = sqrt(p[13] / p[11]) * (A * B) / (C * D);
-    const double i_Kir = p[2] * g_Kir * (V - E_K);
-    const double i_Na = p[1] * (V - E_Na) + 3 * i_pump;
+    const double g_Kir = gfac / (C * D);
+    const double i_Kir = glK * g_Kir * (V - E_K);
+    const double i_Na = glNa * (V - E_Na) + 3 * i_pump;
     const double i_K = i_Kir - 2 * i_pump;
-    const double i_Cl = p[0] * (V - E_Cl);
-    p[5] = i_Na;
-    p[6] = i_K;
-    p[7] = i_Cl;
-    dy[0] = (-i_K - i_Na - i_Cl) / p[3];
+    const double i_Cl = glCl * (V - E_Cl);
+    I_Na = i_Na;
+    I_K = i_K;
+    I_Cl = i_Cl;
+    dy[0] = (-i_K - i_Na - i_Cl) / Cm;
   }
+  template <class Row>
+  KN_HD void finish(const Row& p) const { p[5] = I_Na; p[6] = I_K; p[7] = I_Cl; }
 };

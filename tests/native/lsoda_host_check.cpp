@@ -9,8 +9,10 @@ static bool g_init = false;
 template <class M>
 static int run(double* y, double* p, double t0, double t1, double rtol, double atol, int* stats) {
   Lsoda<M::NS, M> s;
-  int rc = s.integrate(&g_cf, y, t0, t1, rtol, atol, p, 10000);
-  // currents: whatever the last RHS call inside LSODA stored in p (the reference's semantic)
+  double work[Lsoda<M::NS, M>::WORK];
+  s.f.prepare(p);
+  int rc = s.integrate(&g_cf, work, y, t0, t1, rtol, atol, 10000);
+  s.f.finish(p);   // currents: whatever the last RHS call inside LSODA computed (the reference's semantic)
   if (stats) { stats[0] = s.nfe; stats[1] = s.nst; stats[2] = s.nje; stats[3] = s.mused; stats[4] = s.nqu; }
   return rc;
 }
@@ -25,9 +27,9 @@ extern "C" int lsoda_host(int model, double* y, double* p, double t0, double t1,
 }
 
 extern "C" void lsoda_host_rhs(int model, double t, const double* y, double* dy, double* p) {
-  if (model == 0) ModelHHSI::rhs(t, y, dy, p);
-  else if (model == 1) ModelHHMV::rhs(t, y, dy, p);
-  else ModelGlial::rhs(t, y, dy, p);
+  if (model == 0) { ModelHHSI m; m.prepare(p); m.rhs(t, y, dy); m.finish(p); }
+  else if (model == 1) { ModelHHMV m; m.prepare(p); m.rhs(t, y, dy); m.finish(p); }
+  else { ModelGlial m; m.prepare(p); m.rhs(t, y, dy); m.finish(p); }
 }
 
 extern "C" void lsoda_host_coef(double* elco, double* tesco) {
