@@ -216,47 +216,71 @@ __device__ __forceinline__ int slot_of(const uint32_t* sl, int j) {
 // ---------------------------------------------------------------------------------------------
 // EMI rows: A_emi, P_emi (= A + ICS mass) and b_emi in one pass, membrane coupling included.
 // ---------------------------------------------------------------------------------------------
-template <int GDIM, int NV>
-__global__ __launch_bounds__(KN_ROWS_PER_BLOCK) void emi_rows_kernel(KnDev D, const KnConsts* __restrict__ Cp, int lds_n,
-                                                                     int want_p, int splitting) {
+// LPR = lanes per row: the pairs of one row are dealt round-robin to LPR adjacent lanes, each lane
+// accumulating into its own LDS copy of the block's CSR segment; the copies are summed in a fixed
+// order in the epilogue (bit-reproducible, no atomics).  LPR > 1 shortens the per-thread dependent
+// gather chain and multiplies the number of waves on small meshes.
+template <int GDIM, int NV, int LPR>
+__global__ __launch_bounds__(KN_BLOCK) void emi_rows_kernel(KnDev D, const KnConsts* __restrict__ Cp, int lds_n,
+                                                            int want_p, int splitting) {
   constexpr int NF = (NV == 8) ? 4 : GDIM;
   constexpr int SW = (NV == 8) ? 2 : 1;
   const KnConsts& C = *Cp;
   extern __shared__ double lds[];
   double* segA = lds;
-  double* segP = lds + lds_n;
-  HexTab* T = reinterpret_cast<HexTab*>(lds + 2 * (size_t)lds_n);
+  double* segP = lds + (size_t)LPR * lds_n;
+  HexTab* T = reinterpret_cast<HexTab*>(lds + 2 * (size_t)LPR * lds_n);
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
   const int row0 = D.blk_row0[b], nrows = D.blk_nrows[b], s = D.blk_sub[b];
   const int seg0 = D.rowptr[row0], seglen = D.rowptr[row0 + nrows] - seg0;
-  for (int i = tid; i < seglen; i += KN_ROWS_PER_BLOCK) { segA[i] = 0.0; segP[i] = 0.0; }
+  for (int c = 0; c < LPR; ++c)
+    for (int i = tid; i < seglen; i += KN_BLOCK) { segA[c * lds_n + i] = 0.0; segP[c * lds_n + i] = 0.0; }
   if constexpr (NV == 8) stage_hex_tables(T);
   __syncthreads();
 
   const KnSubConst& sc = C.sc[s];
   const bool cell_side = s > 0;
-  if (tid < nrows) {
-    const int g = row0 + tid;
+  const int rloc = tid / LPR, sub = tid % LPR;
+  const bool valid = rloc < nrows;
+  const int g = row0 + (valid ? rloc : 0);
+  double bacc = 0.0;
+  if (valid) {
+    double* segA_own = segA;   // membrane terms go to copy 0
+    double* segP_own = segP;
+    (void)segA_own; (void)segP_own;
+    double* segA = lds + (size_t)sub * lds_n;
+    double* segP = lds + (size_t)(LPR + sub) * lds_n;
     const int rowbase = D.rowptr[g] - seg0;
     const int lap = rowbase + D.lapoff[g];
-    double bacc = 0.0;
     const int w = tid >> 6, lane = tid & 63;
     const int64_t base = D.sl_ptr[(size_t)b * 4 + w];
     const int np = (int)((D.sl_ptr[(size_t)b * 4 + w + 1] - base) >> 6);
+    Rec r[NV];
+    if constexpr (NV != 8) r[0] = load_rec(D.VR, g);   // the row's own vertex, once
     for (int p = 0; p < np; ++p) {
       const int64_t ent = base + (int64_t)p * KN_SLICE + lane;
-      const int pc = D.pair_cell[ent];
-      if (pc < 0) continue;
       uint32_t sl[SW];
+      int li = 0;
+      if constexpr (NV != 8) {
+        // simplex entry: the row's vertex is local vertex 0, the entry names the other NV-1
+        const int4 e = D.pair_ent[ent];
+        if (e.x < 0) continue;
+        r[1] = load_rec(D.VR, e.x);
+        r[2] = load_rec(D.VR, e.y);
+        if constexpr (NV == 4) r[3] = load_rec(D.VR, e.z);
+        sl[0] = (uint32_t)e.w;
+      } else {
+        const int pc = D.pair_cell[ent];
+        if (pc < 0) continue;
 #pragma unroll
-      for (int k = 0; k < SW; ++k) sl[k] = D.pair_slots[ent * SW + k];
-      const int li = pc & 7;
-      Rec r[NV];
-      load_cell<NV>(D, pc >> 3, r);
+        for (int k = 0; k < SW; ++k) sl[k] = D.pair_slots[ent * SW + k];
+        li = pc & 7;
+        load_cell<NV>(D, pc >> 3, r);
+      }
       if constexpr (NV != 8) {
         double d[NV];
-        const double vol = simplex_row<GDIM>(r, li, d);
+        const double vol = simplex_row<GDIM>(r, 0, d);
         double cb0 = 0, cb1 = 0, cb2 = 0, sd = 0;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -311,7 +335,7 @@ __global__ __launch_bounds__(KN_ROWS_PER_BLOCK) void emi_rows_kernel(KnDev D, co
       }
     }
     // membrane coupling C_phi (u_i - u_e)(v_i - v_e) and Robin RHS (emiWeakForm.py:160-165,228-239)
-    const int m = D.gam_idx[g];
+    const int m = sub == 0 ? D.gam_idx[g] : -1;
     if (m >= 0) {
       const int* fown = cell_side ? D.fi : D.fe;
       for (int e = D.mptr[m]; e < D.mptr[m + 1]; ++e) {
@@ -345,56 +369,81 @@ __global__ __launch_bounds__(KN_ROWS_PER_BLOCK) void emi_rows_kernel(KnDev D, co
         bacc += (cell_side ? 1.0 : -1.0) * C.C_phi * gs;
       }
     }
-    D.b_emi[g] = bacc;
   }
+#pragma unroll
+  for (int m = 1; m < LPR; m <<= 1) bacc += __shfl_xor(bacc, m);   // fixed-shape tree over the row's lanes
+  if (valid && sub == 0) D.b_emi[g] = bacc;
   __syncthreads();
-  for (int i = tid; i < seglen; i += KN_ROWS_PER_BLOCK) {
-    D.A_emi[seg0 + i] = segA[i];
-    if (want_p) D.P_emi[seg0 + i] = segP[i];
+  for (int i = tid; i < seglen; i += KN_BLOCK) {
+    double a = segA[i], p = segP[i];
+#pragma unroll
+    for (int c = 1; c < LPR; ++c) { a += segA[c * lds_n + i]; p += segP[c * lds_n + i]; }
+    D.A_emi[seg0 + i] = a;
+    if (want_p) D.P_emi[seg0 + i] = p;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // KNP rows: the K-1 diagonal blocks (mass/dt + diffusion + drift) and the volume part of b_knp.
 // ---------------------------------------------------------------------------------------------
-template <int GDIM, int NV>
-__global__ __launch_bounds__(KN_ROWS_PER_BLOCK) void knp_rows_kernel(KnDev D, const KnConsts* __restrict__ Cp, int lds_n) {
+template <int GDIM, int NV, int LPR>
+__global__ __launch_bounds__(KN_BLOCK) void knp_rows_kernel(KnDev D, const KnConsts* __restrict__ Cp, int lds_n) {
   const KnConsts& C = *Cp;
+  constexpr int NF = (NV == 8) ? 4 : GDIM;
   constexpr int SW = (NV == 8) ? 2 : 1;
   extern __shared__ double lds[];
   double* seg0k = lds;
-  double* seg1k = lds + lds_n;
-  HexTab* T = reinterpret_cast<HexTab*>(lds + 2 * (size_t)lds_n);
+  double* seg1k = lds + (size_t)LPR * lds_n;
+  HexTab* T = reinterpret_cast<HexTab*>(lds + 2 * (size_t)LPR * lds_n);
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
   const int row0 = D.blk_row0[b], nrows = D.blk_nrows[b], s = D.blk_sub[b];
   const int seg0 = D.rowptrL[row0], seglen = D.rowptrL[row0 + nrows] - seg0;
-  for (int i = tid; i < seglen; i += KN_ROWS_PER_BLOCK) { seg0k[i] = 0.0; seg1k[i] = 0.0; }
+  for (int c = 0; c < LPR; ++c)
+    for (int i = tid; i < seglen; i += KN_BLOCK) { seg0k[c * lds_n + i] = 0.0; seg1k[c * lds_n + i] = 0.0; }
   if constexpr (NV == 8) stage_hex_tables(T);
   __syncthreads();
 
   const KnSubConst& sc = C.sc[s];
   const int v0 = C.voff[s], nvs = C.voff[s + 1] - v0;
   const double* fs0 = (D.fsrc && s == 0) ? D.fsrc : nullptr;
-  if (tid < nrows) {
-    const int g = row0 + tid;
+  const int rloc = tid / LPR, sub = tid % LPR;
+  const bool valid = rloc < nrows;
+  const int g = row0 + (valid ? rloc : 0);
+  double b0 = 0.0, b1 = 0.0;
+  if (valid) {
+    double* seg0k = lds + (size_t)sub * lds_n;
+    double* seg1k = lds + (size_t)(LPR + sub) * lds_n;
     const int lap = D.rowptrL[g] - seg0;
-    double b0 = 0.0, b1 = 0.0;
     const int w = tid >> 6, lane = tid & 63;
     const int64_t base = D.sl_ptr[(size_t)b * 4 + w];
     const int np = (int)((D.sl_ptr[(size_t)b * 4 + w + 1] - base) >> 6);
+    Rec r[NV];
+    if constexpr (NV != 8) r[0] = load_rec(D.VR, g);
     for (int p = 0; p < np; ++p) {
       const int64_t ent = base + (int64_t)p * KN_SLICE + lane;
-      const int pc = D.pair_cell[ent];
-      if (pc < 0) continue;
       uint32_t sl[SW];
+      int li = 0;
+      int cv[NV];
+      if constexpr (NV != 8) {
+        const int4 e = D.pair_ent[ent];
+        if (e.x < 0) continue;
+        cv[0] = g; cv[1] = e.x; cv[2] = e.y;
+        r[1] = load_rec(D.VR, e.x);
+        r[2] = load_rec(D.VR, e.y);
+        if constexpr (NV == 4) { cv[3] = e.z; r[3] = load_rec(D.VR, e.z); }
+        sl[0] = (uint32_t)e.w;
+      } else {
+        const int pc = D.pair_cell[ent];
+        if (pc < 0) continue;
 #pragma unroll
-      for (int k = 0; k < SW; ++k) sl[k] = D.pair_slots[ent * SW + k];
-      const int li = pc & 7;
-      Rec r[NV];
-      load_cell<NV>(D, pc >> 3, r);
+        for (int k = 0; k < SW; ++k) sl[k] = D.pair_slots[ent * SW + k];
+        li = pc & 7;
+        load_cell<NV>(D, pc >> 3, r);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) cv[j] = D.cells[(size_t)(pc >> 3) * NV + j];
+      }
       double f0[NV], f1[NV];  // (1/dt) c_prev + f_source at the cell vertices
-      const int* cv = D.cells + (size_t)(pc >> 3) * NV;
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         f0[j] = r[j].c0 * C.inv_dt;
@@ -403,7 +452,7 @@ __global__ __launch_bounds__(KN_ROWS_PER_BLOCK) void knp_rows_kernel(KnDev D, co
       }
       if constexpr (NV != 8) {
         double d[NV];
-        const double vol = simplex_row<GDIM>(r, li, d);
+        const double vol = simplex_row<GDIM>(r, 0, d);
         double gp = 0;
 #pragma unroll
         for (int j = 0; j < NV; ++j) gp += r[j].phi * d[j];
@@ -453,6 +502,23 @@ __global__ __launch_bounds__(KN_ROWS_PER_BLOCK) void knp_rows_kernel(KnDev D, co
         }
       }
     }
+    // membrane Robin/coupling contributions, precomputed per (facet, side) by knp_membrane_kernel
+    const int m = sub == 0 ? D.gam_idx[g] : -1;
+    if (m >= 0) {
+      const int side = s > 0 ? 1 : 0;
+      for (int e = D.mptr[m]; e < D.mptr[m + 1]; ++e) {
+        const int ent = D.mentry[e];
+        const int fg = ent >> 3, a = ent & 7;
+        if (D.fmodel[fg] < 0) continue;
+        const double* cg = D.gam_contrib + ((size_t)(fg * 2 + side) * NF + a) * 2;
+        b0 += cg[0];
+        b1 += cg[1];
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < LPR; m <<= 1) { b0 += __shfl_xor(b0, m); b1 += __shfl_xor(b1, m); }
+  if (valid && sub == 0) {
     const size_t bb = (size_t)(KN_MAXK - 1) * v0 + (size_t)(g - v0);
     D.b_knp[bb] = b0;
     D.b_knp[bb + nvs] = b1;
@@ -461,13 +527,21 @@ __global__ __launch_bounds__(KN_ROWS_PER_BLOCK) void knp_rows_kernel(KnDev D, co
   const int64_t subnnz0 = D.rowptrL[v0], subnnz = D.rowptrL[v0 + nvs] - subnnz0;
   double* out0 = D.A_knp + (size_t)(KN_MAXK - 1) * subnnz0 + (seg0 - subnnz0);
   double* out1 = out0 + subnnz;
-  for (int i = tid; i < seglen; i += KN_ROWS_PER_BLOCK) { out0[i] = seg0k[i]; out1[i] = seg1k[i]; }
+  for (int i = tid; i < seglen; i += KN_BLOCK) {
+    double a0 = seg0k[i], a1 = seg1k[i];
+#pragma unroll
+    for (int c = 1; c < LPR; ++c) { a0 += seg0k[c * lds_n + i]; a1 += seg1k[c * lds_n + i]; }
+    out0[i] = a0;
+    out1[i] = a1;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
-// KNP membrane-facet kernel: the rational Robin/coupling integrand of knpWeakForm.py:168-214,
-// degree-6 quadrature, one thread per membrane row (ECS-side and cell-side copies), adding into
-// b_knp after the row kernel.  Quadrature tables are staged in LDS.
+// KNP membrane-facet kernel: the rational Robin/coupling integrand of knpWeakForm.py:168-214 with
+// degree-6 quadrature (tables staged in LDS).  One thread per (membrane facet, side): it evaluates the
+// integrand once per quadrature point and tests it against all NF facet basis functions, writing
+// NF x 2 (ions) partial integrals to `gam_contrib`; the row kernel adds them into b_knp in a fixed
+// order, so nothing is accumulated atomically.
 // ---------------------------------------------------------------------------------------------
 template <int NF>
 __global__ __launch_bounds__(256) void knp_membrane_kernel(KnDev D, const KnConsts* __restrict__ Cp, int splitting) {
@@ -480,89 +554,91 @@ __global__ __launch_bounds__(256) void knp_membrane_kernel(KnDev D, const KnCons
   const double* qw = qt;
   const double* qN = qt + nq;
   const double* qdN = qt + nq * (1 + NF);
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= D.M) return;
-  const int g = D.mrow[m];
-  int s = 0;
-  for (int t = 1; t < C.n_sub; ++t) s += g >= C.voff[t];
-  const bool cell_side = s > 0;
-  double acc0 = 0.0, acc1 = 0.0;
-  for (int e = D.mptr[m]; e < D.mptr[m + 1]; ++e) {
-    const int ent = D.mentry[e];
-    const int fg = ent >> 3, a = ent & 7;
-    const int ms = D.fmodel[fg];
-    if (ms < 0) continue;
-    Rec pe[NF], pi[NF];
-    double pm[NF], I0[NF], I1[NF], It[NF];
-    int si = 0;  // sub-domain of the cell side of this facet
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * D.nftot) return;
+  const int fg = t >> 1;
+  const bool cell_side = t & 1;
+  const int ms = D.fmodel[fg];
+  double* out = D.gam_contrib + (size_t)t * NF * 2;
+  if (ms < 0) {
+#pragma unroll
+    for (int i = 0; i < NF * 2; ++i) out[i] = 0.0;
+    return;
+  }
+  Rec pe[NF], pi[NF];
+  double pm[NF], I0[NF], I1[NF], It[NF];
+  int si = 0;  // sub-domain of the cell side of this facet
+#pragma unroll
+  for (int bb = 0; bb < NF; ++bb) {
+    const int vi = D.fi[(size_t)fg * NF + bb];
+    pe[bb] = load_rec(D.VR, D.fe[(size_t)fg * NF + bb]);
+    pi[bb] = load_rec(D.VR, vi);
+    const int q = D.fq[(size_t)fg * NF + bb];
+    pm[bb] = D.phiM[q];
+    const double* ich = D.Ich + (size_t)ms * KN_MAXK * D.NQtot + q;
+    I0[bb] = ich[0];
+    I1[bb] = ich[D.NQtot];
+    It[bb] = I0[bb] + I1[bb] + ich[2 * (size_t)D.NQtot];
+    if (bb == 0) for (int tt = 1; tt < C.n_sub; ++tt) si += vi >= C.voff[tt];
+  }
+  const KnSubConst& so = C.sc[cell_side ? si : 0];   // own-side constants
+  double meas = 0.0;
+  if constexpr (NF != 4) meas = facet_measure<NF>(pe);
+  double acc0[NF], acc1[NF];
+#pragma unroll
+  for (int a = 0; a < NF; ++a) { acc0[a] = 0.0; acc1[a] = 0.0; }
+  const double sgn = cell_side ? 1.0 : -1.0;
+  for (int q = 0; q < nq; ++q) {
+    double c0 = 0, c1 = 0, c2 = 0, ph_e = 0, ph_i = 0, pmq = 0, i0 = 0, i1 = 0, it = 0;
 #pragma unroll
     for (int bb = 0; bb < NF; ++bb) {
-      const int vi = D.fi[(size_t)fg * NF + bb];
-      pe[bb] = load_rec(D.VR, D.fe[(size_t)fg * NF + bb]);
-      pi[bb] = load_rec(D.VR, vi);
-      const int q = D.fq[(size_t)fg * NF + bb];
-      pm[bb] = D.phiM[q];
-      const double* ich = D.Ich + (size_t)ms * KN_MAXK * D.NQtot + q;
-      I0[bb] = ich[0];
-      I1[bb] = ich[D.NQtot];
-      It[bb] = I0[bb] + I1[bb] + ich[2 * (size_t)D.NQtot];
-      if (bb == 0) for (int t = 1; t < C.n_sub; ++t) si += vi >= C.voff[t];
+      const double N = qN[q * NF + bb];
+      const Rec& o = cell_side ? pi[bb] : pe[bb];
+      c0 += N * o.c0; c1 += N * o.c1; c2 += N * o.c2;
+      ph_e += N * pe[bb].phi; ph_i += N * pi[bb].phi;
+      pmq += N * pm[bb]; i0 += N * I0[bb]; i1 += N * I1[bb]; it += N * It[bb];
     }
-    const KnSubConst& se = C.sc[0];
-    const KnSubConst& sx = C.sc[si];
-    const KnSubConst& so = cell_side ? sx : se;   // own side constants
-    double meas = 0.0;
-    if constexpr (NF != 4) meas = facet_measure<NF>(pe);
-    for (int q = 0; q < nq; ++q) {
-      double c0 = 0, c1 = 0, c2 = 0, ph_e = 0, ph_i = 0, pmq = 0, i0 = 0, i1 = 0, it = 0;
+    double wq;
+    if constexpr (NF == 4) {
+      // surface Jacobian of the bilinear facet at this point
+      double ux = 0, uy = 0, uz = 0, vx = 0, vy = 0, vz = 0;
 #pragma unroll
-      for (int bb = 0; bb < NF; ++bb) {
-        const double N = qN[q * NF + bb];
-        const Rec& o = cell_side ? pi[bb] : pe[bb];
-        c0 += N * o.c0; c1 += N * o.c1; c2 += N * o.c2;
-        ph_e += N * pe[bb].phi; ph_i += N * pi[bb].phi;
-        pmq += N * pm[bb]; i0 += N * I0[bb]; i1 += N * I1[bb]; it += N * It[bb];
+      for (int bb = 0; bb < 4; ++bb) {
+        const double da = qdN[(q * 4 + bb) * 2], db = qdN[(q * 4 + bb) * 2 + 1];
+        ux += da * pe[bb].x; uy += da * pe[bb].y; uz += da * pe[bb].z;
+        vx += db * pe[bb].x; vy += db * pe[bb].y; vz += db * pe[bb].z;
       }
-      double wq;
-      if constexpr (NF == 4) {
-        // surface Jacobian of the bilinear facet at this point
-        double ux = 0, uy = 0, uz = 0, vx = 0, vy = 0, vz = 0;
+      const double nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+      wq = qw[q] * sqrt(nx * nx + ny * ny + nz * nz);
+    } else {
+      wq = qw[q] * meas * (NF == 2 ? 1.0 : 2.0);  // reference measure 1 (interval), 1/2 (triangle)
+    }
+    const double asum = so.az2D[0] * c0 + so.az2D[1] * c1 + so.az2D[2] * c2;
+    const double jump = ph_i - ph_e;
+    double f0, f1;
+    {
+      const double al = so.az2D[0] * c0 / asum;
+      const double Cc = al * C.C_M / (C.F * C.z[0] * C.dt);
+      double gr = pmq - C.dt / (C.C_M * al) * i0;
+      if (splitting) gr += (C.dt / C.C_M) * it;
+      f0 = wq * sgn * (Cc * gr - Cc * jump);
+    }
+    {
+      const double al = so.az2D[1] * c1 / asum;
+      const double Cc = al * C.C_M / (C.F * C.z[1] * C.dt);
+      double gr = pmq - C.dt / (C.C_M * al) * i1;
+      if (splitting) gr += (C.dt / C.C_M) * it;
+      f1 = wq * sgn * (Cc * gr - Cc * jump);
+    }
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-          const double da = qdN[(q * 4 + bb) * 2], db = qdN[(q * 4 + bb) * 2 + 1];
-          ux += da * pe[bb].x; uy += da * pe[bb].y; uz += da * pe[bb].z;
-          vx += db * pe[bb].x; vy += db * pe[bb].y; vz += db * pe[bb].z;
-        }
-        const double nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
-        wq = qw[q] * sqrt(nx * nx + ny * ny + nz * nz);
-      } else {
-        wq = qw[q] * meas * (NF == 2 ? 1.0 : 2.0);  // reference measure 1 (interval), 1/2 (triangle)
-      }
+    for (int a = 0; a < NF; ++a) {
       const double Na = qN[q * NF + a];
-      const double asum = so.az2D[0] * c0 + so.az2D[1] * c1 + so.az2D[2] * c2;
-      const double jump = ph_i - ph_e;
-      const double sgn = cell_side ? 1.0 : -1.0;
-      // ion 0
-      {
-        const double al = so.az2D[0] * c0 / asum;
-        const double Cc = al * C.C_M / (C.F * C.z[0] * C.dt);
-        double gr = pmq - C.dt / (C.C_M * al) * i0;
-        if (splitting) gr += (C.dt / C.C_M) * it;
-        acc0 += wq * Na * sgn * (Cc * gr - Cc * jump);
-      }
-      {
-        const double al = so.az2D[1] * c1 / asum;
-        const double Cc = al * C.C_M / (C.F * C.z[1] * C.dt);
-        double gr = pmq - C.dt / (C.C_M * al) * i1;
-        if (splitting) gr += (C.dt / C.C_M) * it;
-        acc1 += wq * Na * sgn * (Cc * gr - Cc * jump);
-      }
+      acc0[a] += Na * f0;
+      acc1[a] += Na * f1;
     }
   }
-  const int v0 = C.voff[s], nvs = C.voff[s + 1] - v0;
-  const size_t bb = (size_t)(KN_MAXK - 1) * v0 + (size_t)(g - v0);
-  D.b_knp[bb] += acc0;
-  D.b_knp[bb + nvs] += acc1;
+#pragma unroll
+  for (int a = 0; a < NF; ++a) { out[2 * a] = acc0[a]; out[2 * a + 1] = acc1[a]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -659,31 +735,54 @@ int set_lds_limit(K kernel, size_t bytes) {
 
 }  // namespace
 
+template <int GDIM, int NV>
+static int launch_emi(knpemi_handle* h, size_t lds, int lds_n, int want_p, int split) {
+  const KnDev& D = h->dev;
+  dim3 grid(D.nblocks), block(KN_BLOCK);
+  int rc = 0;
+#define KN_CASE(L)                                                                                   \
+  case L:                                                                                            \
+    if ((rc = set_lds_limit(emi_rows_kernel<GDIM, NV, L>, lds))) return rc;                          \
+    {                                                                                                \
+      KnProfScope prof(h, KNPEMI_K_EMI_ROWS);                                                        \
+      hipLaunchKernelGGL((emi_rows_kernel<GDIM, NV, L>), grid, block, lds, h->stream, D, h->d_consts, \
+                         lds_n, want_p, split);                                                      \
+    }                                                                                                \
+    break;
+  switch (h->lpr) { KN_CASE(1) KN_CASE(2) KN_CASE(4) KN_CASE(8) default: kn_set_error("bad lanes-per-row"); return KNPEMI_EINVAL; }
+#undef KN_CASE
+  return check_launch("emi_rows_kernel");
+}
+
+template <int GDIM, int NV>
+static int launch_knp(knpemi_handle* h, size_t lds, int lds_n) {
+  const KnDev& D = h->dev;
+  dim3 grid(D.nblocks), block(KN_BLOCK);
+  int rc = 0;
+#define KN_CASE(L)                                                                                   \
+  case L:                                                                                            \
+    if ((rc = set_lds_limit(knp_rows_kernel<GDIM, NV, L>, lds))) return rc;                          \
+    {                                                                                                \
+      KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                        \
+      hipLaunchKernelGGL((knp_rows_kernel<GDIM, NV, L>), grid, block, lds, h->stream, D, h->d_consts, \
+                         lds_n);                                                                     \
+    }                                                                                                \
+    break;
+  switch (h->lpr) { KN_CASE(1) KN_CASE(2) KN_CASE(4) KN_CASE(8) default: kn_set_error("bad lanes-per-row"); return KNPEMI_EINVAL; }
+#undef KN_CASE
+  return check_launch("knp_rows_kernel");
+}
+
 int kn_launch_emi_rows(knpemi_handle* h, int flags) {
   const KnDev& D = h->dev;
   if (D.nblocks == 0) return KNPEMI_OK;
   const int lds_n = h->lds_doubles_emi;
-  size_t lds = (size_t)2 * lds_n * sizeof(double) + (h->NV == 8 ? sizeof(HexTab) : 0);
+  const size_t lds = (size_t)2 * h->lpr * lds_n * sizeof(double) + (h->NV == 8 ? sizeof(HexTab) : 0);
   if (lds > 160 * 1024) { kn_set_error("EMI row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   const int want_p = (flags & KNPEMI_WANT_P) ? 1 : 0, split = (flags & KNPEMI_NO_SPLITTING) ? 0 : 1;
-  dim3 grid(D.nblocks), block(KN_ROWS_PER_BLOCK);
-  int rc;
-  if (h->cell_kind == KNPEMI_TRIANGLE) rc = set_lds_limit(emi_rows_kernel<2, 3>, lds);
-  else if (h->cell_kind == KNPEMI_TETRAHEDRON) rc = set_lds_limit(emi_rows_kernel<3, 4>, lds);
-  else rc = set_lds_limit(emi_rows_kernel<3, 8>, lds);
-  if (rc) return rc;
-  KnProfScope prof(h, KNPEMI_K_EMI_ROWS);
-  if (h->cell_kind == KNPEMI_TRIANGLE) {
-    if ((rc = set_lds_limit(emi_rows_kernel<2, 3>, lds))) return rc;
-    hipLaunchKernelGGL((emi_rows_kernel<2, 3>), grid, block, lds, h->stream, D, h->d_consts, lds_n, want_p, split);
-  } else if (h->cell_kind == KNPEMI_TETRAHEDRON) {
-    if ((rc = set_lds_limit(emi_rows_kernel<3, 4>, lds))) return rc;
-    hipLaunchKernelGGL((emi_rows_kernel<3, 4>), grid, block, lds, h->stream, D, h->d_consts, lds_n, want_p, split);
-  } else {
-    if ((rc = set_lds_limit(emi_rows_kernel<3, 8>, lds))) return rc;
-    hipLaunchKernelGGL((emi_rows_kernel<3, 8>), grid, block, lds, h->stream, D, h->d_consts, lds_n, want_p, split);
-  }
-  return check_launch("emi_rows_kernel");
+  if (h->cell_kind == KNPEMI_TRIANGLE) return launch_emi<2, 3>(h, lds, lds_n, want_p, split);
+  if (h->cell_kind == KNPEMI_TETRAHEDRON) return launch_emi<3, 4>(h, lds, lds_n, want_p, split);
+  return launch_emi<3, 8>(h, lds, lds_n, want_p, split);
 }
 
 int kn_launch_knp_rows(knpemi_handle* h, int flags) {
@@ -691,31 +790,20 @@ int kn_launch_knp_rows(knpemi_handle* h, int flags) {
   const KnDev& D = h->dev;
   if (D.nblocks == 0) return KNPEMI_OK;
   const int lds_n = h->lds_doubles_knp;
-  size_t lds = (size_t)2 * lds_n * sizeof(double) + (h->NV == 8 ? sizeof(HexTab) : 0);
+  const size_t lds = (size_t)2 * h->lpr * lds_n * sizeof(double) + (h->NV == 8 ? sizeof(HexTab) : 0);
   if (lds > 160 * 1024) { kn_set_error("KNP row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
-  dim3 grid(D.nblocks), block(KN_ROWS_PER_BLOCK);
-  int rc;
-  KnProfScope prof(h, KNPEMI_K_KNP_ROWS);
-  if (h->cell_kind == KNPEMI_TRIANGLE) {
-    if ((rc = set_lds_limit(knp_rows_kernel<2, 3>, lds))) return rc;
-    hipLaunchKernelGGL((knp_rows_kernel<2, 3>), grid, block, lds, h->stream, D, h->d_consts, lds_n);
-  } else if (h->cell_kind == KNPEMI_TETRAHEDRON) {
-    if ((rc = set_lds_limit(knp_rows_kernel<3, 4>, lds))) return rc;
-    hipLaunchKernelGGL((knp_rows_kernel<3, 4>), grid, block, lds, h->stream, D, h->d_consts, lds_n);
-  } else {
-    if ((rc = set_lds_limit(knp_rows_kernel<3, 8>, lds))) return rc;
-    hipLaunchKernelGGL((knp_rows_kernel<3, 8>), grid, block, lds, h->stream, D, h->d_consts, lds_n);
-  }
-  return check_launch("knp_rows_kernel");
+  if (h->cell_kind == KNPEMI_TRIANGLE) return launch_knp<2, 3>(h, lds, lds_n);
+  if (h->cell_kind == KNPEMI_TETRAHEDRON) return launch_knp<3, 4>(h, lds, lds_n);
+  return launch_knp<3, 8>(h, lds, lds_n);
 }
 
 int kn_launch_knp_membrane(knpemi_handle* h, int flags) {
   const KnDev& D = h->dev;
-  if (D.M == 0) return KNPEMI_OK;
+  if (D.nftot == 0) return KNPEMI_OK;
   const int split = (flags & KNPEMI_NO_SPLITTING) ? 0 : 1;
   const int NF = h->NF;
   const size_t lds = (size_t)D.nq_gamma * (1 + NF + (NF == 4 ? 2 * NF : 0)) * sizeof(double);
-  dim3 grid((D.M + 255) / 256), block(256);
+  dim3 grid((2 * D.nftot + 255) / 256), block(256);
   KnProfScope prof(h, KNPEMI_K_KNP_MEMBRANE);
   if (NF == 2) hipLaunchKernelGGL((knp_membrane_kernel<2>), grid, block, lds, h->stream, D, h->d_consts, split);
   else if (NF == 3) hipLaunchKernelGGL((knp_membrane_kernel<3>), grid, block, lds, h->stream, D, h->d_consts, split);

@@ -5,6 +5,7 @@
 // (src/knpemi/pdeSolver.py:46-66,121-139: sparsity patterns, dof maps, entity maps) and inside
 // scifem.compute_interface_data (src/knpemi/emiWeakForm.py:39-42).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -255,36 +256,64 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
     }
   }
 
+  // ---- lanes per row: enough workgroups to fill 256 CUs several times over on small meshes --------
+  {
+    int lpr = 1;
+    while (lpr < 8 && (int64_t)Ntot * lpr < (int64_t)1024 * KN_BLOCK) lpr *= 2;
+    if (const char* env = getenv("KNPEMI_LPR")) {
+      int v = atoi(env);
+      if (v == 1 || v == 2 || v == 4 || v == 8) lpr = v;
+    }
+    h->lpr = lpr;
+  }
+  const int LPR = h->lpr, RPB = KN_BLOCK / LPR, RPS = KN_SLICE / LPR;
+
   // ---- row blocks (never straddle a sub-domain) and sliced ELL of (row, cell) pairs ----------------
   std::vector<int> blk_row0, blk_nrows, blk_sub;
   for (int s = 0; s < S; ++s)
-    for (int r0 = h->voff[s]; r0 < h->voff[s + 1]; r0 += KN_ROWS_PER_BLOCK) {
+    for (int r0 = h->voff[s]; r0 < h->voff[s + 1]; r0 += RPB) {
       blk_row0.push_back(r0);
-      blk_nrows.push_back(std::min(KN_ROWS_PER_BLOCK, h->voff[s + 1] - r0));
+      blk_nrows.push_back(std::min(RPB, h->voff[s + 1] - r0));
       blk_sub.push_back(s);
     }
   const int nblocks = (int)blk_row0.size();
-  const int SPB = KN_ROWS_PER_BLOCK / KN_SLICE;  // slices per block
+  const int SPB = KN_BLOCK / KN_SLICE;  // slices (wavefronts) per block
   const int SW = NV == 8 ? 2 : 1;
   std::vector<int64_t> sl_ptr((size_t)nblocks * SPB + 1, 0);
   for (int b = 0; b < nblocks; ++b)
     for (int w = 0; w < SPB; ++w) {
       int64_t mx = 0;
-      int ga = blk_row0[b] + w * KN_SLICE, gb = std::min(blk_row0[b] + blk_nrows[b], ga + KN_SLICE);
-      for (int g = ga; g < gb; ++g) mx = std::max(mx, v2c_ptr[g + 1] - v2c_ptr[g]);
+      int ga = blk_row0[b] + w * RPS, gb = std::min(blk_row0[b] + blk_nrows[b], ga + RPS);
+      for (int g = ga; g < gb; ++g) mx = std::max(mx, (v2c_ptr[g + 1] - v2c_ptr[g] + LPR - 1) / LPR);
       sl_ptr[(size_t)b * SPB + w + 1] = sl_ptr[(size_t)b * SPB + w] + mx * KN_SLICE;
     }
-  std::vector<int> pair_cell((size_t)sl_ptr.back(), -1);
-  std::vector<uint32_t> pair_slots((size_t)sl_ptr.back() * SW, 0);
+  const bool simplex = NV != 8;
+  std::vector<int> pair_cell(simplex ? 0 : (size_t)sl_ptr.back(), -1);
+  std::vector<uint32_t> pair_slots(simplex ? 0 : (size_t)sl_ptr.back() * SW, 0);
+  std::vector<int> pair_ent(simplex ? (size_t)sl_ptr.back() * 4 : 0, -1);
   for (int b = 0; b < nblocks; ++b)
     for (int t = 0; t < blk_nrows[b]; ++t) {
-      const int g = blk_row0[b] + t, w = t / KN_SLICE, lane = t % KN_SLICE;
+      const int g = blk_row0[b] + t, w = t / RPS, rs = t % RPS;
       const int* rb = &colindL[rowptrL[g]];
       const int* re = &colindL[rowptrL[g + 1]];
       for (int64_t p = v2c_ptr[g]; p < v2c_ptr[g + 1]; ++p) {
-        size_t ent = (size_t)sl_ptr[(size_t)b * SPB + w] + (size_t)(p - v2c_ptr[g]) * KN_SLICE + lane;
-        pair_cell[ent] = v2c[p];
+        const int64_t pi = p - v2c_ptr[g];
+        const int lane = rs * LPR + (int)(pi % LPR);
+        size_t ent = (size_t)sl_ptr[(size_t)b * SPB + w] + (size_t)(pi / LPR) * KN_SLICE + lane;
         const int* cv = &cells[(size_t)(v2c[p] >> 3) * NV];
+        if (simplex) {
+          const int li = v2c[p] & 7;
+          uint32_t slots = 0;
+          for (int j = 0; j < NV; ++j) {
+            const int v = cv[(li + j) % NV];   // j = 0 is the row's own vertex
+            slots |= (uint32_t)(std::lower_bound(rb, re, v) - rb) << (8 * j);
+            if (j > 0) pair_ent[ent * 4 + (j - 1)] = v;
+          }
+          if (NV == 3) pair_ent[ent * 4 + 2] = 0;
+          pair_ent[ent * 4 + 3] = (int)slots;
+          continue;
+        }
+        pair_cell[ent] = v2c[p];
         for (int j = 0; j < NV; ++j) {
           uint32_t slot = (uint32_t)(std::lower_bound(rb, re, cv[j]) - rb);
           pair_slots[ent * SW + (j >> 2)] |= slot << (8 * (j & 3));
@@ -340,6 +369,11 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   if ((rc = dev_upload(h, blk_nrows, &D.blk_nrows))) return rc;
   if ((rc = dev_upload(h, blk_sub, &D.blk_sub))) return rc;
   if ((rc = dev_upload(h, sl_ptr, &D.sl_ptr))) return rc;
+  {
+    const int* pe = nullptr;
+    if ((rc = dev_upload(h, pair_ent, &pe))) return rc;
+    D.pair_ent = reinterpret_cast<const int4*>(pe);
+  }
   if ((rc = dev_upload(h, pair_cell, &D.pair_cell))) return rc;
   if ((rc = dev_upload(h, pair_slots, &D.pair_slots))) return rc;
   if ((rc = dev_upload(h, rowptr, &D.rowptr))) return rc;
@@ -366,6 +400,7 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   if ((rc = dev_zeros(h, (size_t)(K - 1) * D.nnzL, &D.A_knp))) return rc;
   if ((rc = dev_zeros(h, (size_t)(K - 1) * Ntot, &D.b_knp))) return rc;
   if ((rc = dev_zeros(h, (size_t)NQtot, &D.phiM))) return rc;
+  if ((rc = dev_zeros(h, (size_t)std::max(1, nftot) * 2 * NF * 2, &D.gam_contrib))) return rc;
   if ((rc = dev_zeros(h, (size_t)std::max(1, h->moff[S]) * K * std::max(1, NQtot), &D.Ich))) return rc;
   h->stage_len = (size_t)std::max(Ntot, 1) * (K - 1) + 2 * (size_t)std::max(NQtot, 1);
   if ((rc = dev_zeros(h, h->stage_len, &h->d_stage))) return rc;
@@ -560,9 +595,9 @@ extern "C" int knpemi_assemble_knp(knpemi_handle* h, int flags) {
   if (!h) return fail(KNPEMI_EINVAL, "null handle");
   if (!h->have_params) return fail(KNPEMI_EINVAL, "knpemi_assemble_knp: knpemi_set_params not called");
   KN_HIP(hipSetDevice(h->device));
-  int rc = kn_launch_knp_rows(h, flags);
+  int rc = kn_launch_knp_membrane(h, flags);   // partial integrals first, the row kernel adds them
   if (rc) return rc;
-  return kn_launch_knp_membrane(h, flags);
+  return kn_launch_knp_rows(h, flags);
 }
 
 extern "C" int knpemi_csr_dims(knpemi_handle* h, int which, int64_t* n_rows, int64_t* nnz) {

@@ -14,7 +14,7 @@
 #define KN_MAXK KNPEMI_MAX_IONS
 #define KN_MAXSUB KNPEMI_MAX_SUB
 #define KN_REC 8          // doubles per vertex record: x y z _ | c0 c1 c_elim phi
-#define KN_ROWS_PER_BLOCK 256
+#define KN_BLOCK 256          // threads per row-kernel workgroup (rows per block = KN_BLOCK / lanes-per-row)
 #define KN_SLICE 64       // rows per sliced-ELL slice == wavefront width on gfx950
 
 // Per-sub-domain constants folded on the host from knpemi_params (double arithmetic identical
@@ -44,17 +44,21 @@ struct KnDev {
   int Ntot, nctot, NQtot, nftot;
   int nblocks;                // row blocks; a block never straddles two sub-domains
   const int* blk_row0;        // [nblocks] first global row of the block
-  const int* blk_nrows;       // [nblocks] rows in the block (<= KN_ROWS_PER_BLOCK)
+  const int* blk_nrows;       // [nblocks] rows in the block (<= KN_BLOCK / lpr)
   const int* blk_sub;         // [nblocks] sub-domain of the block
   double* VR;                 // [Ntot][KN_REC]
   double* csol;               // [K-1][Ntot]  solver output c (block order handled by offsets)
   double* fsrc;               // [K-1][N_0] optional ECS source term (NULL when unused)
   const int* cells;           // [nctot][NV] global vertex ids
   // sliced ELL of (row, incident cell) pairs
-  const int64_t* sl_ptr;      // [4*nblocks+1] entry offsets (multiples of KN_SLICE); slice
-                              // 4*b + w holds rows blk_row0[b] + 64*w .. of block b
-  const int* pair_cell;       // cell*8 + local index, -1 = padding
-  const uint32_t* pair_slots; // NV<=4: 4 x uint8 slots; hex: two consecutive words per entry
+  const int64_t* sl_ptr;      // [4*nblocks+1] entry offsets (multiples of KN_SLICE); slice 4*b + w
+                              // holds the 64/lpr rows blk_row0[b] + (64/lpr)*w .. of block b; lane
+                              // r*lpr + j of step p reads pair p*lpr + j of row r of the slice
+  const int4* pair_ent;       // simplices: {v1, v2, v3, slots}: the other vertices of the incident cell
+                              // (the row's vertex is local vertex 0) and 4 x uint8 row-relative CSR
+                              // slots (byte 0 = diagonal); x = -1 marks padding
+  const int* pair_cell;       // hexahedra: cell*8 + local index, -1 = padding
+  const uint32_t* pair_slots; // hexahedra: 8 x uint8 slots in two consecutive words per entry
   // EMI CSR (monolithic) and Laplacian-pattern CSR (KNP blocks share it per sub-domain)
   const int* rowptr; const int* colind; const uint8_t* lapoff;
   const int* rowptrL; const int* colindL;
@@ -70,6 +74,7 @@ struct KnDev {
   const int* fe; const int* fi; const int* fq;   // [nftot][NF] global ids
   const int* fmodel;          // [nftot] global model slot or -1
   const int* q2e; const int* q2i;                // [NQtot] global vertex ids
+  double* gam_contrib;        // [nftot][2 sides][NF][2 ions] membrane partial integrals of b_knp
   double* phiM;               // [NQtot]
   double* Ich;                // [n_model_slots][K][stride NQtot] (indexed by global q)
   int M;
@@ -101,6 +106,7 @@ struct knpemi_handle {
   const void* d_lsoda_coef = nullptr;  // LsodaCoef tables (kernels_ode.hip)
   KnDev dev{};
   int have_params = 0;
+  int lpr = 1;                         // lanes per row of the row kernels (1, 2, 4 or 8)
   int lds_doubles_emi = 0, lds_doubles_knp = 0; // per-block LDS segment sizes (doubles)
   std::vector<void*> allocs;  // everything hipMalloc'ed
   std::vector<KnOdeModel> ode; // [moff[n_sub]]
