@@ -210,3 +210,50 @@ def test_device_stepper_matches_dropin_path(hip_lib):
         res.append((ode.states.copy(), s.phi_M_prev[1].x._a.copy(), s.c_prev[1][0].x._a.copy(), b_emi, b_knp))
     for a, b in zip(*res):
         assert np.array_equal(a, b)
+
+
+def test_ten_time_steps_2d_match_oracle(hip_lib):
+    """BASELINE configs[0]: 2D idealized mesh, 3 ions + HH, 10 time steps.  The whole loop of
+    run_2D.py:341-372 through the knpemi API (GPU assembly + ODE sweep, direct host solves) against the
+    oracle loop (oracle/driver.py)."""
+    import adapters
+    import driver
+    from knpemi import update_ode_variables, update_pde_variables
+    from knpemi.pdeSolver import create_solver_emi, create_solver_knp
+    s = Setup("2d", 1, g_syn=10.0)
+    o, P, params, ions = s.oracle()
+    c_all, _, _, _ = s.oracle_fields()
+    ode = s.mem_models[0]['ode']
+    mask = np.array([x[0] < 20e-6 for x in ode.dof_locations])
+    run = driver.OracleRun(P, params, ions, "hh_si", c_all, ode.states.copy(), ode.parameters.copy(),
+                           ode.dof_locations, mask, {o.MODELS["hh_si"]["pidx"]["stim_amplitude"]: 10.0},
+                           {'z': -1, 0: 0.0, 1: 0.0})
+    emi = create_solver_emi(s.a_emi, s.L_emi, s.phi, s.entity_maps, s.subdomain_list, None, direct=True, p=s.p_emi)
+    knp = create_solver_knp(s.a_knp, s.L_knp, s.c, s.entity_maps, s.subdomain_list, None, direct=True, p=s.p_knp)
+    for k in range(10):
+        update_ode_variables(ode, s.c_prev, s.phi_M_prev[1], s.ion_list, s.subdomain_list, s.mesh, s.ct, 1, k)
+        ode.step_lsoda(s.dt, s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
+        ode.get_membrane_potential(s.phi_M_prev[1])
+        for ion, f in s.mem_models[0]['I_ch_k'].items():
+            ode.get_parameter("I_ch_" + ion, f)
+        emi.solve()
+        knp.solve()
+        update_pde_variables(s.c, s.c_prev, s.phi, s.phi_M_prev, s.physical_parameters, s.ion_list,
+                             s.subdomain_list, s.mesh, s.ct)
+        run.step()
+    # potentials are defined up to a common constant: compare phi_M and the zero-mean potential
+    assert rel_err(s.phi_M_prev[1].x._a, run.phiM[1]) < 1e-8
+    x_gpu = np.concatenate([s.phi[0].x._a, s.phi[1].x._a])
+    x_ref = np.concatenate([run.phi[0], run.phi[1]])
+    assert rel_err(x_gpu - x_gpu.mean(), x_ref - x_ref.mean()) < 1e-8
+    for t in (0, 1):
+        for k in range(3):
+            ref = run.c_all[t][k]
+            got = s.c_prev[t][k].x._a if k < 2 else s.ion_list[-1][f'c_{t}'].x._a
+            assert rel_err(got, ref) < 1e-10
+    assert rel_err(ode.states, run.states) < 1e-8
+    # physics sanity: the synaptic stimulus (x < 20 um) has depolarised the (electrotonically compact)
+    # cell by more than 10 mV, slightly more at the stimulated end
+    x = ode.dof_locations[:, 0]
+    v = s.phi_M_prev[1].x._a
+    assert v.mean() > -0.0744 + 0.010 and v[x < 15e-6].mean() > v[x > 40e-6].mean()
