@@ -100,6 +100,7 @@ class LinearProblem:
         self.P = None
         self.b = None
         self.nullspace = None
+        self._b_mms = None
 
     # -- assembly on the GPU ---------------------------------------------------------
     def assemble(self):
@@ -114,6 +115,11 @@ class LinearProblem:
             self.A = dp.csr(L.A_EMI)
             self.P = dp.csr(L.P_EMI) if want_p else None
             self.b = dp.rhs(L.B_EMI)
+            if f.mms is not None:   # manufactured sources (host scaffolding, knpemi/mms.py)
+                if self._b_mms is None:
+                    from .mms import emi_mms_rhs
+                    self._b_mms = emi_mms_rhs(f)
+                self.b = self.b + self._b_mms
         else:
             for tag in f.subdomain_list:
                 dp.push(L.F_PHI, dp.sub_index[tag], 0, f.phi[tag])

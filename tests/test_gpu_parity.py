@@ -257,3 +257,47 @@ def test_ten_time_steps_2d_match_oracle(hip_lib):
     x = ode.dof_locations[:, 0]
     v = s.phi_M_prev[1].x._a
     assert v.mean() > -0.0744 + 0.010 and v[x < 15e-6].mean() > v[x > 40e-6].mean()
+
+
+def test_mms_emi_convergence(hip_lib):
+    """BASELINE configs[3]: manufactured solution of tests/run_mms_emi.py on the unit square with
+    ICS = [0.25, 0.75]^2; GPU-assembled operator + diffusive RHS, L2 errors must converge at rate ~2
+    (the reference only prints them)."""
+    import contextlib
+    import io
+    from knpemi import create_functions_emi, create_functions_knp, emi_system, set_initial_conditions
+    from knpemi.fem import Constant, extract_submesh, make_mesh_mms
+    from knpemi.mms import l2_error
+    from knpemi.pdeSolver import create_solver_emi
+    from mms_problem import CONC, MMS, MMSMembraneModel
+    errs = []
+    for M in (16, 32, 64):
+        mesh, ct, ft = make_mesh_mms(M)
+        s1, i2p, iv2p, _, _ = extract_submesh(mesh, ct, 1)
+        s0, e2p, ev2p, _, _ = extract_submesh(mesh, ct, 0)
+        g, g2p, gv2p, _, _ = extract_submesh(mesh, ft, 1)
+        subs = {0: dict(name="ECS", mesh_sub=s0, sub_to_parent=e2p, sub_vertex_to_parent=ev2p),
+                1: dict(name="neuron", mesh_sub=s1, sub_to_parent=i2p, sub_vertex_to_parent=iv2p, mesh_mem=g,
+                        mem_to_parent=g2p)}
+        one = lambda m: Constant(m, 1.0)
+        pp = {'dt': one(mesh), 'F': one(mesh), 'psi': one(mesh), 'C_phi': one(mesh), 'C_M': one(mesh),
+              'R': one(mesh), 'temperature': one(mesh), 'rho': {0: Constant(s0, 0.0), 1: Constant(s1, 0.0)}}
+        ions = [dict(z=zz, name=n, D={0: one(s0), 1: one(s1)}) for n, zz in (("a", 1.0), ("b", -1.0), ("c", 1.0))]
+        phi, phi_M_prev = create_functions_emi(subs, degree=1)
+        c, c_prev = create_functions_knp(subs, ions, degree=1)
+        for ion in ions:
+            fe, fi = CONC[ion['name']]
+            ion['c_init'] = {0: fe(s0.x.T), 1: fi(s1.x.T)}
+        set_initial_conditions(ions, subs, c_prev)
+        mm = MMSMembraneModel()
+        mm.tag = 1
+        subs[1]['mem_models'] = [{'ode': mm, 'I_ch_k': {'a': 0.0, 'b': 0.0, 'c': 0.0}}]
+        a, p, Lf, dx, bc = emi_system(mesh, ct, ft, pp, ions, subs, phi, phi_M_prev, c_prev, 1.0, mms=MMS)
+        problem = create_solver_emi(a, Lf, phi, [g2p, e2p, i2p], subs, None, bcs=[bc])
+        problem.solve()
+        phi_e, phi_i = problem.u
+        errs.append((l2_error(phi_i, MMS["phi_i_exact"]), l2_error(phi_e, MMS["phi_e_exact"])))
+    errs = np.array(errs)
+    rates = np.log2(errs[:-1] / errs[1:])
+    print("MMS L2 errors (phi_i, phi_e):", errs, "rates:", rates)
+    assert np.all(rates[-1] > 1.8) and np.all(errs[-1] < 5e-3)

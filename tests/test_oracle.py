@@ -121,3 +121,44 @@ def test_ode_golden_reproduced_by_oracle():
             o.ode_sweep(model, st, pa, k * dt, dt)
             ref = g[f"{key}_traj"][k]
             assert rel_err(st[0], ref[:st.shape[1]]) < 1e-12
+
+
+def test_oracle_mms_emi_convergence():
+    """Analytic known answer for the oracle's EMI forms (volume + membrane coupling): the manufactured
+    potentials of the reference's tests/run_mms_emi.py:166-179 are recovered at second order in L2."""
+    import types
+    import scipy.sparse.linalg as spla
+    from knpemi import mms as M
+    from knpemi.fem import Function, extract_submesh, functionspace, make_mesh_mms
+    from knpemi.pdeSolver import _apply_bcs
+    from mms_problem import CONC, MMS
+    errs = []
+    for Mx in (16, 32, 64):
+        mesh, ct, ft = make_mesh_mms(Mx)
+        s1, i2p, iv2p, _, _ = extract_submesh(mesh, ct, 1)
+        s0, e2p, ev2p, _, _ = extract_submesh(mesh, ct, 0)
+        g, g2p, _, _, _ = extract_submesh(mesh, ft, 1)
+        subs = {0: dict(mesh_sub=s0, sub_to_parent=e2p, sub_vertex_to_parent=ev2p),
+                1: dict(mesh_sub=s1, sub_to_parent=i2p, sub_vertex_to_parent=iv2p, mesh_mem=g, mem_to_parent=g2p,
+                        mem_models=[{'ode': types.SimpleNamespace(tag=1), 'I_ch_k': {}}])}
+        P = o.OracleProblem(mesh.x, mesh.cells, mesh.cell_type, ct.dense(), mesh.facets[ft.indices], ft.values,
+                            {0: [], 1: [1]})
+        params = dict(dt=1.0, F=1.0, psi=1.0, C_M=1.0, C_phi=1.0)
+        ions = [dict(name=n, z=z, D={0: 1.0, 1: 1.0}) for n, z in (("a", 1.0), ("b", -1.0), ("c", 1.0))]
+        c_all = {t: [CONC[n][min(t, 1)](P.sub[t]["x"].T) for n in "abc"] for t in (0, 1)}
+        zq = np.zeros(P.NQ[1])
+        A, _, b = o.assemble_emi(P, params, ions, c_all, {1: zq}, {1: [dict(tag=1, I_ch_k={n: zq for n in "abc"})]},
+                                 splitting_scheme=False)
+        form = types.SimpleNamespace(mms=MMS, subdomain_list=subs, mesh=mesh, ct=ct, ft=ft,
+                                     physical_params={'C_phi': 1.0})
+        b = b + M.emi_mms_rhs(form)
+        phi = {0: Function(functionspace(s0)), 1: Function(functionspace(s1))}
+        bc = M.emi_dirichlet_bc(mesh, ft, subs, phi, MMS)
+        A2, b2 = _apply_bcs(A, b, [bc], [0, P.N[0]])
+        xs = spla.splu(A2.tocsc()).solve(b2)
+        phi[0].x.array[:] = xs[:P.N[0]]
+        phi[1].x.array[:] = xs[P.N[0]:]
+        errs.append((M.l2_error(phi[1], MMS["phi_i_exact"]), M.l2_error(phi[0], MMS["phi_e_exact"])))
+    errs = np.array(errs)
+    rates = np.log2(errs[:-1] / errs[1:])
+    assert np.all(rates > 1.85) and np.all(errs[-1] < 2e-3), (errs, rates)
