@@ -257,20 +257,11 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_kernel(KnDev D, const KnCon
     const int64_t base = D.sl_ptr[(size_t)b * 4 + w];
     const int np = (int)((D.sl_ptr[(size_t)b * 4 + w + 1] - base) >> 6);
     Rec r[NV];
-    if constexpr (NV != 8) r[0] = load_rec(D.VR, g);   // the row's own vertex, once
     for (int p = 0; p < np; ++p) {
       const int64_t ent = base + (int64_t)p * KN_SLICE + lane;
       uint32_t sl[SW];
       int li = 0;
-      if constexpr (NV != 8) {
-        // simplex entry: the row's vertex is local vertex 0, the entry names the other NV-1
-        const int4 e = D.pair_ent[ent];
-        if (e.x < 0) continue;
-        r[1] = load_rec(D.VR, e.x);
-        r[2] = load_rec(D.VR, e.y);
-        if constexpr (NV == 4) r[3] = load_rec(D.VR, e.z);
-        sl[0] = (uint32_t)e.w;
-      } else {
+      {
         const int pc = D.pair_cell[ent];
         if (pc < 0) continue;
 #pragma unroll
@@ -419,21 +410,12 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_kernel(KnDev D, const KnCon
     const int64_t base = D.sl_ptr[(size_t)b * 4 + w];
     const int np = (int)((D.sl_ptr[(size_t)b * 4 + w + 1] - base) >> 6);
     Rec r[NV];
-    if constexpr (NV != 8) r[0] = load_rec(D.VR, g);
     for (int p = 0; p < np; ++p) {
       const int64_t ent = base + (int64_t)p * KN_SLICE + lane;
       uint32_t sl[SW];
       int li = 0;
       int cv[NV];
-      if constexpr (NV != 8) {
-        const int4 e = D.pair_ent[ent];
-        if (e.x < 0) continue;
-        cv[0] = g; cv[1] = e.x; cv[2] = e.y;
-        r[1] = load_rec(D.VR, e.x);
-        r[2] = load_rec(D.VR, e.y);
-        if constexpr (NV == 4) { cv[3] = e.z; r[3] = load_rec(D.VR, e.z); }
-        sl[0] = (uint32_t)e.w;
-      } else {
+      {
         const int pc = D.pair_cell[ent];
         if (pc < 0) continue;
 #pragma unroll
@@ -534,6 +516,265 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_kernel(KnDev D, const KnCon
     out0[i] = a0;
     out1[i] = a1;
   }
+}
+
+
+// =============================================================================================
+// Simplex row kernels, version 2: neighbour records staged in LDS.
+//
+// The Laplacian row of vertex g lists exactly the vertices of its incident cells, so a (row, cell)
+// pair needs nothing but NV row-relative slot bytes.  Phase A gathers, once per row block, the 48-byte
+// record of every entry of the block's Laplacian segment into LDS (~15 gathers per row instead of
+// 3 per incident cell, i.e. 72 for a Kuhn tetrahedral mesh) and zeroes the accumulators; phase B
+// walks the pairs (4 bytes each, coalesced), reads the NV records from LDS and accumulates with
+// LDS fp64 adds (ds_add_f64).  All lanes that add into a given row belong to one wavefront, so the
+// order of the adds is fixed by program order and lane order: results are bit-reproducible.
+// =============================================================================================
+struct Rec6 {
+  double x, y, z, a, b, c;   // EMI: c_prev0, c_prev1, c_elim;  KNP: f0, f1 (= c_prev/dt + f_source), phi
+};
+
+__device__ __forceinline__ Rec6 lds_rec(const double* recs, int i) {
+  const double2* p = reinterpret_cast<const double2*>(recs + (size_t)i * 6);
+  const double2 u = p[0], v = p[1], w = p[2];
+  return Rec6{u.x, u.y, v.x, v.y, w.x, w.y};
+}
+
+template <int GDIM>
+__device__ __forceinline__ double simplex_row0(const Rec6 (&r)[GDIM + 1], double (&d)[GDIM + 1]) {
+  // gradient dot products of lambda_0 with all lambda_j, and the cell measure
+  if constexpr (GDIM == 2) {
+    const double e1x = r[1].x - r[0].x, e1y = r[1].y - r[0].y;
+    const double e2x = r[2].x - r[0].x, e2y = r[2].y - r[0].y;
+    const double det = e1x * e2y - e1y * e2x, inv = 1.0 / det;
+    const double g1x = e2y * inv, g1y = -e2x * inv;
+    const double g2x = -e1y * inv, g2y = e1x * inv;
+    const double g0x = -(g1x + g2x), g0y = -(g1y + g2y);
+    d[0] = g0x * g0x + g0y * g0y;
+    d[1] = g0x * g1x + g0y * g1y;
+    d[2] = g0x * g2x + g0y * g2y;
+    return 0.5 * fabs(det);
+  } else {
+    const double ax = r[1].x - r[0].x, ay = r[1].y - r[0].y, az = r[1].z - r[0].z;
+    const double bx = r[2].x - r[0].x, by = r[2].y - r[0].y, bz = r[2].z - r[0].z;
+    const double cx = r[3].x - r[0].x, cy = r[3].y - r[0].y, cz = r[3].z - r[0].z;
+    double g1x = by * cz - bz * cy, g1y = bz * cx - bx * cz, g1z = bx * cy - by * cx;
+    double g2x = cy * az - cz * ay, g2y = cz * ax - cx * az, g2z = cx * ay - cy * ax;
+    double g3x = ay * bz - az * by, g3y = az * bx - ax * bz, g3z = ax * by - ay * bx;
+    const double det = ax * g1x + ay * g1y + az * g1z, inv = 1.0 / det;
+    g1x *= inv; g1y *= inv; g1z *= inv;
+    g2x *= inv; g2y *= inv; g2z *= inv;
+    g3x *= inv; g3y *= inv; g3z *= inv;
+    const double g0x = -(g1x + g2x + g3x), g0y = -(g1y + g2y + g3y), g0z = -(g1z + g2z + g3z);
+    d[0] = g0x * g0x + g0y * g0y + g0z * g0z;
+    d[1] = g0x * g1x + g0y * g1y + g0z * g1z;
+    d[2] = g0x * g2x + g0y * g2y + g0z * g2z;
+    d[3] = g0x * g3x + g0y * g3y + g0z * g3z;
+    return fabs(det) * (1.0 / 6.0);
+  }
+}
+
+template <int GDIM, int LPR>
+__global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n,
+                                                        int want_p, int splitting) {
+  constexpr int NV = GDIM + 1, NF = GDIM;
+  const KnConsts& C = *Cp;
+  extern __shared__ __align__(16) double lds[];
+  double* accA = lds;
+  double* accP = lds + acc_n;
+  double* recs = lds + 2 * (size_t)acc_n;
+  const int tid = threadIdx.x;
+  const int b = logical_block(blockIdx.x, D.nblocks);
+  const int row0 = D.blk_row0[b], nrows = D.blk_nrows[b], s = D.blk_sub[b];
+  const int seg0 = D.rowptr[row0], seglen = D.rowptr[row0 + nrows] - seg0;
+  const int segL0 = D.rowptrL[row0], nnzLb = D.rowptrL[row0 + nrows] - segL0;
+  // phase A: zero accumulators, stage the records of the block's Laplacian entries
+  for (int i = tid; i < seglen; i += KN_BLOCK) { accA[i] = 0.0; accP[i] = 0.0; }
+  for (int i = tid; i < nnzLb; i += KN_BLOCK) {
+    const int v = D.colindL[segL0 + i];
+    const double2* src = reinterpret_cast<const double2*>(D.VR + (size_t)v * KN_REC);
+    const double2 u0 = src[0], u1 = src[1], u2 = src[2], u3 = src[3];   // x y | z _ | c0 c1 | c2 phi
+    double2* dst = reinterpret_cast<double2*>(recs + (size_t)i * 6);
+    dst[0] = u0; dst[1] = double2{u1.x, u2.x}; dst[2] = double2{u2.y, u3.x};
+  }
+  __syncthreads();
+
+  const KnSubConst& sc = C.sc[s];
+  const bool cell_side = s > 0;
+  const int rloc = tid / LPR, sub = tid % LPR;
+  const bool valid = rloc < nrows;
+  const int g = row0 + (valid ? rloc : 0);
+  double bacc = 0.0;
+  if (valid) {
+    const int rowbase = D.rowptr[g] - seg0;
+    const int lap = rowbase + D.lapoff[g];
+    const int rL = D.rowptrL[g] - segL0;
+    const int w = tid >> 6, lane = tid & 63;
+    const int64_t base = D.sl_ptr[(size_t)b * 4 + w];
+    const int np = (int)((D.sl_ptr[(size_t)b * 4 + w + 1] - base) >> 6);
+    for (int p = 0; p < np; ++p) {
+      const uint32_t sl = D.pair_sl[base + (int64_t)p * KN_SLICE + lane];
+      if (sl == 0xFFFFFFFFu) continue;
+      int slot[NV];
+      Rec6 r[NV];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        slot[j] = (sl >> (8 * j)) & 255;
+        r[j] = lds_rec(recs, rL + slot[j]);
+      }
+      double d[NV];
+      const double vol = simplex_row0<GDIM>(r, d);
+      double cb0 = 0, cb1 = 0, cb2 = 0, sd = 0;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        cb0 += r[j].a; cb1 += r[j].b; cb2 += r[j].c;
+        sd += (sc.sig[0] * r[j].a + sc.sig[1] * r[j].b + sc.sig[2] * r[j].c) * d[j];
+      }
+      const double kbar = (sc.kap[0] * cb0 + sc.kap[1] * cb1 + sc.kap[2] * cb2) * (1.0 / NV);
+      const double m = vol * (1.0 / ((GDIM + 1) * (GDIM + 2)));
+      bacc -= vol * sd;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const double a = vol * kbar * d[j];
+        unsafeAtomicAdd(&accA[lap + slot[j]], a);
+        if (want_p) unsafeAtomicAdd(&accP[lap + slot[j]], cell_side ? a + (j == 0 ? 2.0 * m : m) : a);
+      }
+    }
+    // membrane coupling C_phi (u_i - u_e)(v_i - v_e) and Robin RHS (emiWeakForm.py:160-165,228-239)
+    const int m = sub == 0 ? D.gam_idx[g] : -1;
+    if (m >= 0) {
+      const int* fown = cell_side ? D.fi : D.fe;
+      for (int e = D.mptr[m]; e < D.mptr[m + 1]; ++e) {
+        const int ent = D.mentry[e];
+        const int fg = ent >> 3, a = ent & 7;
+        const int ms = D.fmodel[fg];
+        if (ms < 0) continue;
+        const uint64_t sl = D.mslots[e];
+        Rec p[NF];
+#pragma unroll
+        for (int bb = 0; bb < NF; ++bb) p[bb] = load_rec(D.VR, fown[(size_t)fg * NF + bb]);
+        double Mr[NF];
+        facet_mass_row<NF>(p, a, Mr);
+        double gs = 0.0;
+#pragma unroll
+        for (int bb = 0; bb < NF; ++bb) {
+          const int q = D.fq[(size_t)fg * NF + bb];
+          double gq = D.phiM[q];
+          if (!splitting) {
+            double it = 0.0;
+            for (int k = 0; k < KN_MAXK; ++k) it += D.Ich[((size_t)ms * KN_MAXK + k) * D.NQtot + q];
+            gq -= it / C.C_phi;
+          }
+          gs += Mr[bb] * gq;
+          const double val = C.C_phi * Mr[bb];
+          const int io = rowbase + (int)((sl >> (8 * bb)) & 255);
+          const int it2 = rowbase + (int)((sl >> (8 * (4 + bb))) & 255);
+          unsafeAtomicAdd(&accA[io], val);
+          unsafeAtomicAdd(&accA[it2], -val);
+          if (want_p) { unsafeAtomicAdd(&accP[io], val); unsafeAtomicAdd(&accP[it2], -val); }
+        }
+        bacc += (cell_side ? 1.0 : -1.0) * C.C_phi * gs;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < LPR; m <<= 1) bacc += __shfl_xor(bacc, m);
+  if (valid && sub == 0) D.b_emi[g] = bacc;
+  __syncthreads();
+  for (int i = tid; i < seglen; i += KN_BLOCK) {
+    D.A_emi[seg0 + i] = accA[i];
+    if (want_p) D.P_emi[seg0 + i] = accP[i];
+  }
+}
+
+template <int GDIM, int LPR>
+__global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n) {
+  constexpr int NV = GDIM + 1, NF = GDIM;
+  const KnConsts& C = *Cp;
+  extern __shared__ __align__(16) double lds[];
+  double* acc0 = lds;
+  double* acc1 = lds + acc_n;
+  double* recs = lds + 2 * (size_t)acc_n;
+  const int tid = threadIdx.x;
+  const int b = logical_block(blockIdx.x, D.nblocks);
+  const int row0 = D.blk_row0[b], nrows = D.blk_nrows[b], s = D.blk_sub[b];
+  const int segL0 = D.rowptrL[row0], nnzLb = D.rowptrL[row0 + nrows] - segL0;
+  const int v0 = C.voff[s], nvs = C.voff[s + 1] - v0;
+  const double* fs0 = (D.fsrc && s == 0) ? D.fsrc : nullptr;
+  for (int i = tid; i < nnzLb; i += KN_BLOCK) {
+    acc0[i] = 0.0; acc1[i] = 0.0;
+    const int v = D.colindL[segL0 + i];
+    const double2* src = reinterpret_cast<const double2*>(D.VR + (size_t)v * KN_REC);
+    const double2 u0 = src[0], u1 = src[1], u2 = src[2], u3 = src[3];   // x y | z _ | c0 c1 | c2 phi
+    double f0 = u2.x * C.inv_dt, f1 = u2.y * C.inv_dt;   // (1/dt) c_prev (+ f_source on the ECS)
+    if (fs0) { f0 += fs0[v]; f1 += fs0[nvs + v]; }
+    double2* dst = reinterpret_cast<double2*>(recs + (size_t)i * 6);
+    dst[0] = u0; dst[1] = double2{u1.x, f0}; dst[2] = double2{f1, u3.y};
+  }
+  __syncthreads();
+
+  const KnSubConst& sc = C.sc[s];
+  const int rloc = tid / LPR, sub = tid % LPR;
+  const bool valid = rloc < nrows;
+  const int g = row0 + (valid ? rloc : 0);
+  double b0 = 0.0, b1 = 0.0;
+  if (valid) {
+    const int rL = D.rowptrL[g] - segL0;
+    const int w = tid >> 6, lane = tid & 63;
+    const int64_t base = D.sl_ptr[(size_t)b * 4 + w];
+    const int np = (int)((D.sl_ptr[(size_t)b * 4 + w + 1] - base) >> 6);
+    for (int p = 0; p < np; ++p) {
+      const uint32_t sl = D.pair_sl[base + (int64_t)p * KN_SLICE + lane];
+      if (sl == 0xFFFFFFFFu) continue;
+      int slot[NV];
+      Rec6 r[NV];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        slot[j] = (sl >> (8 * j)) & 255;
+        r[j] = lds_rec(recs, rL + slot[j]);
+      }
+      double d[NV];
+      const double vol = simplex_row0<GDIM>(r, d);
+      double gp = 0;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) gp += r[j].c * d[j];
+      const double m = vol * (1.0 / ((GDIM + 1) * (GDIM + 2)));
+      const double drift = gp * vol * (1.0 / (GDIM + 1));
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const double mm = (j == 0) ? 2.0 * m : m;
+        unsafeAtomicAdd(&acc0[rL + slot[j]], mm * C.inv_dt + sc.D[0] * vol * d[j] + sc.zpsiD[0] * drift);
+        unsafeAtomicAdd(&acc1[rL + slot[j]], mm * C.inv_dt + sc.D[1] * vol * d[j] + sc.zpsiD[1] * drift);
+        b0 += mm * r[j].a;
+        b1 += mm * r[j].b;
+      }
+    }
+    // membrane Robin/coupling contributions, precomputed per (facet, side) by knp_membrane_kernel
+    const int m = sub == 0 ? D.gam_idx[g] : -1;
+    if (m >= 0) {
+      const int side = s > 0 ? 1 : 0;
+      for (int e = D.mptr[m]; e < D.mptr[m + 1]; ++e) {
+        const int ent = D.mentry[e];
+        const int fg = ent >> 3, a = ent & 7;
+        if (D.fmodel[fg] < 0) continue;
+        const double* cg = D.gam_contrib + ((size_t)(fg * 2 + side) * NF + a) * 2;
+        b0 += cg[0];
+        b1 += cg[1];
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < LPR; m <<= 1) { b0 += __shfl_xor(b0, m); b1 += __shfl_xor(b1, m); }
+  if (valid && sub == 0) {
+    const size_t bb = (size_t)(KN_MAXK - 1) * v0 + (size_t)(g - v0);
+    D.b_knp[bb] = b0;
+    D.b_knp[bb + nvs] = b1;
+  }
+  __syncthreads();
+  const int64_t subnnz0 = D.rowptrL[v0], subnnz = D.rowptrL[v0 + nvs] - subnnz0;
+  double* out0 = D.A_knp + (size_t)(KN_MAXK - 1) * subnnz0 + (segL0 - subnnz0);
+  double* out1 = out0 + subnnz;
+  for (int i = tid; i < nnzLb; i += KN_BLOCK) { out0[i] = acc0[i]; out1[i] = acc1[i]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -773,15 +1014,60 @@ static int launch_knp(knpemi_handle* h, size_t lds, int lds_n) {
   return check_launch("knp_rows_kernel");
 }
 
+template <int GDIM>
+static int launch_emi_v2(knpemi_handle* h, int want_p, int split) {
+  const KnDev& D = h->dev;
+  const int acc_n = (h->lds_doubles_emi + 1) & ~1;
+  const size_t lds = ((size_t)2 * acc_n + 6 * (size_t)h->lds_doubles_knp) * sizeof(double);
+  if (lds > 160 * 1024) { kn_set_error("EMI row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
+  dim3 grid(D.nblocks), block(KN_BLOCK);
+  int rc = 0;
+#define KN_CASE(L)                                                                                  \
+  case L:                                                                                           \
+    if ((rc = set_lds_limit(emi_rows_v2<GDIM, L>, lds))) return rc;                                 \
+    {                                                                                               \
+      KnProfScope prof(h, KNPEMI_K_EMI_ROWS);                                                       \
+      hipLaunchKernelGGL((emi_rows_v2<GDIM, L>), grid, block, lds, h->stream, D, h->d_consts, acc_n, \
+                         want_p, split);                                                            \
+    }                                                                                               \
+    break;
+  switch (h->lpr) { KN_CASE(1) KN_CASE(2) KN_CASE(4) KN_CASE(8) default: kn_set_error("bad lanes-per-row"); return KNPEMI_EINVAL; }
+#undef KN_CASE
+  return check_launch("emi_rows_v2");
+}
+
+template <int GDIM>
+static int launch_knp_v2(knpemi_handle* h) {
+  const KnDev& D = h->dev;
+  const int acc_n = (h->lds_doubles_knp + 1) & ~1;
+  const size_t lds = ((size_t)2 * acc_n + 6 * (size_t)h->lds_doubles_knp) * sizeof(double);
+  if (lds > 160 * 1024) { kn_set_error("KNP row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
+  dim3 grid(D.nblocks), block(KN_BLOCK);
+  int rc = 0;
+#define KN_CASE(L)                                                                                  \
+  case L:                                                                                           \
+    if ((rc = set_lds_limit(knp_rows_v2<GDIM, L>, lds))) return rc;                                 \
+    {                                                                                               \
+      KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                       \
+      hipLaunchKernelGGL((knp_rows_v2<GDIM, L>), grid, block, lds, h->stream, D, h->d_consts, acc_n); \
+    }                                                                                               \
+    break;
+  switch (h->lpr) { KN_CASE(1) KN_CASE(2) KN_CASE(4) KN_CASE(8) default: kn_set_error("bad lanes-per-row"); return KNPEMI_EINVAL; }
+#undef KN_CASE
+  return check_launch("knp_rows_v2");
+}
+
 int kn_launch_emi_rows(knpemi_handle* h, int flags) {
   const KnDev& D = h->dev;
   if (D.nblocks == 0) return KNPEMI_OK;
+  if (h->NV != 8) {
+    const int want_p = (flags & KNPEMI_WANT_P) ? 1 : 0, split = (flags & KNPEMI_NO_SPLITTING) ? 0 : 1;
+    return h->gdim == 2 ? launch_emi_v2<2>(h, want_p, split) : launch_emi_v2<3>(h, want_p, split);
+  }
   const int lds_n = h->lds_doubles_emi;
   const size_t lds = (size_t)2 * h->lpr * lds_n * sizeof(double) + (h->NV == 8 ? sizeof(HexTab) : 0);
   if (lds > 160 * 1024) { kn_set_error("EMI row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   const int want_p = (flags & KNPEMI_WANT_P) ? 1 : 0, split = (flags & KNPEMI_NO_SPLITTING) ? 0 : 1;
-  if (h->cell_kind == KNPEMI_TRIANGLE) return launch_emi<2, 3>(h, lds, lds_n, want_p, split);
-  if (h->cell_kind == KNPEMI_TETRAHEDRON) return launch_emi<3, 4>(h, lds, lds_n, want_p, split);
   return launch_emi<3, 8>(h, lds, lds_n, want_p, split);
 }
 
@@ -789,11 +1075,10 @@ int kn_launch_knp_rows(knpemi_handle* h, int flags) {
   (void)flags;
   const KnDev& D = h->dev;
   if (D.nblocks == 0) return KNPEMI_OK;
+  if (h->NV != 8) return h->gdim == 2 ? launch_knp_v2<2>(h) : launch_knp_v2<3>(h);
   const int lds_n = h->lds_doubles_knp;
   const size_t lds = (size_t)2 * h->lpr * lds_n * sizeof(double) + (h->NV == 8 ? sizeof(HexTab) : 0);
   if (lds > 160 * 1024) { kn_set_error("KNP row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
-  if (h->cell_kind == KNPEMI_TRIANGLE) return launch_knp<2, 3>(h, lds, lds_n);
-  if (h->cell_kind == KNPEMI_TETRAHEDRON) return launch_knp<3, 4>(h, lds, lds_n);
   return launch_knp<3, 8>(h, lds, lds_n);
 }
 

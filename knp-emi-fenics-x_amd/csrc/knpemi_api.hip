@@ -258,8 +258,10 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
 
   // ---- lanes per row: enough workgroups to fill 256 CUs several times over on small meshes --------
   {
-    int lpr = 1;
-    while (lpr < 8 && (int64_t)Ntot * lpr < (int64_t)1024 * KN_BLOCK) lpr *= 2;
+    // simplices (v2 kernels stage 48 B per Laplacian entry in LDS): 64-row blocks for tetrahedra,
+    // 128-row blocks for triangles; hexahedra: enough workgroups to fill the chip on small meshes
+    int lpr = NV == 4 ? 4 : (NV == 3 ? 2 : 1);
+    while (NV == 8 && lpr < 8 && (int64_t)Ntot * lpr < (int64_t)1024 * KN_BLOCK) lpr *= 2;
     if (const char* env = getenv("KNPEMI_LPR")) {
       int v = atoi(env);
       if (v == 1 || v == 2 || v == 4 || v == 8) lpr = v;
@@ -290,7 +292,7 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   const bool simplex = NV != 8;
   std::vector<int> pair_cell(simplex ? 0 : (size_t)sl_ptr.back(), -1);
   std::vector<uint32_t> pair_slots(simplex ? 0 : (size_t)sl_ptr.back() * SW, 0);
-  std::vector<int> pair_ent(simplex ? (size_t)sl_ptr.back() * 4 : 0, -1);
+  std::vector<uint32_t> pair_sl(simplex ? (size_t)sl_ptr.back() : 0, 0xFFFFFFFFu);
   for (int b = 0; b < nblocks; ++b)
     for (int t = 0; t < blk_nrows[b]; ++t) {
       const int g = blk_row0[b] + t, w = t / RPS, rs = t % RPS;
@@ -307,10 +309,8 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
           for (int j = 0; j < NV; ++j) {
             const int v = cv[(li + j) % NV];   // j = 0 is the row's own vertex
             slots |= (uint32_t)(std::lower_bound(rb, re, v) - rb) << (8 * j);
-            if (j > 0) pair_ent[ent * 4 + (j - 1)] = v;
           }
-          if (NV == 3) pair_ent[ent * 4 + 2] = 0;
-          pair_ent[ent * 4 + 3] = (int)slots;
+          pair_sl[ent] = slots;
           continue;
         }
         pair_cell[ent] = v2c[p];
@@ -369,11 +369,7 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   if ((rc = dev_upload(h, blk_nrows, &D.blk_nrows))) return rc;
   if ((rc = dev_upload(h, blk_sub, &D.blk_sub))) return rc;
   if ((rc = dev_upload(h, sl_ptr, &D.sl_ptr))) return rc;
-  {
-    const int* pe = nullptr;
-    if ((rc = dev_upload(h, pair_ent, &pe))) return rc;
-    D.pair_ent = reinterpret_cast<const int4*>(pe);
-  }
+  if ((rc = dev_upload(h, pair_sl, &D.pair_sl))) return rc;
   if ((rc = dev_upload(h, pair_cell, &D.pair_cell))) return rc;
   if ((rc = dev_upload(h, pair_slots, &D.pair_slots))) return rc;
   if ((rc = dev_upload(h, rowptr, &D.rowptr))) return rc;

@@ -54,9 +54,8 @@ struct KnDev {
   const int64_t* sl_ptr;      // [4*nblocks+1] entry offsets (multiples of KN_SLICE); slice 4*b + w
                               // holds the 64/lpr rows blk_row0[b] + (64/lpr)*w .. of block b; lane
                               // r*lpr + j of step p reads pair p*lpr + j of row r of the slice
-  const int4* pair_ent;       // simplices: {v1, v2, v3, slots}: the other vertices of the incident cell
-                              // (the row's vertex is local vertex 0) and 4 x uint8 row-relative CSR
-                              // slots (byte 0 = diagonal); x = -1 marks padding
+  const uint32_t* pair_sl;    // simplices: NV x uint8 slots of the cell's vertices in the row's Laplacian
+                              // segment (byte 0 = the row's own vertex); 0xFFFFFFFF marks padding
   const int* pair_cell;       // hexahedra: cell*8 + local index, -1 = padding
   const uint32_t* pair_slots; // hexahedra: 8 x uint8 slots in two consecutive words per entry
   // EMI CSR (monolithic) and Laplacian-pattern CSR (KNP blocks share it per sub-domain)
