@@ -530,6 +530,8 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_kernel(KnDev D, const KnCon
 // LDS fp64 adds (ds_add_f64).  All lanes that add into a given row belong to one wavefront, so the
 // order of the adds is fixed by program order and lane order: results are bit-reproducible.
 // =============================================================================================
+#define KN_PREFETCH 8   // pair entries per lane fetched ahead into registers
+
 struct Rec6 {
   double x, y, z, a, b, c;   // EMI: c_prev0, c_prev1, c_elim;  KNP: f0, f1 (= c_prev/dt + f_source), phi
 };
@@ -574,6 +576,69 @@ __device__ __forceinline__ double simplex_row0(const Rec6 (&r)[GDIM + 1], double
   }
 }
 
+
+// Block descriptor (uniform) and the staging of the block's Laplacian-entry records: all index loads
+// are issued together, then all record loads, so a wave waits for memory twice instead of 2 x trips.
+struct BlkInfo {
+  int row0, nrows, sub, seg0, seglen, segL0, nnzLb, slbase, np;
+};
+
+__device__ __forceinline__ BlkInfo load_blk(const KnDev& D, int b, int wave) {
+  const int4* p = D.blk_info + 4 * (size_t)b;
+  const int4 i0 = p[0], i1 = p[1], i2 = p[2], i3 = p[3];
+  BlkInfo B;
+  B.row0 = i0.x; B.nrows = i0.y; B.sub = i0.z; B.seg0 = i0.w;
+  B.seglen = i1.x; B.segL0 = i1.y; B.nnzLb = i1.z;
+  B.slbase = wave == 0 ? i2.x : (wave == 1 ? i2.y : (wave == 2 ? i2.z : i2.w));
+  B.np = wave == 0 ? i3.x : (wave == 1 ? i3.y : (wave == 2 ? i3.z : i3.w));
+  return B;
+}
+
+#define KN_STAGE 5   // Laplacian entries per thread staged with batched loads (256 threads x 5 = 1280)
+
+template <bool KNP>
+__device__ __forceinline__ void stage_records(const KnDev& D, const BlkInfo& B, double* recs, int tid,
+                                              double inv_dt, const double* fs0, int nvs) {
+  int vv[KN_STAGE];
+#pragma unroll
+  for (int k = 0; k < KN_STAGE; ++k) {
+    const int i = tid + k * KN_BLOCK;
+    vv[k] = i < B.nnzLb ? D.colindL[B.segL0 + i] : -1;
+  }
+  double2 u[KN_STAGE][4];
+#pragma unroll
+  for (int k = 0; k < KN_STAGE; ++k)
+    if (vv[k] >= 0) {
+      const double2* src = reinterpret_cast<const double2*>(D.VR + (size_t)vv[k] * KN_REC);
+      u[k][0] = src[0]; u[k][1] = src[1]; u[k][2] = src[2]; u[k][3] = src[3];   // x y | z _ | c0 c1 | c2 phi
+    }
+#pragma unroll
+  for (int k = 0; k < KN_STAGE; ++k)
+    if (vv[k] >= 0) {
+      double2* dst = reinterpret_cast<double2*>(recs + (size_t)(tid + k * KN_BLOCK) * 6);
+      if constexpr (KNP) {
+        double f0 = u[k][2].x * inv_dt, f1 = u[k][2].y * inv_dt;   // (1/dt) c_prev (+ f_source on the ECS)
+        if (fs0) { f0 += fs0[vv[k]]; f1 += fs0[nvs + vv[k]]; }
+        dst[0] = u[k][0]; dst[1] = double2{u[k][1].x, f0}; dst[2] = double2{f1, u[k][3].y};
+      } else {
+        dst[0] = u[k][0]; dst[1] = double2{u[k][1].x, u[k][2].x}; dst[2] = double2{u[k][2].y, u[k][3].x};
+      }
+    }
+  for (int i = tid + KN_STAGE * KN_BLOCK; i < B.nnzLb; i += KN_BLOCK) {   // oversized blocks only
+    const int v = D.colindL[B.segL0 + i];
+    const double2* src = reinterpret_cast<const double2*>(D.VR + (size_t)v * KN_REC);
+    const double2 u0 = src[0], u1 = src[1], u2 = src[2], u3 = src[3];
+    double2* dst = reinterpret_cast<double2*>(recs + (size_t)i * 6);
+    if constexpr (KNP) {
+      double f0 = u2.x * inv_dt, f1 = u2.y * inv_dt;
+      if (fs0) { f0 += fs0[v]; f1 += fs0[nvs + v]; }
+      dst[0] = u0; dst[1] = double2{u1.x, f0}; dst[2] = double2{f1, u3.y};
+    } else {
+      dst[0] = u0; dst[1] = double2{u1.x, u2.x}; dst[2] = double2{u2.y, u3.x};
+    }
+  }
+}
+
 template <int GDIM, int LPR>
 __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n,
                                                         int want_p, int splitting) {
@@ -585,43 +650,42 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
   double* recs = lds + 2 * (size_t)acc_n;
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
-  const int row0 = D.blk_row0[b], nrows = D.blk_nrows[b], s = D.blk_sub[b];
-  const int seg0 = D.rowptr[row0], seglen = D.rowptr[row0 + nrows] - seg0;
-  const int segL0 = D.rowptrL[row0], nnzLb = D.rowptrL[row0 + nrows] - segL0;
+  const BlkInfo B = load_blk(D, b, tid >> 6);
+  const int row0 = B.row0, nrows = B.nrows, s = B.sub, seg0 = B.seg0, seglen = B.seglen;
+  // this lane's pair entries and row descriptor: issued first, their latency overlaps phase A
+  const int rloc = tid / LPR, sub = tid % LPR;
+  const bool valid = rloc < nrows;
+  const int g = row0 + (valid ? rloc : 0);
+  const int64_t base = (int64_t)B.slbase * KN_SLICE + (tid & 63);
+  const int np = B.np;
+  uint32_t slr[KN_PREFETCH];
+#pragma unroll
+  for (int p = 0; p < KN_PREFETCH; ++p)
+    slr[p] = (valid && p < np) ? D.pair_sl[base + (int64_t)p * KN_SLICE] : 0xFFFFFFFFu;
+  const int4 ri = D.row_info[g];
   // phase A: zero accumulators, stage the records of the block's Laplacian entries
   for (int i = tid; i < seglen; i += KN_BLOCK) { accA[i] = 0.0; accP[i] = 0.0; }
-  for (int i = tid; i < nnzLb; i += KN_BLOCK) {
-    const int v = D.colindL[segL0 + i];
-    const double2* src = reinterpret_cast<const double2*>(D.VR + (size_t)v * KN_REC);
-    const double2 u0 = src[0], u1 = src[1], u2 = src[2], u3 = src[3];   // x y | z _ | c0 c1 | c2 phi
-    double2* dst = reinterpret_cast<double2*>(recs + (size_t)i * 6);
-    dst[0] = u0; dst[1] = double2{u1.x, u2.x}; dst[2] = double2{u2.y, u3.x};
-  }
+  stage_records<false>(D, B, recs, tid, 0.0, nullptr, 0);
   __syncthreads();
 
   const KnSubConst& sc = C.sc[s];
   const bool cell_side = s > 0;
-  const int rloc = tid / LPR, sub = tid % LPR;
-  const bool valid = rloc < nrows;
-  const int g = row0 + (valid ? rloc : 0);
   double bacc = 0.0;
   if (valid) {
-    const int rowbase = D.rowptr[g] - seg0;
-    const int lap = rowbase + D.lapoff[g];
-    const int rL = D.rowptrL[g] - segL0;
-    const int w = tid >> 6, lane = tid & 63;
-    const int64_t base = D.sl_ptr[(size_t)b * 4 + w];
-    const int np = (int)((D.sl_ptr[(size_t)b * 4 + w + 1] - base) >> 6);
-    for (int p = 0; p < np; ++p) {
-      const uint32_t sl = D.pair_sl[base + (int64_t)p * KN_SLICE + lane];
-      if (sl == 0xFFFFFFFFu) continue;
+    const int rowbase = ri.x, lap = ri.y, rL = ri.z;
+    // The diagonal entry receives a term from every pair: keep it in registers and add it once.
+    // P differs from A only on cell-side rows (ICS mass), so ECS rows accumulate A alone.
+    const bool acc_p = want_p && cell_side;
+    int diag = -1;
+    double dA = 0.0, dP = 0.0;
+    Rec6 r[NV];
+    auto do_pair = [&](uint32_t sl) {
       int slot[NV];
-      Rec6 r[NV];
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        slot[j] = (sl >> (8 * j)) & 255;
-        r[j] = lds_rec(recs, rL + slot[j]);
-      }
+      for (int j = 0; j < NV; ++j) slot[j] = (sl >> (8 * j)) & 255;
+      if (diag < 0) { diag = slot[0]; r[0] = lds_rec(recs, rL + diag); }   // the row's own vertex, once
+#pragma unroll
+      for (int j = 1; j < NV; ++j) r[j] = lds_rec(recs, rL + slot[j]);
       double d[NV];
       const double vol = simplex_row0<GDIM>(r, d);
       double cb0 = 0, cb1 = 0, cb2 = 0, sd = 0;
@@ -633,15 +697,28 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
       const double kbar = (sc.kap[0] * cb0 + sc.kap[1] * cb1 + sc.kap[2] * cb2) * (1.0 / NV);
       const double m = vol * (1.0 / ((GDIM + 1) * (GDIM + 2)));
       bacc -= vol * sd;
+      dA += vol * kbar * d[0];
+      dP += vol * kbar * d[0] + 2.0 * m;
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
+      for (int j = 1; j < NV; ++j) {
         const double a = vol * kbar * d[j];
         unsafeAtomicAdd(&accA[lap + slot[j]], a);
-        if (want_p) unsafeAtomicAdd(&accP[lap + slot[j]], cell_side ? a + (j == 0 ? 2.0 * m : m) : a);
+        if (acc_p) unsafeAtomicAdd(&accP[lap + slot[j]], a + m);
       }
+    };
+#pragma unroll
+    for (int p = 0; p < KN_PREFETCH; ++p)
+      if (slr[p] != 0xFFFFFFFFu) do_pair(slr[p]);
+    for (int p = KN_PREFETCH; p < np; ++p) {
+      const uint32_t sl = D.pair_sl[base + (int64_t)p * KN_SLICE];
+      if (sl != 0xFFFFFFFFu) do_pair(sl);
+    }
+    if (diag >= 0) {
+      unsafeAtomicAdd(&accA[lap + diag], dA);
+      if (acc_p) unsafeAtomicAdd(&accP[lap + diag], dP);
     }
     // membrane coupling C_phi (u_i - u_e)(v_i - v_e) and Robin RHS (emiWeakForm.py:160-165,228-239)
-    const int m = sub == 0 ? D.gam_idx[g] : -1;
+    const int m = sub == 0 ? ri.w : -1;
     if (m >= 0) {
       const int* fown = cell_side ? D.fi : D.fe;
       for (int e = D.mptr[m]; e < D.mptr[m + 1]; ++e) {
@@ -671,7 +748,7 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
           const int it2 = rowbase + (int)((sl >> (8 * (4 + bb))) & 255);
           unsafeAtomicAdd(&accA[io], val);
           unsafeAtomicAdd(&accA[it2], -val);
-          if (want_p) { unsafeAtomicAdd(&accP[io], val); unsafeAtomicAdd(&accP[it2], -val); }
+          if (acc_p) { unsafeAtomicAdd(&accP[io], val); unsafeAtomicAdd(&accP[it2], -val); }
         }
         bacc += (cell_side ? 1.0 : -1.0) * C.C_phi * gs;
       }
@@ -682,8 +759,9 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
   if (valid && sub == 0) D.b_emi[g] = bacc;
   __syncthreads();
   for (int i = tid; i < seglen; i += KN_BLOCK) {
-    D.A_emi[seg0 + i] = accA[i];
-    if (want_p) D.P_emi[seg0 + i] = accP[i];
+    const double a = accA[i];
+    D.A_emi[seg0 + i] = a;
+    if (want_p) D.P_emi[seg0 + i] = cell_side ? accP[i] : a;
   }
 }
 
@@ -697,42 +775,38 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
   double* recs = lds + 2 * (size_t)acc_n;
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
-  const int row0 = D.blk_row0[b], nrows = D.blk_nrows[b], s = D.blk_sub[b];
-  const int segL0 = D.rowptrL[row0], nnzLb = D.rowptrL[row0 + nrows] - segL0;
+  const BlkInfo B = load_blk(D, b, tid >> 6);
+  const int row0 = B.row0, nrows = B.nrows, s = B.sub, segL0 = B.segL0, nnzLb = B.nnzLb;
   const int v0 = C.voff[s], nvs = C.voff[s + 1] - v0;
   const double* fs0 = (D.fsrc && s == 0) ? D.fsrc : nullptr;
-  for (int i = tid; i < nnzLb; i += KN_BLOCK) {
-    acc0[i] = 0.0; acc1[i] = 0.0;
-    const int v = D.colindL[segL0 + i];
-    const double2* src = reinterpret_cast<const double2*>(D.VR + (size_t)v * KN_REC);
-    const double2 u0 = src[0], u1 = src[1], u2 = src[2], u3 = src[3];   // x y | z _ | c0 c1 | c2 phi
-    double f0 = u2.x * C.inv_dt, f1 = u2.y * C.inv_dt;   // (1/dt) c_prev (+ f_source on the ECS)
-    if (fs0) { f0 += fs0[v]; f1 += fs0[nvs + v]; }
-    double2* dst = reinterpret_cast<double2*>(recs + (size_t)i * 6);
-    dst[0] = u0; dst[1] = double2{u1.x, f0}; dst[2] = double2{f1, u3.y};
-  }
-  __syncthreads();
-
-  const KnSubConst& sc = C.sc[s];
   const int rloc = tid / LPR, sub = tid % LPR;
   const bool valid = rloc < nrows;
   const int g = row0 + (valid ? rloc : 0);
+  const int64_t base = (int64_t)B.slbase * KN_SLICE + (tid & 63);
+  const int np = B.np;
+  uint32_t slr[KN_PREFETCH];
+#pragma unroll
+  for (int p = 0; p < KN_PREFETCH; ++p)
+    slr[p] = (valid && p < np) ? D.pair_sl[base + (int64_t)p * KN_SLICE] : 0xFFFFFFFFu;
+  const int4 ri = D.row_info[g];
+  for (int i = tid; i < nnzLb; i += KN_BLOCK) { acc0[i] = 0.0; acc1[i] = 0.0; }
+  stage_records<true>(D, B, recs, tid, C.inv_dt, fs0, nvs);
+  __syncthreads();
+
+  const KnSubConst& sc = C.sc[s];
   double b0 = 0.0, b1 = 0.0;
   if (valid) {
-    const int rL = D.rowptrL[g] - segL0;
-    const int w = tid >> 6, lane = tid & 63;
-    const int64_t base = D.sl_ptr[(size_t)b * 4 + w];
-    const int np = (int)((D.sl_ptr[(size_t)b * 4 + w + 1] - base) >> 6);
-    for (int p = 0; p < np; ++p) {
-      const uint32_t sl = D.pair_sl[base + (int64_t)p * KN_SLICE + lane];
-      if (sl == 0xFFFFFFFFu) continue;
+    const int rL = ri.z;
+    int diag = -1;
+    double d0 = 0.0, d1 = 0.0;   // diagonal entries of the two ion blocks, added once after the loop
+    Rec6 r[NV];
+    auto do_pair = [&](uint32_t sl) {
       int slot[NV];
-      Rec6 r[NV];
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        slot[j] = (sl >> (8 * j)) & 255;
-        r[j] = lds_rec(recs, rL + slot[j]);
-      }
+      for (int j = 0; j < NV; ++j) slot[j] = (sl >> (8 * j)) & 255;
+      if (diag < 0) { diag = slot[0]; r[0] = lds_rec(recs, rL + diag); }
+#pragma unroll
+      for (int j = 1; j < NV; ++j) r[j] = lds_rec(recs, rL + slot[j]);
       double d[NV];
       const double vol = simplex_row0<GDIM>(r, d);
       double gp = 0;
@@ -740,17 +814,31 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
       for (int j = 0; j < NV; ++j) gp += r[j].c * d[j];
       const double m = vol * (1.0 / ((GDIM + 1) * (GDIM + 2)));
       const double drift = gp * vol * (1.0 / (GDIM + 1));
+      d0 += 2.0 * m * C.inv_dt + sc.D[0] * vol * d[0] + sc.zpsiD[0] * drift;
+      d1 += 2.0 * m * C.inv_dt + sc.D[1] * vol * d[0] + sc.zpsiD[1] * drift;
+      b0 += 2.0 * m * r[0].a;
+      b1 += 2.0 * m * r[0].b;
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const double mm = (j == 0) ? 2.0 * m : m;
-        unsafeAtomicAdd(&acc0[rL + slot[j]], mm * C.inv_dt + sc.D[0] * vol * d[j] + sc.zpsiD[0] * drift);
-        unsafeAtomicAdd(&acc1[rL + slot[j]], mm * C.inv_dt + sc.D[1] * vol * d[j] + sc.zpsiD[1] * drift);
-        b0 += mm * r[j].a;
-        b1 += mm * r[j].b;
+      for (int j = 1; j < NV; ++j) {
+        unsafeAtomicAdd(&acc0[rL + slot[j]], m * C.inv_dt + sc.D[0] * vol * d[j] + sc.zpsiD[0] * drift);
+        unsafeAtomicAdd(&acc1[rL + slot[j]], m * C.inv_dt + sc.D[1] * vol * d[j] + sc.zpsiD[1] * drift);
+        b0 += m * r[j].a;
+        b1 += m * r[j].b;
       }
+    };
+#pragma unroll
+    for (int p = 0; p < KN_PREFETCH; ++p)
+      if (slr[p] != 0xFFFFFFFFu) do_pair(slr[p]);
+    for (int p = KN_PREFETCH; p < np; ++p) {
+      const uint32_t sl = D.pair_sl[base + (int64_t)p * KN_SLICE];
+      if (sl != 0xFFFFFFFFu) do_pair(sl);
+    }
+    if (diag >= 0) {
+      unsafeAtomicAdd(&acc0[rL + diag], d0);
+      unsafeAtomicAdd(&acc1[rL + diag], d1);
     }
     // membrane Robin/coupling contributions, precomputed per (facet, side) by knp_membrane_kernel
-    const int m = sub == 0 ? D.gam_idx[g] : -1;
+    const int m = sub == 0 ? ri.w : -1;
     if (m >= 0) {
       const int side = s > 0 ? 1 : 0;
       for (int e = D.mptr[m]; e < D.mptr[m + 1]; ++e) {

@@ -348,6 +348,26 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
     mptr.push_back((int)mentry.size());
   }
 
+  // ---- per-block / per-row descriptors: one scalar load per block, one 16-byte load per row ----------
+  std::vector<int> blk_info((size_t)nblocks * 16, 0), row_info((size_t)Ntot * 4, 0);
+  for (int b = 0; b < nblocks; ++b) {
+    int* bi = &blk_info[(size_t)b * 16];
+    const int g0 = blk_row0[b], g1 = g0 + blk_nrows[b];
+    bi[0] = g0; bi[1] = blk_nrows[b]; bi[2] = blk_sub[b]; bi[3] = rowptr[g0];
+    bi[4] = rowptr[g1] - rowptr[g0]; bi[5] = rowptrL[g0]; bi[6] = rowptrL[g1] - rowptrL[g0];
+    for (int w = 0; w < SPB; ++w) {
+      bi[8 + w] = (int)(sl_ptr[(size_t)b * SPB + w] / KN_SLICE);
+      bi[12 + w] = (int)((sl_ptr[(size_t)b * SPB + w + 1] - sl_ptr[(size_t)b * SPB + w]) / KN_SLICE);
+    }
+    for (int g = g0; g < g1; ++g) {
+      int* ri = &row_info[(size_t)g * 4];
+      ri[0] = rowptr[g] - rowptr[g0];
+      ri[1] = ri[0] + lapoff[g];
+      ri[2] = rowptrL[g] - rowptrL[g0];
+      ri[3] = gam_idx[g];
+    }
+  }
+
   // ---- LDS segment sizes ----------------------------------------------------------------------------------
   for (int b = 0; b < nblocks; ++b) {
     int g0 = blk_row0[b], g1 = g0 + blk_nrows[b];
@@ -368,6 +388,13 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   if ((rc = dev_upload(h, blk_row0, &D.blk_row0))) return rc;
   if ((rc = dev_upload(h, blk_nrows, &D.blk_nrows))) return rc;
   if ((rc = dev_upload(h, blk_sub, &D.blk_sub))) return rc;
+  {
+    const int* bi = nullptr; const int* ri = nullptr;
+    if ((rc = dev_upload(h, blk_info, &bi))) return rc;
+    if ((rc = dev_upload(h, row_info, &ri))) return rc;
+    D.blk_info = reinterpret_cast<const int4*>(bi);
+    D.row_info = reinterpret_cast<const int4*>(ri);
+  }
   if ((rc = dev_upload(h, sl_ptr, &D.sl_ptr))) return rc;
   if ((rc = dev_upload(h, pair_sl, &D.pair_sl))) return rc;
   if ((rc = dev_upload(h, pair_cell, &D.pair_cell))) return rc;

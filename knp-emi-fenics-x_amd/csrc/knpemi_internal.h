@@ -46,6 +46,9 @@ struct KnDev {
   const int* blk_row0;        // [nblocks] first global row of the block
   const int* blk_nrows;       // [nblocks] rows in the block (<= KN_BLOCK / lpr)
   const int* blk_sub;         // [nblocks] sub-domain of the block
+  const int4* blk_info;       // [nblocks][4]: {row0, nrows, sub, rowptr[row0]} {EMI seg length, rowptrL[row0],
+                              //   Laplacian seg length, 0} {slice entry bases / 64} {slice steps}
+  const int4* row_info;       // [Ntot]: {rowptr[g] - seg0, that + lapoff[g], rowptrL[g] - segL0, gam_idx[g]}
   double* VR;                 // [Ntot][KN_REC]
   double* csol;               // [K-1][Ntot]  solver output c (block order handled by offsets)
   double* fsrc;               // [K-1][N_0] optional ECS source term (NULL when unused)
