@@ -72,6 +72,14 @@ extern "C" {
 /* assemble flags */
 #define KNPEMI_WANT_P 1       /* also fill P_EMI (fused with A_EMI, one pass) */
 #define KNPEMI_NO_SPLITTING 2 /* splitting_scheme=False (emiWeakForm.py:234-236, knpWeakForm.py:201-206) */
+/* Overlap of the ODE sweep with the EMI matrix assembly (they are independent: only the membrane
+ * Robin term of b_emi needs the ODE output phi_M_prev / I_ch).
+ *   KNPEMI_SKIP_MEMBRANE_RHS: knpemi_assemble_emi leaves that term out; add it later with
+ *                             knpemi_assemble_emi_membrane_rhs (same flags for splitting);
+ *   KNPEMI_ON_AUX_STREAM:     knpemi_assemble_emi runs on the handle's auxiliary stream, ordered after
+ *                             everything enqueued so far; knpemi_join() orders the main stream after it. */
+#define KNPEMI_SKIP_MEMBRANE_RHS 4
+#define KNPEMI_ON_AUX_STREAM 8
 
 typedef struct knpemi_handle knpemi_handle;
 
@@ -130,6 +138,8 @@ int knpemi_get_field(knpemi_handle* h, int field, int sub, int idx, double* host
  * (run_3D.py:355-356 -> dolfinx assemble_matrix/assemble_vector over FFCx kernels). */
 int knpemi_assemble_emi(knpemi_handle* h, int flags);
 int knpemi_assemble_knp(knpemi_handle* h, int flags);
+int knpemi_assemble_emi_membrane_rhs(knpemi_handle* h, int flags);
+int knpemi_join(knpemi_handle* h);
 
 /* CSR access.  A_EMI/P_EMI: square, unknown order [phi_0, phi_1, ...] (pdeSolver.py:42).
  * A_KNP: block diagonal, unknown order [c[0][0], c[0][1], c[1][0], ...] (pdeSolver.py:117). */

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_kernel(KnDev D, const KnCon
   const int rloc = tid / LPR, sub = tid % LPR;
   const bool valid = rloc < nrows;
   const int g = row0 + (valid ? rloc : 0);
-  double bacc = 0.0;
+  double bacc = 0.0, gam = 0.0;   // volume part / membrane Robin part of b_emi
   if (valid) {
     double* segA_own = segA;   // membrane terms go to copy 0
     double* segP_own = segP;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_kernel(KnDev D, const KnCon
         for (int bb = 0; bb < NF; ++bb) {
           const int q = D.fq[(size_t)fg * NF + bb];
           double gq = D.phiM[q];
-          if (!splitting) {
+          if (!(splitting & 1)) {
             double it = 0.0;
             for (int k = 0; k < KN_MAXK; ++k) it += D.Ich[((size_t)ms * KN_MAXK + k) * D.NQtot + q];
             gq -= it / C.C_phi;
@@ -357,13 +357,13 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_kernel(KnDev D, const KnCon
           segA[io] += val; segP[io] += val;
           segA[it2] -= val; segP[it2] -= val;
         }
-        bacc += (cell_side ? 1.0 : -1.0) * C.C_phi * gs;
+        if (!(splitting & 2)) gam += (cell_side ? 1.0 : -1.0) * C.C_phi * gs;
       }
     }
   }
 #pragma unroll
   for (int m = 1; m < LPR; m <<= 1) bacc += __shfl_xor(bacc, m);   // fixed-shape tree over the row's lanes
-  if (valid && sub == 0) D.b_emi[g] = bacc;
+  if (valid && sub == 0) D.b_emi[g] = bacc + gam;
   __syncthreads();
   for (int i = tid; i < seglen; i += KN_BLOCK) {
     double a = segA[i], p = segP[i];
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
 
   const KnSubConst& sc = C.sc[s];
   const bool cell_side = s > 0;
-  double bacc = 0.0;
+  double bacc = 0.0, gam = 0.0;   // volume part / membrane Robin part of b_emi
   if (valid) {
     const int rowbase = ri.x, lap = ri.y, rL = ri.z;
     // The diagonal entry receives a term from every pair: keep it in registers and add it once.
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
         for (int bb = 0; bb < NF; ++bb) {
           const int q = D.fq[(size_t)fg * NF + bb];
           double gq = D.phiM[q];
-          if (!splitting) {
+          if (!(splitting & 1)) {
             double it = 0.0;
             for (int k = 0; k < KN_MAXK; ++k) it += D.Ich[((size_t)ms * KN_MAXK + k) * D.NQtot + q];
             gq -= it / C.C_phi;
@@ -750,13 +750,13 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
           unsafeAtomicAdd(&accA[it2], -val);
           if (acc_p) { unsafeAtomicAdd(&accP[io], val); unsafeAtomicAdd(&accP[it2], -val); }
         }
-        bacc += (cell_side ? 1.0 : -1.0) * C.C_phi * gs;
+        if (!(splitting & 2)) gam += (cell_side ? 1.0 : -1.0) * C.C_phi * gs;
       }
     }
   }
 #pragma unroll
   for (int m = 1; m < LPR; m <<= 1) bacc += __shfl_xor(bacc, m);
-  if (valid && sub == 0) D.b_emi[g] = bacc;
+  if (valid && sub == 0) D.b_emi[g] = bacc + gam;
   __syncthreads();
   for (int i = tid; i < seglen; i += KN_BLOCK) {
     const double a = accA[i];
@@ -1040,6 +1040,45 @@ __global__ void halo_kernel(KnDev D, int kind, int pack, const int* __restrict__
   }
 }
 
+// Membrane Robin term of b_emi alone (emiWeakForm.py:228-239), for the runs that assemble the EMI
+// matrix beside the ODE sweep: one thread per membrane row, same arithmetic and entry order as the
+// row kernels, so b_emi is bit-identical to the fused path.
+template <int NF>
+__global__ __launch_bounds__(256) void emi_membrane_rhs_kernel(KnDev D, const KnConsts* __restrict__ Cp, int splitting) {
+  const KnConsts& C = *Cp;
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= D.M) return;
+  const int g = D.mrow[m];
+  const bool cell_side = g >= C.voff[1];
+  const int* fown = cell_side ? D.fi : D.fe;
+  double gam = 0.0;
+  for (int e = D.mptr[m]; e < D.mptr[m + 1]; ++e) {
+    const int ent = D.mentry[e];
+    const int fg = ent >> 3, a = ent & 7;
+    const int ms = D.fmodel[fg];
+    if (ms < 0) continue;
+    Rec p[NF];
+#pragma unroll
+    for (int bb = 0; bb < NF; ++bb) p[bb] = load_rec(D.VR, fown[(size_t)fg * NF + bb]);
+    double Mr[NF];
+    facet_mass_row<NF>(p, a, Mr);
+    double gs = 0.0;
+#pragma unroll
+    for (int bb = 0; bb < NF; ++bb) {
+      const int q = D.fq[(size_t)fg * NF + bb];
+      double gq = D.phiM[q];
+      if (!splitting) {
+        double it = 0.0;
+        for (int k = 0; k < KN_MAXK; ++k) it += D.Ich[((size_t)ms * KN_MAXK + k) * D.NQtot + q];
+        gq -= it / C.C_phi;
+      }
+      gs += Mr[bb] * gq;
+    }
+    gam += (cell_side ? 1.0 : -1.0) * C.C_phi * gs;
+  }
+  D.b_emi[g] = D.b_emi[g] + gam;
+}
+
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -1074,7 +1113,7 @@ static int launch_emi(knpemi_handle* h, size_t lds, int lds_n, int want_p, int s
     if ((rc = set_lds_limit(emi_rows_kernel<GDIM, NV, L>, lds))) return rc;                          \
     {                                                                                                \
       KnProfScope prof(h, KNPEMI_K_EMI_ROWS);                                                        \
-      hipLaunchKernelGGL((emi_rows_kernel<GDIM, NV, L>), grid, block, lds, h->stream, D, h->d_consts, \
+      hipLaunchKernelGGL((emi_rows_kernel<GDIM, NV, L>), grid, block, lds, h->cur, D, h->d_consts, \
                          lds_n, want_p, split);                                                      \
     }                                                                                                \
     break;
@@ -1093,7 +1132,7 @@ static int launch_knp(knpemi_handle* h, size_t lds, int lds_n) {
     if ((rc = set_lds_limit(knp_rows_kernel<GDIM, NV, L>, lds))) return rc;                          \
     {                                                                                                \
       KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                        \
-      hipLaunchKernelGGL((knp_rows_kernel<GDIM, NV, L>), grid, block, lds, h->stream, D, h->d_consts, \
+      hipLaunchKernelGGL((knp_rows_kernel<GDIM, NV, L>), grid, block, lds, h->cur, D, h->d_consts, \
                          lds_n);                                                                     \
     }                                                                                                \
     break;
@@ -1115,7 +1154,7 @@ static int launch_emi_v2(knpemi_handle* h, int want_p, int split) {
     if ((rc = set_lds_limit(emi_rows_v2<GDIM, L>, lds))) return rc;                                 \
     {                                                                                               \
       KnProfScope prof(h, KNPEMI_K_EMI_ROWS);                                                       \
-      hipLaunchKernelGGL((emi_rows_v2<GDIM, L>), grid, block, lds, h->stream, D, h->d_consts, acc_n, \
+      hipLaunchKernelGGL((emi_rows_v2<GDIM, L>), grid, block, lds, h->cur, D, h->d_consts, acc_n, \
                          want_p, split);                                                            \
     }                                                                                               \
     break;
@@ -1137,7 +1176,7 @@ static int launch_knp_v2(knpemi_handle* h) {
     if ((rc = set_lds_limit(knp_rows_v2<GDIM, L>, lds))) return rc;                                 \
     {                                                                                               \
       KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                       \
-      hipLaunchKernelGGL((knp_rows_v2<GDIM, L>), grid, block, lds, h->stream, D, h->d_consts, acc_n); \
+      hipLaunchKernelGGL((knp_rows_v2<GDIM, L>), grid, block, lds, h->cur, D, h->d_consts, acc_n); \
     }                                                                                               \
     break;
   switch (h->lpr) { KN_CASE(1) KN_CASE(2) KN_CASE(4) KN_CASE(8) default: kn_set_error("bad lanes-per-row"); return KNPEMI_EINVAL; }
@@ -1149,13 +1188,15 @@ int kn_launch_emi_rows(knpemi_handle* h, int flags) {
   const KnDev& D = h->dev;
   if (D.nblocks == 0) return KNPEMI_OK;
   if (h->NV != 8) {
-    const int want_p = (flags & KNPEMI_WANT_P) ? 1 : 0, split = (flags & KNPEMI_NO_SPLITTING) ? 0 : 1;
+    const int want_p = (flags & KNPEMI_WANT_P) ? 1 : 0;
+    const int split = ((flags & KNPEMI_NO_SPLITTING) ? 0 : 1) | ((flags & KNPEMI_SKIP_MEMBRANE_RHS) ? 2 : 0);
     return h->gdim == 2 ? launch_emi_v2<2>(h, want_p, split) : launch_emi_v2<3>(h, want_p, split);
   }
   const int lds_n = h->lds_doubles_emi;
   const size_t lds = (size_t)2 * h->lpr * lds_n * sizeof(double) + (h->NV == 8 ? sizeof(HexTab) : 0);
   if (lds > 160 * 1024) { kn_set_error("EMI row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
-  const int want_p = (flags & KNPEMI_WANT_P) ? 1 : 0, split = (flags & KNPEMI_NO_SPLITTING) ? 0 : 1;
+  const int want_p = (flags & KNPEMI_WANT_P) ? 1 : 0;
+    const int split = ((flags & KNPEMI_NO_SPLITTING) ? 0 : 1) | ((flags & KNPEMI_SKIP_MEMBRANE_RHS) ? 2 : 0);
   return launch_emi<3, 8>(h, lds, lds_n, want_p, split);
 }
 
@@ -1178,10 +1219,21 @@ int kn_launch_knp_membrane(knpemi_handle* h, int flags) {
   const size_t lds = (size_t)D.nq_gamma * (1 + NF + (NF == 4 ? 2 * NF : 0)) * sizeof(double);
   dim3 grid((2 * D.nftot + 255) / 256), block(256);
   KnProfScope prof(h, KNPEMI_K_KNP_MEMBRANE);
-  if (NF == 2) hipLaunchKernelGGL((knp_membrane_kernel<2>), grid, block, lds, h->stream, D, h->d_consts, split);
-  else if (NF == 3) hipLaunchKernelGGL((knp_membrane_kernel<3>), grid, block, lds, h->stream, D, h->d_consts, split);
-  else hipLaunchKernelGGL((knp_membrane_kernel<4>), grid, block, lds, h->stream, D, h->d_consts, split);
+  if (NF == 2) hipLaunchKernelGGL((knp_membrane_kernel<2>), grid, block, lds, h->cur, D, h->d_consts, split);
+  else if (NF == 3) hipLaunchKernelGGL((knp_membrane_kernel<3>), grid, block, lds, h->cur, D, h->d_consts, split);
+  else hipLaunchKernelGGL((knp_membrane_kernel<4>), grid, block, lds, h->cur, D, h->d_consts, split);
   return check_launch("knp_membrane_kernel");
+}
+
+int kn_launch_emi_membrane_rhs(knpemi_handle* h, int flags) {
+  const KnDev& D = h->dev;
+  if (D.M == 0) return KNPEMI_OK;
+  const int split = (flags & KNPEMI_NO_SPLITTING) ? 0 : 1;
+  dim3 grid((D.M + 255) / 256), block(256);
+  if (h->NF == 2) hipLaunchKernelGGL((emi_membrane_rhs_kernel<2>), grid, block, 0, h->stream, D, h->d_consts, split);
+  else if (h->NF == 3) hipLaunchKernelGGL((emi_membrane_rhs_kernel<3>), grid, block, 0, h->stream, D, h->d_consts, split);
+  else hipLaunchKernelGGL((emi_membrane_rhs_kernel<4>), grid, block, 0, h->stream, D, h->d_consts, split);
+  return check_launch("emi_membrane_rhs_kernel");
 }
 
 int kn_launch_update_pde(knpemi_handle* h) {
@@ -1189,7 +1241,7 @@ int kn_launch_update_pde(knpemi_handle* h) {
   const int n = std::max(D.Ntot, D.NQtot);
   if (n == 0) return KNPEMI_OK;
   KnProfScope prof(h, KNPEMI_K_UPDATE);
-  hipLaunchKernelGGL(update_pde_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, D, h->d_consts);
+  hipLaunchKernelGGL(update_pde_kernel, dim3((n + 255) / 256), dim3(256), 0, h->cur, D, h->d_consts);
   return check_launch("update_pde_kernel");
 }
 

@@ -125,6 +125,10 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   std::unique_ptr<knpemi_handle, void (*)(knpemi_handle*)> guard(h, knpemi_destroy);
   h->device = device;
   KN_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  KN_HIP(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+  h->cur = h->stream;
+  KN_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  KN_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   KN_HIP(hipEventCreate(&h->ev0));
   KN_HIP(hipEventCreate(&h->ev1));
   h->gdim = d->gdim; h->cell_kind = d->cell_kind; h->NV = NV; h->NF = NF;
@@ -447,7 +451,11 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
 extern "C" void knpemi_destroy(knpemi_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  if (h->aux) (void)hipStreamSynchronize(h->aux);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->aux) (void)hipStreamDestroy(h->aux);
   for (void* p : h->allocs) (void)hipFree(p);
   for (auto& v : h->prof_ev) for (hipEvent_t e : v) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -495,6 +503,7 @@ extern "C" int knpemi_set_params(knpemi_handle* h, const knpemi_params* p) {
 
 extern "C" int knpemi_sync(knpemi_handle* h) {
   if (!h) return fail(KNPEMI_EINVAL, "null handle");
+  KN_HIP(hipStreamSynchronize(h->aux));
   KN_HIP(hipStreamSynchronize(h->stream));
   return KNPEMI_OK;
 }
@@ -611,7 +620,32 @@ extern "C" int knpemi_assemble_emi(knpemi_handle* h, int flags) {
   if (!h) return fail(KNPEMI_EINVAL, "null handle");
   if (!h->have_params) return fail(KNPEMI_EINVAL, "knpemi_assemble_emi: knpemi_set_params not called");
   KN_HIP(hipSetDevice(h->device));
+  if (flags & KNPEMI_ON_AUX_STREAM) {
+    // fork: the auxiliary stream starts after everything enqueued on the main stream so far
+    KN_HIP(hipEventRecord(h->ev_fork, h->stream));
+    KN_HIP(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+    h->cur = h->aux;
+    int rc = kn_launch_emi_rows(h, flags);
+    h->cur = h->stream;
+    if (rc) return rc;
+    KN_HIP(hipEventRecord(h->ev_join, h->aux));
+    return KNPEMI_OK;
+  }
   return kn_launch_emi_rows(h, flags);
+}
+
+extern "C" int knpemi_join(knpemi_handle* h) {
+  if (!h) return fail(KNPEMI_EINVAL, "null handle");
+  KN_HIP(hipSetDevice(h->device));
+  KN_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_assemble_emi_membrane_rhs(knpemi_handle* h, int flags) {
+  if (!h) return fail(KNPEMI_EINVAL, "null handle");
+  if (!h->have_params) return fail(KNPEMI_EINVAL, "knpemi_assemble_emi_membrane_rhs: knpemi_set_params not called");
+  KN_HIP(hipSetDevice(h->device));
+  return kn_launch_emi_membrane_rhs(h, flags);
 }
 
 extern "C" int knpemi_assemble_knp(knpemi_handle* h, int flags) {

@@ -98,7 +98,10 @@ struct KnOdeModel {
 
 struct knpemi_handle {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;          // main stream
+  hipStream_t aux = nullptr;             // auxiliary stream (EMI matrix assembly beside the ODE sweep)
+  hipStream_t cur = nullptr;             // stream the row-kernel launchers enqueue on (stream or aux)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int gdim = 0, cell_kind = 0, NV = 0, NF = 0, n_sub = 0, K = 0;
   std::vector<int> n_vert, n_cell, n_q, n_facet, n_models;
@@ -132,11 +135,11 @@ struct KnProfScope {
       if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
       v.push_back(a); v.push_back(b);
     }
-    (void)hipEventRecord(v[h->prof_used[k]], h->stream);
+    (void)hipEventRecord(v[h->prof_used[k]], h->cur);
   }
   ~KnProfScope() {
     if (!on) return;
-    (void)hipEventRecord(h->prof_ev[k][h->prof_used[k] + 1], h->stream);
+    (void)hipEventRecord(h->prof_ev[k][h->prof_used[k] + 1], h->cur);
     h->prof_used[k] += 2;
   }
 };
@@ -155,6 +158,7 @@ void kn_set_error(const std::string& msg);
 // kernel launchers (kernels_*.hip) ------------------------------------------------------------
 int kn_launch_emi_rows(knpemi_handle* h, int flags);
 int kn_launch_knp_rows(knpemi_handle* h, int flags);
+int kn_launch_emi_membrane_rhs(knpemi_handle* h, int flags);
 int kn_launch_knp_membrane(knpemi_handle* h, int flags);
 int kn_launch_ode_step(knpemi_handle* h, int slot, double t0, double dt, double rtol, double atol,
                        int flags, const int32_t* ion_param, int v_index);

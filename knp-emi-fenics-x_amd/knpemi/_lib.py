@@ -20,7 +20,7 @@ MAX_IONS, MAX_SUB, MAX_MODELS = 3, 8, 4
 F_PHI, F_C, F_C_PREV, F_C_ELIM, F_PHI_M, F_I_CH, F_SOURCE = range(7)
 A_EMI, P_EMI, A_KNP = 0, 1, 2
 B_EMI, B_KNP = 0, 1
-WANT_P, NO_SPLITTING = 1, 2
+WANT_P, NO_SPLITTING, SKIP_MEMBRANE_RHS, ON_AUX_STREAM = 1, 2, 4, 8
 ODE_SET_V, ODE_SET_TRACES = 1, 2
 K_ODE, K_EMI_ROWS, K_KNP_ROWS, K_KNP_MEMBRANE, K_UPDATE = range(5)
 KERNEL_NAMES = ["ode_step_kernel", "emi_rows_kernel", "knp_rows_kernel", "knp_membrane_kernel", "update_pde_kernel"]
@@ -73,6 +73,8 @@ SIGNATURES = {
     "knpemi_get_field": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_dbl_p, C.c_size_t]),
     "knpemi_assemble_emi": (C.c_int, [C.c_void_p, C.c_int]),
     "knpemi_assemble_knp": (C.c_int, [C.c_void_p, C.c_int]),
+    "knpemi_assemble_emi_membrane_rhs": (C.c_int, [C.c_void_p, C.c_int]),
+    "knpemi_join": (C.c_int, [C.c_void_p]),
     "knpemi_csr_dims": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "knpemi_get_csr_pattern": (C.c_int, [C.c_void_p, C.c_int, c_int_p, c_int_p]),
     "knpemi_get_csr_values": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p]),

@@ -23,7 +23,7 @@ from . import _lib as L
 
 class DeviceStepper:
     def __init__(self, forms_emi, forms_knp, c, c_prev, phi, phi_M_prev, solve_emi=None, solve_knp=None,
-                 assemble_knp_twice=False):
+                 assemble_knp_twice=False, overlap=True):
         a = forms_emi[0]
         self.dp = a.dp
         self.a = a
@@ -31,6 +31,7 @@ class DeviceStepper:
         self.c, self.c_prev, self.phi, self.phi_M_prev = c, c_prev, phi, phi_M_prev
         self.solve_emi, self.solve_knp = solve_emi, solve_knp
         self.assemble_knp_twice = assemble_knp_twice
+        self.overlap = overlap
         self.k = 0
         self.models = []   # (MembraneModel, stimulus, locator)
         dp = self.dp
@@ -103,13 +104,21 @@ class DeviceStepper:
     def step(self, halo=None):
         dp, lib = self.dp, self.lib
         flags = L.ODE_SET_TRACES | (L.ODE_SET_V if self.k > 0 else 0)
+        if self.overlap:
+            # the EMI matrix (A, P, volume part of b) does not depend on the ODE output: assemble it on the
+            # auxiliary stream while the ODE sweep runs on the main one
+            L.check(lib.knpemi_assemble_emi(dp.h, self.flags_emi | L.SKIP_MEMBRANE_RHS | L.ON_AUX_STREAM))
         for m in self.models:
             L.check(lib.knpemi_ode_step(dp.h, m._sub, m._model, float(m.time), self.dt, m.rtol, m.atol,
                                         flags, L.iptr(m._ion_param), int(m.V_index)))
             m.time = m.time + self.dt
         if halo is not None:
             halo.exchange_membrane()
-        L.check(lib.knpemi_assemble_emi(dp.h, self.flags_emi))
+        if self.overlap:
+            L.check(lib.knpemi_join(dp.h))
+            L.check(lib.knpemi_assemble_emi_membrane_rhs(dp.h, self.flags_emi))
+        else:
+            L.check(lib.knpemi_assemble_emi(dp.h, self.flags_emi))
         if self.solve_emi is not None:
             self.solve_emi(dp)
             if halo is not None:

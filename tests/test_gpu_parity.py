@@ -177,7 +177,7 @@ def test_device_stepper_matches_dropin_path(hip_lib):
     from knpemi.pdeSolver import create_solver_emi, create_solver_knp
     from knpemi.stepper import DeviceStepper
     res = []
-    for mode in ("dropin", "stepper"):
+    for mode in ("dropin", "stepper", "stepper_no_overlap"):
         s = Setup("tet", 0, g_syn=10.0)
         s.perturb()
         # physically sensible "solution" fields: c close to c_prev, phi_i - phi_e close to rest
@@ -186,9 +186,9 @@ def test_device_stepper_matches_dropin_path(hip_lib):
                 s.c[t][k].x.array[:] = s.c_prev[t][k].x._a * 1.001
         s.phi[1].x.array[:] += -0.0744
         ode = s.mem_models[0]['ode']
-        if mode == "stepper":
+        if mode.startswith("stepper"):
             st = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp), s.c, s.c_prev, s.phi,
-                               s.phi_M_prev)
+                               s.phi_M_prev, overlap=(mode == "stepper"))
             st.add_membrane_model(ode, s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
             for _ in range(3):
                 st.step()
@@ -208,8 +208,9 @@ def test_device_stepper_matches_dropin_path(hip_lib):
                 update_pde_variables(s.c, s.c_prev, s.phi, s.phi_M_prev, s.physical_parameters, s.ion_list,
                                      s.subdomain_list, s.mesh, s.ct)
         res.append((ode.states.copy(), s.phi_M_prev[1].x._a.copy(), s.c_prev[1][0].x._a.copy(), b_emi, b_knp))
-    for a, b in zip(*res):
-        assert np.array_equal(a, b)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert np.array_equal(a, b)
 
 
 def test_ten_time_steps_2d_match_oracle(hip_lib):
