@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-steps", type=int, default=3, help="oracle steps timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run the EMI matrix assembly after the ODE sweep instead of beside it (aux stream)")
     ap.add_argument("--knp-twice", action="store_true",
                     help="assemble A_knp twice per step as the reference does (p = a, knpWeakForm.py:319)")
     args = ap.parse_args()
@@ -157,7 +159,8 @@ def main():
         s.phi[tag].x.array[:] = (-0.0744 if tag > 0 else 0.0) + 1e-3 * np.sin(2 * np.pi * x[:, 0] / L_x)
 
     stepper = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp),
-                            s.c, s.c_prev, s.phi, s.phi_M_prev, assemble_knp_twice=args.knp_twice)
+                            s.c, s.c_prev, s.phi, s.phi_M_prev, assemble_knp_twice=args.knp_twice,
+                            overlap=not args.no_overlap)
     dp = stepper.dp
     for mm in s.mem_models:
         stepper.add_membrane_model(mm['ode'], s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
@@ -230,6 +233,7 @@ def main():
                                    f"{int(dp.n_q.sum())} membrane ODE dofs/GPU, 3 ions (K, Cl, Na eliminated), HH, "
                                    f"g_syn=10 for x<20um, dt=1e-4",
                        "dofs_per_step": dofs_total, "A_knp_assemblies_per_step": 2 if args.knp_twice else 1,
+                       "emi_matrix_beside_ode_sweep": not args.no_overlap,
                        "partition": "x-slabs" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -580,7 +580,7 @@ __device__ __forceinline__ double simplex_row0(const Rec6 (&r)[GDIM + 1], double
 // Block descriptor (uniform) and the staging of the block's Laplacian-entry records: all index loads
 // are issued together, then all record loads, so a wave waits for memory twice instead of 2 x trips.
 struct BlkInfo {
-  int row0, nrows, sub, seg0, seglen, segL0, nnzLb, slbase, np;
+  int row0, nrows, sub, seg0, seglen, segL0, nnzLb, uoff, nuniq, slbase, np;
 };
 
 __device__ __forceinline__ BlkInfo load_blk(const KnDev& D, int b, int wave) {
@@ -588,23 +588,27 @@ __device__ __forceinline__ BlkInfo load_blk(const KnDev& D, int b, int wave) {
   const int4 i0 = p[0], i1 = p[1], i2 = p[2], i3 = p[3];
   BlkInfo B;
   B.row0 = i0.x; B.nrows = i0.y; B.sub = i0.z; B.seg0 = i0.w;
-  B.seglen = i1.x; B.segL0 = i1.y; B.nnzLb = i1.z;
+  B.seglen = i1.x; B.segL0 = i1.y; B.nnzLb = i1.z; B.uoff = i1.w;
   B.slbase = wave == 0 ? i2.x : (wave == 1 ? i2.y : (wave == 2 ? i2.z : i2.w));
-  B.np = wave == 0 ? i3.x : (wave == 1 ? i3.y : (wave == 2 ? i3.z : i3.w));
+  B.np = ((unsigned)i3.x >> (8 * wave)) & 255;
+  B.nuniq = i3.y;
   return B;
 }
 
-#define KN_STAGE 5   // Laplacian entries per thread staged with batched loads (256 threads x 5 = 1280)
+#define KN_STAGE 3   // distinct vertices per thread staged with batched loads (256 threads x 3 = 768)
 
+// Phase A of the v2 kernels: the 48-byte records of the block's distinct vertices go to `recs`, the
+// 2-byte local index of every Laplacian entry to `eloc`.
 template <bool KNP>
-__device__ __forceinline__ void stage_records(const KnDev& D, const BlkInfo& B, double* recs, int tid,
+__device__ __forceinline__ void stage_records(const KnDev& D, const BlkInfo& B, double* recs, uint16_t* eloc, int tid,
                                               double inv_dt, const double* fs0, int nvs) {
   int vv[KN_STAGE];
 #pragma unroll
   for (int k = 0; k < KN_STAGE; ++k) {
     const int i = tid + k * KN_BLOCK;
-    vv[k] = i < B.nnzLb ? D.colindL[B.segL0 + i] : -1;
+    vv[k] = i < B.nuniq ? D.blk_uverts[B.uoff + i] : -1;
   }
+  for (int i = tid; i < B.nnzLb; i += KN_BLOCK) eloc[i] = D.ent_loc[B.segL0 + i];
   double2 u[KN_STAGE][4];
 #pragma unroll
   for (int k = 0; k < KN_STAGE; ++k)
@@ -624,8 +628,8 @@ __device__ __forceinline__ void stage_records(const KnDev& D, const BlkInfo& B, 
         dst[0] = u[k][0]; dst[1] = double2{u[k][1].x, u[k][2].x}; dst[2] = double2{u[k][2].y, u[k][3].x};
       }
     }
-  for (int i = tid + KN_STAGE * KN_BLOCK; i < B.nnzLb; i += KN_BLOCK) {   // oversized blocks only
-    const int v = D.colindL[B.segL0 + i];
+  for (int i = tid + KN_STAGE * KN_BLOCK; i < B.nuniq; i += KN_BLOCK) {   // oversized blocks only
+    const int v = D.blk_uverts[B.uoff + i];
     const double2* src = reinterpret_cast<const double2*>(D.VR + (size_t)v * KN_REC);
     const double2 u0 = src[0], u1 = src[1], u2 = src[2], u3 = src[3];
     double2* dst = reinterpret_cast<double2*>(recs + (size_t)i * 6);
@@ -641,13 +645,14 @@ __device__ __forceinline__ void stage_records(const KnDev& D, const BlkInfo& B, 
 
 template <int GDIM, int LPR>
 __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n,
-                                                        int want_p, int splitting) {
+                                                        int rec_n, int want_p, int splitting) {
   constexpr int NV = GDIM + 1, NF = GDIM;
   const KnConsts& C = *Cp;
   extern __shared__ __align__(16) double lds[];
   double* accA = lds;
   double* accP = lds + acc_n;
   double* recs = lds + 2 * (size_t)acc_n;
+  uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + 6 * (size_t)rec_n);
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
   const BlkInfo B = load_blk(D, b, tid >> 6);
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
   const int4 ri = D.row_info[g];
   // phase A: zero accumulators, stage the records of the block's Laplacian entries
   for (int i = tid; i < seglen; i += KN_BLOCK) { accA[i] = 0.0; accP[i] = 0.0; }
-  stage_records<false>(D, B, recs, tid, 0.0, nullptr, 0);
+  stage_records<false>(D, B, recs, eloc, tid, 0.0, nullptr, 0);
   __syncthreads();
 
   const KnSubConst& sc = C.sc[s];
@@ -683,9 +688,9 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
       int slot[NV];
 #pragma unroll
       for (int j = 0; j < NV; ++j) slot[j] = (sl >> (8 * j)) & 255;
-      if (diag < 0) { diag = slot[0]; r[0] = lds_rec(recs, rL + diag); }   // the row's own vertex, once
+      if (diag < 0) { diag = slot[0]; r[0] = lds_rec(recs, eloc[rL + diag]); }   // the row's own vertex, once
 #pragma unroll
-      for (int j = 1; j < NV; ++j) r[j] = lds_rec(recs, rL + slot[j]);
+      for (int j = 1; j < NV; ++j) r[j] = lds_rec(recs, eloc[rL + slot[j]]);
       double d[NV];
       const double vol = simplex_row0<GDIM>(r, d);
       double cb0 = 0, cb1 = 0, cb2 = 0, sd = 0;
@@ -766,13 +771,14 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
 }
 
 template <int GDIM, int LPR>
-__global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n) {
+__global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n, int rec_n) {
   constexpr int NV = GDIM + 1, NF = GDIM;
   const KnConsts& C = *Cp;
   extern __shared__ __align__(16) double lds[];
   double* acc0 = lds;
   double* acc1 = lds + acc_n;
   double* recs = lds + 2 * (size_t)acc_n;
+  uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + 6 * (size_t)rec_n);
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
   const BlkInfo B = load_blk(D, b, tid >> 6);
@@ -790,7 +796,7 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
     slr[p] = (valid && p < np) ? D.pair_sl[base + (int64_t)p * KN_SLICE] : 0xFFFFFFFFu;
   const int4 ri = D.row_info[g];
   for (int i = tid; i < nnzLb; i += KN_BLOCK) { acc0[i] = 0.0; acc1[i] = 0.0; }
-  stage_records<true>(D, B, recs, tid, C.inv_dt, fs0, nvs);
+  stage_records<true>(D, B, recs, eloc, tid, C.inv_dt, fs0, nvs);
   __syncthreads();
 
   const KnSubConst& sc = C.sc[s];
@@ -804,9 +810,9 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
       int slot[NV];
 #pragma unroll
       for (int j = 0; j < NV; ++j) slot[j] = (sl >> (8 * j)) & 255;
-      if (diag < 0) { diag = slot[0]; r[0] = lds_rec(recs, rL + diag); }
+      if (diag < 0) { diag = slot[0]; r[0] = lds_rec(recs, eloc[rL + diag]); }
 #pragma unroll
-      for (int j = 1; j < NV; ++j) r[j] = lds_rec(recs, rL + slot[j]);
+      for (int j = 1; j < NV; ++j) r[j] = lds_rec(recs, eloc[rL + slot[j]]);
       double d[NV];
       const double vol = simplex_row0<GDIM>(r, d);
       double gp = 0;
@@ -1144,8 +1150,8 @@ static int launch_knp(knpemi_handle* h, size_t lds, int lds_n) {
 template <int GDIM>
 static int launch_emi_v2(knpemi_handle* h, int want_p, int split) {
   const KnDev& D = h->dev;
-  const int acc_n = (h->lds_doubles_emi + 1) & ~1;
-  const size_t lds = ((size_t)2 * acc_n + 6 * (size_t)h->lds_doubles_knp) * sizeof(double);
+  const int acc_n = (h->lds_doubles_emi + 1) & ~1, rec_n = h->lds_uniq_max;
+  const size_t lds = ((size_t)2 * acc_n + 6 * (size_t)rec_n) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
   if (lds > 160 * 1024) { kn_set_error("EMI row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   dim3 grid(D.nblocks), block(KN_BLOCK);
   int rc = 0;
@@ -1155,7 +1161,7 @@ static int launch_emi_v2(knpemi_handle* h, int want_p, int split) {
     {                                                                                               \
       KnProfScope prof(h, KNPEMI_K_EMI_ROWS);                                                       \
       hipLaunchKernelGGL((emi_rows_v2<GDIM, L>), grid, block, lds, h->cur, D, h->d_consts, acc_n, \
-                         want_p, split);                                                            \
+                         rec_n, want_p, split);                                                            \
     }                                                                                               \
     break;
   switch (h->lpr) { KN_CASE(1) KN_CASE(2) KN_CASE(4) KN_CASE(8) default: kn_set_error("bad lanes-per-row"); return KNPEMI_EINVAL; }
@@ -1166,8 +1172,8 @@ static int launch_emi_v2(knpemi_handle* h, int want_p, int split) {
 template <int GDIM>
 static int launch_knp_v2(knpemi_handle* h) {
   const KnDev& D = h->dev;
-  const int acc_n = (h->lds_doubles_knp + 1) & ~1;
-  const size_t lds = ((size_t)2 * acc_n + 6 * (size_t)h->lds_doubles_knp) * sizeof(double);
+  const int acc_n = (h->lds_doubles_knp + 1) & ~1, rec_n = h->lds_uniq_max;
+  const size_t lds = ((size_t)2 * acc_n + 6 * (size_t)rec_n) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
   if (lds > 160 * 1024) { kn_set_error("KNP row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   dim3 grid(D.nblocks), block(KN_BLOCK);
   int rc = 0;
@@ -1176,7 +1182,7 @@ static int launch_knp_v2(knpemi_handle* h) {
     if ((rc = set_lds_limit(knp_rows_v2<GDIM, L>, lds))) return rc;                                 \
     {                                                                                               \
       KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                       \
-      hipLaunchKernelGGL((knp_rows_v2<GDIM, L>), grid, block, lds, h->cur, D, h->d_consts, acc_n); \
+      hipLaunchKernelGGL((knp_rows_v2<GDIM, L>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n); \
     }                                                                                               \
     break;
   switch (h->lpr) { KN_CASE(1) KN_CASE(2) KN_CASE(4) KN_CASE(8) default: kn_set_error("bad lanes-per-row"); return KNPEMI_EINVAL; }

@@ -353,15 +353,34 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   }
 
   // ---- per-block / per-row descriptors: one scalar load per block, one 16-byte load per row ----------
-  std::vector<int> blk_info((size_t)nblocks * 16, 0), row_info((size_t)Ntot * 4, 0);
+  std::vector<int> blk_info((size_t)nblocks * 16, 0), row_info((size_t)Ntot * 4, 0), blk_uverts;
+  std::vector<uint16_t> ent_loc(colindL.size(), 0);
   for (int b = 0; b < nblocks; ++b) {
     int* bi = &blk_info[(size_t)b * 16];
     const int g0 = blk_row0[b], g1 = g0 + blk_nrows[b];
     bi[0] = g0; bi[1] = blk_nrows[b]; bi[2] = blk_sub[b]; bi[3] = rowptr[g0];
     bi[4] = rowptr[g1] - rowptr[g0]; bi[5] = rowptrL[g0]; bi[6] = rowptrL[g1] - rowptrL[g0];
+    uint32_t steps = 0;
     for (int w = 0; w < SPB; ++w) {
       bi[8 + w] = (int)(sl_ptr[(size_t)b * SPB + w] / KN_SLICE);
-      bi[12 + w] = (int)((sl_ptr[(size_t)b * SPB + w + 1] - sl_ptr[(size_t)b * SPB + w]) / KN_SLICE);
+      const int64_t np = (sl_ptr[(size_t)b * SPB + w + 1] - sl_ptr[(size_t)b * SPB + w]) / KN_SLICE;
+      if (np > 255) return fail(KNPEMI_EINVAL, "a vertex has too many incident cells for the pair layout");
+      steps |= (uint32_t)np << (8 * w);
+    }
+    bi[12] = (int)steps;
+    // distinct vertices touched by the block's rows (sorted: consecutive ids = contiguous records)
+    {
+      std::vector<int> u(colindL.begin() + rowptrL[g0], colindL.begin() + rowptrL[g1]);
+      std::sort(u.begin(), u.end());
+      u.erase(std::unique(u.begin(), u.end()), u.end());
+      if (u.size() > 65535) return fail(KNPEMI_EINVAL, "row block touches more than 65535 vertices");
+      bi[7] = (int)blk_uverts.size();
+      bi[13] = (int)u.size();
+      h->lds_uniq_max = std::max(h->lds_uniq_max, (int)u.size());
+      for (int p = rowptrL[g0]; p < rowptrL[g1]; ++p)
+        ent_loc[p] = (uint16_t)(std::lower_bound(u.begin(), u.end(), colindL[p]) - u.begin());
+      blk_uverts.insert(blk_uverts.end(), u.begin(), u.end());
+      if (blk_uverts.size() > (size_t)INT32_MAX) return fail(KNPEMI_EINVAL, "mesh too large for int32 block lists");
     }
     for (int g = g0; g < g1; ++g) {
       int* ri = &row_info[(size_t)g * 4];
@@ -397,6 +416,8 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
     if ((rc = dev_upload(h, blk_info, &bi))) return rc;
     if ((rc = dev_upload(h, row_info, &ri))) return rc;
     D.blk_info = reinterpret_cast<const int4*>(bi);
+    if ((rc = dev_upload(h, blk_uverts, &D.blk_uverts))) return rc;
+    if ((rc = dev_upload(h, ent_loc, &D.ent_loc))) return rc;
     D.row_info = reinterpret_cast<const int4*>(ri);
   }
   if ((rc = dev_upload(h, sl_ptr, &D.sl_ptr))) return rc;

@@ -47,7 +47,10 @@ struct KnDev {
   const int* blk_nrows;       // [nblocks] rows in the block (<= KN_BLOCK / lpr)
   const int* blk_sub;         // [nblocks] sub-domain of the block
   const int4* blk_info;       // [nblocks][4]: {row0, nrows, sub, rowptr[row0]} {EMI seg length, rowptrL[row0],
-                              //   Laplacian seg length, 0} {slice entry bases / 64} {slice steps}
+                              //   Laplacian seg length, offset into blk_uverts} {slice entry bases / 64}
+                              //   {4 x uint8 slice steps, #distinct vertices, 0, 0}
+  const int* blk_uverts;      // concatenated per-block sorted lists of the distinct vertices its rows touch
+  const uint16_t* ent_loc;    // [nnzL] position of every Laplacian entry's vertex in its block's list
   const int4* row_info;       // [Ntot]: {rowptr[g] - seg0, that + lapoff[g], rowptrL[g] - segL0, gam_idx[g]}
   double* VR;                 // [Ntot][KN_REC]
   double* csol;               // [K-1][Ntot]  solver output c (block order handled by offsets)
@@ -113,6 +116,7 @@ struct knpemi_handle {
   int have_params = 0;
   int lpr = 1;                         // lanes per row of the row kernels (1, 2, 4 or 8)
   int lds_doubles_emi = 0, lds_doubles_knp = 0; // per-block LDS segment sizes (doubles)
+  int lds_uniq_max = 0;                         // most distinct vertices touched by one row block
   std::vector<void*> allocs;  // everything hipMalloc'ed
   std::vector<KnOdeModel> ode; // [moff[n_sub]]
   // host copies of patterns for export
