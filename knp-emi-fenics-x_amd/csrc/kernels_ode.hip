@@ -14,6 +14,8 @@
 // Tables are stored transposed on the device ([column][dof]) so that neighbouring threads read
 // neighbouring addresses; the ODE work itself is latency/compute bound (fp64 exp/log, divergent
 // step control), not HBM bound.
+#include <cstdlib>
+
 #include "knpemi_internal.h"
 #include "membrane_models.h"
 
@@ -33,20 +35,25 @@ struct OdeArgs {
 
 constexpr int ODE_BLOCK = 64;
 
-template <class M>
+// LANES = M::NS: lane c of every group of NS adjacent lanes integrates component c of one membrane dof
+// (lsoda_core.h); LANES = 1: one thread per dof.
+template <class M, int LANES>
 __global__ __launch_bounds__(ODE_BLOCK) void ode_step_kernel(KnDev D, OdeArgs a, const LsodaCoef* __restrict__ cf) {
-  using Integrator = Lsoda<M::NS, M, ODE_BLOCK>;
-  // LSODA's dynamically indexed state (Nordsieck history, coefficients, iteration matrix) lives in LDS,
-  // one column per lane; the rest of the integrator state stays in registers.
+  using Integrator = Lsoda<M::NS, M, ODE_BLOCK, LANES>;
+  constexpr int NI = Integrator::NI;
+  // LSODA's dynamically indexed state (Nordsieck history, method coefficients, and for LANES = 1 the
+  // iteration matrix) lives in LDS, one column per lane; the rest stays in registers.
   __shared__ double work[Integrator::WORK * ODE_BLOCK];
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = gt / LANES, comp = gt % LANES;
   if (q >= a.nq) return;
   const int qg = a.q0 + q;
   const StridedRow<0> p{a.params + q, (size_t)a.nq};   // this dof's parameter row in the transposed table
-  double y[M::NS];
+  double y[NI];
 #pragma unroll
-  for (int j = 0; j < M::NS; ++j) y[j] = a.states[(size_t)j * a.nq + q];
-  // 1. concentration traces (record components 4..6 hold c_0, c_1, c_eliminated) -> parameter columns
+  for (int j = 0; j < NI; ++j) y[j] = a.states[(size_t)(comp + j) * a.nq + q];
+  // 1. concentration traces (record components 4..6 hold c_0, c_1, c_eliminated) -> parameter columns.
+  //    With several lanes per dof every lane writes the same values and later reads only its own stores.
   if (a.flags & KNPEMI_ODE_SET_TRACES) {
     const double* re = D.VR + (size_t)D.q2e[qg] * KN_REC + 4;
     const double* ri = D.VR + (size_t)D.q2i[qg] * KN_REC + 4;
@@ -58,29 +65,29 @@ __global__ __launch_bounds__(ODE_BLOCK) void ode_step_kernel(KnDev D, OdeArgs a,
   if (a.flags & KNPEMI_ODE_SET_V) {
     const double v = D.phiM[qg];
 #pragma unroll
-    for (int j = 0; j < M::NS; ++j) y[j] = (j == a.v_index) ? v : y[j];
+    for (int j = 0; j < NI; ++j) y[j] = (comp + j == a.v_index) ? v : y[j];
   }
   // 2. stimulus + LSODA (the parameter row is read once by prepare(); only the currents change)
   if (a.n_stim > 0 && (!a.mask || a.mask[q]))
     for (int i = 0; i < a.n_stim; ++i) p[a.stim_idx[i]] = a.stim_val[i];
   Integrator s;
   s.f.prepare(p);
-  const int rc = s.integrate(cf, work + threadIdx.x, y, a.t0, a.t0 + a.dt, a.rtol, a.atol, 10000);
-  // 3. write back: currents into the parameter row (the reference's RHS side effect), state row,
-  //    phi_M_prev <- V and the I_ch_k fields
-  s.f.finish(p);
-  double v_out = y[0];
+  const int rc = s.integrate(cf, work + threadIdx.x, y, a.t0, a.t0 + a.dt, a.rtol, a.atol, 10000, comp);
+  // 3. write back: state row, phi_M_prev <- V; the lane that owns V stores the currents (the reference's
+  //    RHS side effect) into the parameter row and the I_ch_k fields
 #pragma unroll
-  for (int j = 0; j < M::NS; ++j) {
-    a.states[(size_t)j * a.nq + q] = y[j];
-    v_out = (j == a.v_index) ? y[j] : v_out;
+  for (int j = 0; j < NI; ++j) {
+    a.states[(size_t)(comp + j) * a.nq + q] = y[j];
+    if (comp + j == a.v_index) D.phiM[qg] = y[j];
   }
-  D.phiM[qg] = v_out;
-  for (int k = 0; k < KN_MAXK; ++k)
-    D.Ich[((size_t)a.model_slot * KN_MAXK + k) * a.NQtot + qg] = p[a.ion_param[3 * k + 2]];
-  atomicAdd(&a.stats[0], (unsigned long long)s.nfe);
-  atomicAdd(&a.stats[1], (unsigned long long)s.nst);
-  if (rc != 0) atomicAdd(&a.stats[2], 1ull);
+  if (LANES == 1 || comp == M::CURRENT_LANE) {
+    s.f.finish(p);
+    for (int k = 0; k < KN_MAXK; ++k)
+      D.Ich[((size_t)a.model_slot * KN_MAXK + k) * a.NQtot + qg] = p[a.ion_param[3 * k + 2]];
+    atomicAdd(&a.stats[0], (unsigned long long)s.nfe);
+    atomicAdd(&a.stats[1], (unsigned long long)s.nst);
+    if (rc != 0) atomicAdd(&a.stats[2], 1ull);
+  }
 }
 
 }  // namespace
@@ -116,17 +123,23 @@ int kn_launch_ode_step(knpemi_handle* h, int slot, double t0, double dt, double 
   // counters accumulate over launches; knpemi_ode_stats() reads and resets them
   // 64-thread workgroups: the sweep has only n_q (10^3..10^5) threads, so spread the waves over as
   // many CUs as possible instead of stacking four of them on one.
-  dim3 grid((m.nq + ODE_BLOCK - 1) / ODE_BLOCK), block(ODE_BLOCK);
+  // KNPEMI_ODE_LANES=1 selects the one-thread-per-dof variant (diagnostics: both give identical bits)
+  const char* lanes_env = getenv("KNPEMI_ODE_LANES");
+  const bool one_lane = lanes_env && atoi(lanes_env) == 1;
+  const int lanes = (m.n_states == 4 && !one_lane) ? 4 : 1;
+  dim3 grid(((size_t)m.nq * lanes + ODE_BLOCK - 1) / ODE_BLOCK), block(ODE_BLOCK);
   KnProfScope prof(h, KNPEMI_K_ODE);
   switch (m.model_id) {
     case KNPEMI_MODEL_HH_SI:
-      hipLaunchKernelGGL((ode_step_kernel<ModelHHSI>), grid, block, 0, h->stream, h->dev, a, cf);
+      if (lanes == 4) hipLaunchKernelGGL((ode_step_kernel<ModelHHSI, 4>), grid, block, 0, h->stream, h->dev, a, cf);
+      else hipLaunchKernelGGL((ode_step_kernel<ModelHHSI, 1>), grid, block, 0, h->stream, h->dev, a, cf);
       break;
     case KNPEMI_MODEL_HH_MV:
-      hipLaunchKernelGGL((ode_step_kernel<ModelHHMV>), grid, block, 0, h->stream, h->dev, a, cf);
+      if (lanes == 4) hipLaunchKernelGGL((ode_step_kernel<ModelHHMV, 4>), grid, block, 0, h->stream, h->dev, a, cf);
+      else hipLaunchKernelGGL((ode_step_kernel<ModelHHMV, 1>), grid, block, 0, h->stream, h->dev, a, cf);
       break;
     default:
-      hipLaunchKernelGGL((ode_step_kernel<ModelGlial>), grid, block, 0, h->stream, h->dev, a, cf);
+      hipLaunchKernelGGL((ode_step_kernel<ModelGlial, 1>), grid, block, 0, h->stream, h->dev, a, cf);
       break;
   }
   hipError_t e = hipGetLastError();

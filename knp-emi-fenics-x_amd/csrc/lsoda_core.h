@@ -105,21 +105,52 @@ inline void lsoda_fill_coef(LsodaCoef* c) {
 // (Nordsieck history, method coefficients, iteration matrix).  The host build uses 1 (a private
 // array); the HIP kernel points `work` at LDS with STRIDE = workgroup size so that lane l owns the
 // column l: conflict-free, and an order of magnitude lower latency than scratch memory.
-template <int N, class F, int STRIDE = 1>
+//
+// LANES: number of GPU lanes that share one ODE system.  LANES = 1: one thread integrates all N
+// components (host build, and N = 1 models).  LANES = N (device only): lane c of a group of N adjacent
+// lanes owns component c -- every vector operation of the algorithm becomes one scalar operation per
+// lane, norms become a max over the group (exact, so all lanes of a group take identical decisions and
+// the results are bit-identical to LANES = 1), the right-hand side is evaluated component-wise by
+// `F::rhs_lane` after an all-gather of the state, and the N x N iteration matrix is gathered and
+// factorised redundantly by every lane.
+template <int L>
+KN_HD double kn_group_max(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int m = 1; m < L; m <<= 1) v = fmax(v, __shfl_xor(v, m));
+#endif
+  return v;
+}
+
+template <int L>
+KN_HD double kn_group_get(double v, int k) {   // value held by lane k of this lane's group
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __shfl(v, (int)((__lane_id() & ~(unsigned)(L - 1)) | (unsigned)k));
+#else
+  (void)k;
+  return v;
+#endif
+}
+
+template <int N, class F, int STRIDE = 1, int LANES = 1>
 struct Lsoda {
   static constexpr int MXORDN = 12, MXORDS = 5, MAXCOR = 3, MSBP = 20, MXNCF = 10;
-  static constexpr int WORK = 15 * N + 14 + N * N;   // doubles of work storage per integrator
+  static constexpr int NI = N / LANES;               // components held by one lane
+  static constexpr int WORK = 15 * NI + 14 + (LANES == 1 ? N * N : 0);   // doubles of strided work storage
+  static_assert(LANES == 1 || LANES == N, "one lane per system or one lane per component");
 
   const LsodaCoef* cf;
   F f;        // model functor: caches the parameter row, keeps the side-effect currents
   double rtol, atol;
   double* work;
   // YH(1..13, N): Nordsieck array (row 14 only bounds a dead branch of methodswitch)
-  KN_HD double& YH(int j, int i) { return work[(j * N + i) * STRIDE]; }
-  KN_HD double& EL(int i) { return work[(15 * N + i) * STRIDE]; }
-  KN_HD double& WM(int i, int j) { return work[(15 * N + 14 + i * N + j) * STRIDE]; }
+  KN_HD double& YH(int j, int i) { return work[(j * NI + i) * STRIDE]; }
+  KN_HD double& EL(int i) { return work[(15 * NI + i) * STRIDE]; }
+  KN_HD double& WM(int i, int j) { return work[(15 * NI + 14 + i * N + j) * STRIDE]; }
   int ipvt[N];
-  double ewt[N], savf[N], acor[N], y[N];
+  double ewt[NI], savf[NI], acor[NI], y[NI];
+  double lu[LANES == 1 ? 1 : N][LANES == 1 ? 1 : N];   // LANES = N: factorised iteration matrix (registers)
+  int comp = 0;                                         // LANES = N: the component this lane owns
   double h, hu, tn, hold, rc, crate, conit, el0, rmax, pdest, pdlast, pdnorm, ratio, tsw;
   int nq, l, meth, mused, miter, ialth, ipup, jcur, jstart, kflag, icount, irflag, nslp, nst, nfe,
       nje, lmax, maxord, nqu, ierpj;
@@ -137,23 +168,35 @@ struct Lsoda {
 
   KN_HD double vmnorm(const double* v) const {
     double vm = 0.0;
-    _Pragma("unroll") for (int i = 0; i < N; ++i) vm = fmax(vm, fabs(v[i]) * ewt[i]);
-    return vm;
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) vm = fmax(vm, fabs(v[i]) * ewt[i]);
+    return kn_group_max<LANES>(vm);
   }
 
   KN_HD double vmnorm_yh(int j) {
     double vm = 0.0;
-    _Pragma("unroll") for (int i = 0; i < N; ++i) vm = fmax(vm, fabs(YH(j, i)) * ewt[i]);
-    return vm;
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) vm = fmax(vm, fabs(YH(j, i)) * ewt[i]);
+    return kn_group_max<LANES>(vm);
+  }
+
+  // right-hand side: all components (LANES = 1) or this lane's component after an all-gather
+  KN_HD void eval_rhs(double t, const double* yv, double* out) {
+    if constexpr (LANES == 1) {
+      f.rhs(t, yv, out);
+    } else {
+      double ya[N];
+      _Pragma("unroll") for (int k = 0; k < N; ++k) ya[k] = kn_group_get<LANES>(yv[0], k);
+      out[0] = f.rhs_lane(comp, t, ya);
+    }
   }
 
   KN_HD bool ewset(const double* yc) {
-    _Pragma("unroll") for (int i = 0; i < N; ++i) {
+    double bad = 0.0;
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) {
       const double e = rtol * fabs(yc[i]) + atol;
-      if (!(e > 0.0)) return false;
+      if (!(e > 0.0)) bad = 1.0;
       ewt[i] = 1.0 / e;
     }
-    return true;
+    return kn_group_max<LANES>(bad) == 0.0;
   }
 
   KN_HD void resetcoeff() {
@@ -177,7 +220,7 @@ struct Lsoda {
     double r = 1.0;
     for (int j = 2; j <= l; ++j) {
       r *= *rh;
-      _Pragma("unroll") for (int i = 0; i < N; ++i) YH(j, i) *= r;
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) YH(j, i) *= r;
     }
     h *= *rh;
     rc *= *rh;
@@ -188,7 +231,7 @@ struct Lsoda {
     tn = told;
     for (int j = nq; j >= 1; --j)
       for (int i1 = j; i1 <= nq; ++i1)
-        _Pragma("unroll") for (int i = 0; i < N; ++i) YH(i1, i) -= YH(i1 + 1, i);
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) YH(i1, i) -= YH(i1 + 1, i);
   }
 
   KN_HD void corfailure(double told, double* rh, int* ncf, int* corflag) {
@@ -206,56 +249,155 @@ struct Lsoda {
 
   // Finite-difference Jacobian, P = I - h*el0*J, LU factorisation (PRJA with miter = 2).
   KN_HDN void prja(double t) {
-    nje++;
-    ierpj = 0;
-    jcur = 1;
-    const double hl0 = h * el0;
-    double fac = vmnorm(savf);
-    double r0 = 1000.0 * fabs(h) * KN_ETA * (double)N * fac;
-    if (r0 == 0.0) r0 = 1.0;
-    const double sqrteta = 1.4901161193847656e-08;
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const double yj = y[j];
-      const double r = fmax(sqrteta * fabs(yj), r0 / ewt[j]);
-      y[j] += r;
-      fac = -hl0 / r;
-      f.rhs(t, y, acor);
-      _Pragma("unroll") for (int i = 0; i < N; ++i) WM(i, j) = (acor[i] - savf[i]) * fac;
-      y[j] = yj;
-    }
-    nfe += N;
-    double an = 0.0;  // fnorm: weighted max-row-sum norm of (-h*el0*J)
-    _Pragma("unroll") for (int i = 0; i < N; ++i) {
-      double sum = 0.0;
-      for (int j = 0; j < N; ++j) sum += fabs(WM(i, j)) / ewt[j];
-      an = fmax(an, sum * ewt[i]);
-    }
-    pdnorm = an / fabs(hl0);
-    _Pragma("unroll") for (int i = 0; i < N; ++i) WM(i, i) += 1.0;
-    // dgefa: Gaussian elimination with partial pivoting (LINPACK column-oriented variant)
-#pragma unroll
-    for (int k = 0; k < N - 1; ++k) {
-      int piv = k;
-      double mx = fabs(WM(k, k));
-      for (int i = k + 1; i < N; ++i)
-        if (fabs(WM(i, k)) > mx) { mx = fabs(WM(i, k)); piv = i; }
-      ipvt[k] = piv;
-      if (WM(piv, k) == 0.0) { ierpj = 1; continue; }
-      if (piv != k) { const double t2 = WM(piv, k); WM(piv, k) = WM(k, k); WM(k, k) = t2; }
-      const double tinv = -1.0 / WM(k, k);
-      for (int i = k + 1; i < N; ++i) WM(i, k) *= tinv;
-      for (int j = k + 1; j < N; ++j) {
-        double t2 = WM(piv, j);
-        if (piv != k) { WM(piv, j) = WM(k, j); WM(k, j) = t2; }
-        for (int i = k + 1; i < N; ++i) WM(i, j) += t2 * WM(i, k);
+    if constexpr (LANES == 1) {
+      nje++;
+      ierpj = 0;
+      jcur = 1;
+      const double hl0 = h * el0;
+      double fac = vmnorm(savf);
+      double r0 = 1000.0 * fabs(h) * KN_ETA * (double)N * fac;
+      if (r0 == 0.0) r0 = 1.0;
+      const double sqrteta = 1.4901161193847656e-08;
+  #pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const double yj = y[j];
+        const double r = fmax(sqrteta * fabs(yj), r0 / ewt[j]);
+        y[j] += r;
+        fac = -hl0 / r;
+        f.rhs(t, y, acor);
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) WM(i, j) = (acor[i] - savf[i]) * fac;
+        y[j] = yj;
       }
+      nfe += N;
+      double an = 0.0;  // fnorm: weighted max-row-sum norm of (-h*el0*J)
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) {
+        double sum = 0.0;
+        for (int j = 0; j < N; ++j) sum += fabs(WM(i, j)) / ewt[j];
+        an = fmax(an, sum * ewt[i]);
+      }
+      pdnorm = an / fabs(hl0);
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) WM(i, i) += 1.0;
+      // dgefa: Gaussian elimination with partial pivoting (LINPACK column-oriented variant)
+  #pragma unroll
+      for (int k = 0; k < N - 1; ++k) {
+        int piv = k;
+        double mx = fabs(WM(k, k));
+        for (int i = k + 1; i < N; ++i)
+          if (fabs(WM(i, k)) > mx) { mx = fabs(WM(i, k)); piv = i; }
+        ipvt[k] = piv;
+        if (WM(piv, k) == 0.0) { ierpj = 1; continue; }
+        if (piv != k) { const double t2 = WM(piv, k); WM(piv, k) = WM(k, k); WM(k, k) = t2; }
+        const double tinv = -1.0 / WM(k, k);
+        for (int i = k + 1; i < N; ++i) WM(i, k) *= tinv;
+        for (int j = k + 1; j < N; ++j) {
+          double t2 = WM(piv, j);
+          if (piv != k) { WM(piv, j) = WM(k, j); WM(k, j) = t2; }
+          for (int i = k + 1; i < N; ++i) WM(i, j) += t2 * WM(i, k);
+        }
+      }
+      ipvt[N - 1] = N - 1;  // (ipvt is only indexed with unrolled constants)
+      if (WM(N - 1, N - 1) == 0.0) ierpj = 1;
     }
-    ipvt[N - 1] = N - 1;  // (ipvt is only indexed with unrolled constants)
-    if (WM(N - 1, N - 1) == 0.0) ierpj = 1;
+    else {
+      nje++;
+      ierpj = 0;
+      jcur = 1;
+      const double hl0 = h * el0;
+      double fac = vmnorm(savf);
+      double r0 = 1000.0 * fabs(h) * KN_ETA * (double)N * fac;
+      if (r0 == 0.0) r0 = 1.0;
+      const double sqrteta = 1.4901161193847656e-08;
+      double ya[N], ea[N], row[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) { ya[k] = kn_group_get<LANES>(y[0], k); ea[k] = kn_group_get<LANES>(ewt[0], k); }
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const double yj = ya[j];
+        const double r = fmax(sqrteta * fabs(yj), r0 / ea[j]);
+        ya[j] += r;
+        fac = -hl0 / r;
+        const double aj = f.rhs_lane(comp, t, ya);
+        row[j] = (aj - savf[0]) * fac;
+        ya[j] = yj;
+      }
+      nfe += N;
+      double sum = 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) sum += fabs(row[j]) / ea[j];
+      pdnorm = kn_group_max<LANES>(sum * ewt[0]) / fabs(hl0);
+#pragma unroll
+      for (int j = 0; j < N; ++j) row[j] += (j == comp) ? 1.0 : 0.0;
+      // every lane gathers the whole matrix and factorises it (dgefa, selects instead of dynamic indices)
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) lu[i][j] = kn_group_get<LANES>(row[j], i);
+#pragma unroll
+      for (int k = 0; k < N - 1; ++k) {
+        int piv = k;
+        double mx = fabs(lu[k][k]);
+#pragma unroll
+        for (int i = k + 1; i < N; ++i)
+          if (fabs(lu[i][k]) > mx) { mx = fabs(lu[i][k]); piv = i; }
+        ipvt[k] = piv;
+        if (mx == 0.0) { ierpj = 1; continue; }
+        // swap rows' entries of column k.. between piv and k as LINPACK does (column by column)
+#pragma unroll
+        for (int j = k; j < N; ++j) {
+          double tp = lu[k][j];
+#pragma unroll
+          for (int i = k + 1; i < N; ++i) tp = (i == piv) ? lu[i][j] : tp;
+          const double tk = lu[k][j];
+#pragma unroll
+          for (int i = k + 1; i < N; ++i) lu[i][j] = (i == piv) ? tk : lu[i][j];
+          lu[k][j] = tp;
+        }
+        const double tinv = -1.0 / lu[k][k];
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) lu[i][k] *= tinv;
+#pragma unroll
+        for (int j = k + 1; j < N; ++j) {
+          const double t2 = lu[k][j];
+#pragma unroll
+          for (int i = k + 1; i < N; ++i) lu[i][j] += t2 * lu[i][k];
+        }
+      }
+      ipvt[N - 1] = N - 1;
+      if (lu[N - 1][N - 1] == 0.0) ierpj = 1;
+    }
   }
 
   KN_HD void solsy(double* b) {  // dgesl, job = 0 (selects instead of b[piv]: b stays in registers)
+    if constexpr (LANES > 1) {
+      double ba[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) ba[k] = kn_group_get<LANES>(b[0], k);
+#pragma unroll
+      for (int k = 0; k < N - 1; ++k) {
+        const int piv = ipvt[k];
+        double t2 = ba[k];
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) t2 = (i == piv) ? ba[i] : t2;
+        const double bk = ba[k];
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) ba[i] = (i == piv) ? bk : ba[i];
+        ba[k] = t2;
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) ba[i] += t2 * lu[i][k];
+      }
+#pragma unroll
+      for (int k = N - 1; k >= 0; --k) {
+        ba[k] /= lu[k][k];
+        const double t2 = -ba[k];
+#pragma unroll
+        for (int i = 0; i < k; ++i) ba[i] += t2 * lu[i][k];
+      }
+      double own = ba[0];
+#pragma unroll
+      for (int k = 1; k < N; ++k) own = (k == comp) ? ba[k] : own;
+      b[0] = own;
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < N - 1; ++k) {
       const int piv = ipvt[k];
@@ -284,8 +426,8 @@ struct Lsoda {
     *m = 0;
     *corflag = 0;
     *del = 0.0;
-    _Pragma("unroll") for (int i = 0; i < N; ++i) y[i] = YH(1, i);
-    f.rhs(tn, y, savf);
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) y[i] = YH(1, i);
+    eval_rhs(tn, y, savf);
     nfe++;
     while (true) {
       if (*m == 0) {
@@ -297,23 +439,23 @@ struct Lsoda {
           crate = 0.7;
           if (ierpj != 0) { corfailure(told, rh, ncf, corflag); return; }
         }
-        _Pragma("unroll") for (int i = 0; i < N; ++i) acor[i] = 0.0;
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) acor[i] = 0.0;
       }
       if (miter == 0) {
-        _Pragma("unroll") for (int i = 0; i < N; ++i) {
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) {
           savf[i] = h * savf[i] - YH(2, i);
           y[i] = savf[i] - acor[i];
         }
         *del = vmnorm(y);
-        _Pragma("unroll") for (int i = 0; i < N; ++i) {
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) {
           y[i] = YH(1, i) + EL(1) * savf[i];
           acor[i] = savf[i];
         }
       } else {
-        _Pragma("unroll") for (int i = 0; i < N; ++i) y[i] = h * savf[i] - (YH(2, i) + acor[i]);
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) y[i] = h * savf[i] - (YH(2, i) + acor[i]);
         solsy(y);
         *del = vmnorm(y);
-        _Pragma("unroll") for (int i = 0; i < N; ++i) {
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) {
           acor[i] += y[i];
           y[i] = YH(1, i) + EL(1) * acor[i];
         }
@@ -340,12 +482,12 @@ struct Lsoda {
         *m = 0;
         rate = 0.0;
         *del = 0.0;
-        _Pragma("unroll") for (int i = 0; i < N; ++i) y[i] = YH(1, i);
-        f.rhs(tn, y, savf);
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) y[i] = YH(1, i);
+        eval_rhs(tn, y, savf);
         nfe++;
       } else {
         *delp = *del;
-        f.rhs(tn, y, savf);
+        eval_rhs(tn, y, savf);
         nfe++;
       }
     }
@@ -458,7 +600,7 @@ struct Lsoda {
           const double r = EL(l) / (double)l;
           nq = l;
           l = nq + 1;
-          _Pragma("unroll") for (int i = 0; i < N; ++i) YH(l, i) = acor[i] * r;
+          _Pragma("unroll") for (int i = 0; i < NI; ++i) YH(l, i) = acor[i] * r;
           *orderflag = 2;
           return;
         }
@@ -481,7 +623,7 @@ struct Lsoda {
 
   KN_HD void endstoda() {
     const double r = 1.0 / tesco(nqu, 2);
-    _Pragma("unroll") for (int i = 0; i < N; ++i) acor[i] *= r;
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) acor[i] *= r;
     hold = h;
     jstart = 1;
   }
@@ -543,7 +685,7 @@ struct Lsoda {
         tn += h;
         for (int j = nq; j >= 1; --j)
           for (int i1 = j; i1 <= nq; ++i1)
-            _Pragma("unroll") for (int i = 0; i < N; ++i) YH(i1, i) += YH(i1 + 1, i);
+            _Pragma("unroll") for (int i = 0; i < NI; ++i) YH(i1, i) += YH(i1 + 1, i);
         pnorm = vmnorm_yh(1);
         correction(pnorm, &del, &delp, told, &ncf, &rh, &m, &corflag);
         if (corflag == 0) break;
@@ -568,7 +710,7 @@ struct Lsoda {
         mused = meth;
         for (int j = 1; j <= l; ++j) {
           r = EL(j);
-          _Pragma("unroll") for (int i = 0; i < N; ++i) YH(j, i) += r * acor[i];
+          _Pragma("unroll") for (int i = 0; i < NI; ++i) YH(j, i) += r * acor[i];
         }
         icount--;
         if (icount < 0) {
@@ -579,7 +721,7 @@ struct Lsoda {
             rmax = 10.0;
             // endstoda() uses the coefficients of the method that took the step
             const double rr = 1.0 / cf->tesco[mused - 1][nqu][2];
-            _Pragma("unroll") for (int i = 0; i < N; ++i) acor[i] *= rr;
+            _Pragma("unroll") for (int i = 0; i < NI; ++i) acor[i] *= rr;
             hold = h;
             jstart = 1;
             break;
@@ -589,7 +731,7 @@ struct Lsoda {
         if (ialth == 0) {
           rhup = 0.0;
           if (l != lmax) {
-            _Pragma("unroll") for (int i = 0; i < N; ++i) savf[i] = acor[i] - YH(lmax, i);
+            _Pragma("unroll") for (int i = 0; i < NI; ++i) savf[i] = acor[i] - YH(lmax, i);
             dup = vmnorm(savf) / tesco(nq, 3);
             exup = 1.0 / (double)(l + 1);
             rhup = 1.0 / (1.4 * pow(dup, exup) + 0.0000014);
@@ -611,7 +753,7 @@ struct Lsoda {
           break;
         }
         if (ialth > 1 || l == lmax) { endstoda(); break; }
-        _Pragma("unroll") for (int i = 0; i < N; ++i) YH(lmax, i) = acor[i];
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) YH(lmax, i) = acor[i];
         endstoda();
         break;
       }
@@ -648,10 +790,10 @@ struct Lsoda {
       }
       rh = 0.1;
       h *= rh;
-      _Pragma("unroll") for (int i = 0; i < N; ++i) y[i] = YH(1, i);
-      f.rhs(tn, y, savf);
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) y[i] = YH(1, i);
+      eval_rhs(tn, y, savf);
       nfe++;
-      _Pragma("unroll") for (int i = 0; i < N; ++i) YH(2, i) = h * savf[i];
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) YH(2, i) = h * savf[i];
       ipup = miter;
       ialth = 5;
       if (nq == 1) continue;
@@ -664,13 +806,14 @@ struct Lsoda {
   // Integrate y0 from t0 to tout (istate = 1, itask = 1).  Returns 0 on success, a negative
   // ODEPACK-style code otherwise.  On success y0 holds y(tout).
   KN_HDN int integrate(const LsodaCoef* coef, double* work_, double* y0, double t0, double tout,
-                       double rtol_, double atol_, int mxstep) {
+                       double rtol_, double atol_, int mxstep, int comp_ = 0) {
     cf = coef;
     work = work_;
+    comp = comp_;
     rtol = rtol_;
     atol = atol_;
     for (int j = 0; j < 15; ++j)
-      _Pragma("unroll") for (int i = 0; i < N; ++i) YH(j, i) = 0.0;
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) YH(j, i) = 0.0;
     tn = t0;
     tsw = t0;
     maxord = MXORDN;
@@ -678,10 +821,10 @@ struct Lsoda {
     nst = 0; nje = 0; nslp = 0;
     hu = 0.0; nqu = 0; mused = 0; miter = 0; meth = 1;
     nq = 1; l = 2;
-    _Pragma("unroll") for (int i = 0; i < N; ++i) y[i] = y0[i];
-    f.rhs(t0, y, savf);
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) y[i] = y0[i];
+    eval_rhs(t0, y, savf);
     nfe = 1;
-    _Pragma("unroll") for (int i = 0; i < N; ++i) { YH(1, i) = y[i]; YH(2, i) = savf[i]; }
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) { YH(1, i) = y[i]; YH(2, i) = savf[i]; }
     if (!ewset(y)) return -6;
     // initial step size (DLSODA block c)
     const double tdist = fabs(tout - t0);
@@ -689,7 +832,7 @@ struct Lsoda {
     if (tdist < 2.0 * KN_ETA * w0) return -3;
     double tol = rtol;
     if (tol <= 0.0) {
-      _Pragma("unroll") for (int i = 0; i < N; ++i) {
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) {
         const double ayi = fabs(y[i]);
         if (ayi != 0.0) tol = fmax(tol, atol / ayi);
       }
@@ -702,10 +845,10 @@ struct Lsoda {
     h0 = fmin(h0, tdist);
     h0 = (tout - t0) >= 0.0 ? h0 : -h0;
     h = h0;
-    _Pragma("unroll") for (int i = 0; i < N; ++i) YH(2, i) *= h0;
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) YH(2, i) *= h0;
     while (true) {
       if (nst > 0) {
-        _Pragma("unroll") for (int i = 0; i < N; ++i) y[i] = YH(1, i);
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) y[i] = YH(1, i);
         if (!ewset(y)) return -6;
       }
       if (nst >= mxstep) return -1;
@@ -721,9 +864,9 @@ struct Lsoda {
       if ((tn - tout) * h < 0.0) continue;
       // intdy, k = 0
       const double s = (tout - tn) / h;
-      _Pragma("unroll") for (int i = 0; i < N; ++i) y0[i] = YH(l, i);
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) y0[i] = YH(l, i);
       for (int jj = l - 1; jj >= 1; --jj)
-        _Pragma("unroll") for (int i = 0; i < N; ++i) y0[i] = YH(jj, i) + s * y0[i];
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) y0[i] = YH(jj, i) + s * y0[i];
       return 0;
     }
   }

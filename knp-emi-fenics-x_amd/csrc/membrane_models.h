@@ -59,6 +59,34 @@ struct ModelHHSI {
     I_K = i_K;
     dy[3] = (-i_K - i_Na) / Cm;
   }
+  // Component-wise evaluation for the one-lane-per-component integrator: lane c computes dy[c].  The
+  // four lanes of a system run the same instruction stream; what differs per lane (exponent
+  // arguments, rate-law variant) is chosen with selects, so there is no divergence.  Every expression
+  // is the one `rhs` evaluates, hence bit-identical results.  The side-effect currents are those of
+  // the lane that owns V (CURRENT_LANE).
+  static constexpr int CURRENT_LANE = 3;
+  KN_HD double rhs_lane(int c, double t, const double* y) const {
+    const double m = y[0], h = y[1], n = y[2], V = y[3];
+    const double u = 1.0e3 * (V + 65.0e-3);
+    const double n1 = c == 0 ? (25. - u) : (c == 1 ? -u : (c == 2 ? (10. - u) : -fmod(t, 0.03)));
+    const double d1 = c == 1 ? 20. : (c == 3 ? 0.002 : 10.);
+    const double n2 = c == 1 ? (30. - u) : -u;
+    const double d2 = c == 0 ? 18. : (c == 1 ? 10. : 80.);
+    const double e1 = exp(n1 / d1), e2 = exp(n2 / d2);
+    const double k1 = c == 0 ? 0.1e3 : 0.01e3;
+    const double alpha = c == 1 ? 0.07e3 * e1 : k1 * n1 / (e1 - 1);
+    const double k2 = c == 0 ? 4.e3 : 0.125e3;
+    const double beta = c == 1 ? 1.e3 / (e2 + 1) : k2 * e2;
+    const double gate = c == 0 ? m : (c == 1 ? h : n);
+    const double dgate = (1 - gate) * alpha - gate * beta;
+    const double i_stim = stim * e1 * (t < 125e-3 ? 1.0 : 0.0);
+    const double i_Na = (glNa + gNa * h * (m * m * m) + i_stim) * (V - E_Na) + 3 * i_pump;
+    const double n2q = n * n;
+    const double i_K = (glK + gK * (n2q * n2q)) * (V - E_K) - 2 * i_pump;
+    I_Na = i_Na;
+    I_K = i_K;
+    return c == 3 ? (-i_K - i_Na) / Cm : dgate;
+  }
   template <class Row>
   KN_HD void finish(const Row& p) const { p[15] = I_Na; p[16] = I_K; p[17] = 0.0; }
 };
@@ -95,6 +123,30 @@ struct ModelHHMV {
     I_Na = i_Na;
     I_K = i_K;
     dy[3] = (-i_K - i_Na) / Cm;
+  }
+  // component-wise evaluation, see ModelHHSI::rhs_lane
+  static constexpr int CURRENT_LANE = 3;
+  KN_HD double rhs_lane(int c, double t, const double* y) const {
+    const double m = y[0], h = y[1], n = y[2], V = y[3];
+    const double u = V + 65.0;
+    const double n1 = c == 0 ? (25. - u) : (c == 1 ? -u : (c == 2 ? (10. - u) : -fmod(t, 30.0)));
+    const double d1 = c == 1 ? 20. : (c == 3 ? 2.0 : 10.);
+    const double n2 = c == 1 ? (30. - u) : -u;
+    const double d2 = c == 0 ? 18. : (c == 1 ? 10. : 80.);
+    const double e1 = exp(n1 / d1), e2 = exp(n2 / d2);
+    const double k1 = c == 0 ? 0.1 : 0.01;
+    const double alpha = c == 1 ? 0.07 * e1 : k1 * n1 / (e1 - 1);
+    const double k2 = c == 0 ? 4. : 0.125;
+    const double beta = c == 1 ? 1. / (e2 + 1) : k2 * e2;
+    const double gate = c == 0 ? m : (c == 1 ? h : n);
+    const double dgate = (1 - gate) * alpha - gate * beta;
+    const double i_stim = stim * e1 * (t < 125 ? 1.0 : 0.0);
+    const double i_Na = (glNa + gNa * h * (m * m * m) + i_stim) * (V - E_Na) + 3 * i_pump;
+    const double n2q = n * n;
+    const double i_K = (glK + gK * (n2q * n2q)) * (V - E_K) - 2 * i_pump;
+    I_Na = i_Na;
+    I_K = i_K;
+    return c == 3 ? (-i_K - i_Na) / Cm : dgate;
   }
   template <class Row>
   KN_HD void finish(const Row& p) const { p[15] = I_Na; p[16] = I_K; p[17] = 0.0; }
@@ -134,6 +186,12 @@ struct ModelGlial {
     I_K = i_K;
     I_Cl = i_Cl;
     dy[0] = (-i_K - i_Na - i_Cl) / Cm;
+  }
+  static constexpr int CURRENT_LANE = 0;
+  KN_HD double rhs_lane(int, double t, const double* y) const {
+    double dy[1];
+    rhs(t, y, dy);
+    return dy[0];
   }
   template <class Row>
   KN_HD void finish(const Row& p) const { p[5] = I_Na; p[6] = I_K; p[7] = I_Cl; }

@@ -302,3 +302,47 @@ def test_mms_emi_convergence(hip_lib):
     rates = np.log2(errs[:-1] / errs[1:])
     print("MMS L2 errors (phi_i, phi_e):", errs, "rates:", rates)
     assert np.all(rates[-1] > 1.8) and np.all(errs[-1] < 5e-3)
+
+
+@pytest.mark.parametrize("key", ["hh_si_stim0", "hh_si_stim10", "hh_mv_stim0", "hh_mv_stim1", "glial_stim0"])
+def test_all_membrane_models_match_golden_trajectories(hip_lib, key):
+    """Every device RHS (HH-SI, HH-mV, glial) integrated by the GPU LSODA against the committed ODEPACK
+    trajectories (tests/golden/ode_models.npz): states to 1e-8, side-effect currents to 1e-6."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ode_models.npz"))
+    model = key.rsplit("_stim", 1)[0]
+    s = Setup("2d", 1, model=model)
+    ode = s.mem_models[0]['ode']
+    ode.states[:] = g[f"{key}_y0"]
+    ode.parameters[:] = g[f"{key}_p0"]
+    dt = float(g[f"{key}_dt"])
+    ns = ode.states.shape[1]
+    ich = [ode.ode.parameter_indices(f"I_ch_{n}") for n in ("Na", "K", "Cl")]
+    for k in range(10):
+        ode._pending_flags = 0          # parameters are used as they are (no trace refresh)
+        ode.step_lsoda(dt, None)
+        gold = g[f"{key}_traj"][k]
+        assert np.abs(ode.states - gold[:ns]).max() <= 1e-8 * np.abs(gold[:ns]).max()
+        assert np.abs(ode.parameters[:, ich] - gold[ns:]).max() <= 1e-6 * max(np.abs(gold[ns:]).max(), 1e-3)
+    assert np.all(ode.states == ode.states[0])      # identical inputs -> identical bits on every dof
+
+
+def test_lane_parallel_lsoda_matches_one_thread_per_dof(hip_lib, monkeypatch):
+    """The 4-lanes-per-dof integrator (one lane per state component) takes exactly the decisions of the
+    sequential one (same step and RHS-evaluation counts); the states agree to rounding (the compiler
+    contracts multiply-adds differently in the two RHS code shapes, so not to the last bit)."""
+    from knpemi.utils import update_ode_variables
+    out = []
+    for lanes in ("4", "1"):
+        monkeypatch.setenv("KNPEMI_ODE_LANES", lanes)
+        s = Setup("2d", 2, g_syn=10.0)
+        s.perturb()
+        s.phi_M_prev[1].x.array[:] = -0.0744
+        ode = s.mem_models[0]['ode']
+        for k in range(3):
+            update_ode_variables(ode, s.c_prev, s.phi_M_prev[1], s.ion_list, s.subdomain_list, s.mesh, s.ct, 1, k)
+            ode.step_lsoda(s.dt, s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
+            ode.get_membrane_potential(s.phi_M_prev[1])
+        out.append((ode.states.copy(), ode.parameters.copy(), ode.last_stats))
+    assert rel_err(out[0][0], out[1][0]) < 1e-10
+    assert out[0][2]["n_rhs"] == out[1][2]["n_rhs"] and out[0][2]["n_steps"] == out[1][2]["n_steps"]
