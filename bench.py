@@ -68,20 +68,28 @@ def algorithmic_bytes(s, dp):
 
 
 def cpu_baseline(s, n_steps):
-    """Oracle (numpy/scipy restatement, 1 core) timed on this host on a bounded sample:
-    full EMI + KNP assembly and update, LSODA sweep on every 8th membrane dof (scaled up)."""
+    """C++ port of the reference path (oracle/knpemi_cpu.cpp: scalar element loops with CSR scatter-add, one
+    LSODA integration per membrane dof; checked against the numpy oracle by tests/test_cpu_port.py), timed
+    on ONE core of this host for `n_steps` whole steps of the same workload.  The CSR patterns come from one
+    untimed oracle assembly."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import adapters
+    import cpu_port
     o, P, params, ions = adapters.oracle_problem(s)
     c_all, phi, phiM, mm = adapters.oracle_fields(s)
+    A, _, _ = o.assemble_emi(P, params, ions, c_all, phiM, mm)
+    Ak, _ = o.assemble_knp(P, params, ions, c_all, phi, phiM, mm, s.dt)
+    port = cpu_port.CpuPort(P, params, ions, A, Ak)
     ode = s.mem_models[0]['ode']
-    ix = o.MODELS[ode.ode.MODEL_ID]["pidx"]
-    st, pa = ode.states.copy(), ode.parameters.copy()
+    model = ode.ode.MODEL_ID
+    ix = o.MODELS[model]["pidx"]
+    st, pa = np.ascontiguousarray(ode.states.copy()), np.ascontiguousarray(ode.parameters.copy())
     mask = np.fromiter(map(s.stim_params['stimulus_locator'], ode.dof_locations), dtype=bool)
-    stim = {ix[k]: v for k, v in s.stim_params['stimulus'].items()}
-    rows = list(range(0, ode.nodes, 8))
-    rho = {'z': -1, **{t: 0.0 for t in s.subdomain_list}}
+    sidx = [ix[k] for k in s.stim_params['stimulus']]
+    sval = [float(v) for v in s.stim_params['stimulus'].values()]
+    Ich = np.stack([mm[1][0]["I_ch_k"][n] for n in ("K", "Cl", "Na")])
+    mid = {"hh_si": 0, "hh_mv": 1, "glial": 2}[model]
     t_asm = t_ode = 0.0
     for k in range(n_steps):
         t0 = time.perf_counter()
@@ -89,16 +97,19 @@ def cpu_baseline(s, n_steps):
             te, ti = P.trace(1, c_all[0][kk], c_all[1][kk])
             pa[:, ix[f"{name}_e"]] = te
             pa[:, ix[f"{name}_i"]] = ti
-        o.ode_sweep(ode.ode.MODEL_ID, st, pa, k * s.dt, s.dt, mask, stim, rows=rows)
+        failed, _ = port.ode_sweep(mid, st, pa, k * s.dt, s.dt, mask, sidx, sval)
+        assert failed == 0
         t1 = time.perf_counter()
-        o.assemble_emi(P, params, ions, c_all, phiM, mm)
-        o.assemble_knp(P, params, ions, c_all, phi, phiM, mm, s.dt)
-        c_new = {t: [c_all[t][0].copy(), c_all[t][1].copy()] for t in c_all}
-        o.update_pde_variables(P, ions, rho, c_new, c_all, phi, phiM)
+        port.assemble_emi(c_all, phiM, Ich)
+        port.assemble_knp(c_all, phi, phiM, Ich)
+        te, ti = P.trace(1, phi[0], phi[1])      # end-of-step update (vector copies + trace)
+        phiM[1][:] = ti - te
+        for t in c_all:
+            c_all[t][2][:] = -(ions[0]["z"] * c_all[t][0] + ions[1]["z"] * c_all[t][1]) / ions[2]["z"]
         t2 = time.perf_counter()
-        t_ode += (t1 - t0) * ode.nodes / len(rows)
+        t_ode += t1 - t0
         t_asm += t2 - t1
-    return (t_asm + t_ode) / n_steps, t_asm / n_steps, t_ode / n_steps, len(rows)
+    return (t_asm + t_ode) / n_steps, t_asm / n_steps, t_ode / n_steps, ode.nodes
 
 
 def main():
@@ -107,7 +118,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-steps", type=int, default=3, help="oracle steps timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=100, help="CPU-port steps timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the EMI matrix assembly after the ODE sweep instead of beside it (aux stream)")
     ap.add_argument("--knp-twice", action="store_true",
@@ -245,9 +256,9 @@ def main():
                 t_step, t_asm, t_ode, nrows = cpu_baseline(s, args.cpu_steps)
             out["cpu_baseline"] = {
                 "value": dofs_total / t_step, "unit": "dofs/s", "cores": 1, "kind": "port",
-                "sample": f"{args.cpu_steps} steps of the numpy/scipy oracle on the same mesh: full EMI+KNP assembly and "
-                          f"update ({t_asm:.2f} s/step), LSODA sweep on {nrows} of {s.mem_models[0]['ode'].nodes} "
-                          f"membrane dofs scaled to all ({t_ode:.2f} s/step)"}
+                "sample": f"{args.cpu_steps} whole steps of the C++ port (oracle/knpemi_cpu.cpp) on the same mesh, 1 thread: "
+                          f"EMI (A, P, b) + KNP (A, b) assembly and update {t_asm * 1e3:.0f} ms/step, LSODA sweep over all "
+                          f"{nrows} membrane dofs {t_ode * 1e3:.0f} ms/step; the reference itself cannot run here"}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
