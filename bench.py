@@ -185,9 +185,12 @@ def main():
         torch.cuda.synchronize()
 
     lib = dp.lib
-    # warm-up: bracket every kernel to find the dominant one
-    L.check(lib.knpemi_profile(dp.h, 0x1F))
     for _ in range(args.warmup):
+        stepper.step(halo)
+    sync()
+    # untimed profiling pass: every kernel bracketed by HIP events -> per-kernel averages, dominant kernel
+    L.check(lib.knpemi_profile(dp.h, 0x1F))
+    for _ in range(5):
         stepper.step(halo)
     sync()
     per_kernel = {}
