@@ -860,6 +860,7 @@ extern "C" int knpemi_ode_set_tables(knpemi_handle* h, int sub, int model, const
   int slot = ode_slot(h, sub, model, 1);
   if (slot < 0) return KNPEMI_EINVAL;
   KnOdeModel& m = h->ode[slot];
+  if (m.nq == 0) return KNPEMI_OK;
   KN_HIP(hipSetDevice(h->device));
   std::vector<double> t;
   if (states) {
@@ -881,6 +882,7 @@ extern "C" int knpemi_ode_get_tables(knpemi_handle* h, int sub, int model, doubl
   int slot = ode_slot(h, sub, model, 1);
   if (slot < 0) return KNPEMI_EINVAL;
   KnOdeModel& m = h->ode[slot];
+  if (m.nq == 0) return KNPEMI_OK;
   KN_HIP(hipSetDevice(h->device));
   std::vector<double> t;
   if (states) {
@@ -912,7 +914,7 @@ extern "C" int knpemi_ode_set_stimulus(knpemi_handle* h, int sub, int model, con
     m.stim_val[i] = values[i];
   }
   m.n_stim = n_pairs;
-  if (mask) {
+  if (mask && m.nq > 0) {
     if (!m.d_mask) {
       int rc = dev_zeros(h, (size_t)m.nq, &m.d_mask);
       if (rc) return rc;

@@ -283,7 +283,7 @@ def assemble_emi(P, params, ions, c_all, phi_M_prev, mem_models, splitting_schem
         nv = cells.shape[1]
         rows.append(np.repeat(dofs, nv, axis=1))
         cols.append(np.tile(dofs, (1, nv)))
-        vals.append(Aloc.reshape(len(cells), -1))
+        vals.append(Aloc.reshape(len(cells), nv * nv))
         # RHS: - F z_k D_k grad(c_k) . grad(v) for all K ions (emiWeakForm.py:211-217)
         for ion, c in zip(ions, c_all[tag]):
             gc = np.einsum("ca,cqag->cqg", c[cells], G)
@@ -294,7 +294,7 @@ def assemble_emi(P, params, ions, c_all, phi_M_prev, mem_models, splitting_schem
             Mloc = np.einsum("q,cq,qa,qb->cab", wtsm, detm, phim, phim)
             prow.append(np.repeat(dofs, nv, axis=1))
             pcol.append(np.tile(dofs, (1, nv)))
-            pval.append(Mloc.reshape(len(cells), -1))
+            pval.append(Mloc.reshape(len(cells), nv * nv))
     # membrane coupling (emiWeakForm.py:160-165, 228-239)
     for tag in P.tags[1:]:
         m = P.mem[tag]
@@ -309,7 +309,7 @@ def assemble_emi(P, params, ions, c_all, phi_M_prev, mem_models, splitting_schem
             for R, Cc, sgn in ((I, I, 1.0), (I, E, -1.0), (E, I, -1.0), (E, E, 1.0)):
                 rows.append(np.repeat(R, nf, axis=1))
                 cols.append(np.tile(Cc, (1, nf)))
-                vals.append(sgn * Ms.reshape(len(E), -1))
+                vals.append(sgn * Ms.reshape(len(E), nf * nf))
             g = phi_M_prev[tag].copy()
             if not splitting_scheme:
                 g = g - sum(mm["I_ch_k"].values()) / C_phi
@@ -367,7 +367,7 @@ def assemble_knp(P, params, ions, c_all, phi, phi_M_prev, mem_models, dt, splitt
             Aloc = mass / dt + D * stiff + z * psi * D * drift
             rows.append(np.repeat(dofs, nv, axis=1))
             cols.append(np.tile(dofs, (1, nv)))
-            vals.append(Aloc.reshape(len(cells), -1))
+            vals.append(Aloc.reshape(len(cells), nv * nv))
             rhs = c_all[tag][k][cells] / dt
             if tag == 0 and f_source is not None and k in f_source:
                 rhs = rhs + f_source[k][cells]

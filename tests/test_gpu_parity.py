@@ -348,3 +348,130 @@ def test_lane_parallel_lsoda_matches_one_thread_per_dof(hip_lib, monkeypatch):
     # rounding-level differences may flip a convergence test here and there: counts agree to < 0.5 %
     for key in ("n_rhs", "n_steps"):
         assert abs(out[0][2][key] - out[1][2][key]) <= 0.005 * out[1][2][key]
+
+
+def _custom_problem(mesh, ct, ft, cell_specs, dt=1e-4):
+    """Build functions/forms through the knpemi API for an arbitrary tagging.
+    cell_specs = {cell tag: [(facet tag, model name), ...]} (ECS = tag 0 is implicit)."""
+    import contextlib
+    import io
+    from helpers import C_M, FARADAY, PSI, load_model
+    from knpemi import (create_functions_emi, create_functions_knp, emi_system, knp_system,
+                        set_initial_conditions, setup_membrane_model)
+    from knpemi.fem import Constant, extract_submesh
+    tags = [0] + sorted(cell_specs)
+    subs = {}
+    for t in tags:
+        sm, e2p, v2p, _, _ = extract_submesh(mesh, ct, t)
+        subs[t] = dict(tag=t, name=f"sub{t}", mesh_sub=sm, sub_to_parent=e2p, sub_vertex_to_parent=v2p)
+        if t > 0:
+            mtags = [ftag for ftag, _ in cell_specs[t]]
+            g, g2p, _, _, _ = extract_submesh(mesh, ft, mtags)
+            subs[t].update(mesh_mem=g, mem_to_parent=g2p, membrane_tags=mtags,
+                           ode_models={ftag: load_model(m) for ftag, m in cell_specs[t]})
+    rho = {'z': -1, **{t: Constant(subs[t]['mesh_sub'], 0.1 * t) for t in tags}}
+    pp = {'dt': Constant(mesh, dt), 'F': Constant(mesh, FARADAY), 'psi': Constant(mesh, PSI),
+          'C_phi': Constant(mesh, C_M / dt), 'C_M': Constant(mesh, C_M), 'rho': rho}
+    init = {"Na": (100.7, 12.8), "K": (3.3, 124.2), "Cl": (104.0, 137.0)}
+    Dv = {"Na": 1.33e-9, "K": 1.96e-9, "Cl": 2.03e-9}
+    ions = [dict(name=n, z=z, D={t: Constant(None, Dv[n] * (1 + 0.1 * t)) for t in tags},
+                 c_init={t: Constant(None, init[n][0 if t == 0 else 1]) for t in tags})
+            for n, z in (("K", 1.0), ("Cl", -1.0), ("Na", 1.0))]
+    with contextlib.redirect_stdout(io.StringIO()):
+        phi, phi_M_prev = create_functions_emi(subs, degree=1)
+        c, c_prev = create_functions_knp(subs, ions, degree=1)
+        set_initial_conditions(ions, subs, c_prev)
+        for t in tags[1:]:
+            subs[t]['mem_models'] = setup_membrane_model({'stimulus': {}, 'stimulus_locator': None}, pp,
+                                                         subs[t]['ode_models'], ft, phi_M_prev[t].function_space, ions)
+    a_emi, p_emi, L_emi = emi_system(mesh, ct, ft, pp, ions, subs, phi, phi_M_prev, c_prev, dt)
+    a_knp, p_knp, L_knp = knp_system(mesh, ct, ft, pp, ions, subs, phi, phi_M_prev, c, c_prev, dt)
+    ns = type("S", (), {})()
+    ns.__dict__.update(mesh=mesh, ct=ct, ft=ft, subdomain_list=subs, ion_list=ions, physical_parameters=pp, dt=dt,
+                       phi=phi, phi_M_prev=phi_M_prev, c=c, c_prev=c_prev, a_emi=a_emi, p_emi=p_emi, L_emi=L_emi,
+                       a_knp=a_knp, p_knp=p_knp, L_knp=L_knp, entity_maps=[])
+    # seeded, physically sensible perturbation
+    rng = np.random.default_rng(7)
+    for t in tags:
+        for f in c_prev[t] + [ions[-1][f'c_{t}']]:
+            f.x.array[:] *= 1.0 + 1e-3 * rng.uniform(-1, 1, f.x.array.shape[0])
+        phi[t].x.array[:] = 1e-3 * rng.uniform(-1, 1, phi[t].x.array.shape[0])
+        if t > 0:
+            phi_M_prev[t].x.array[:] = -0.07 + 1e-3 * rng.uniform(-1, 1, phi_M_prev[t].x.array.shape[0])
+            for mm in subs[t]['mem_models']:
+                for f in mm['I_ch_k'].values():
+                    f.x.array[:] = 1e-2 * rng.uniform(-1, 1, f.x.array.shape[0])
+    return ns
+
+
+def _compare_with_oracle(s, subdomains):
+    import adapters
+    from knpemi.pdeSolver import create_solver_emi, create_solver_knp
+    o, P, params, ions = adapters.oracle_problem(s, subdomains)
+    c_all, phi, phiM, mm = adapters.oracle_fields(s)
+    emi = create_solver_emi(s.a_emi, s.L_emi, s.phi, [], s.subdomain_list, None, p=s.p_emi, direct=False)
+    knp = create_solver_knp(s.a_knp, s.L_knp, s.c, [], s.subdomain_list, None, p=s.p_knp)
+    A, b = emi.assemble()
+    Ak, bk = knp.assemble()
+    Ao, Po, bo = o.assemble_emi(P, params, ions, c_all, phiM, mm)
+    Ako, bko = o.assemble_knp(P, params, ions, c_all, phi, phiM, mm, s.dt)
+    return dict(A_emi=csr_rel_err(A, Ao), P_emi=csr_rel_err(emi.P, Po), b_emi=rel_err(b, bo),
+                A_knp=csr_rel_err(Ak, Ako), b_knp=rel_err(bk, bko))
+
+
+def test_three_subdomains_two_cell_types(hip_lib):
+    """config-5 style tagging (local_astrocyte_depolarization/run_stim_duration.py:168-181): ECS + cell
+    tag 1 (HH) + cell tag 2 (glial), each with its own membrane space and model; different D and rho per
+    sub-domain; assembly and the end-of-step update against the oracle."""
+    from knpemi import update_pde_variables
+    from knpemi.fem import make_mesh_3D
+    mesh, ct, ft = make_mesh_3D(0, "tetrahedron", axon_tags=(1, 1, 2, 2))
+    s = _custom_problem(mesh, ct, ft, {1: [(1, "hh_si")], 2: [(2, "glial")]})
+    errs = _compare_with_oracle(s, {0: [], 1: [1], 2: [2]})
+    assert max(errs.values()) < TOL, errs
+    import adapters
+    o, P, params, ions = adapters.oracle_problem(s, {0: [], 1: [1], 2: [2]})
+    c_all, phi, phiM, _ = adapters.oracle_fields(s)
+    for t in s.subdomain_list:
+        for k in range(2):
+            s.c[t][k].x.array[:] = s.c_prev[t][k].x._a * 1.01
+    c_new = {t: [f.x._a.copy() for f in s.c[t]] for t in s.subdomain_list}
+    update_pde_variables(s.c, s.c_prev, s.phi, s.phi_M_prev, s.physical_parameters, s.ion_list,
+                         s.subdomain_list, s.mesh, s.ct)
+    o.update_pde_variables(P, ions, {'z': -1, 0: 0.0, 1: 0.1, 2: 0.2}, c_new, c_all, phi, phiM)
+    for t in s.subdomain_list:
+        assert rel_err(s.ion_list[-1][f'c_{t}'].x._a, c_all[t][2]) < 1e-14
+        if t > 0:
+            assert rel_err(s.phi_M_prev[t].x._a, phiM[t]) < 1e-14
+
+
+def test_several_membrane_tags_on_one_cell(hip_lib):
+    """benchmark/run_stim_duration.py:163-166 style: one cell whose membrane carries two facet tags, each
+    with its own MembraneModel on the same Q; a third tag has no model and must not be integrated."""
+    from knpemi.fem import make_mesh_2D, meshtags
+    mesh, ct, ft = make_mesh_2D(1)
+    vals = ft.values.copy()
+    mem = np.flatnonzero(vals == 1)
+    xm = mesh.x[mesh.facets[ft.indices[mem]]].mean(axis=1)[:, 0]
+    vals[mem[xm > 20e-6]] = 6
+    vals[mem[xm > 45e-6]] = 7          # tag 7: part of the membrane space, but no model -> not integrated
+    ft2 = meshtags(mesh, 1, ft.indices, vals)
+    s = _custom_problem(mesh, ct, ft2, {1: [(1, "hh_si"), (6, "hh_si")]})
+    # the membrane space must contain the facets of all three tags
+    s2 = None
+    errs = _compare_with_oracle(s, {0: [], 1: [1, 6]})
+    assert max(errs.values()) < TOL, errs
+
+
+def test_empty_cell_subdomain(hip_lib):
+    """make_mesh_2D(0): the ICS is empty; the library must accept a cellular
+    sub-domain without cells, membrane or ODE points and still assemble the ECS blocks."""
+    from knpemi.fem import make_mesh_2D
+    mesh, ct, ft = make_mesh_2D(0)
+    assert (ct.values == 1).sum() == 0
+    s = _custom_problem(mesh, ct, ft, {1: [(1, "hh_si")]})
+    errs = _compare_with_oracle(s, {0: [], 1: [1]})
+    assert max(errs.values()) < TOL, errs
+    ode = s.subdomain_list[1]['mem_models'][0]['ode']
+    assert ode.nodes == 0
+    ode.step_lsoda(1e-4, None)
