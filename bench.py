@@ -236,6 +236,15 @@ def main():
     if rank == 0:
         bytes_alg = algorithmic_bytes(s, dp)
         achieved = bytes_alg[dominant] / (dom_us * 1e-6) / 1e9
+        # HBM bytes per launch measured with rocprofv3 PMC counters (committed, profiles/r01_traffic.json):
+        # PMC collection needs its own profiler passes and cannot run inside this process
+        traffic = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))[args.workload][dominant]
+            if world == 1:
+                traffic = (2.0 * tr["FETCH_SIZE_KiB"] + tr["WRITE_SIZE_KiB"]) * 1024.0
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "assembled dofs/s (volume + membrane-facet assembly + membrane ODE sweep) per timestep; "
                       "3D idealized mesh, fp64",
@@ -250,7 +259,7 @@ def main():
                        "emi_matrix_beside_ode_sweep": not args.no_overlap,
                        "partition": "x-slabs" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_alg[dominant], "avg_launch_us": dom_us},
             "kernels_us": per_kernel,
         }
