@@ -178,6 +178,8 @@ def main():
     halo = getattr(s, "halo", None)
     if halo is not None:
         halo.attach(dp)
+        halo.exchange_bulk()        # ghosts start from their owners' values
+        halo.exchange_membrane()
 
     def sync():
         if dist is not None:
