@@ -28,6 +28,7 @@ extern "C" {
 #define KNPEMI_EINVAL (-1)   /* bad argument / unsupported configuration */
 #define KNPEMI_EHIP (-2)     /* HIP runtime error (no device, launch failure, ...) */
 #define KNPEMI_ENOMEM (-3)
+#define KNPEMI_ESOLVE (-5)   /* Krylov solver did not converge (ksp_error_if_not_converged, pdeSolver.py:20,27) */
 #define KNPEMI_EODE (-4)     /* LSODA reported failure on at least one membrane dof
                                 (`assert success`, src/knpemi/odeSolver.py:121) */
 
@@ -155,6 +156,23 @@ int knpemi_device_rhs(knpemi_handle* h, int which, const double** b);
  * (`which` = KNPEMI_B_EMI -> phi, KNPEMI_B_KNP -> c).  on_device != 0: x is a device pointer. */
 int knpemi_set_solution(knpemi_handle* h, int which, const double* x, int on_device);
 int knpemi_get_solution(knpemi_handle* h, int which, double* x);
+
+/* Linear solves on the device (adjacent to the hot path): the KSP solve inside
+ * problem_emi.solve() / problem_knp.solve() with the iterative options of pdeSolver.py:24-35,99-110.
+ * EMI: preconditioned CG on A_EMI x = B_EMI with the constant null space projected out (:74-78);
+ * KNP: right-preconditioned BiCGStab on the block-diagonal system.  Both start from the current fields
+ * (ksp_initial_guess_nonzero), stop at ||r|| <= max(atol, rtol ||b||) and write the solution back into
+ * phi / c.  Returns KNPEMI_ESOLVE when maxit is reached. */
+enum { KNPEMI_PC_JACOBI = 0, KNPEMI_PC_AMG = 1 };
+int knpemi_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* iters, double* relres);
+int knpemi_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* iters, double* relres);
+/* Preconditioner of the device solve of system `which` (KNPEMI_B_EMI / KNPEMI_B_KNP): the counterpart of
+ * pc_type / pc_hypre_type in pdeSolver.py:27-34,102-109.  KNPEMI_PC_AMG: smoothed-aggregation V(1,1) cycle,
+ * strength threshold `theta` (<= 0: default 0.08); the hierarchy is (re)built at the next solve and kept for
+ * the following time steps (rebuilt when the iteration count has doubled).  Default: AMG for both. */
+int knpemi_solver_setup(knpemi_handle* h, int which, int precond, double theta);
+/* levels / operator complexity / number of builds of the AMG hierarchy of `which` (0 levels: not built). */
+int knpemi_solver_info(knpemi_handle* h, int which, int* levels, double* op_complexity, int* builds);
 
 /* Membrane ODEs: MembraneModel (src/knpemi/odeSolver.py:6-188).  `states`/`params` are the
  * row-major [n_q][n_states|n_params] tables `MembraneModel.states/.parameters`. */

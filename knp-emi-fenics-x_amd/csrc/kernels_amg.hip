@@ -1,0 +1,399 @@
+// Smoothed-aggregation algebraic multigrid used as the preconditioner of the device Krylov solves
+// (SURVEY.md section 8 f1).  The reference preconditions with hypre BoomerAMG through PETSc
+// (src/knpemi/pdeSolver.py:24-35,99-110: pc_type hypre, boomeramg, one V-cycle per application); this is
+// the MI355X-side counterpart: a V(1,1) cycle with damped-Jacobi smoothing whose levels are CSR SpMVs.
+//
+// Set-up (host, once per hierarchy): strength graph |a_ij| >= theta sqrt(a_ii a_jj), greedy
+// aggregation, tentative piecewise-constant prolongator smoothed once with damped Jacobi
+// (P = (I - 4/(3 rho) D^-1 A) T, rho = the Gershgorin bound of D^-1 A), Galerkin products R A P, until the
+// level is small enough for an explicit dense inverse.  The idealized EMI geometries are 35:1 cables meshed with
+// 10:1 elements and sub-domains coupled only through the weak membrane capacitance: the strength graph
+// semi-coarsens the cross-sections and never aggregates across the membrane, which is what brings CG from
+// ~1000 Jacobi iterations to ~15.
+//
+// The hierarchy is frozen: the matrix of the current time step is used on the finest level (smoothing,
+// residuals), the coarse operators are those of the step the hierarchy was built at.  It is a preconditioner
+// only, so the solve still converges to the current system; the Krylov driver rebuilds when the iteration count
+// has doubled (the conductivities drift slowly with the concentrations).
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "knpemi_internal.h"
+
+namespace {
+
+struct HostCsr {
+  int n = 0, m = 0;
+  std::vector<int> rp, ci;
+  std::vector<double> v;
+};
+
+// ---- host set-up ---------------------------------------------------------------------------------
+
+std::vector<double> diagonal(const HostCsr& A) {
+  std::vector<double> d(A.n, 1.0);
+  for (int i = 0; i < A.n; ++i)
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j)
+      if (A.ci[j] == i) d[i] = A.v[j];
+  return d;
+}
+
+// greedy aggregation on the strength graph (three passes: roots with free neighbourhoods, attach
+// leftovers to a neighbouring aggregate, remaining isolated points become their own aggregates)
+int aggregate(const HostCsr& A, const std::vector<double>& d, double theta, std::vector<int>& agg) {
+  const int n = A.n;
+  std::vector<int> srp(n + 1, 0), sci;
+  sci.reserve(A.ci.size());
+  for (int i = 0; i < n; ++i) {
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+      const int c = A.ci[j];
+      if (c != i && std::fabs(A.v[j]) >= theta * std::sqrt(std::fabs(d[i] * d[c]))) sci.push_back(c);
+    }
+    srp[i + 1] = (int)sci.size();
+  }
+  agg.assign(n, -1);
+  int na = 0;
+  for (int i = 0; i < n; ++i) {
+    if (agg[i] >= 0 || srp[i] == srp[i + 1]) continue;
+    bool free_nb = true;
+    for (int j = srp[i]; j < srp[i + 1] && free_nb; ++j) free_nb = agg[sci[j]] < 0;
+    if (!free_nb) continue;
+    agg[i] = na;
+    for (int j = srp[i]; j < srp[i + 1]; ++j) agg[sci[j]] = na;
+    ++na;
+  }
+  std::vector<int> pass1(agg);
+  for (int i = 0; i < n; ++i) {
+    if (pass1[i] >= 0) continue;
+    for (int j = srp[i]; j < srp[i + 1]; ++j)
+      if (pass1[sci[j]] >= 0) { agg[i] = pass1[sci[j]]; break; }
+  }
+  for (int i = 0; i < n; ++i) {
+    if (agg[i] >= 0) continue;
+    agg[i] = na;
+    for (int j = srp[i]; j < srp[i + 1]; ++j)
+      if (agg[sci[j]] < 0) agg[sci[j]] = na;
+    ++na;
+  }
+  return na;
+}
+
+// C = A * B (Gustavson, columns of each row sorted)
+HostCsr spgemm(const HostCsr& A, const HostCsr& B) {
+  HostCsr C;
+  C.n = A.n; C.m = B.m;
+  C.rp.assign(A.n + 1, 0);
+  std::vector<int> mark(B.m, -1), cols;
+  std::vector<double> acc(B.m, 0.0);
+  for (int i = 0; i < A.n; ++i) {
+    cols.clear();
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+      const int k = A.ci[j];
+      const double a = A.v[j];
+      for (int l = B.rp[k]; l < B.rp[k + 1]; ++l) {
+        const int c = B.ci[l];
+        if (mark[c] != i) { mark[c] = i; acc[c] = 0.0; cols.push_back(c); }
+        acc[c] += a * B.v[l];
+      }
+    }
+    std::sort(cols.begin(), cols.end());
+    for (int c : cols) { C.ci.push_back(c); C.v.push_back(acc[c]); }
+    C.rp[i + 1] = (int)C.ci.size();
+  }
+  return C;
+}
+
+HostCsr transpose(const HostCsr& A) {
+  HostCsr T;
+  T.n = A.m; T.m = A.n;
+  T.rp.assign(A.m + 1, 0);
+  for (int c : A.ci) ++T.rp[c + 1];
+  for (int i = 0; i < A.m; ++i) T.rp[i + 1] += T.rp[i];
+  T.ci.resize(A.ci.size()); T.v.resize(A.v.size());
+  std::vector<int> pos(T.rp.begin(), T.rp.end() - 1);
+  for (int i = 0; i < A.n; ++i)
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+      const int p = pos[A.ci[j]]++;
+      T.ci[p] = i; T.v[p] = A.v[j];
+    }
+  return T;
+}
+
+double gershgorin_rho(const HostCsr& A, const std::vector<double>& d) {
+  double rho = 0.0;
+  for (int i = 0; i < A.n; ++i) {
+    double s = 0.0;
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) s += std::fabs(A.v[j]);
+    rho = std::max(rho, s / std::fabs(d[i]));
+  }
+  return rho > 0 ? rho : 1.0;
+}
+
+// P = (I - w D^-1 A) T for the piecewise-constant T of `agg`
+HostCsr smoothed_prolongator(const HostCsr& A, const std::vector<double>& d, const std::vector<int>& agg, int na, double w) {
+  HostCsr P;
+  P.n = A.n; P.m = na;
+  P.rp.assign(A.n + 1, 0);
+  std::vector<int> mark(na, -1), cols;
+  std::vector<double> acc(na, 0.0);
+  for (int i = 0; i < A.n; ++i) {
+    cols.clear();
+    auto add = [&](int c, double v) {
+      if (mark[c] != i) { mark[c] = i; acc[c] = 0.0; cols.push_back(c); }
+      acc[c] += v;
+    };
+    add(agg[i], 1.0);
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) add(agg[A.ci[j]], -w * A.v[j] / d[i]);
+    std::sort(cols.begin(), cols.end());
+    for (int c : cols) { P.ci.push_back(c); P.v.push_back(acc[c]); }
+    P.rp[i + 1] = (int)P.ci.size();
+  }
+  return P;
+}
+
+// explicit inverse of the dense coarsest operator (+ shift * 1 1^T / n when it carries the constant null space)
+bool dense_inverse(const HostCsr& A, bool singular, std::vector<double>& inv) {
+  const int n = A.n;
+  std::vector<double> M((size_t)n * n, 0.0);
+  double tr = 0.0;
+  for (int i = 0; i < n; ++i)
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+      M[(size_t)i * n + A.ci[j]] = A.v[j];
+      if (A.ci[j] == i) tr += A.v[j];
+    }
+  if (singular) {
+    const double s = tr / n / n;
+    for (auto& x : M) x += s;
+  }
+  inv.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) inv[(size_t)i * n + i] = 1.0;
+  for (int k = 0; k < n; ++k) {
+    int piv = k;
+    for (int i = k + 1; i < n; ++i)
+      if (std::fabs(M[(size_t)i * n + k]) > std::fabs(M[(size_t)piv * n + k])) piv = i;
+    if (M[(size_t)piv * n + k] == 0.0) return false;
+    if (piv != k)
+      for (int j = 0; j < n; ++j) {
+        std::swap(M[(size_t)k * n + j], M[(size_t)piv * n + j]);
+        std::swap(inv[(size_t)k * n + j], inv[(size_t)piv * n + j]);
+      }
+    const double ip = 1.0 / M[(size_t)k * n + k];
+    for (int j = 0; j < n; ++j) { M[(size_t)k * n + j] *= ip; inv[(size_t)k * n + j] *= ip; }
+    for (int i = 0; i < n; ++i) {
+      if (i == k) continue;
+      const double f = M[(size_t)i * n + k];
+      if (f == 0.0) continue;
+      for (int j = 0; j < n; ++j) {
+        M[(size_t)i * n + j] -= f * M[(size_t)k * n + j];
+        inv[(size_t)i * n + j] -= f * inv[(size_t)k * n + j];
+      }
+    }
+  }
+  return true;
+}
+
+// ---- device kernels -------------------------------------------------------------------------------
+
+enum { M_AX = 0, M_RES, M_ADD, M_JAC };
+
+// LPR lanes per row.  M_AX: y = A x; M_RES: y = r - A x; M_ADD: y += A x; M_JAC: y = x + w dinv (r - A x)
+template <int MODE, int LPR>
+__global__ __launch_bounds__(256) void amg_spmv_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ colind,
+                                                       const double* __restrict__ vals, const double* __restrict__ x,
+                                                       const double* __restrict__ r, const double* __restrict__ dinv,
+                                                       double w, double* y) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = t / LPR, l = t % LPR;
+  double acc = 0.0;
+  if (row < n) {
+    const int a = rowptr[row], b = rowptr[row + 1];
+    for (int j = a + l; j < b; j += LPR) acc += vals[j] * x[colind[j]];
+  }
+#pragma unroll
+  for (int m = LPR / 2; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+  if (row < n && l == 0) {
+    if (MODE == M_AX) y[row] = acc;
+    else if (MODE == M_RES) y[row] = r[row] - acc;
+    else if (MODE == M_ADD) y[row] += acc;
+    else y[row] = x[row] + w * dinv[row] * (r[row] - acc);
+  }
+}
+
+__global__ void amg_jacobi0_kernel(int n, double w, const double* __restrict__ dinv, const double* __restrict__ r,
+                                   double* __restrict__ x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = w * dinv[i] * r[i];
+}
+
+__global__ void amg_diag_inv_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ colind,
+                                    const double* __restrict__ vals, double* __restrict__ dinv) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  double d = 1.0;
+  for (int j = rowptr[row]; j < rowptr[row + 1]; ++j)
+    if (colind[j] == row) d = vals[j];
+  dinv[row] = d != 0.0 ? 1.0 / d : 1.0;
+}
+
+// x = Minv r for the dense coarsest level: one wavefront per row
+__global__ __launch_bounds__(256) void amg_dense_kernel(int n, const double* __restrict__ Minv, const double* __restrict__ r,
+                                                        double* __restrict__ x) {
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+  double acc = 0.0;
+  if (row < n)
+    for (int j = l; j < n; j += 64) acc += Minv[(size_t)row * n + j] * r[j];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+  if (row < n && l == 0) x[row] = acc;
+}
+
+template <int MODE>
+void launch_spmv(hipStream_t st, int n, int avg_row, const int* rp, const int* ci, const double* v, const double* x,
+                 const double* r, const double* dinv, double w, double* y) {
+  if (avg_row > 8) {
+    dim3 g(((size_t)n * 16 + 255) / 256);
+    hipLaunchKernelGGL((amg_spmv_kernel<MODE, 16>), g, dim3(256), 0, st, n, rp, ci, v, x, r, dinv, w, y);
+  } else {
+    dim3 g(((size_t)n * 4 + 255) / 256);
+    hipLaunchKernelGGL((amg_spmv_kernel<MODE, 4>), g, dim3(256), 0, st, n, rp, ci, v, x, r, dinv, w, y);
+  }
+}
+
+template <class T>
+int upload(KnAmg& G, const std::vector<T>& src, T** dst, hipStream_t st) {
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+  KN_HIP(hipMalloc(&p, bytes));
+  G.allocs.push_back(p);
+  if (!src.empty()) KN_HIP(hipMemcpyAsync(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, st));
+  *dst = static_cast<T*>(p);
+  return KNPEMI_OK;
+}
+
+int upload_csr(KnAmg& G, const HostCsr& A, KnAmgCsr& D, hipStream_t st) {
+  int rc;
+  D.n = A.n; D.m = A.m; D.nnz = (int)A.ci.size();
+  if ((rc = upload(G, A.rp, &D.rp, st))) return rc;
+  if ((rc = upload(G, A.ci, &D.ci, st))) return rc;
+  return upload(G, A.v, &D.v, st);
+}
+
+}  // namespace
+
+void kn_amg_free(KnAmg& G) {
+  for (void* p : G.allocs) (void)hipFree(p);
+  G.allocs.clear();
+  G.lev.clear();
+  G.built = false;
+}
+
+// Build the hierarchy for the n x n device CSR (rowptr, colind, vals).  `singular`: the operator has the
+// constant null space (EMI).
+int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const int* d_colind, const double* d_vals,
+                 bool singular) {
+  kn_amg_free(G);
+  hipStream_t st = h->stream;
+  HostCsr A;
+  A.n = A.m = n;
+  A.rp.resize(n + 1);
+  KN_HIP(hipMemcpyAsync(A.rp.data(), d_rowptr, (n + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+  KN_HIP(hipStreamSynchronize(st));
+  const int nnz = A.rp[n];
+  A.ci.resize(nnz); A.v.resize(nnz);
+  KN_HIP(hipMemcpyAsync(A.ci.data(), d_colind, nnz * sizeof(int), hipMemcpyDeviceToHost, st));
+  KN_HIP(hipMemcpyAsync(A.v.data(), d_vals, nnz * sizeof(double), hipMemcpyDeviceToHost, st));
+  KN_HIP(hipStreamSynchronize(st));
+  for (double x : A.v)
+    if (!(x == x)) { kn_set_error("AMG set-up: operator contains NaN"); return KNPEMI_EINVAL; }
+
+  const double theta = G.theta;
+  const int n_dense = 256, max_levels = 12;
+  int rc;
+  G.singular = singular;
+  size_t work = 0;
+  HostCsr cur = std::move(A);
+  for (int l = 0; l < max_levels; ++l) {
+    KnAmgLevel L;
+    L.n = cur.n;
+    std::vector<double> d = diagonal(cur);
+    const double rho = gershgorin_rho(cur, d);
+    L.omega = 4.0 / (3.0 * rho);
+    L.avg_row = cur.n ? (int)(cur.ci.size() / (size_t)cur.n) : 0;
+    if (l == 0) {   // the finest operator is the caller's CSR of the current step
+      L.A.n = L.A.m = cur.n; L.A.nnz = (int)cur.ci.size();
+      L.A.rp = const_cast<int*>(d_rowptr); L.A.ci = const_cast<int*>(d_colind); L.A.v = const_cast<double*>(d_vals);
+    } else if ((rc = upload_csr(G, cur, L.A, st))) return rc;
+    std::vector<double> dinv(cur.n);
+    for (int i = 0; i < cur.n; ++i) dinv[i] = d[i] != 0.0 ? 1.0 / d[i] : 1.0;
+    if ((rc = upload(G, dinv, &L.dinv, st))) return rc;
+    std::vector<int> agg;
+    const int na = cur.n > n_dense ? aggregate(cur, d, theta, agg) : 0;
+    if (cur.n <= n_dense || na >= cur.n * 0.9 || l == max_levels - 1) {
+      if (cur.n > 4096) { kn_set_error("AMG set-up: coarsening stagnated"); return KNPEMI_ESOLVE; }
+      std::vector<double> inv;
+      if (!dense_inverse(cur, singular, inv)) { kn_set_error("AMG set-up: singular coarsest operator"); return KNPEMI_ESOLVE; }
+      if ((rc = upload(G, inv, &L.dense_inv, st))) return rc;
+      L.nc = 0;
+      G.lev.push_back(L);
+      work += 3 * (size_t)cur.n;
+      break;
+    }
+    HostCsr P = smoothed_prolongator(cur, d, agg, na, L.omega);
+    HostCsr R = transpose(P);
+    L.nc = na;
+    L.p_row = std::max(1, (int)(P.ci.size() / (size_t)P.n));
+    L.r_row = std::max(1, (int)(R.ci.size() / (size_t)R.n));
+    if ((rc = upload_csr(G, P, L.P, st))) return rc;
+    if ((rc = upload_csr(G, R, L.R, st))) return rc;
+    G.lev.push_back(L);
+    work += 3 * (size_t)cur.n;
+    cur = spgemm(R, spgemm(cur, P));
+  }
+  // per-level work vectors x, r, t (level 0 uses the caller's r and z for r and x)
+  void* p = nullptr;
+  KN_HIP(hipMalloc(&p, std::max<size_t>(work, 1) * sizeof(double)));
+  G.allocs.push_back(p);
+  double* w = static_cast<double*>(p);
+  for (auto& L : G.lev) { L.x = w; L.r = w + L.n; L.t = w + 2 * (size_t)L.n; w += 3 * (size_t)L.n; }
+  KN_HIP(hipStreamSynchronize(st));
+  G.built = true;
+  G.n = n;
+  size_t tot = 0;
+  for (auto& L : G.lev) tot += L.A.nnz;
+  G.op_complexity = G.lev[0].A.nnz ? (double)tot / G.lev[0].A.nnz : 1.0;
+  return KNPEMI_OK;
+}
+
+// z = V(1,1)-cycle applied to r (both of the finest size); the finest operator/diagonal are those of the
+// current step (`vals`, `dinv0`).
+int kn_amg_apply(knpemi_handle* h, KnAmg& G, const double* vals, const double* dinv0, const double* r, double* z) {
+  hipStream_t st = h->stream;
+  const int nl = (int)G.lev.size();
+  for (int l = 0; l < nl; ++l) {
+    KnAmgLevel& L = G.lev[l];
+    const double* rl = l == 0 ? r : L.r;
+    double* xl = l == 0 ? z : L.x;
+    const double* Av = l == 0 ? vals : L.A.v;
+    const double* dinv = l == 0 ? dinv0 : L.dinv;
+    if (L.nc == 0) {
+      dim3 g(((size_t)L.n * 64 + 255) / 256);
+      hipLaunchKernelGGL(amg_dense_kernel, g, dim3(256), 0, st, L.n, L.dense_inv, rl, xl);
+      break;
+    }
+    hipLaunchKernelGGL(amg_jacobi0_kernel, dim3((L.n + 255) / 256), dim3(256), 0, st, L.n, L.omega, dinv, rl, xl);
+    launch_spmv<M_RES>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, xl, rl, nullptr, 0.0, L.t);
+    launch_spmv<M_AX>(st, L.nc, L.r_row, L.R.rp, L.R.ci, L.R.v, L.t, nullptr, nullptr, 0.0, G.lev[l + 1].r);
+  }
+  for (int l = nl - 2; l >= 0; --l) {
+    KnAmgLevel& L = G.lev[l];
+    const double* rl = l == 0 ? r : L.r;
+    double* xl = l == 0 ? z : L.x;
+    const double* Av = l == 0 ? vals : L.A.v;
+    const double* dinv = l == 0 ? dinv0 : L.dinv;
+    launch_spmv<M_ADD>(st, L.n, L.p_row, L.P.rp, L.P.ci, L.P.v, G.lev[l + 1].x, nullptr, nullptr, 0.0, xl);
+    launch_spmv<M_JAC>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, xl, rl, dinv, L.omega, L.t);
+    KN_HIP(hipMemcpyAsync(xl, L.t, (size_t)L.n * sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
+  return KNPEMI_OK;
+}

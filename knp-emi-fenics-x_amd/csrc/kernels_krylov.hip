@@ -1,0 +1,347 @@
+// Device-resident Krylov solves for the two sub-problems (the row next to the
+// hot path).  The reference hands its systems to PETSc (src/knpemi/pdeSolver.py:13-38,88-113): CG +
+// hypre BoomerAMG for the symmetric positive semi-definite EMI system with the constant null space
+// attached (:74-78), GMRES + BoomerAMG for the non-symmetric block-diagonal KNP system, both with a
+// non-zero initial guess (the previous solution).  Here: CG preconditioned with a smoothed-aggregation
+// V-cycle (kernels_amg.hip; Jacobi selectable) with the right-hand side and the solution projected onto
+// zero mean, and Jacobi-preconditioned BiCGStab (the KNP blocks are mass-dominated at the reference's
+// dt), working in place on the assembled device CSR.
+//
+// All vectors and scalars stay on the device; the host reads back one residual norm every few
+// iterations to test convergence.  Reductions are two-stage with a fixed summation order, so the solves
+// are bit-reproducible.
+#include "knpemi_internal.h"
+
+namespace {
+
+constexpr int RED_BLOCKS = 512, RED_THREADS = 256;
+
+// sc[] layout (device scalars)
+enum { S_RHO = 0, S_RHO_OLD, S_PAP, S_ALPHA, S_BETA, S_OMEGA, S_RR, S_BB, S_TS, S_TT, S_MEAN, S_TMP, S_N };
+
+// y = A * (x .* dinv?) : 16 lanes per row
+template <bool SCALED>
+__global__ __launch_bounds__(256) void spmv_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ colind,
+                                                   const double* __restrict__ vals, const double* __restrict__ x,
+                                                   const double* __restrict__ dinv, double* __restrict__ y) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = t >> 4, l = t & 15;
+  double acc = 0.0;
+  if (row < n) {
+    const int a = rowptr[row], b = rowptr[row + 1];
+    for (int j = a + l; j < b; j += 16) {
+      const int c = colind[j];
+      acc += vals[j] * (SCALED ? x[c] * dinv[c] : x[c]);
+    }
+  }
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+  if (row < n && l == 0) y[row] = acc;
+}
+
+__global__ void diag_inv_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ colind,
+                                const double* __restrict__ vals, double* __restrict__ dinv) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  double d = 1.0;
+  for (int j = rowptr[row]; j < rowptr[row + 1]; ++j)
+    if (colind[j] == row) d = vals[j];
+  dinv[row] = d != 0.0 ? 1.0 / d : 1.0;
+}
+
+// up to three dot products in one pass: partial[k][block]
+__global__ __launch_bounds__(RED_THREADS) void dots_partial_kernel(int n, int nd, const double* a0, const double* b0,
+                                                                   const double* a1, const double* b1, const double* a2,
+                                                                   const double* b2, double* __restrict__ partial) {
+  __shared__ double sh[3][RED_THREADS];
+  double s0 = 0, s1 = 0, s2 = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    s0 += a0[i] * b0[i];
+    if (nd > 1) s1 += a1[i] * b1[i];
+    if (nd > 2) s2 += a2[i] * b2[i];
+  }
+  sh[0][threadIdx.x] = s0; sh[1][threadIdx.x] = s1; sh[2][threadIdx.x] = s2;
+  __syncthreads();
+  for (int w = RED_THREADS / 2; w > 0; w >>= 1) {
+    if (threadIdx.x < w)
+      for (int k = 0; k < nd; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    for (int k = 0; k < nd; ++k) partial[k * RED_BLOCKS + blockIdx.x] = sh[k][0];
+}
+
+// second stage + the scalar algebra of the algorithm step `op`
+enum { OP_STORE3 = 0, OP_CG_INIT, OP_CG_PAP, OP_CG_RHO, OP_BI_RHO, OP_BI_ALPHA, OP_BI_OMEGA, OP_MEAN };
+
+__global__ __launch_bounds__(RED_THREADS) void dots_final_kernel(int nb, int nd, const double* __restrict__ partial,
+                                                                 double* __restrict__ sc, int op, int d0, int d1, int d2,
+                                                                 double scale) {
+  __shared__ double sh[3][RED_THREADS];
+  for (int k = 0; k < nd; ++k) {
+    double s = 0;
+    for (int i = threadIdx.x; i < nb; i += RED_THREADS) s += partial[k * RED_BLOCKS + i];
+    sh[k][threadIdx.x] = s;
+  }
+  __syncthreads();
+  for (int w = RED_THREADS / 2; w > 0; w >>= 1) {
+    if (threadIdx.x < w)
+      for (int k = 0; k < nd; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const double v0 = sh[0][0], v1 = nd > 1 ? sh[1][0] : 0.0, v2 = nd > 2 ? sh[2][0] : 0.0;
+  switch (op) {
+    case OP_STORE3: sc[d0] = v0; if (nd > 1) sc[d1] = v1; if (nd > 2) sc[d2] = v2; break;
+    case OP_MEAN: sc[S_MEAN] = v0 * scale; break;
+    case OP_CG_INIT: sc[S_RHO] = v0; sc[S_RR] = v1; break;                                  // r.z, r.r
+    case OP_CG_PAP: sc[S_PAP] = v0; sc[S_ALPHA] = sc[S_RHO] / v0; break;                     // p.Ap
+    case OP_CG_RHO: sc[S_BETA] = v0 / sc[S_RHO]; sc[S_RHO] = v0; sc[S_RR] = v1; break;       // r.z, r.r
+    case OP_BI_RHO:                                                                          // rhat.r
+      sc[S_BETA] = (v0 / sc[S_RHO]) * (sc[S_ALPHA] / sc[S_OMEGA]);
+      sc[S_RHO] = v0;
+      break;
+    case OP_BI_ALPHA: sc[S_ALPHA] = sc[S_RHO] / v0; break;                                   // rhat.v
+    case OP_BI_OMEGA: sc[S_OMEGA] = v1 != 0.0 ? v0 / v1 : 0.0; break;                        // t.s, t.t
+  }
+}
+
+enum { V_RESID = 0, V_SHIFT, V_CG_XR, V_CG_P, V_JACOBI, V_BI_P, V_BI_S, V_COPY };
+
+// small fused vector updates; scalars are read from device memory
+__global__ void vec_kernel(int n, int op, const double* __restrict__ sc, double* __restrict__ a, double* __restrict__ b,
+                           const double* __restrict__ c, const double* __restrict__ d, const double* __restrict__ e) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  switch (op) {
+    case V_RESID: a[i] = c[i] - d[i]; break;                                   // r = b - Ax
+    case V_SHIFT: a[i] -= sc[S_MEAN]; break;                                   // a -= mean
+    case V_CG_XR: a[i] += sc[S_ALPHA] * c[i]; b[i] -= sc[S_ALPHA] * d[i]; break;   // x += alpha p; r -= alpha q
+    case V_JACOBI: a[i] = c[i] * d[i]; break;                                  // z = r .* dinv
+    case V_CG_P: a[i] = c[i] + sc[S_BETA] * a[i]; break;                       // p = z + beta p
+    case V_BI_P: a[i] = c[i] + sc[S_BETA] * (a[i] - sc[S_OMEGA] * d[i]); break;  // p = r + beta (p - omega v)
+    case V_BI_S: a[i] = c[i] - sc[S_ALPHA] * d[i]; break;                      // s = r - alpha v
+    case V_COPY: a[i] = c[i]; break;
+  }
+}
+
+// dinv != NULL: p, s are the unpreconditioned directions (Jacobi applied here); else they are M^-1 p, M^-1 s
+__global__ void bicg_update_kernel(int n, const double* __restrict__ sc, double* __restrict__ x, double* __restrict__ r,
+                                   const double* __restrict__ p, const double* __restrict__ s, const double* __restrict__ sres,
+                                   const double* __restrict__ t, const double* __restrict__ dinv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double d = dinv ? dinv[i] : 1.0;
+  x[i] += sc[S_ALPHA] * (p[i] * d) + sc[S_OMEGA] * (s[i] * d);
+  r[i] = sres[i] - sc[S_OMEGA] * t[i];
+}
+
+struct Ctx {
+  knpemi_handle* h;
+  int n;
+  const int* rowptr; const int* colind; const double* vals;
+  double* sc; double* partial;
+};
+
+inline dim3 grid1(int n) { return dim3((n + 255) / 256); }
+
+void spmv(const Ctx& c, const double* x, double* y, const double* dinv) {
+  dim3 g(((size_t)c.n * 16 + 255) / 256);
+  if (dinv) hipLaunchKernelGGL((spmv_kernel<true>), g, dim3(256), 0, c.h->stream, c.n, c.rowptr, c.colind, c.vals, x, dinv, y);
+  else hipLaunchKernelGGL((spmv_kernel<false>), g, dim3(256), 0, c.h->stream, c.n, c.rowptr, c.colind, c.vals, x, dinv, y);
+}
+
+void dots(const Ctx& c, int nd, const double* a0, const double* b0, const double* a1, const double* b1, const double* a2,
+          const double* b2, int op, int d0 = 0, int d1 = 0, int d2 = 0, double scale = 1.0) {
+  const int nb = std::min(RED_BLOCKS, (c.n + RED_THREADS - 1) / RED_THREADS);
+  hipLaunchKernelGGL(dots_partial_kernel, dim3(nb), dim3(RED_THREADS), 0, c.h->stream, c.n, nd, a0, b0, a1, b1, a2, b2,
+                     c.partial);
+  hipLaunchKernelGGL(dots_final_kernel, dim3(1), dim3(RED_THREADS), 0, c.h->stream, nb, nd, c.partial, c.sc, op, d0, d1,
+                     d2, scale);
+}
+
+void vec(const Ctx& c, int op, double* a, double* b, const double* cc, const double* d) {
+  hipLaunchKernelGGL(vec_kernel, grid1(c.n), dim3(256), 0, c.h->stream, c.n, op, c.sc, a, b, cc, d, (const double*)nullptr);
+}
+
+int read_scalars(const Ctx& c, double* host, int count) {
+  KN_HIP(hipMemcpyAsync(host, c.sc, count * sizeof(double), hipMemcpyDeviceToHost, c.h->stream));
+  KN_HIP(hipStreamSynchronize(c.h->stream));
+  return KNPEMI_OK;
+}
+
+}  // namespace
+
+// Workspace: 10 vectors of the larger system + ones + scalars + partials (allocated on first use).
+static int ensure_work(knpemi_handle* h, size_t n) {
+  if (h->kry_n >= n) return KNPEMI_OK;
+  void* p = nullptr;
+  const size_t doubles = 11 * n + 64 + 3 * RED_BLOCKS;
+  KN_HIP(hipMalloc(&p, doubles * sizeof(double)));
+  h->allocs.push_back(p);
+  KN_HIP(hipMemsetAsync(p, 0, doubles * sizeof(double), h->stream));
+  h->kry = static_cast<double*>(p);
+  h->kry_n = n;
+  std::vector<double> ones(n, 1.0);
+  KN_HIP(hipMemcpyAsync(h->kry + 10 * n, ones.data(), n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  return KNPEMI_OK;
+}
+
+// Jacobi-PCG on A_emi x = b_emi, x = phi (record component 7, gathered into a contiguous vector first).
+int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* iters, double* relres) {
+  KnDev& D = h->dev;
+  const int n = D.Ntot;
+  int rc = ensure_work(h, (size_t)std::max(1, h->K - 1) * D.Ntot);
+  if (rc) return rc;
+  const size_t N = h->kry_n;
+  double *x = h->kry, *r = x + N, *z = r + N, *p = z + N, *q = p + N, *b = q + N, *dinv = b + N, *ones = h->kry + 10 * N;
+  Ctx c{h, n, D.rowptr, D.colind, D.A_emi, h->kry + 11 * N, h->kry + 11 * N + 64};
+  // x0 = current phi (ksp_initial_guess_nonzero), b = b_emi projected onto zero mean (constant null space)
+  if ((rc = kn_launch_field_gather(h, D.VR + 7, KN_REC, x, n))) return rc;
+  vec(c, V_COPY, b, nullptr, D.b_emi, nullptr);
+  dots(c, 1, b, ones, nullptr, nullptr, nullptr, nullptr, OP_MEAN, 0, 0, 0, 1.0 / n);
+  vec(c, V_SHIFT, b, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL(diag_inv_kernel, grid1(n), dim3(256), 0, h->stream, n, c.rowptr, c.colind, c.vals, dinv);
+  KnAmg& G = h->amg_emi;
+  const bool amg = h->pc_emi == KNPEMI_PC_AMG;
+  if (amg && (!G.built || G.n != n)) {
+    if ((rc = kn_amg_setup(h, G, n, D.rowptr, D.colind, D.A_emi, true))) return rc;
+    G.its_ref = -1;
+    ++G.builds;
+  }
+  auto precond = [&]() -> int {
+    if (amg) return kn_amg_apply(h, G, D.A_emi, dinv, r, z);
+    vec(c, V_JACOBI, z, nullptr, r, dinv);
+    return KNPEMI_OK;
+  };
+  const int chunk = amg ? 2 : 8;
+  spmv(c, x, q, nullptr);
+  vec(c, V_RESID, r, nullptr, b, q);
+  if ((rc = precond())) return rc;
+  vec(c, V_COPY, p, nullptr, z, nullptr);
+  dots(c, 2, r, z, r, r, nullptr, nullptr, OP_CG_INIT);
+  dots(c, 1, b, b, nullptr, nullptr, nullptr, nullptr, OP_STORE3, S_BB);
+  double sc[S_N];
+  if ((rc = read_scalars(c, sc, S_N))) return rc;
+  const double bnorm = std::sqrt(sc[S_BB]);
+  const double target = std::max(atol, rtol * (bnorm > 0 ? bnorm : 1.0));
+  int it = 0;
+  double rn = std::sqrt(sc[S_RR]);
+  while (rn > target && it < maxit) {
+    for (int k = 0; k < chunk && it < maxit; ++k, ++it) {
+      spmv(c, p, q, nullptr);
+      dots(c, 1, p, q, nullptr, nullptr, nullptr, nullptr, OP_CG_PAP);
+      vec(c, V_CG_XR, x, r, p, q);
+      if ((rc = precond())) return rc;
+      dots(c, 2, r, z, r, r, nullptr, nullptr, OP_CG_RHO);
+      vec(c, V_CG_P, p, nullptr, z, nullptr);
+    }
+    if ((rc = read_scalars(c, sc, S_N))) return rc;
+    rn = std::sqrt(sc[S_RR]);
+    if (!(rn == rn)) { kn_set_error("EMI CG broke down (NaN residual)"); return KNPEMI_EINVAL; }
+  }
+  // solution orthogonal to constants, then into the phi component of the vertex records
+  dots(c, 1, x, ones, nullptr, nullptr, nullptr, nullptr, OP_MEAN, 0, 0, 0, 1.0 / n);
+  vec(c, V_SHIFT, x, nullptr, nullptr, nullptr);
+  if ((rc = kn_launch_field_scatter(h, x, D.VR + 7, n, KN_REC))) return rc;
+  if (iters) *iters = it;
+  if (relres) *relres = bnorm > 0 ? rn / bnorm : rn;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { kn_set_error(std::string("krylov (emi): ") + hipGetErrorString(e)); return KNPEMI_EHIP; }
+  if (amg) {   // frozen hierarchy: rebuild at the next solve once it has visibly aged
+    if (G.its_ref < 0) G.its_ref = it;
+    else if (it > 2 * G.its_ref + 4) G.built = false;
+  }
+  if (rn > target) { kn_set_error("EMI CG did not converge (ksp_error_if_not_converged)"); return KNPEMI_ESOLVE; }
+  return KNPEMI_OK;
+}
+
+// Jacobi-BiCGStab on the block-diagonal KNP system; x = c (csol, converted to the block order).
+int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* iters, double* relres) {
+  KnDev& D = h->dev;
+  const int KS = h->K - 1;
+  const int n = KS * D.Ntot;
+  int rc = ensure_work(h, (size_t)std::max(1, h->K - 1) * D.Ntot);
+  if (rc) return rc;
+  if (!D.krowptr) { kn_set_error("KNP monolithic pattern missing"); return KNPEMI_EINVAL; }
+  const size_t N = h->kry_n;
+  double *x = h->kry, *r = x + N, *rhat = r + N, *p = rhat + N, *v = p + N, *s = v + N, *t = s + N, *dinv = t + N;
+  double *phat = h->kry + 8 * N, *shat = h->kry + 9 * N;
+  Ctx c{h, n, D.krowptr, D.kcolind, D.A_knp, h->kry + 11 * N, h->kry + 11 * N + 64};
+  // x0 = previous concentrations in the block order [c[0][0], c[0][1], c[1][0], ...]
+  for (int sd = 0; sd < h->n_sub; ++sd)
+    for (int k = 0; k < KS; ++k) {
+      const size_t nv = h->n_vert[sd];
+      if (!nv) continue;
+      KN_HIP(hipMemcpyAsync(x + (size_t)KS * h->voff[sd] + k * nv, D.csol + (size_t)k * D.Ntot + h->voff[sd],
+                            nv * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
+  hipLaunchKernelGGL(diag_inv_kernel, grid1(n), dim3(256), 0, h->stream, n, c.rowptr, c.colind, c.vals, dinv);
+  KnAmg& G = h->amg_knp;
+  const bool amg = h->pc_knp == KNPEMI_PC_AMG;
+  if (amg && (!G.built || G.n != n)) {
+    if ((rc = kn_amg_setup(h, G, n, D.krowptr, D.kcolind, D.A_knp, false))) return rc;
+    G.its_ref = -1;
+    ++G.builds;
+  }
+  spmv(c, x, v, nullptr);
+  vec(c, V_RESID, r, nullptr, D.b_knp, v);
+  vec(c, V_COPY, rhat, nullptr, r, nullptr);
+  KN_HIP(hipMemsetAsync(p, 0, (size_t)n * sizeof(double), h->stream));
+  KN_HIP(hipMemsetAsync(v, 0, (size_t)n * sizeof(double), h->stream));
+  double init[S_N] = {0};
+  init[S_RHO] = init[S_ALPHA] = init[S_OMEGA] = 1.0;
+  KN_HIP(hipMemcpyAsync(c.sc, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  dots(c, 2, r, r, D.b_knp, D.b_knp, nullptr, nullptr, OP_STORE3, S_RR, S_BB);
+  double sc[S_N];
+  if ((rc = read_scalars(c, sc, S_N))) return rc;
+  const double bnorm = std::sqrt(sc[S_BB]);
+  const double target = std::max(atol, rtol * (bnorm > 0 ? bnorm : 1.0));
+  double rn = std::sqrt(sc[S_RR]);
+  int it = 0;
+  while (rn > target && it < maxit) {
+    for (int k = 0; k < (amg ? 1 : 4) && it < maxit; ++k, ++it) {
+      dots(c, 1, rhat, r, nullptr, nullptr, nullptr, nullptr, OP_BI_RHO);
+      vec(c, V_BI_P, p, nullptr, r, v);
+      if (amg) {
+        if ((rc = kn_amg_apply(h, G, D.A_knp, dinv, p, phat))) return rc;
+        spmv(c, phat, v, nullptr);
+      } else spmv(c, p, v, dinv);                           // v = A M^-1 p
+      dots(c, 1, rhat, v, nullptr, nullptr, nullptr, nullptr, OP_BI_ALPHA);
+      vec(c, V_BI_S, s, nullptr, r, v);
+      if (amg) {
+        if ((rc = kn_amg_apply(h, G, D.A_knp, dinv, s, shat))) return rc;
+        spmv(c, shat, t, nullptr);
+      } else spmv(c, s, t, dinv);                           // t = A M^-1 s
+      dots(c, 2, t, s, t, t, nullptr, nullptr, OP_BI_OMEGA);
+      if (amg)
+        hipLaunchKernelGGL(bicg_update_kernel, grid1(n), dim3(256), 0, h->stream, n, c.sc, x, r, phat, shat, s, t,
+                           (const double*)nullptr);
+      else
+        hipLaunchKernelGGL(bicg_update_kernel, grid1(n), dim3(256), 0, h->stream, n, c.sc, x, r, p, s, s, t, dinv);
+      dots(c, 1, r, r, nullptr, nullptr, nullptr, nullptr, OP_STORE3, S_RR);
+    }
+    if ((rc = read_scalars(c, sc, S_N))) return rc;
+    rn = std::sqrt(sc[S_RR]);
+    if (!(rn == rn)) { kn_set_error("KNP BiCGStab broke down (NaN residual)"); return KNPEMI_EINVAL; }
+  }
+  for (int sd = 0; sd < h->n_sub; ++sd)
+    for (int k = 0; k < KS; ++k) {
+      const size_t nv = h->n_vert[sd];
+      if (!nv) continue;
+      KN_HIP(hipMemcpyAsync(D.csol + (size_t)k * D.Ntot + h->voff[sd], x + (size_t)KS * h->voff[sd] + k * nv,
+                            nv * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
+  if (iters) *iters = it;
+  if (relres) *relres = bnorm > 0 ? rn / bnorm : rn;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { kn_set_error(std::string("krylov (knp): ") + hipGetErrorString(e)); return KNPEMI_EHIP; }
+  if (amg) {
+    if (G.its_ref < 0) G.its_ref = it;
+    else if (it > 2 * G.its_ref + 4) G.built = false;
+  }
+  if (rn > target) { kn_set_error("KNP BiCGStab did not converge (ksp_error_if_not_converged)"); return KNPEMI_ESOLVE; }
+  return KNPEMI_OK;
+}

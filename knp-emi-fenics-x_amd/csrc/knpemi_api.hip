@@ -450,6 +450,22 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   if ((rc = dev_zeros(h, (size_t)NQtot, &D.phiM))) return rc;
   if ((rc = dev_zeros(h, (size_t)std::max(1, nftot) * 2 * NF * 2, &D.gam_contrib))) return rc;
   if ((rc = dev_zeros(h, (size_t)std::max(1, h->moff[S]) * K * std::max(1, NQtot), &D.Ich))) return rc;
+  {
+    std::vector<int> krp((size_t)(K - 1) * Ntot + 1, 0), kci((size_t)(K - 1) * colindL.size());
+    int64_t row = 0, pos = 0;
+    for (int s = 0; s < S; ++s) {
+      const int v0 = h->voff[s], nv = h->n_vert[s];
+      for (int k = 0; k < K - 1; ++k) {
+        const int64_t shift = (int64_t)(K - 1) * v0 + (int64_t)k * nv - v0;
+        for (int v = 0; v < nv; ++v) {
+          for (int p = rowptrL[v0 + v]; p < rowptrL[v0 + v + 1]; ++p) kci[pos++] = (int)(colindL[p] + shift);
+          krp[++row] = (int)pos;
+        }
+      }
+    }
+    if ((rc = dev_upload(h, krp, &D.krowptr))) return rc;
+    if ((rc = dev_upload(h, kci, &D.kcolind))) return rc;
+  }
   h->stage_len = (size_t)std::max(Ntot, 1) * (K - 1) + 2 * (size_t)std::max(NQtot, 1);
   if ((rc = dev_zeros(h, h->stage_len, &h->d_stage))) return rc;
 
@@ -477,6 +493,8 @@ extern "C" void knpemi_destroy(knpemi_handle* h) {
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->aux) (void)hipStreamDestroy(h->aux);
+  kn_amg_free(h->amg_emi);
+  kn_amg_free(h->amg_knp);
   for (void* p : h->allocs) (void)hipFree(p);
   for (auto& v : h->prof_ev) for (hipEvent_t e : v) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -676,6 +694,43 @@ extern "C" int knpemi_assemble_knp(knpemi_handle* h, int flags) {
   int rc = kn_launch_knp_membrane(h, flags);   // partial integrals first, the row kernel adds them
   if (rc) return rc;
   return kn_launch_knp_rows(h, flags);
+}
+
+extern "C" int knpemi_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* iters, double* relres) {
+  if (!h) return fail(KNPEMI_EINVAL, "null handle");
+  if (!(rtol >= 0) || !(atol >= 0) || maxit < 0) return fail(KNPEMI_EINVAL, "knpemi_solve_emi: bad tolerances");
+  KN_HIP(hipSetDevice(h->device));
+  KN_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));   // a matrix assembled on the auxiliary stream is complete
+  return kn_solve_emi(h, rtol, atol, maxit, iters, relres);
+}
+
+extern "C" int knpemi_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* iters, double* relres) {
+  if (!h) return fail(KNPEMI_EINVAL, "null handle");
+  if (!(rtol >= 0) || !(atol >= 0) || maxit < 0) return fail(KNPEMI_EINVAL, "knpemi_solve_knp: bad tolerances");
+  KN_HIP(hipSetDevice(h->device));
+  return kn_solve_knp(h, rtol, atol, maxit, iters, relres);
+}
+
+extern "C" int knpemi_solver_setup(knpemi_handle* h, int which, int precond, double theta) {
+  if (!h) return fail(KNPEMI_EINVAL, "null handle");
+  if (which != KNPEMI_B_EMI && which != KNPEMI_B_KNP) return fail(KNPEMI_EINVAL, "knpemi_solver_setup: unknown system");
+  if (precond != KNPEMI_PC_JACOBI && precond != KNPEMI_PC_AMG)
+    return fail(KNPEMI_EINVAL, "knpemi_solver_setup: unknown preconditioner");
+  KnAmg& G = which == KNPEMI_B_EMI ? h->amg_emi : h->amg_knp;
+  (which == KNPEMI_B_EMI ? h->pc_emi : h->pc_knp) = precond;
+  G.theta = theta > 0 ? theta : 0.08;
+  G.built = false;
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_solver_info(knpemi_handle* h, int which, int* levels, double* op_complexity, int* builds) {
+  if (!h) return fail(KNPEMI_EINVAL, "null handle");
+  if (which != KNPEMI_B_EMI && which != KNPEMI_B_KNP) return fail(KNPEMI_EINVAL, "knpemi_solver_info: unknown system");
+  const KnAmg& G = which == KNPEMI_B_EMI ? h->amg_emi : h->amg_knp;
+  if (levels) *levels = (int)G.lev.size();
+  if (op_complexity) *op_complexity = G.op_complexity;
+  if (builds) *builds = G.builds;
+  return KNPEMI_OK;
 }
 
 extern "C" int knpemi_csr_dims(knpemi_handle* h, int which, int64_t* n_rows, int64_t* nnz) {

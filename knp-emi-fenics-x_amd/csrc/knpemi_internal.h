@@ -69,6 +69,7 @@ struct KnDev {
   const int* rowptrL; const int* colindL;
   double* A_emi; double* P_emi; double* b_emi;
   double* A_knp; double* b_knp;          // block order (sub, ion)
+  const int* krowptr; const int* kcolind; // monolithic block-diagonal KNP pattern (Krylov solve, export)
   int64_t nnz, nnzL;
   // membrane
   const int* gam_idx;         // [Ntot] membrane-row index or -1
@@ -99,6 +100,33 @@ struct KnOdeModel {
   unsigned long long* d_stats = nullptr; // [3]: rhs evals, steps, failures
 };
 
+// Algebraic multigrid hierarchy (kernels_amg.hip)
+struct KnAmgCsr { int n = 0, m = 0, nnz = 0; int* rp = nullptr; int* ci = nullptr; double* v = nullptr; };
+struct KnAmgLevel {
+  int n = 0, nc = 0;                 // size, size of the next coarser level (0: dense coarsest level)
+  int avg_row = 0, p_row = 0, r_row = 0;
+  double omega = 0.0;                // Jacobi damping 4 / (3 rho)
+  KnAmgCsr A, P, R;
+  double* dinv = nullptr;
+  double* dense_inv = nullptr;       // [n][n] explicit inverse on the coarsest level
+  double *x = nullptr, *r = nullptr, *t = nullptr;
+};
+struct KnAmg {
+  std::vector<KnAmgLevel> lev;
+  std::vector<void*> allocs;
+  bool built = false, singular = false;
+  int n = 0;
+  double theta = 0.08;               // strength threshold
+  double op_complexity = 1.0;
+  int its_ref = -1;                  // iterations of the first solve after the build (rebuild trigger)
+  int builds = 0;
+};
+void kn_amg_free(KnAmg& G);
+struct knpemi_handle;
+int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const int* d_colind, const double* d_vals,
+                 bool singular);
+int kn_amg_apply(knpemi_handle* h, KnAmg& G, const double* vals, const double* dinv0, const double* r, double* z);
+
 struct knpemi_handle {
   int device = 0;
   hipStream_t stream = nullptr;          // main stream
@@ -122,6 +150,9 @@ struct knpemi_handle {
   // host copies of patterns for export
   std::vector<int> h_rowptr, h_colind, h_rowptrL, h_colindL;
   double* d_stage = nullptr; size_t stage_len = 0;   // staging buffer for strided field I/O
+  double* kry = nullptr; size_t kry_n = 0;           // Krylov workspace (kernels_krylov.hip)
+  KnAmg amg_emi, amg_knp;
+  int pc_emi = KNPEMI_PC_AMG, pc_knp = KNPEMI_PC_AMG;
   // per-kernel event profiling (knpemi_profile)
   uint32_t prof_mask = 0;
   std::vector<hipEvent_t> prof_ev[KNPEMI_N_KERNELS];  // begin/end pairs
@@ -167,6 +198,8 @@ int kn_launch_knp_membrane(knpemi_handle* h, int flags);
 int kn_launch_ode_step(knpemi_handle* h, int slot, double t0, double dt, double rtol, double atol,
                        int flags, const int32_t* ion_param, int v_index);
 int kn_launch_update_pde(knpemi_handle* h);
+int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* iters, double* relres);
+int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* iters, double* relres);
 int kn_launch_halo(knpemi_handle* h, int kind, int pack, const int32_t* idx, int n, double* buf);
 int kn_launch_field_scatter(knpemi_handle* h, const double* src, double* dst, int n, int dst_stride);
 int kn_launch_field_gather(knpemi_handle* h, const double* src, int src_stride, double* dst, int n);

@@ -13,7 +13,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libknpemi_hip.so")
 
-OK, EINVAL, EHIP, ENOMEM, EODE = 0, -1, -2, -3, -4
+OK, EINVAL, EHIP, ENOMEM, EODE, ESOLVE = 0, -1, -2, -3, -4, -5
+PC_JACOBI, PC_AMG = 0, 1
 TRIANGLE, TETRAHEDRON, HEXAHEDRON = 0, 1, 2
 MODEL_HH_SI, MODEL_HH_MV, MODEL_GLIAL = 0, 1, 2
 MAX_IONS, MAX_SUB, MAX_MODELS = 3, 8, 4
@@ -75,6 +76,10 @@ SIGNATURES = {
     "knpemi_assemble_knp": (C.c_int, [C.c_void_p, C.c_int]),
     "knpemi_assemble_emi_membrane_rhs": (C.c_int, [C.c_void_p, C.c_int]),
     "knpemi_join": (C.c_int, [C.c_void_p]),
+    "knpemi_solve_emi": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int), c_dbl_p]),
+    "knpemi_solve_knp": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int), c_dbl_p]),
+    "knpemi_solver_setup": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double]),
+    "knpemi_solver_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), c_dbl_p, C.POINTER(C.c_int)]),
     "knpemi_csr_dims": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "knpemi_get_csr_pattern": (C.c_int, [C.c_void_p, C.c_int, c_int_p, c_int_p]),
     "knpemi_get_csr_values": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p]),

@@ -261,6 +261,26 @@ class DeviceProblem:
         x = np.ascontiguousarray(x, np.float64)
         L.check(self.lib.knpemi_set_solution(self.h, which, x.ctypes.data_as(C.c_void_p), 0))
 
+    def get_solution(self, which, n):
+        x = np.empty(n, np.float64)
+        L.check(self.lib.knpemi_get_solution(self.h, which, L.dptr(x)))
+        return x
+
+    def solve(self, which, rtol, atol, maxit=10000):
+        """Device Krylov solve of the assembled system (`knpemi_solve_emi/knp`); returns (iterations, relres)."""
+        it, rr = C.c_int(), C.c_double()
+        fn = self.lib.knpemi_solve_emi if which == L.B_EMI else self.lib.knpemi_solve_knp
+        L.check(fn(self.h, float(rtol), float(atol), int(maxit), C.byref(it), C.byref(rr)))
+        return it.value, rr.value
+
+    def solver_setup(self, which, precond, theta=0.0):
+        L.check(self.lib.knpemi_solver_setup(self.h, which, precond, float(theta)))
+
+    def solver_info(self, which):
+        lev, b, oc = C.c_int(), C.c_int(), C.c_double()
+        L.check(self.lib.knpemi_solver_info(self.h, which, C.byref(lev), C.byref(oc), C.byref(b)))
+        return dict(levels=lev.value, op_complexity=oc.value, builds=b.value)
+
     def update_pde(self):
         L.check(self.lib.knpemi_update_pde(self.h))
 

@@ -6,10 +6,14 @@ Functions passed as unknowns in place and returns them), `.solver.getIterationNu
 `.A`, `.u` (`run_3D.py:355-360`, `tests/run_mms_emi.py:321-323`).
 
 `.solve()` = GPU assembly (the hot path: `knpemi_assemble_emi/knp`) followed by a
-linear solve.  The Krylov/AMG solve is *adjacent* to the hot path (SURVEY.md
-section 8 f1, "next"): in this round it runs on the host with SciPy (sparse LU, or
-CG / GMRES preconditioned with an incomplete LU of P) standing in for PETSc's
-MUMPS / hypre options (`pdeSolver.py:13-38,88-113`).
+linear solve (adjacent to the hot path):
+
+* `direct=False` (the reference's CG / GMRES + hypre options, `pdeSolver.py:24-35,99-110`):
+  device-resident Krylov solve on the assembled CSR (`knpemi_solve_emi`: PCG with the
+  constant null space projected out; `knpemi_solve_knp`: BiCGStab; smoothed-aggregation AMG for both), same `rtol` /
+  `atol` / `ksp_max_it = 1000` semantics on the true residual, non-zero initial guess;
+* `direct=True` (MUMPS LU, `pdeSolver.py:15-21`) and systems with Dirichlet conditions
+  (MMS): sparse LU on the host with SciPy as a stand-in.
 """
 from __future__ import annotations
 
@@ -168,7 +172,40 @@ class LinearProblem:
         self.solver.iterations = count[0]
         return x
 
+    def _solve_on_device(self):
+        """direct=False: assemble and solve on the GPU, then mirror the solution into the Functions."""
+        f, dp = self.a, self.dp
+        dp.set_params(f.physical_params, f.ion_list, f.dt)
+        _push_common(dp, f)
+        which = L.B_EMI if self.system == "emi" else L.B_KNP
+        for fn, (field, sub, idx) in zip(self.u, self._unknown_fields()):
+            dp.push(field, sub, idx, fn)                     # initial guess = current unknowns
+        if self.system == "emi":
+            if not f.splitting_scheme:
+                _push_currents(dp, f)
+            dp.assemble_emi(want_p=False, splitting_scheme=f.splitting_scheme)
+        else:
+            for tag in f.subdomain_list:
+                dp.push(L.F_PHI, dp.sub_index[tag], 0, f.phi[tag])
+            _push_currents(dp, f)
+            dp.assemble_knp(splitting_scheme=f.splitting_scheme)
+        its, relres = dp.solve(which, self.rtol, self.atol, maxit=1000)
+        self.solver.iterations, self.solver.residual_norm = its, relres
+        for fn, (field, sub, idx) in zip(self.u, self._unknown_fields()):
+            dp.pull(field, sub, idx, fn)
+            fn.x.scatter_forward()
+        return self.u
+
+    def _unknown_fields(self):
+        dp = self.dp
+        if self.system == "emi":
+            return [(L.F_PHI, dp.sub_index[tag], 0) for tag in self.a.subdomain_list]
+        n_solved = len(self.a.ion_list) - 1
+        return [(L.F_C, dp.sub_index[tag], k) for tag in self.a.subdomain_list for k in range(n_solved)]
+
     def solve(self):
+        if not self.direct and not self.bcs and self.a.mms is None:
+            return self._solve_on_device()
         A, b = self.assemble()
         sizes = [f.x._a.shape[0] for f in self.u]
         offsets = np.concatenate([[0], np.cumsum(sizes)])

@@ -23,12 +23,18 @@ from . import _lib as L
 
 class DeviceStepper:
     def __init__(self, forms_emi, forms_knp, c, c_prev, phi, phi_M_prev, solve_emi=None, solve_knp=None,
-                 assemble_knp_twice=False, overlap=True):
+                 assemble_knp_twice=False, overlap=True, device_solves=None):
         a = forms_emi[0]
         self.dp = a.dp
         self.a = a
         self.lib = self.dp.lib
         self.c, self.c_prev, self.phi, self.phi_M_prev = c, c_prev, phi, phi_M_prev
+        if device_solves is not None:
+            # (rtol_emi, rtol_knp): Krylov solves on the device between the assemblies (knpemi_solve_emi/knp)
+            rtol_emi, rtol_knp = device_solves
+            self.iterations = []
+            solve_emi = lambda dp: self.iterations.append(("emi",) + dp.solve(L.B_EMI, rtol_emi, 1e-40))
+            solve_knp = lambda dp: self.iterations.append(("knp",) + dp.solve(L.B_KNP, rtol_knp, 2e-40))
         self.solve_emi, self.solve_knp = solve_emi, solve_knp
         self.assemble_knp_twice = assemble_knp_twice
         self.overlap = overlap

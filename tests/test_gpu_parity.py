@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 from helpers import Setup, csr_rel_err, rel_err
+from knpemi import _lib as L
 
 pytestmark = pytest.mark.gpu
 
@@ -475,3 +476,84 @@ def test_empty_cell_subdomain(hip_lib):
     ode = s.subdomain_list[1]['mem_models'][0]['ode']
     assert ode.nodes == 0
     ode.step_lsoda(1e-4, None)
+
+
+@pytest.mark.parametrize("kind,r", [("2d", 1), ("tet", 0), ("hex", 0)])
+def test_device_krylov_solves_match_direct_solves(hip_lib, kind, r):
+    """`direct=False`: Jacobi-PCG (EMI, constant null space) and Jacobi-BiCGStab (KNP) on the device against
+    SciPy sparse LU of the same GPU-assembled systems."""
+    import scipy.sparse.linalg as spla
+    import driver
+    from knpemi.pdeSolver import create_solver_emi, create_solver_knp
+    s = Setup(kind, r)
+    s.perturb()
+    s.phi[1].x.array[:] += -0.0744
+    for t in s.subdomain_list:
+        for k in range(2):
+            s.c[t][k].x.array[:] = s.c_prev[t][k].x._a
+    emi_d = create_solver_emi(s.a_emi, s.L_emi, s.phi, s.entity_maps, s.subdomain_list, None, direct=True, p=s.p_emi)
+    A, b = emi_d.assemble()
+    x_ref = driver.solve_singular(A, b)
+    emi = create_solver_emi(s.a_emi, s.L_emi, s.phi, s.entity_maps, s.subdomain_list, None, direct=False, p=s.p_emi,
+                            rtol=1e-12, atol=1e-40)
+    emi.solve()
+    x = np.concatenate([s.phi[0].x._a, s.phi[1].x._a])
+    assert rel_err(x - x.mean(), x_ref - x_ref.mean()) < 1e-7
+    assert 0 < emi.solver.getIterationNumber() <= 1000
+    knp_d = create_solver_knp(s.a_knp, s.L_knp, s.c, s.entity_maps, s.subdomain_list, None, direct=True, p=s.p_knp)
+    Ak, bk = knp_d.assemble()                      # uses the phi just solved for
+    xk_ref = spla.splu(Ak.tocsc()).solve(bk)
+    knp = create_solver_knp(s.a_knp, s.L_knp, s.c, s.entity_maps, s.subdomain_list, None, direct=False, p=s.p_knp,
+                            rtol=1e-12, atol=1e-40)
+    knp.solve()
+    xk = np.concatenate([f.x._a for t in s.subdomain_list for f in s.c[t]])
+    assert rel_err(xk, xk_ref) < 1e-9
+    assert 0 < knp.solver.getIterationNumber() <= 1000
+    info = emi.dp.solver_info(L.B_EMI)
+    assert info["builds"] == 1 and info["levels"] >= 2 and info["op_complexity"] < 4
+    # Jacobi preconditioning (selectable) reaches the same solutions with more iterations
+    its_amg = emi.solver.getIterationNumber()
+    emi.dp.solver_setup(L.B_EMI, L.PC_JACOBI)
+    emi.dp.solver_setup(L.B_KNP, L.PC_JACOBI)
+    for f in (s.phi[0], s.phi[1]):
+        f.x.array[:] = 0.0
+    emi.rtol = 1e-10
+    emi.dp.push(L.F_PHI, 0, 0, s.phi[0])
+    its, relres = (emi.dp.push(L.F_PHI, 1, 0, s.phi[1]), emi.dp.solve(L.B_EMI, 1e-10, 1e-40, 20000))[1]
+    assert its > its_amg and relres <= 1e-10
+    x = emi.dp.get_solution(L.B_EMI, len(x_ref))
+    assert rel_err(x - x.mean(), x_ref - x_ref.mean()) < 1e-6
+    with pytest.raises(L.KnpemiError):          # ksp_error_if_not_converged
+        emi.dp.push(L.F_PHI, 0, 0, s.phi[0])
+        emi.dp.solve(L.B_EMI, 1e-14, 1e-40, 3)
+
+
+def test_device_resident_time_loop_matches_oracle(hip_lib):
+    """Ten steps of the 2D problem entirely on the device (DeviceStepper with device Krylov solves, no host
+    transfers inside the loop) against the oracle loop with direct solves."""
+    import driver
+    from knpemi.stepper import DeviceStepper
+    s = Setup("2d", 1, g_syn=10.0)
+    o, P, params, ions = s.oracle()
+    c_all, _, _, _ = s.oracle_fields()
+    ode = s.mem_models[0]['ode']
+    mask = np.array([x[0] < 20e-6 for x in ode.dof_locations])
+    run = driver.OracleRun(P, params, ions, "hh_si", c_all, ode.states.copy(), ode.parameters.copy(),
+                           ode.dof_locations, mask, {o.MODELS["hh_si"]["pidx"]["stim_amplitude"]: 10.0},
+                           {'z': -1, 0: 0.0, 1: 0.0})
+    for t in s.subdomain_list:      # initial guess of the first KNP solve
+        for k in range(2):
+            s.c[t][k].x.array[:] = s.c_prev[t][k].x._a
+    st = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp), s.c, s.c_prev, s.phi, s.phi_M_prev,
+                       device_solves=(1e-12, 1e-13))
+    st.add_membrane_model(ode, s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
+    for k in range(10):
+        st.step()
+        run.step()
+    st.download()
+    assert rel_err(s.phi_M_prev[1].x._a, run.phiM[1]) < 1e-6
+    for t in (0, 1):
+        for k in range(2):
+            assert rel_err(s.c_prev[t][k].x._a, run.c_all[t][k]) < 1e-8
+    assert rel_err(ode.states, run.states) < 1e-6
+    assert all(it[1] <= 1000 for it in st.iterations)
