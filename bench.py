@@ -112,6 +112,35 @@ def cpu_baseline(s, n_steps):
     return (t_asm + t_ode) / n_steps, t_asm / n_steps, t_ode / n_steps, ode.nodes
 
 
+def with_solves(s, stepper, n_steps, torch):
+    """Whole time steps of run_3D.py:345-368 on the device, Krylov solves included: the
+    same stepper with `knpemi_solve_emi` (CG + AMG, rtol 1e-5) and `knpemi_solve_knp` (BiCGStab + AMG, rtol 1e-7)
+    between the assemblies.  Not part of `value`."""
+    from knpemi import _lib as L
+    dp = stepper.dp
+    its = {"emi": [], "knp": []}
+    stepper.solve_emi = lambda d: its["emi"].append(d.solve(L.B_EMI, 1e-5, 1e-40, 1000)[0])
+    stepper.solve_knp = lambda d: its["knp"].append(d.solve(L.B_KNP, 1e-7, 2e-40, 1000)[0])
+    for _ in range(3):
+        stepper.step()           # builds the AMG hierarchies
+    torch.cuda.synchronize()
+    its = {"emi": [], "knp": []}
+    stepper.solve_emi = lambda d: its["emi"].append(d.solve(L.B_EMI, 1e-5, 1e-40, 1000)[0])
+    stepper.solve_knp = lambda d: its["knp"].append(d.solve(L.B_KNP, 1e-7, 2e-40, 1000)[0])
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        stepper.step()
+    dp.sync()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n_steps * 1e3
+    stepper.solve_emi = stepper.solve_knp = None
+    info = {k: dp.solver_info(w) for k, w in (("emi", L.B_EMI), ("knp", L.B_KNP))}
+    return {"ms_per_step": ms, "steps": n_steps,
+            "emi": {"solver": "CG + SA-AMG V(1,1), rtol 1e-5", "iterations_avg": sum(its["emi"]) / n_steps, **info["emi"]},
+            "knp": {"solver": "BiCGStab + SA-AMG V(1,1), rtol 1e-7", "iterations_avg": sum(its["knp"]) / n_steps,
+                    **info["knp"]}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,6 +148,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-steps", type=int, default=100, help="CPU-port steps timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--solve-steps", type=int, default=20,
+                    help="extra untimed-for-`value` pass: whole time steps including the device Krylov solves "
+                         "(rtol 1e-5 / 1e-7 as run_3D.py:296-305), reported as `with_solves` (0 = skip; N = 1 only)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the EMI matrix assembly after the ODE sweep instead of beside it (aux stream)")
     ap.add_argument("--knp-twice", action="store_true",
@@ -265,6 +297,8 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_alg[dominant], "avg_launch_us": dom_us},
             "kernels_us": per_kernel,
         }
+        if args.solve_steps > 0 and world == 1:
+            out["with_solves"] = with_solves(s, stepper, args.solve_steps, torch)
         if args.cpu_steps > 0 and world == 1:
             with contextlib.redirect_stdout(quiet):
                 t_step, t_asm, t_ode, nrows = cpu_baseline(s, args.cpu_steps)

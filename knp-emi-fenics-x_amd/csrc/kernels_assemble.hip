@@ -1,12 +1,12 @@
 // gfx950 assembly kernels of the knpemi hot path.
 //
-// Design: "owner-computes rows".  One thread owns one matrix row
-// (= one sub-mesh vertex); it walks the cells incident to its vertex (sliced-ELL list, coalesced
-// index reads), recomputes the closed-form P1 element row (or the Gauss-quadrature Q1 row) from
-// 64-byte vertex records gathered through L2, and accumulates into the block's slice of the CSR
-// value array held in LDS.  A block of 256 consecutive rows owns a contiguous CSR range, so the
-// final write to HBM is a plain coalesced stream: no atomics, bit-reproducible results, and the
-// matrix, the preconditioner and the RHS come out of one pass over the mesh.
+// Design: "owner-computes rows".  A block of 256 / LPR consecutive matrix rows
+// (= sub-mesh vertices) owns a contiguous CSR range.  It stages the 48-byte records of the distinct
+// vertices its rows touch in LDS once, then LPR lanes per row walk the cells incident to the row's
+// vertex (sliced-ELL list, coalesced index reads), recompute the closed-form P1 element row (or the
+// Gauss-quadrature Q1 row) and accumulate into the block's slice of the CSR value array held in LDS.
+// The final write to HBM is a plain coalesced stream: no global atomics, bit-reproducible results,
+// and the matrix, the preconditioner and the RHS come out of one pass over the mesh.
 //
 // Forms restated (paths relative to the reference repository):
 //   EMI  a, p, L : src/knpemi/emiWeakForm.py:138-241
@@ -37,50 +37,6 @@ __device__ __forceinline__ Rec load_rec(const double* __restrict__ VR, int v) {
 
 // Gradient dot products d[j] = grad(lambda_li) . grad(lambda_j) and the cell measure of a P1
 // simplex (closed form; FFCx reaches the same numbers with a 1-point rule).
-template <int GDIM>
-__device__ __forceinline__ double simplex_row(const Rec (&r)[GDIM + 1], int li, double (&d)[GDIM + 1]);
-
-template <>
-__device__ __forceinline__ double simplex_row<2>(const Rec (&r)[3], int li, double (&d)[3]) {
-  const double e1x = r[1].x - r[0].x, e1y = r[1].y - r[0].y;
-  const double e2x = r[2].x - r[0].x, e2y = r[2].y - r[0].y;
-  const double det = e1x * e2y - e1y * e2x, inv = 1.0 / det;
-  const double g1x = e2y * inv, g1y = -e2x * inv;
-  const double g2x = -e1y * inv, g2y = e1x * inv;
-  const double g0x = -(g1x + g2x), g0y = -(g1y + g2y);
-  const double lx = li == 0 ? g0x : (li == 1 ? g1x : g2x);
-  const double ly = li == 0 ? g0y : (li == 1 ? g1y : g2y);
-  d[0] = lx * g0x + ly * g0y;
-  d[1] = lx * g1x + ly * g1y;
-  d[2] = lx * g2x + ly * g2y;
-  return 0.5 * fabs(det);
-}
-
-template <>
-__device__ __forceinline__ double simplex_row<3>(const Rec (&r)[4], int li, double (&d)[4]) {
-  const double ax = r[1].x - r[0].x, ay = r[1].y - r[0].y, az = r[1].z - r[0].z;
-  const double bx = r[2].x - r[0].x, by = r[2].y - r[0].y, bz = r[2].z - r[0].z;
-  const double cx = r[3].x - r[0].x, cy = r[3].y - r[0].y, cz = r[3].z - r[0].z;
-  // cofactors: grad l1 = (b x c)/det, grad l2 = (c x a)/det, grad l3 = (a x b)/det
-  double g1x = by * cz - bz * cy, g1y = bz * cx - bx * cz, g1z = bx * cy - by * cx;
-  double g2x = cy * az - cz * ay, g2y = cz * ax - cx * az, g2z = cx * ay - cy * ax;
-  double g3x = ay * bz - az * by, g3y = az * bx - ax * bz, g3z = ax * by - ay * bx;
-  const double det = ax * g1x + ay * g1y + az * g1z, inv = 1.0 / det;
-  g1x *= inv; g1y *= inv; g1z *= inv;
-  g2x *= inv; g2y *= inv; g2z *= inv;
-  g3x *= inv; g3y *= inv; g3z *= inv;
-  const double g0x = -(g1x + g2x + g3x), g0y = -(g1y + g2y + g3y), g0z = -(g1z + g2z + g3z);
-  const double lx = li == 0 ? g0x : (li == 1 ? g1x : (li == 2 ? g2x : g3x));
-  const double ly = li == 0 ? g0y : (li == 1 ? g1y : (li == 2 ? g2y : g3y));
-  const double lz = li == 0 ? g0z : (li == 1 ? g1z : (li == 2 ? g2z : g3z));
-  d[0] = lx * g0x + ly * g0y + lz * g0z;
-  d[1] = lx * g1x + ly * g1y + lz * g1z;
-  d[2] = lx * g2x + ly * g2y + lz * g2z;
-  d[3] = lx * g3x + ly * g3y + lz * g3z;
-  return fabs(det) * (1.0 / 6.0);
-}
-
-// measure of a membrane facet from its own-side vertex records
 template <int NF>
 __device__ __forceinline__ double facet_measure(const Rec (&p)[NF]) {
   if constexpr (NF == 2) {
@@ -131,393 +87,6 @@ __device__ __forceinline__ void facet_mass_row(const Rec (&p)[NF], int a, double
     for (int b = 0; b < NF; ++b) M[b] = (b == a) ? 2.0 * m : m;
   }
 }
-
-// ---------------------------------------------------------------------------------------------
-// Q1 hexahedron: 2x2x2 Gauss tables staged in LDS (basis values and reference gradients)
-// ---------------------------------------------------------------------------------------------
-struct HexTab {
-  double N[8][8];      // [q][v]
-  double dN[8][8][3];  // [q][v][t]
-};
-
-__device__ __forceinline__ void stage_hex_tables(HexTab* T) {
-  const double g0 = 0.5 - 0.28867513459481287, g1 = 0.5 + 0.28867513459481287;
-  for (int i = threadIdx.x; i < 64; i += blockDim.x) {
-    const int q = i >> 3, v = i & 7;
-    double f[3], df[3];
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-      const double x = ((q >> ax) & 1) ? g1 : g0;
-      const bool hi = (v >> ax) & 1;
-      f[ax] = hi ? x : 1.0 - x;
-      df[ax] = hi ? 1.0 : -1.0;
-    }
-    T->N[q][v] = f[0] * f[1] * f[2];
-    T->dN[q][v][0] = df[0] * f[1] * f[2];
-    T->dN[q][v][1] = f[0] * df[1] * f[2];
-    T->dN[q][v][2] = f[0] * f[1] * df[2];
-  }
-}
-
-// Physical gradients of the 8 basis functions at Gauss point q; returns w*|det J| (w = 1/8).
-__device__ __forceinline__ double hex_point(const HexTab* T, const Rec (&r)[8], int q, double (&G)[8][3]) {
-  double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-#pragma unroll
-  for (int v = 0; v < 8; ++v)
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const double dn = T->dN[q][v][t];
-      J[0][t] += r[v].x * dn; J[1][t] += r[v].y * dn; J[2][t] += r[v].z * dn;
-    }
-  const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-  const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
-  const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-  const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02, inv = 1.0 / det;
-  // Jinv[t][g]
-  const double i00 = c00 * inv, i01 = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * inv,
-               i02 = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * inv;
-  const double i10 = c01 * inv, i11 = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * inv,
-               i12 = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * inv;
-  const double i20 = c02 * inv, i21 = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * inv,
-               i22 = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * inv;
-#pragma unroll
-  for (int v = 0; v < 8; ++v) {
-    const double a = T->dN[q][v][0], b = T->dN[q][v][1], c = T->dN[q][v][2];
-    G[v][0] = a * i00 + b * i10 + c * i20;
-    G[v][1] = a * i01 + b * i11 + c * i21;
-    G[v][2] = a * i02 + b * i12 + c * i22;
-  }
-  return 0.125 * fabs(det);
-}
-
-template <int NV>
-__device__ __forceinline__ void load_cell(const KnDev& D, int cell, Rec (&r)[NV]) {
-  const int* cv = D.cells + (size_t)cell * NV;
-  if constexpr (NV == 4 || NV == 8) {
-    const int4 a = *reinterpret_cast<const int4*>(cv);
-    r[0] = load_rec(D.VR, a.x); r[1] = load_rec(D.VR, a.y);
-    r[2] = load_rec(D.VR, a.z); r[3] = load_rec(D.VR, a.w);
-    if constexpr (NV == 8) {
-      const int4 b = *reinterpret_cast<const int4*>(cv + 4);
-      r[4] = load_rec(D.VR, b.x); r[5] = load_rec(D.VR, b.y);
-      r[6] = load_rec(D.VR, b.z); r[7] = load_rec(D.VR, b.w);
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) r[j] = load_rec(D.VR, cv[j]);
-  }
-}
-
-template <int NV>
-__device__ __forceinline__ int slot_of(const uint32_t* sl, int j) {
-  return (sl[j >> 2] >> (8 * (j & 3))) & 255;
-}
-
-// ---------------------------------------------------------------------------------------------
-// EMI rows: A_emi, P_emi (= A + ICS mass) and b_emi in one pass, membrane coupling included.
-// ---------------------------------------------------------------------------------------------
-// LPR = lanes per row: the pairs of one row are dealt round-robin to LPR adjacent lanes, each lane
-// accumulating into its own LDS copy of the block's CSR segment; the copies are summed in a fixed
-// order in the epilogue (bit-reproducible, no atomics).  LPR > 1 shortens the per-thread dependent
-// gather chain and multiplies the number of waves on small meshes.
-template <int GDIM, int NV, int LPR>
-__global__ __launch_bounds__(KN_BLOCK) void emi_rows_kernel(KnDev D, const KnConsts* __restrict__ Cp, int lds_n,
-                                                            int want_p, int splitting) {
-  constexpr int NF = (NV == 8) ? 4 : GDIM;
-  constexpr int SW = (NV == 8) ? 2 : 1;
-  const KnConsts& C = *Cp;
-  extern __shared__ double lds[];
-  double* segA = lds;
-  double* segP = lds + (size_t)LPR * lds_n;
-  HexTab* T = reinterpret_cast<HexTab*>(lds + 2 * (size_t)LPR * lds_n);
-  const int tid = threadIdx.x;
-  const int b = logical_block(blockIdx.x, D.nblocks);
-  const int row0 = D.blk_row0[b], nrows = D.blk_nrows[b], s = D.blk_sub[b];
-  const int seg0 = D.rowptr[row0], seglen = D.rowptr[row0 + nrows] - seg0;
-  for (int c = 0; c < LPR; ++c)
-    for (int i = tid; i < seglen; i += KN_BLOCK) { segA[c * lds_n + i] = 0.0; segP[c * lds_n + i] = 0.0; }
-  if constexpr (NV == 8) stage_hex_tables(T);
-  __syncthreads();
-
-  const KnSubConst& sc = C.sc[s];
-  const bool cell_side = s > 0;
-  const int rloc = tid / LPR, sub = tid % LPR;
-  const bool valid = rloc < nrows;
-  const int g = row0 + (valid ? rloc : 0);
-  double bacc = 0.0, gam = 0.0;   // volume part / membrane Robin part of b_emi
-  if (valid) {
-    double* segA_own = segA;   // membrane terms go to copy 0
-    double* segP_own = segP;
-    (void)segA_own; (void)segP_own;
-    double* segA = lds + (size_t)sub * lds_n;
-    double* segP = lds + (size_t)(LPR + sub) * lds_n;
-    const int rowbase = D.rowptr[g] - seg0;
-    const int lap = rowbase + D.lapoff[g];
-    const int w = tid >> 6, lane = tid & 63;
-    const int64_t base = D.sl_ptr[(size_t)b * 4 + w];
-    const int np = (int)((D.sl_ptr[(size_t)b * 4 + w + 1] - base) >> 6);
-    Rec r[NV];
-    for (int p = 0; p < np; ++p) {
-      const int64_t ent = base + (int64_t)p * KN_SLICE + lane;
-      uint32_t sl[SW];
-      int li = 0;
-      {
-        const int pc = D.pair_cell[ent];
-        if (pc < 0) continue;
-#pragma unroll
-        for (int k = 0; k < SW; ++k) sl[k] = D.pair_slots[ent * SW + k];
-        li = pc & 7;
-        load_cell<NV>(D, pc >> 3, r);
-      }
-      if constexpr (NV != 8) {
-        double d[NV];
-        const double vol = simplex_row<GDIM>(r, 0, d);
-        double cb0 = 0, cb1 = 0, cb2 = 0, sd = 0;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-          cb0 += r[j].c0; cb1 += r[j].c1; cb2 += r[j].c2;
-          sd += (sc.sig[0] * r[j].c0 + sc.sig[1] * r[j].c1 + sc.sig[2] * r[j].c2) * d[j];
-        }
-        const double kbar = (sc.kap[0] * cb0 + sc.kap[1] * cb1 + sc.kap[2] * cb2) * (1.0 / NV);
-        const double m = vol * (1.0 / ((GDIM + 1) * (GDIM + 2)));
-        bacc -= vol * sd;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-          const double a = vol * kbar * d[j];
-          const int idx = lap + slot_of<NV>(sl, j);
-          segA[idx] += a;
-          segP[idx] += cell_side ? a + (j == li ? 2.0 * m : m) : a;
-        }
-      } else {
-        double kv[8], sv[8], ra[8], rm[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          kv[j] = sc.kap[0] * r[j].c0 + sc.kap[1] * r[j].c1 + sc.kap[2] * r[j].c2;
-          sv[j] = sc.sig[0] * r[j].c0 + sc.sig[1] * r[j].c1 + sc.sig[2] * r[j].c2;
-          ra[j] = 0.0; rm[j] = 0.0;
-        }
-        for (int q = 0; q < 8; ++q) {
-          double G[8][3];
-          const double wd = hex_point(T, r, q, G);
-          double lx = 0, ly = 0, lz = 0, kq = 0;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const bool me = j == li;
-            lx = me ? G[j][0] : lx; ly = me ? G[j][1] : ly; lz = me ? G[j][2] : lz;
-            kq += T->N[q][j] * kv[j];
-          }
-          const double Nl = T->N[q][li];
-          double sd = 0;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const double dj = lx * G[j][0] + ly * G[j][1] + lz * G[j][2];
-            ra[j] += wd * kq * dj;
-            rm[j] += wd * Nl * T->N[q][j];
-            sd += sv[j] * dj;
-          }
-          bacc -= wd * sd;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int idx = lap + slot_of<NV>(sl, j);
-          segA[idx] += ra[j];
-          segP[idx] += cell_side ? ra[j] + rm[j] : ra[j];
-        }
-      }
-    }
-    // membrane coupling C_phi (u_i - u_e)(v_i - v_e) and Robin RHS (emiWeakForm.py:160-165,228-239)
-    const int m = sub == 0 ? D.gam_idx[g] : -1;
-    if (m >= 0) {
-      const int* fown = cell_side ? D.fi : D.fe;
-      for (int e = D.mptr[m]; e < D.mptr[m + 1]; ++e) {
-        const int ent = D.mentry[e];
-        const int fg = ent >> 3, a = ent & 7;
-        const int ms = D.fmodel[fg];
-        if (ms < 0) continue;
-        const uint64_t sl = D.mslots[e];
-        Rec p[NF];
-#pragma unroll
-        for (int bb = 0; bb < NF; ++bb) p[bb] = load_rec(D.VR, fown[(size_t)fg * NF + bb]);
-        double Mr[NF];
-        facet_mass_row<NF>(p, a, Mr);
-        double gs = 0.0;
-#pragma unroll
-        for (int bb = 0; bb < NF; ++bb) {
-          const int q = D.fq[(size_t)fg * NF + bb];
-          double gq = D.phiM[q];
-          if (!(splitting & 1)) {
-            double it = 0.0;
-            for (int k = 0; k < KN_MAXK; ++k) it += D.Ich[((size_t)ms * KN_MAXK + k) * D.NQtot + q];
-            gq -= it / C.C_phi;
-          }
-          gs += Mr[bb] * gq;
-          const double val = C.C_phi * Mr[bb];
-          const int io = rowbase + (int)((sl >> (8 * bb)) & 255);
-          const int it2 = rowbase + (int)((sl >> (8 * (4 + bb))) & 255);
-          segA[io] += val; segP[io] += val;
-          segA[it2] -= val; segP[it2] -= val;
-        }
-        if (!(splitting & 2)) gam += (cell_side ? 1.0 : -1.0) * C.C_phi * gs;
-      }
-    }
-  }
-#pragma unroll
-  for (int m = 1; m < LPR; m <<= 1) bacc += __shfl_xor(bacc, m);   // fixed-shape tree over the row's lanes
-  if (valid && sub == 0) D.b_emi[g] = bacc + gam;
-  __syncthreads();
-  for (int i = tid; i < seglen; i += KN_BLOCK) {
-    double a = segA[i], p = segP[i];
-#pragma unroll
-    for (int c = 1; c < LPR; ++c) { a += segA[c * lds_n + i]; p += segP[c * lds_n + i]; }
-    D.A_emi[seg0 + i] = a;
-    if (want_p) D.P_emi[seg0 + i] = p;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// KNP rows: the K-1 diagonal blocks (mass/dt + diffusion + drift) and the volume part of b_knp.
-// ---------------------------------------------------------------------------------------------
-template <int GDIM, int NV, int LPR>
-__global__ __launch_bounds__(KN_BLOCK) void knp_rows_kernel(KnDev D, const KnConsts* __restrict__ Cp, int lds_n) {
-  const KnConsts& C = *Cp;
-  constexpr int NF = (NV == 8) ? 4 : GDIM;
-  constexpr int SW = (NV == 8) ? 2 : 1;
-  extern __shared__ double lds[];
-  double* seg0k = lds;
-  double* seg1k = lds + (size_t)LPR * lds_n;
-  HexTab* T = reinterpret_cast<HexTab*>(lds + 2 * (size_t)LPR * lds_n);
-  const int tid = threadIdx.x;
-  const int b = logical_block(blockIdx.x, D.nblocks);
-  const int row0 = D.blk_row0[b], nrows = D.blk_nrows[b], s = D.blk_sub[b];
-  const int seg0 = D.rowptrL[row0], seglen = D.rowptrL[row0 + nrows] - seg0;
-  for (int c = 0; c < LPR; ++c)
-    for (int i = tid; i < seglen; i += KN_BLOCK) { seg0k[c * lds_n + i] = 0.0; seg1k[c * lds_n + i] = 0.0; }
-  if constexpr (NV == 8) stage_hex_tables(T);
-  __syncthreads();
-
-  const KnSubConst& sc = C.sc[s];
-  const int v0 = C.voff[s], nvs = C.voff[s + 1] - v0;
-  const double* fs0 = (D.fsrc && s == 0) ? D.fsrc : nullptr;
-  const int rloc = tid / LPR, sub = tid % LPR;
-  const bool valid = rloc < nrows;
-  const int g = row0 + (valid ? rloc : 0);
-  double b0 = 0.0, b1 = 0.0;
-  if (valid) {
-    double* seg0k = lds + (size_t)sub * lds_n;
-    double* seg1k = lds + (size_t)(LPR + sub) * lds_n;
-    const int lap = D.rowptrL[g] - seg0;
-    const int w = tid >> 6, lane = tid & 63;
-    const int64_t base = D.sl_ptr[(size_t)b * 4 + w];
-    const int np = (int)((D.sl_ptr[(size_t)b * 4 + w + 1] - base) >> 6);
-    Rec r[NV];
-    for (int p = 0; p < np; ++p) {
-      const int64_t ent = base + (int64_t)p * KN_SLICE + lane;
-      uint32_t sl[SW];
-      int li = 0;
-      int cv[NV];
-      {
-        const int pc = D.pair_cell[ent];
-        if (pc < 0) continue;
-#pragma unroll
-        for (int k = 0; k < SW; ++k) sl[k] = D.pair_slots[ent * SW + k];
-        li = pc & 7;
-        load_cell<NV>(D, pc >> 3, r);
-#pragma unroll
-        for (int j = 0; j < NV; ++j) cv[j] = D.cells[(size_t)(pc >> 3) * NV + j];
-      }
-      double f0[NV], f1[NV];  // (1/dt) c_prev + f_source at the cell vertices
-#pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        f0[j] = r[j].c0 * C.inv_dt;
-        f1[j] = r[j].c1 * C.inv_dt;
-        if (fs0) { f0[j] += fs0[cv[j]]; f1[j] += fs0[nvs + cv[j]]; }
-      }
-      if constexpr (NV != 8) {
-        double d[NV];
-        const double vol = simplex_row<GDIM>(r, 0, d);
-        double gp = 0;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) gp += r[j].phi * d[j];
-        const double m = vol * (1.0 / ((GDIM + 1) * (GDIM + 2)));
-        const double drift = gp * vol * (1.0 / (GDIM + 1));
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-          const double mm = (j == li) ? 2.0 * m : m;
-          const int idx = lap + slot_of<NV>(sl, j);
-          seg0k[idx] += mm * C.inv_dt + sc.D[0] * vol * d[j] + sc.zpsiD[0] * drift;
-          seg1k[idx] += mm * C.inv_dt + sc.D[1] * vol * d[j] + sc.zpsiD[1] * drift;
-          b0 += mm * f0[j];
-          b1 += mm * f1[j];
-        }
-      } else {
-        double r0[8], r1[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { r0[j] = 0.0; r1[j] = 0.0; }
-        for (int q = 0; q < 8; ++q) {
-          double G[8][3];
-          const double wd = hex_point(T, r, q, G);
-          double lx = 0, ly = 0, lz = 0, px = 0, py = 0, pz = 0, fq0 = 0, fq1 = 0;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const bool me = j == li;
-            lx = me ? G[j][0] : lx; ly = me ? G[j][1] : ly; lz = me ? G[j][2] : lz;
-            px += r[j].phi * G[j][0]; py += r[j].phi * G[j][1]; pz += r[j].phi * G[j][2];
-            fq0 += T->N[q][j] * f0[j]; fq1 += T->N[q][j] * f1[j];
-          }
-          const double Nl = T->N[q][li];
-          const double gp = px * lx + py * ly + pz * lz;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const double dj = lx * G[j][0] + ly * G[j][1] + lz * G[j][2];
-            const double Nj = T->N[q][j];
-            r0[j] += wd * (Nl * Nj * C.inv_dt + sc.D[0] * dj + sc.zpsiD[0] * Nj * gp);
-            r1[j] += wd * (Nl * Nj * C.inv_dt + sc.D[1] * dj + sc.zpsiD[1] * Nj * gp);
-          }
-          b0 += wd * Nl * fq0;
-          b1 += wd * Nl * fq1;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int idx = lap + slot_of<NV>(sl, j);
-          seg0k[idx] += r0[j];
-          seg1k[idx] += r1[j];
-        }
-      }
-    }
-    // membrane Robin/coupling contributions, precomputed per (facet, side) by knp_membrane_kernel
-    const int m = sub == 0 ? D.gam_idx[g] : -1;
-    if (m >= 0) {
-      const int side = s > 0 ? 1 : 0;
-      for (int e = D.mptr[m]; e < D.mptr[m + 1]; ++e) {
-        const int ent = D.mentry[e];
-        const int fg = ent >> 3, a = ent & 7;
-        if (D.fmodel[fg] < 0) continue;
-        const double* cg = D.gam_contrib + ((size_t)(fg * 2 + side) * NF + a) * 2;
-        b0 += cg[0];
-        b1 += cg[1];
-      }
-    }
-  }
-#pragma unroll
-  for (int m = 1; m < LPR; m <<= 1) { b0 += __shfl_xor(b0, m); b1 += __shfl_xor(b1, m); }
-  if (valid && sub == 0) {
-    const size_t bb = (size_t)(KN_MAXK - 1) * v0 + (size_t)(g - v0);
-    D.b_knp[bb] = b0;
-    D.b_knp[bb + nvs] = b1;
-  }
-  __syncthreads();
-  const int64_t subnnz0 = D.rowptrL[v0], subnnz = D.rowptrL[v0 + nvs] - subnnz0;
-  double* out0 = D.A_knp + (size_t)(KN_MAXK - 1) * subnnz0 + (seg0 - subnnz0);
-  double* out1 = out0 + subnnz;
-  for (int i = tid; i < seglen; i += KN_BLOCK) {
-    double a0 = seg0k[i], a1 = seg1k[i];
-#pragma unroll
-    for (int c = 1; c < LPR; ++c) { a0 += seg0k[c * lds_n + i]; a1 += seg1k[c * lds_n + i]; }
-    out0[i] = a0;
-    out1[i] = a1;
-  }
-}
-
 
 // =============================================================================================
 // Simplex row kernels, version 2: neighbour records staged in LDS.
@@ -871,6 +440,423 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
   for (int i = tid; i < nnzLb; i += KN_BLOCK) { out0[i] = acc0[i]; out1[i] = acc1[i]; }
 }
 
+// =============================================================================================
+// Q1 hexahedra, version 2: the same row-block scheme as the simplex kernels (distinct vertex records
+// staged in LDS, LDS fp64 adds, one launch descriptor per block) with the 2x2x2 Gauss tables folded
+// into the instruction stream: every loop over quadrature points and vertices is unrolled with constexpr
+// weights, so no table is read at run time.  Per quadrature point the row of vertex l needs
+//   d_j = grad N_l . grad N_j = dN_j . w,   w = J^-1 (J^-T dN_l)
+// i.e. the Jacobian (from the 12 edge vectors), its inverse and one 3-vector; the physical gradients
+// of the other seven basis functions are never formed.  Nodal fields enter through their reference
+// gradients (edge differences), the mass row M_j = sum_q w_q N_l N_j is shared by the time-derivative,
+// drift and right-hand-side terms.
+// =============================================================================================
+namespace hexq {
+constexpr double G0 = 0.5 - 0.28867513459481287, G1 = 0.5 + 0.28867513459481287;
+__host__ __device__ constexpr double f(int q, int v, int ax) {
+  const double x = ((q >> ax) & 1) ? G1 : G0;
+  return ((v >> ax) & 1) ? x : 1.0 - x;
+}
+__host__ __device__ constexpr double N(int q, int v) { return f(q, v, 0) * f(q, v, 1) * f(q, v, 2); }
+// |dN_v/dxi_t| at point q (independent of bit t of v); the sign is + when bit t of v is set
+__host__ __device__ constexpr double E(int q, int v, int t) { return f(q, v, (t + 1) % 3) * f(q, v, (t + 2) % 3); }
+// k-th vertex (k = 0..3) whose bit t is clear, and the inverse map
+__host__ __device__ constexpr int lo(int t, int k) { return ((k >> t) << (t + 1)) | (k & ((1 << t) - 1)); }
+__host__ __device__ constexpr int kof(int t, int v) { return ((v >> (t + 1)) << t) | (v & ((1 << t) - 1)); }
+struct Point { double E[3][4]; double N[8]; double x[3]; };   // weights of one Gauss point
+struct Table { Point p[8]; };
+constexpr Table make_table() {
+  Table T{};
+  for (int q = 0; q < 8; ++q) {
+    for (int t = 0; t < 3; ++t) {
+      for (int k = 0; k < 4; ++k) T.p[q].E[t][k] = E(q, lo(t, k), t);
+      T.p[q].x[t] = ((q >> t) & 1) ? G1 : G0;
+    }
+    for (int v = 0; v < 8; ++v) T.p[q].N[v] = N(q, v);
+  }
+  return T;
+}
+}  // namespace hexq
+
+// read with a wave-uniform index: the weights arrive in scalar registers
+__constant__ hexq::Table c_hex = hexq::make_table();
+
+struct HexGeo {   // geometry of the row vertex l at one Gauss point
+  double w[3];    // J^-1 J^-T dN_l
+  double wd;      // weight * |det J|
+  double Nl;      // N_l
+};
+
+// edge vectors of the cell: e[t][k] = x[v | 1 << t] - x[v], v = lo(t, k)
+struct HexEdges { double x[3][4], y[3][4], z[3][4]; };
+
+__device__ __forceinline__ HexEdges hex_edges(const Rec6 (&r)[8]) {
+  HexEdges e;
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int v = hexq::lo(t, k), u = v | (1 << t);
+      e.x[t][k] = r[u].x - r[v].x; e.y[t][k] = r[u].y - r[v].y; e.z[t][k] = r[u].z - r[v].z;
+    }
+  return e;
+}
+
+struct HexInv { double i[3][3]; double wd; };   // J^-1[t][g] and weight * |det J|
+
+// Jacobian (from the edge vectors) and its inverse at the Gauss point with weights P
+__device__ __forceinline__ HexInv hex_inverse(const HexEdges& e, const hexq::Point& P) {
+  double J[3][3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    double jx = 0, jy = 0, jz = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { jx += P.E[t][k] * e.x[t][k]; jy += P.E[t][k] * e.y[t][k]; jz += P.E[t][k] * e.z[t][k]; }
+    J[0][t] = jx; J[1][t] = jy; J[2][t] = jz;
+  }
+  const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+  const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+  const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+  const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02, inv = 1.0 / det;
+  HexInv I;
+  I.i[0][0] = c00 * inv; I.i[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * inv;
+  I.i[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * inv;
+  I.i[1][0] = c01 * inv; I.i[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * inv;
+  I.i[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * inv;
+  I.i[2][0] = c02 * inv; I.i[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * inv;
+  I.i[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * inv;
+  I.wd = 0.125 * fabs(det);
+  return I;
+}
+
+// Parallelepipeds (every box mesh of the reference, make_mesh_3D.py:101) have a constant Jacobian: the four
+// edge vectors of each axis coincide.  The row kernels then invert it once per cell instead of per point.
+__device__ __forceinline__ bool hex_is_affine(const HexEdges& e) {
+  double dev = 0.0, len = 0.0;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    len += fabs(e.x[t][0]) + fabs(e.y[t][0]) + fabs(e.z[t][0]);
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      dev += fabs(e.x[t][k] - e.x[t][0]) + fabs(e.y[t][k] - e.y[t][0]) + fabs(e.z[t][k] - e.z[t][0]);
+  }
+  return dev <= 1e-13 * len;
+}
+
+__device__ __forceinline__ HexGeo hex_geo(const HexInv& I, const hexq::Point& P, int l0, int l1, int l2) {
+  const double f0 = l0 ? P.x[0] : 1.0 - P.x[0], f1 = l1 ? P.x[1] : 1.0 - P.x[1], f2 = l2 ? P.x[2] : 1.0 - P.x[2];
+  const double a = (l0 ? f1 : -f1) * f2, b = (l1 ? f0 : -f0) * f2, c = (l2 ? f0 : -f0) * f1;   // dN_l
+  const double g0 = a * I.i[0][0] + b * I.i[1][0] + c * I.i[2][0];
+  const double g1 = a * I.i[0][1] + b * I.i[1][1] + c * I.i[2][1];
+  const double g2 = a * I.i[0][2] + b * I.i[1][2] + c * I.i[2][2];
+  HexGeo G;
+  G.w[0] = I.i[0][0] * g0 + I.i[0][1] * g1 + I.i[0][2] * g2;
+  G.w[1] = I.i[1][0] * g0 + I.i[1][1] * g1 + I.i[1][2] * g2;
+  G.w[2] = I.i[2][0] * g0 + I.i[2][1] * g1 + I.i[2][2] * g2;
+  G.wd = I.wd;
+  G.Nl = f0 * f1 * f2;
+  return G;
+}
+
+// reference gradient of a nodal field given by its edge differences d[t][k]
+__device__ __forceinline__ void hex_ref_grad(const hexq::Point& P, const double (&d)[3][4], double (&g)[3]) {
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += P.E[t][k] * d[t][k];
+    g[t] = s;
+  }
+}
+
+__device__ __forceinline__ void hex_edge_diffs(const double (&u)[8], double (&d)[3][4]) {
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[t][k] = u[hexq::lo(t, k) | (1 << t)] - u[hexq::lo(t, k)];
+}
+
+// acc[j] += dN_j . v   (dN_j[t] = +-E[t][k(j)], the sign is that of bit t of j)
+__device__ __forceinline__ void hex_add_grad_dot(const hexq::Point& P, double (&acc)[8], const double (&v)[3]) {
+  double pv[3][4];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pv[t][k] = P.E[t][k] * v[t];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const double a0 = pv[0][hexq::kof(0, j)], a1 = pv[1][hexq::kof(1, j)], a2 = pv[2][hexq::kof(2, j)];
+    acc[j] += ((j & 1) ? a0 : -a0) + ((j & 2) ? a1 : -a1) + ((j & 4) ? a2 : -a2);
+  }
+}
+
+__device__ __forceinline__ void hex_add_shape(const hexq::Point& P, double (&acc)[8], double a) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] += P.N[j] * a;
+}
+
+__device__ __forceinline__ double hex_interp(const hexq::Point& P, const double (&u)[8]) {
+  double s = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += P.N[j] * u[j];
+  return s;
+}
+
+// Row l of the EMI element matrices of one hexahedron: ra = kappa-stiffness, rm = mass (ICS rows), and
+// the volume right-hand side (emiWeakForm.py:138-241).
+template <bool MASS, bool AFFINE>
+__device__ __forceinline__ void hex_emi_row(const Rec6 (&r)[8], int li, const KnSubConst& sc, double (&ra)[8],
+                                            double (&rm)[8], double& bvol) {
+  double kv[8], sv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    kv[j] = sc.kap[0] * r[j].a + sc.kap[1] * r[j].b + sc.kap[2] * r[j].c;
+    sv[j] = sc.sig[0] * r[j].a + sc.sig[1] * r[j].b + sc.sig[2] * r[j].c;
+    ra[j] = 0.0; rm[j] = 0.0;
+  }
+  double ds[3][4];
+  hex_edge_diffs(sv, ds);
+  const HexEdges e = hex_edges(r);
+  const bool aff = AFFINE || hex_is_affine(e);
+  HexInv I = hex_inverse(e, c_hex.p[0]);
+  const int l0 = li & 1, l1 = (li >> 1) & 1, l2 = (li >> 2) & 1;
+#pragma unroll 1
+  for (int q = 0; q < 8; ++q) {
+    const hexq::Point& P = c_hex.p[q];
+    if (!AFFINE && !aff && q > 0) I = hex_inverse(e, P);
+    const HexGeo G = hex_geo(I, P, l0, l1, l2);
+    const double kq = hex_interp(P, kv);
+    double gs[3];
+    hex_ref_grad(P, ds, gs);
+    bvol -= G.wd * (G.w[0] * gs[0] + G.w[1] * gs[1] + G.w[2] * gs[2]);
+    const double wk = G.wd * kq;
+    const double v[3] = {G.w[0] * wk, G.w[1] * wk, G.w[2] * wk};
+    hex_add_grad_dot(P, ra, v);
+    if (MASS) hex_add_shape(P, rm, G.wd * G.Nl);
+  }
+}
+
+// Row l of the KNP element matrices: M = mass, S = stiffness, Cc = drift (grad phi . grad N_l) N_j
+template <bool AFFINE>
+__device__ __forceinline__ void hex_knp_row(const Rec6 (&r)[8], int li, double (&M)[8], double (&S)[8], double (&Cc)[8]) {
+  double phi[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { phi[j] = r[j].c; M[j] = 0.0; S[j] = 0.0; Cc[j] = 0.0; }
+  double dphi[3][4];
+  hex_edge_diffs(phi, dphi);
+  const HexEdges e = hex_edges(r);
+  const bool aff = AFFINE || hex_is_affine(e);
+  HexInv I = hex_inverse(e, c_hex.p[0]);
+  const int l0 = li & 1, l1 = (li >> 1) & 1, l2 = (li >> 2) & 1;
+#pragma unroll 1
+  for (int q = 0; q < 8; ++q) {
+    const hexq::Point& P = c_hex.p[q];
+    if (!AFFINE && !aff && q > 0) I = hex_inverse(e, P);
+    const HexGeo G = hex_geo(I, P, l0, l1, l2);
+    double gp[3];
+    hex_ref_grad(P, dphi, gp);
+    const double drift = G.w[0] * gp[0] + G.w[1] * gp[1] + G.w[2] * gp[2];   // grad phi . grad N_l
+    const double v[3] = {G.w[0] * G.wd, G.w[1] * G.wd, G.w[2] * G.wd};
+    hex_add_grad_dot(P, S, v);
+    hex_add_shape(P, M, G.wd * G.Nl);
+    hex_add_shape(P, Cc, G.wd * drift);
+  }
+}
+
+template <int LPR, bool AFFINE>
+__global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n,
+                                                            int rec_n, int want_p, int splitting) {
+  constexpr int NF = 4;
+  const KnConsts& C = *Cp;
+  extern __shared__ __align__(16) double lds[];
+  double* accA = lds;
+  double* accP = lds + acc_n;
+  double* recs = lds + 2 * (size_t)acc_n;
+  uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + 6 * (size_t)rec_n);
+  const int tid = threadIdx.x;
+  const int b = logical_block(blockIdx.x, D.nblocks);
+  const BlkInfo B = load_blk(D, b, tid >> 6);
+  const int row0 = B.row0, nrows = B.nrows, s = B.sub, seg0 = B.seg0, seglen = B.seglen;
+  const int rloc = tid / LPR, sub = tid % LPR;
+  const bool valid = rloc < nrows;
+  const int g = row0 + (valid ? rloc : 0);
+  const int64_t base = (int64_t)B.slbase * KN_SLICE + (tid & 63);
+  const int np = B.np;
+  // first pair entry of this lane: issued before phase A so that its latency overlaps the staging
+  int pc0 = -1;
+  uint2 sl0 = {0u, 0u};
+  if (valid && np > 0) {
+    pc0 = D.pair_cell[base];
+    sl0 = *reinterpret_cast<const uint2*>(D.pair_slots + 2 * base);
+  }
+  const int4 ri = D.row_info[g];
+  for (int i = tid; i < seglen; i += KN_BLOCK) { accA[i] = 0.0; accP[i] = 0.0; }
+  stage_records<false>(D, B, recs, eloc, tid, 0.0, nullptr, 0);
+  __syncthreads();
+
+  const KnSubConst& sc = C.sc[s];
+  const bool cell_side = s > 0;
+  double bacc = 0.0, gam = 0.0;
+  if (valid) {
+    const int rowbase = ri.x, lap = ri.y, rL = ri.z;
+    const bool acc_p = want_p && cell_side;
+    auto do_pair = [&](int pc, uint2 sl) {
+      const int li = pc & 7;
+      int slot[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { slot[j] = (sl.x >> (8 * j)) & 255; slot[4 + j] = (sl.y >> (8 * j)) & 255; }
+      Rec6 r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = lds_rec(recs, eloc[rL + slot[j]]);
+      double ra[8], rm[8];
+      if (acc_p) hex_emi_row<true, AFFINE>(r, li, sc, ra, rm, bacc);
+      else hex_emi_row<false, AFFINE>(r, li, sc, ra, rm, bacc);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        unsafeAtomicAdd(&accA[lap + slot[j]], ra[j]);
+        if (acc_p) unsafeAtomicAdd(&accP[lap + slot[j]], ra[j] + rm[j]);
+      }
+    };
+    if (pc0 >= 0) do_pair(pc0, sl0);
+    for (int p = 1; p < np; ++p) {
+      const int64_t ent = base + (int64_t)p * KN_SLICE;
+      const int pc = D.pair_cell[ent];
+      if (pc >= 0) do_pair(pc, *reinterpret_cast<const uint2*>(D.pair_slots + 2 * ent));
+    }
+    // membrane coupling C_phi (u_i - u_e)(v_i - v_e) and Robin RHS (emiWeakForm.py:160-165,228-239)
+    const int m = sub == 0 ? ri.w : -1;
+    if (m >= 0) {
+      const int* fown = cell_side ? D.fi : D.fe;
+      for (int e = D.mptr[m]; e < D.mptr[m + 1]; ++e) {
+        const int ent = D.mentry[e];
+        const int fg = ent >> 3, a = ent & 7;
+        const int ms = D.fmodel[fg];
+        if (ms < 0) continue;
+        const uint64_t sl = D.mslots[e];
+        Rec p[NF];
+#pragma unroll
+        for (int bb = 0; bb < NF; ++bb) p[bb] = load_rec(D.VR, fown[(size_t)fg * NF + bb]);
+        double Mr[NF];
+        facet_mass_row<NF>(p, a, Mr);
+        double gs = 0.0;
+#pragma unroll
+        for (int bb = 0; bb < NF; ++bb) {
+          const int q = D.fq[(size_t)fg * NF + bb];
+          double gq = D.phiM[q];
+          if (!(splitting & 1)) {
+            double it = 0.0;
+            for (int k = 0; k < KN_MAXK; ++k) it += D.Ich[((size_t)ms * KN_MAXK + k) * D.NQtot + q];
+            gq -= it / C.C_phi;
+          }
+          gs += Mr[bb] * gq;
+          const double val = C.C_phi * Mr[bb];
+          const int io = rowbase + (int)((sl >> (8 * bb)) & 255);
+          const int it2 = rowbase + (int)((sl >> (8 * (4 + bb))) & 255);
+          unsafeAtomicAdd(&accA[io], val);
+          unsafeAtomicAdd(&accA[it2], -val);
+          if (acc_p) { unsafeAtomicAdd(&accP[io], val); unsafeAtomicAdd(&accP[it2], -val); }
+        }
+        if (!(splitting & 2)) gam += (cell_side ? 1.0 : -1.0) * C.C_phi * gs;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < LPR; m <<= 1) bacc += __shfl_xor(bacc, m);
+  if (valid && sub == 0) D.b_emi[g] = bacc + gam;
+  __syncthreads();
+  for (int i = tid; i < seglen; i += KN_BLOCK) {
+    const double a = accA[i];
+    D.A_emi[seg0 + i] = a;
+    if (want_p) D.P_emi[seg0 + i] = cell_side ? accP[i] : a;
+  }
+}
+
+template <int LPR, bool AFFINE>
+__global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n, int rec_n) {
+  constexpr int NF = 4;
+  const KnConsts& C = *Cp;
+  extern __shared__ __align__(16) double lds[];
+  double* acc0 = lds;
+  double* acc1 = lds + acc_n;
+  double* recs = lds + 2 * (size_t)acc_n;
+  uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + 6 * (size_t)rec_n);
+  const int tid = threadIdx.x;
+  const int b = logical_block(blockIdx.x, D.nblocks);
+  const BlkInfo B = load_blk(D, b, tid >> 6);
+  const int row0 = B.row0, nrows = B.nrows, s = B.sub, segL0 = B.segL0, nnzLb = B.nnzLb;
+  const int v0 = C.voff[s], nvs = C.voff[s + 1] - v0;
+  const double* fs0 = (D.fsrc && s == 0) ? D.fsrc : nullptr;
+  const int rloc = tid / LPR, sub = tid % LPR;
+  const bool valid = rloc < nrows;
+  const int g = row0 + (valid ? rloc : 0);
+  const int64_t base = (int64_t)B.slbase * KN_SLICE + (tid & 63);
+  const int np = B.np;
+  int pc0 = -1;
+  uint2 sl0 = {0u, 0u};
+  if (valid && np > 0) {
+    pc0 = D.pair_cell[base];
+    sl0 = *reinterpret_cast<const uint2*>(D.pair_slots + 2 * base);
+  }
+  const int4 ri = D.row_info[g];
+  for (int i = tid; i < nnzLb; i += KN_BLOCK) { acc0[i] = 0.0; acc1[i] = 0.0; }
+  stage_records<true>(D, B, recs, eloc, tid, C.inv_dt, fs0, nvs);
+  __syncthreads();
+
+  const KnSubConst& sc = C.sc[s];
+  double b0 = 0.0, b1 = 0.0;
+  if (valid) {
+    const int rL = ri.z;
+    auto do_pair = [&](int pc, uint2 sl) {
+      const int li = pc & 7;
+      int slot[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { slot[j] = (sl.x >> (8 * j)) & 255; slot[4 + j] = (sl.y >> (8 * j)) & 255; }
+      Rec6 r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = lds_rec(recs, eloc[rL + slot[j]]);
+      double M[8], S[8], Cc[8];
+      hex_knp_row<AFFINE>(r, li, M, S, Cc);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        unsafeAtomicAdd(&acc0[rL + slot[j]], M[j] * C.inv_dt + sc.D[0] * S[j] + sc.zpsiD[0] * Cc[j]);
+        unsafeAtomicAdd(&acc1[rL + slot[j]], M[j] * C.inv_dt + sc.D[1] * S[j] + sc.zpsiD[1] * Cc[j]);
+        b0 += M[j] * r[j].a;
+        b1 += M[j] * r[j].b;
+      }
+    };
+    if (pc0 >= 0) do_pair(pc0, sl0);
+    for (int p = 1; p < np; ++p) {
+      const int64_t ent = base + (int64_t)p * KN_SLICE;
+      const int pc = D.pair_cell[ent];
+      if (pc >= 0) do_pair(pc, *reinterpret_cast<const uint2*>(D.pair_slots + 2 * ent));
+    }
+    const int m = sub == 0 ? ri.w : -1;
+    if (m >= 0) {
+      const int side = s > 0 ? 1 : 0;
+      for (int e = D.mptr[m]; e < D.mptr[m + 1]; ++e) {
+        const int ent = D.mentry[e];
+        const int fg = ent >> 3, a = ent & 7;
+        if (D.fmodel[fg] < 0) continue;
+        const double* cg = D.gam_contrib + ((size_t)(fg * 2 + side) * NF + a) * 2;
+        b0 += cg[0];
+        b1 += cg[1];
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < LPR; m <<= 1) { b0 += __shfl_xor(b0, m); b1 += __shfl_xor(b1, m); }
+  if (valid && sub == 0) {
+    const size_t bb = (size_t)(KN_MAXK - 1) * v0 + (size_t)(g - v0);
+    D.b_knp[bb] = b0;
+    D.b_knp[bb + nvs] = b1;
+  }
+  __syncthreads();
+  const int64_t subnnz0 = D.rowptrL[v0], subnnz = D.rowptrL[v0 + nvs] - subnnz0;
+  double* out0 = D.A_knp + (size_t)(KN_MAXK - 1) * subnnz0 + (segL0 - subnnz0);
+  double* out1 = out0 + subnnz;
+  for (int i = tid; i < nnzLb; i += KN_BLOCK) { out0[i] = acc0[i]; out1[i] = acc1[i]; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // KNP membrane-facet kernel: the rational Robin/coupling integrand of knpWeakForm.py:168-214 with
 // degree-6 quadrature (tables staged in LDS).  One thread per (membrane facet, side): it evaluates the
@@ -1109,44 +1095,6 @@ int set_lds_limit(K kernel, size_t bytes) {
 
 }  // namespace
 
-template <int GDIM, int NV>
-static int launch_emi(knpemi_handle* h, size_t lds, int lds_n, int want_p, int split) {
-  const KnDev& D = h->dev;
-  dim3 grid(D.nblocks), block(KN_BLOCK);
-  int rc = 0;
-#define KN_CASE(L)                                                                                   \
-  case L:                                                                                            \
-    if ((rc = set_lds_limit(emi_rows_kernel<GDIM, NV, L>, lds))) return rc;                          \
-    {                                                                                                \
-      KnProfScope prof(h, KNPEMI_K_EMI_ROWS);                                                        \
-      hipLaunchKernelGGL((emi_rows_kernel<GDIM, NV, L>), grid, block, lds, h->cur, D, h->d_consts, \
-                         lds_n, want_p, split);                                                      \
-    }                                                                                                \
-    break;
-  switch (h->lpr) { KN_CASE(1) KN_CASE(2) KN_CASE(4) KN_CASE(8) default: kn_set_error("bad lanes-per-row"); return KNPEMI_EINVAL; }
-#undef KN_CASE
-  return check_launch("emi_rows_kernel");
-}
-
-template <int GDIM, int NV>
-static int launch_knp(knpemi_handle* h, size_t lds, int lds_n) {
-  const KnDev& D = h->dev;
-  dim3 grid(D.nblocks), block(KN_BLOCK);
-  int rc = 0;
-#define KN_CASE(L)                                                                                   \
-  case L:                                                                                            \
-    if ((rc = set_lds_limit(knp_rows_kernel<GDIM, NV, L>, lds))) return rc;                          \
-    {                                                                                                \
-      KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                        \
-      hipLaunchKernelGGL((knp_rows_kernel<GDIM, NV, L>), grid, block, lds, h->cur, D, h->d_consts, \
-                         lds_n);                                                                     \
-    }                                                                                                \
-    break;
-  switch (h->lpr) { KN_CASE(1) KN_CASE(2) KN_CASE(4) KN_CASE(8) default: kn_set_error("bad lanes-per-row"); return KNPEMI_EINVAL; }
-#undef KN_CASE
-  return check_launch("knp_rows_kernel");
-}
-
 template <int GDIM>
 static int launch_emi_v2(knpemi_handle* h, int want_p, int split) {
   const KnDev& D = h->dev;
@@ -1190,31 +1138,68 @@ static int launch_knp_v2(knpemi_handle* h) {
   return check_launch("knp_rows_v2");
 }
 
+static int launch_emi_hex_v2(knpemi_handle* h, int want_p, int split) {
+  const KnDev& D = h->dev;
+  const int acc_n = (h->lds_doubles_emi + 1) & ~1, rec_n = h->lds_uniq_max;
+  const size_t lds = ((size_t)2 * acc_n + 6 * (size_t)rec_n) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
+  if (lds > 160 * 1024) { kn_set_error("EMI row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
+  dim3 grid(D.nblocks), block(KN_BLOCK);
+  int rc = 0;
+#define KN_CASE2(L, AFF)                                                                            \
+    if ((rc = set_lds_limit(emi_rows_hex_v2<L, AFF>, lds))) return rc;                              \
+    {                                                                                               \
+      KnProfScope prof(h, KNPEMI_K_EMI_ROWS);                                                       \
+      hipLaunchKernelGGL((emi_rows_hex_v2<L, AFF>), grid, block, lds, h->cur, D, h->d_consts, acc_n, \
+                         rec_n, want_p, split);                                                     \
+    }
+#define KN_CASE(L)                                                                                  \
+  case L:                                                                                           \
+    if (h->hex_affine) { KN_CASE2(L, true) } else { KN_CASE2(L, false) }                            \
+    break;
+  switch (h->lpr) { KN_CASE(1) KN_CASE(2) KN_CASE(4) KN_CASE(8) default: kn_set_error("bad lanes-per-row"); return KNPEMI_EINVAL; }
+#undef KN_CASE
+#undef KN_CASE2
+  return check_launch("emi_rows_hex_v2");
+}
+
+static int launch_knp_hex_v2(knpemi_handle* h) {
+  const KnDev& D = h->dev;
+  const int acc_n = (h->lds_doubles_knp + 1) & ~1, rec_n = h->lds_uniq_max;
+  const size_t lds = ((size_t)2 * acc_n + 6 * (size_t)rec_n) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
+  if (lds > 160 * 1024) { kn_set_error("KNP row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
+  dim3 grid(D.nblocks), block(KN_BLOCK);
+  int rc = 0;
+#define KN_CASE2(L, AFF)                                                                            \
+    if ((rc = set_lds_limit(knp_rows_hex_v2<L, AFF>, lds))) return rc;                              \
+    {                                                                                               \
+      KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                       \
+      hipLaunchKernelGGL((knp_rows_hex_v2<L, AFF>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n); \
+    }
+#define KN_CASE(L)                                                                                  \
+  case L:                                                                                           \
+    if (h->hex_affine) { KN_CASE2(L, true) } else { KN_CASE2(L, false) }                            \
+    break;
+  switch (h->lpr) { KN_CASE(1) KN_CASE(2) KN_CASE(4) KN_CASE(8) default: kn_set_error("bad lanes-per-row"); return KNPEMI_EINVAL; }
+#undef KN_CASE
+#undef KN_CASE2
+  return check_launch("knp_rows_hex_v2");
+}
+
 int kn_launch_emi_rows(knpemi_handle* h, int flags) {
   const KnDev& D = h->dev;
   if (D.nblocks == 0) return KNPEMI_OK;
-  if (h->NV != 8) {
-    const int want_p = (flags & KNPEMI_WANT_P) ? 1 : 0;
-    const int split = ((flags & KNPEMI_NO_SPLITTING) ? 0 : 1) | ((flags & KNPEMI_SKIP_MEMBRANE_RHS) ? 2 : 0);
-    return h->gdim == 2 ? launch_emi_v2<2>(h, want_p, split) : launch_emi_v2<3>(h, want_p, split);
-  }
-  const int lds_n = h->lds_doubles_emi;
-  const size_t lds = (size_t)2 * h->lpr * lds_n * sizeof(double) + (h->NV == 8 ? sizeof(HexTab) : 0);
-  if (lds > 160 * 1024) { kn_set_error("EMI row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   const int want_p = (flags & KNPEMI_WANT_P) ? 1 : 0;
-    const int split = ((flags & KNPEMI_NO_SPLITTING) ? 0 : 1) | ((flags & KNPEMI_SKIP_MEMBRANE_RHS) ? 2 : 0);
-  return launch_emi<3, 8>(h, lds, lds_n, want_p, split);
+  const int split = ((flags & KNPEMI_NO_SPLITTING) ? 0 : 1) | ((flags & KNPEMI_SKIP_MEMBRANE_RHS) ? 2 : 0);
+  if (h->NV == 8) return launch_emi_hex_v2(h, want_p, split);
+  return h->gdim == 2 ? launch_emi_v2<2>(h, want_p, split) : launch_emi_v2<3>(h, want_p, split);
 }
 
 int kn_launch_knp_rows(knpemi_handle* h, int flags) {
   (void)flags;
   const KnDev& D = h->dev;
   if (D.nblocks == 0) return KNPEMI_OK;
-  if (h->NV != 8) return h->gdim == 2 ? launch_knp_v2<2>(h) : launch_knp_v2<3>(h);
-  const int lds_n = h->lds_doubles_knp;
-  const size_t lds = (size_t)2 * h->lpr * lds_n * sizeof(double) + (h->NV == 8 ? sizeof(HexTab) : 0);
-  if (lds > 160 * 1024) { kn_set_error("KNP row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
-  return launch_knp<3, 8>(h, lds, lds_n);
+  if (h->NV == 8) return launch_knp_hex_v2(h);
+  return h->gdim == 2 ? launch_knp_v2<2>(h) : launch_knp_v2<3>(h);
 }
 
 int kn_launch_knp_membrane(knpemi_handle* h, int flags) {

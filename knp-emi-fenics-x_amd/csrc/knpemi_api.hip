@@ -260,12 +260,33 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
     }
   }
 
+  // ---- hexahedra: is every cell a parallelepiped? (constant Jacobian -> specialised row kernels) -----
+  if (NV == 8) {
+    bool affine = true;
+    for (size_t c = 0; c < (size_t)nctot && affine; ++c) {
+      const int* cv = &cells[c * 8];
+      double dev = 0.0, len = 0.0;
+      for (int t = 0; t < 3; ++t) {
+        double e0[3] = {0, 0, 0};
+        for (int k = 0; k < 4; ++k) {
+          const int v = ((k >> t) << (t + 1)) | (k & ((1 << t) - 1)), u = v | (1 << t);
+          for (int a = 0; a < 3; ++a) {
+            const double e = VR[(size_t)cv[u] * KN_REC + a] - VR[(size_t)cv[v] * KN_REC + a];
+            if (k == 0) { e0[a] = e; len += std::fabs(e); }
+            else dev += std::fabs(e - e0[a]);
+          }
+        }
+      }
+      affine = dev <= 1e-13 * len;
+    }
+    h->hex_affine = affine && getenv("KNPEMI_HEX_GENERAL") == nullptr;
+  }
+
   // ---- lanes per row: enough workgroups to fill 256 CUs several times over on small meshes --------
   {
     // simplices (v2 kernels stage 48 B per Laplacian entry in LDS): 64-row blocks for tetrahedra,
     // 128-row blocks for triangles; hexahedra: enough workgroups to fill the chip on small meshes
-    int lpr = NV == 4 ? 4 : (NV == 3 ? 2 : 1);
-    while (NV == 8 && lpr < 8 && (int64_t)Ntot * lpr < (int64_t)1024 * KN_BLOCK) lpr *= 2;
+    int lpr = NV == 3 ? 2 : 4;   // hexahedra: 8 heavy pairs per row, two per lane
     if (const char* env = getenv("KNPEMI_LPR")) {
       int v = atoi(env);
       if (v == 1 || v == 2 || v == 4 || v == 8) lpr = v;

@@ -143,6 +143,7 @@ struct knpemi_handle {
   KnDev dev{};
   int have_params = 0;
   int lpr = 1;                         // lanes per row of the row kernels (1, 2, 4 or 8)
+  bool hex_affine = false;             // every hexahedron is a parallelepiped (constant Jacobian)
   int lds_doubles_emi = 0, lds_doubles_knp = 0; // per-block LDS segment sizes (doubles)
   int lds_uniq_max = 0;                         // most distinct vertices touched by one row block
   std::vector<void*> allocs;  // everything hipMalloc'ed

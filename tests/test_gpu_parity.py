@@ -36,6 +36,34 @@ def test_assembly_matches_oracle(hip_lib, kind, r, splitting):
     assert max(errs.values()) < TOL, errs
 
 
+def _distorted_hex_mesh(seed=3):
+    """The r = 0 hexahedral box with every vertex moved by up to 15 % of the smallest spacing: trilinear cells
+    with a non-constant Jacobian and non-planar membrane quadrilaterals."""
+    from setup_problem import make_mesh
+    mesh, ct, ft = make_mesh("hex", 0)
+    rng = np.random.default_rng(seed)
+    mesh.x[:] = mesh.x + 0.15 * 0.1e-6 * (2.0 * rng.random(mesh.x.shape) - 1.0)
+    return mesh, ct, ft
+
+
+@pytest.mark.parametrize("splitting", [True, False])
+def test_assembly_matches_oracle_on_distorted_hexahedra(hip_lib, splitting):
+    """General Q1 path (Jacobian inverted at every Gauss point) against the oracle's quadrature."""
+    s = Setup("hex", 0, mesh_data=_distorted_hex_mesh())
+    s.perturb()
+    errs, _ = _assemble_both(s, splitting)
+    assert max(errs.values()) < TOL, errs
+
+
+def test_general_hexahedron_kernel_on_box_mesh(hip_lib, monkeypatch):
+    """KNPEMI_HEX_GENERAL forces the general Q1 kernels (per-cell affinity test at run time) on a box mesh."""
+    monkeypatch.setenv("KNPEMI_HEX_GENERAL", "1")
+    s = Setup("hex", 0)
+    s.perturb()
+    errs, _ = _assemble_both(s)
+    assert max(errs.values()) < TOL, errs
+
+
 def test_assembly_is_bit_reproducible(hip_lib):
     s = Setup("tet", 0)
     s.perturb()
