@@ -195,35 +195,36 @@ bool dense_inverse(const HostCsr& A, bool singular, std::vector<double>& inv) {
 
 // ---- device kernels -------------------------------------------------------------------------------
 
-enum { M_AX = 0, M_RES, M_ADD, M_JAC };
+enum { M_AX = 0, M_PRE, M_ADD, M_JAC };
 
-// LPR lanes per row.  M_AX: y = A x; M_RES: y = r - A x; M_ADD: y += A x; M_JAC: y = x + w dinv (r - A x)
+// LPR lanes per row.
+//   M_AX : y = A x
+//   M_PRE: x = w dinv r (this row), y = r - A (w dinv r)      pre-smoothing from a zero guess + residual
+//   M_ADD: y += A x                                             prolongation
+//   M_JAC: y = x + w dinv (r - A x)                            post-smoothing (y != x)
 template <int MODE, int LPR>
 __global__ __launch_bounds__(256) void amg_spmv_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ colind,
-                                                       const double* __restrict__ vals, const double* __restrict__ x,
+                                                       const double* __restrict__ vals, const double* x,
                                                        const double* __restrict__ r, const double* __restrict__ dinv,
-                                                       double w, double* y) {
+                                                       double w, double* y, double* xout) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int row = t / LPR, l = t % LPR;
   double acc = 0.0;
   if (row < n) {
     const int a = rowptr[row], b = rowptr[row + 1];
-    for (int j = a + l; j < b; j += LPR) acc += vals[j] * x[colind[j]];
+    for (int j = a + l; j < b; j += LPR) {
+      const int c = colind[j];
+      acc += vals[j] * (MODE == M_PRE ? dinv[c] * r[c] : x[c]);
+    }
   }
 #pragma unroll
   for (int m = LPR / 2; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
   if (row < n && l == 0) {
     if (MODE == M_AX) y[row] = acc;
-    else if (MODE == M_RES) y[row] = r[row] - acc;
+    else if (MODE == M_PRE) { y[row] = r[row] - w * acc; xout[row] = w * dinv[row] * r[row]; }
     else if (MODE == M_ADD) y[row] += acc;
     else y[row] = x[row] + w * dinv[row] * (r[row] - acc);
   }
-}
-
-__global__ void amg_jacobi0_kernel(int n, double w, const double* __restrict__ dinv, const double* __restrict__ r,
-                                   double* __restrict__ x) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) x[i] = w * dinv[i] * r[i];
 }
 
 __global__ void amg_diag_inv_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ colind,
@@ -250,13 +251,13 @@ __global__ __launch_bounds__(256) void amg_dense_kernel(int n, const double* __r
 
 template <int MODE>
 void launch_spmv(hipStream_t st, int n, int avg_row, const int* rp, const int* ci, const double* v, const double* x,
-                 const double* r, const double* dinv, double w, double* y) {
+                 const double* r, const double* dinv, double w, double* y, double* xout = nullptr) {
   if (avg_row > 8) {
     dim3 g(((size_t)n * 16 + 255) / 256);
-    hipLaunchKernelGGL((amg_spmv_kernel<MODE, 16>), g, dim3(256), 0, st, n, rp, ci, v, x, r, dinv, w, y);
+    hipLaunchKernelGGL((amg_spmv_kernel<MODE, 16>), g, dim3(256), 0, st, n, rp, ci, v, x, r, dinv, w, y, xout);
   } else {
     dim3 g(((size_t)n * 4 + 255) / 256);
-    hipLaunchKernelGGL((amg_spmv_kernel<MODE, 4>), g, dim3(256), 0, st, n, rp, ci, v, x, r, dinv, w, y);
+    hipLaunchKernelGGL((amg_spmv_kernel<MODE, 4>), g, dim3(256), 0, st, n, rp, ci, v, x, r, dinv, w, y, xout);
   }
 }
 
@@ -328,9 +329,17 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
     for (int i = 0; i < cur.n; ++i) dinv[i] = d[i] != 0.0 ? 1.0 / d[i] : 1.0;
     if ((rc = upload(G, dinv, &L.dinv, st))) return rc;
     std::vector<int> agg;
-    const int na = cur.n > n_dense ? aggregate(cur, d, theta, agg) : 0;
+    int na = 0;
+    if (cur.n > n_dense) {
+      // a threshold that leaves (almost) no strong connections stalls the coarsening: relax it for this level
+      double th = theta;
+      for (int attempt = 0; attempt < 6; ++attempt, th = attempt == 5 ? 0.0 : 0.5 * th) {
+        na = aggregate(cur, d, th, agg);
+        if (na < cur.n * 0.7) break;
+      }
+    }
     if (cur.n <= n_dense || na >= cur.n * 0.9 || l == max_levels - 1) {
-      if (cur.n > 4096) { kn_set_error("AMG set-up: coarsening stagnated"); return KNPEMI_ESOLVE; }
+      if (cur.n > 1024) { kn_set_error("AMG set-up: coarsening stagnated"); return KNPEMI_ESOLVE; }
       std::vector<double> inv;
       if (!dense_inverse(cur, singular, inv)) { kn_set_error("AMG set-up: singular coarsest operator"); return KNPEMI_ESOLVE; }
       if ((rc = upload(G, inv, &L.dense_inv, st))) return rc;
@@ -365,35 +374,37 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
   return KNPEMI_OK;
 }
 
-// z = V(1,1)-cycle applied to r (both of the finest size); the finest operator/diagonal are those of the
-// current step (`vals`, `dinv0`).
-int kn_amg_apply(knpemi_handle* h, KnAmg& G, const double* vals, const double* dinv0, const double* r, double* z) {
+// out = V(1,1)-cycle applied to r (all of the finest size; `scratch` is a work vector, out != scratch != r).
+// The finest operator/diagonal are those of the current step (`vals`, `dinv0`).  Per level: x holds the
+// pre-smoothed iterate and receives the coarse correction, t the residual on the way down and the
+// post-smoothed result on the way up (read by the parent's prolongation): 4 launches per level, no copies,
+// fixed buffers (the sequence can be captured in a hipGraph).
+int kn_amg_apply(knpemi_handle* h, KnAmg& G, const double* vals, const double* dinv0, const double* r, double* scratch,
+                 double* out) {
   hipStream_t st = h->stream;
   const int nl = (int)G.lev.size();
   for (int l = 0; l < nl; ++l) {
     KnAmgLevel& L = G.lev[l];
     const double* rl = l == 0 ? r : L.r;
-    double* xl = l == 0 ? z : L.x;
+    double* xl = l == 0 ? scratch : L.x;
     const double* Av = l == 0 ? vals : L.A.v;
     const double* dinv = l == 0 ? dinv0 : L.dinv;
     if (L.nc == 0) {
       dim3 g(((size_t)L.n * 64 + 255) / 256);
-      hipLaunchKernelGGL(amg_dense_kernel, g, dim3(256), 0, st, L.n, L.dense_inv, rl, xl);
+      hipLaunchKernelGGL(amg_dense_kernel, g, dim3(256), 0, st, L.n, L.dense_inv, rl, nl == 1 ? out : L.t);
       break;
     }
-    hipLaunchKernelGGL(amg_jacobi0_kernel, dim3((L.n + 255) / 256), dim3(256), 0, st, L.n, L.omega, dinv, rl, xl);
-    launch_spmv<M_RES>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, xl, rl, nullptr, 0.0, L.t);
+    launch_spmv<M_PRE>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, nullptr, rl, dinv, L.omega, L.t, xl);
     launch_spmv<M_AX>(st, L.nc, L.r_row, L.R.rp, L.R.ci, L.R.v, L.t, nullptr, nullptr, 0.0, G.lev[l + 1].r);
   }
   for (int l = nl - 2; l >= 0; --l) {
     KnAmgLevel& L = G.lev[l];
     const double* rl = l == 0 ? r : L.r;
-    double* xl = l == 0 ? z : L.x;
+    double* xl = l == 0 ? scratch : L.x;
     const double* Av = l == 0 ? vals : L.A.v;
     const double* dinv = l == 0 ? dinv0 : L.dinv;
-    launch_spmv<M_ADD>(st, L.n, L.p_row, L.P.rp, L.P.ci, L.P.v, G.lev[l + 1].x, nullptr, nullptr, 0.0, xl);
-    launch_spmv<M_JAC>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, xl, rl, dinv, L.omega, L.t);
-    KN_HIP(hipMemcpyAsync(xl, L.t, (size_t)L.n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    launch_spmv<M_ADD>(st, L.n, L.p_row, L.P.rp, L.P.ci, L.P.v, G.lev[l + 1].t, nullptr, nullptr, 0.0, xl);
+    launch_spmv<M_JAC>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, xl, rl, dinv, L.omega, l == 0 ? out : L.t);
   }
   return KNPEMI_OK;
 }

@@ -49,11 +49,20 @@ __global__ void diag_inv_kernel(int n, const int* __restrict__ rowptr, const int
   dinv[row] = d != 0.0 ? 1.0 / d : 1.0;
 }
 
-// up to three dot products in one pass: partial[k][block]
-__global__ __launch_bounds__(RED_THREADS) void dots_partial_kernel(int n, int nd, const double* a0, const double* b0,
-                                                                   const double* a1, const double* b1, const double* a2,
-                                                                   const double* b2, double* __restrict__ partial) {
+// second-stage scalar algebra of the algorithm step `op`
+enum { OP_STORE3 = 0, OP_CG_INIT, OP_CG_PAP, OP_CG_RHO, OP_BI_RHO, OP_BI_ALPHA, OP_BI_OMEGA, OP_MEAN };
+
+// Up to three dot products and the scalar update that consumes them in ONE launch: every block writes its
+// partial sums, the last block to finish (ticket counter) adds the partials in a fixed order and applies
+// `op` to the device scalars.  The summation order does not depend on which block is last, so the solves stay
+// bit-reproducible.
+__global__ __launch_bounds__(RED_THREADS) void dots_kernel(int n, int nd, const double* a0, const double* b0,
+                                                           const double* a1, const double* b1, const double* a2,
+                                                           const double* b2, double* partial, unsigned* ticket,
+                                                           double* __restrict__ sc, int op, int d0, int d1, int d2,
+                                                           double scale) {
   __shared__ double sh[3][RED_THREADS];
+  __shared__ bool last;
   double s0 = 0, s1 = 0, s2 = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     s0 += a0[i] * b0[i];
@@ -67,20 +76,20 @@ __global__ __launch_bounds__(RED_THREADS) void dots_partial_kernel(int n, int nd
       for (int k = 0; k < nd; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + w];
     __syncthreads();
   }
-  if (threadIdx.x == 0)
-    for (int k = 0; k < nd; ++k) partial[k * RED_BLOCKS + blockIdx.x] = sh[k][0];
-}
-
-// second stage + the scalar algebra of the algorithm step `op`
-enum { OP_STORE3 = 0, OP_CG_INIT, OP_CG_PAP, OP_CG_RHO, OP_BI_RHO, OP_BI_ALPHA, OP_BI_OMEGA, OP_MEAN };
-
-__global__ __launch_bounds__(RED_THREADS) void dots_final_kernel(int nb, int nd, const double* __restrict__ partial,
-                                                                 double* __restrict__ sc, int op, int d0, int d1, int d2,
-                                                                 double scale) {
-  __shared__ double sh[3][RED_THREADS];
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < nd; ++k)
+      __hip_atomic_store(&partial[k * RED_BLOCKS + blockIdx.x], sh[k][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  const int nb = gridDim.x;
   for (int k = 0; k < nd; ++k) {
     double s = 0;
-    for (int i = threadIdx.x; i < nb; i += RED_THREADS) s += partial[k * RED_BLOCKS + i];
+    for (int i = threadIdx.x; i < nb; i += RED_THREADS)
+      s += __hip_atomic_load(&partial[k * RED_BLOCKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     sh[k][threadIdx.x] = s;
   }
   __syncthreads();
@@ -90,6 +99,7 @@ __global__ __launch_bounds__(RED_THREADS) void dots_final_kernel(int nb, int nd,
     __syncthreads();
   }
   if (threadIdx.x != 0) return;
+  *ticket = 0;
   const double v0 = sh[0][0], v1 = nd > 1 ? sh[1][0] : 0.0, v2 = nd > 2 ? sh[2][0] : 0.0;
   switch (op) {
     case OP_STORE3: sc[d0] = v0; if (nd > 1) sc[d1] = v1; if (nd > 2) sc[d2] = v2; break;
@@ -154,10 +164,8 @@ void spmv(const Ctx& c, const double* x, double* y, const double* dinv) {
 void dots(const Ctx& c, int nd, const double* a0, const double* b0, const double* a1, const double* b1, const double* a2,
           const double* b2, int op, int d0 = 0, int d1 = 0, int d2 = 0, double scale = 1.0) {
   const int nb = std::min(RED_BLOCKS, (c.n + RED_THREADS - 1) / RED_THREADS);
-  hipLaunchKernelGGL(dots_partial_kernel, dim3(nb), dim3(RED_THREADS), 0, c.h->stream, c.n, nd, a0, b0, a1, b1, a2, b2,
-                     c.partial);
-  hipLaunchKernelGGL(dots_final_kernel, dim3(1), dim3(RED_THREADS), 0, c.h->stream, nb, nd, c.partial, c.sc, op, d0, d1,
-                     d2, scale);
+  hipLaunchKernelGGL(dots_kernel, dim3(nb), dim3(RED_THREADS), 0, c.h->stream, c.n, nd, a0, b0, a1, b1, a2, b2, c.partial,
+                     reinterpret_cast<unsigned*>(c.partial + 3 * RED_BLOCKS), c.sc, op, d0, d1, d2, scale);
 }
 
 void vec(const Ctx& c, int op, double* a, double* b, const double* cc, const double* d) {
@@ -170,13 +178,50 @@ int read_scalars(const Ctx& c, double* host, int count) {
   return KNPEMI_OK;
 }
 
+// Run `chunk` iterations of `body`: captured once into a hipGraph (the launch-bound inner loop of small
+// systems: ~20 launches of a few microseconds per iteration) and replayed; the graph is keyed on everything its
+// kernel arguments depend on.  KNPEMI_NO_GRAPH=1 launches the kernels directly.
+template <class Body>
+int run_chunk(knpemi_handle* h, knpemi_handle::KnGraph& g, uint64_t key, int chunk, Body&& body) {
+  static const bool no_graph = getenv("KNPEMI_NO_GRAPH") != nullptr;
+  int rc = KNPEMI_OK;
+  if (no_graph) {
+    for (int k = 0; k < chunk && !rc; ++k) rc = body();
+    return rc;
+  }
+  if (!g.exec || g.key != key) {
+    if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+    hipGraph_t graph = nullptr;
+    KN_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    for (int k = 0; k < chunk && !rc; ++k) rc = body();
+    hipError_t e = hipStreamEndCapture(h->stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) { kn_set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); return KNPEMI_EHIP; }
+    e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { g.exec = nullptr; kn_set_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); return KNPEMI_EHIP; }
+    g.key = key;
+  }
+  KN_HIP(hipGraphLaunch(g.exec, h->stream));
+  return KNPEMI_OK;
+}
+
+inline uint64_t graph_key(const knpemi_handle* h, const KnAmg& G, bool amg, int chunk, int n) {
+  uint64_t k = reinterpret_cast<uint64_t>(h->kry);
+  k = k * 1000003u + (uint64_t)G.builds;
+  k = k * 1000003u + (amg ? 1u : 0u);
+  k = k * 1000003u + (uint64_t)chunk;
+  k = k * 1000003u + (uint64_t)n;
+  return k | 1u;
+}
+
 }  // namespace
 
 // Workspace: 10 vectors of the larger system + ones + scalars + partials (allocated on first use).
 static int ensure_work(knpemi_handle* h, size_t n) {
   if (h->kry_n >= n) return KNPEMI_OK;
   void* p = nullptr;
-  const size_t doubles = 11 * n + 64 + 3 * RED_BLOCKS;
+  const size_t doubles = 11 * n + 64 + 3 * RED_BLOCKS + 2;   // + ticket counter of dots_kernel
   KN_HIP(hipMalloc(&p, doubles * sizeof(double)));
   h->allocs.push_back(p);
   KN_HIP(hipMemsetAsync(p, 0, doubles * sizeof(double), h->stream));
@@ -211,7 +256,7 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     ++G.builds;
   }
   auto precond = [&]() -> int {
-    if (amg) return kn_amg_apply(h, G, D.A_emi, dinv, r, z);
+    if (amg) return kn_amg_apply(h, G, D.A_emi, dinv, r, q, z);   // q = A p is free here
     vec(c, V_JACOBI, z, nullptr, r, dinv);
     return KNPEMI_OK;
   };
@@ -228,15 +273,21 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   const double target = std::max(atol, rtol * (bnorm > 0 ? bnorm : 1.0));
   int it = 0;
   double rn = std::sqrt(sc[S_RR]);
+  auto iteration = [&]() -> int {
+    spmv(c, p, q, nullptr);
+    dots(c, 1, p, q, nullptr, nullptr, nullptr, nullptr, OP_CG_PAP);
+    vec(c, V_CG_XR, x, r, p, q);
+    if (int e = precond()) return e;
+    dots(c, 2, r, z, r, r, nullptr, nullptr, OP_CG_RHO);
+    vec(c, V_CG_P, p, nullptr, z, nullptr);
+    return KNPEMI_OK;
+  };
+  const uint64_t gkey = graph_key(h, G, amg, chunk, n);
   while (rn > target && it < maxit) {
-    for (int k = 0; k < chunk && it < maxit; ++k, ++it) {
-      spmv(c, p, q, nullptr);
-      dots(c, 1, p, q, nullptr, nullptr, nullptr, nullptr, OP_CG_PAP);
-      vec(c, V_CG_XR, x, r, p, q);
-      if ((rc = precond())) return rc;
-      dots(c, 2, r, z, r, r, nullptr, nullptr, OP_CG_RHO);
-      vec(c, V_CG_P, p, nullptr, z, nullptr);
-    }
+    const int todo = std::min(chunk, maxit - it);
+    if (todo == chunk) { if ((rc = run_chunk(h, h->graph_emi, gkey, chunk, iteration))) return rc; }
+    else for (int k = 0; k < todo; ++k) if ((rc = iteration())) return rc;
+    it += todo;
     if ((rc = read_scalars(c, sc, S_N))) return rc;
     rn = std::sqrt(sc[S_RR]);
     if (!(rn == rn)) { kn_set_error("EMI CG broke down (NaN residual)"); return KNPEMI_EINVAL; }
@@ -301,18 +352,20 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   const double target = std::max(atol, rtol * (bnorm > 0 ? bnorm : 1.0));
   double rn = std::sqrt(sc[S_RR]);
   int it = 0;
-  while (rn > target && it < maxit) {
-    for (int k = 0; k < (amg ? 1 : 4) && it < maxit; ++k, ++it) {
+  const int chunk = amg ? 1 : 4;
+  auto iteration = [&]() -> int {
+    int rc = KNPEMI_OK;
+
       dots(c, 1, rhat, r, nullptr, nullptr, nullptr, nullptr, OP_BI_RHO);
       vec(c, V_BI_P, p, nullptr, r, v);
       if (amg) {
-        if ((rc = kn_amg_apply(h, G, D.A_knp, dinv, p, phat))) return rc;
+        if ((rc = kn_amg_apply(h, G, D.A_knp, dinv, p, t, phat))) return rc;   // t is free here
         spmv(c, phat, v, nullptr);
       } else spmv(c, p, v, dinv);                           // v = A M^-1 p
       dots(c, 1, rhat, v, nullptr, nullptr, nullptr, nullptr, OP_BI_ALPHA);
       vec(c, V_BI_S, s, nullptr, r, v);
       if (amg) {
-        if ((rc = kn_amg_apply(h, G, D.A_knp, dinv, s, shat))) return rc;
+        if ((rc = kn_amg_apply(h, G, D.A_knp, dinv, s, t, shat))) return rc;
         spmv(c, shat, t, nullptr);
       } else spmv(c, s, t, dinv);                           // t = A M^-1 s
       dots(c, 2, t, s, t, t, nullptr, nullptr, OP_BI_OMEGA);
@@ -322,7 +375,14 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
       else
         hipLaunchKernelGGL(bicg_update_kernel, grid1(n), dim3(256), 0, h->stream, n, c.sc, x, r, p, s, s, t, dinv);
       dots(c, 1, r, r, nullptr, nullptr, nullptr, nullptr, OP_STORE3, S_RR);
-    }
+    return rc;
+  };
+  const uint64_t gkey = graph_key(h, G, amg, chunk, n);
+  while (rn > target && it < maxit) {
+    const int todo = std::min(chunk, maxit - it);
+    if (todo == chunk) { if ((rc = run_chunk(h, h->graph_knp, gkey, chunk, iteration))) return rc; }
+    else for (int k = 0; k < todo; ++k) if ((rc = iteration())) return rc;
+    it += todo;
     if ((rc = read_scalars(c, sc, S_N))) return rc;
     rn = std::sqrt(sc[S_RR]);
     if (!(rn == rn)) { kn_set_error("KNP BiCGStab broke down (NaN residual)"); return KNPEMI_EINVAL; }

@@ -516,6 +516,8 @@ extern "C" void knpemi_destroy(knpemi_handle* h) {
   if (h->aux) (void)hipStreamDestroy(h->aux);
   kn_amg_free(h->amg_emi);
   kn_amg_free(h->amg_knp);
+  if (h->graph_emi.exec) (void)hipGraphExecDestroy(h->graph_emi.exec);
+  if (h->graph_knp.exec) (void)hipGraphExecDestroy(h->graph_knp.exec);
   for (void* p : h->allocs) (void)hipFree(p);
   for (auto& v : h->prof_ev) for (hipEvent_t e : v) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);

@@ -125,7 +125,8 @@ void kn_amg_free(KnAmg& G);
 struct knpemi_handle;
 int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const int* d_colind, const double* d_vals,
                  bool singular);
-int kn_amg_apply(knpemi_handle* h, KnAmg& G, const double* vals, const double* dinv0, const double* r, double* z);
+int kn_amg_apply(knpemi_handle* h, KnAmg& G, const double* vals, const double* dinv0, const double* r, double* scratch,
+                 double* out);
 
 struct knpemi_handle {
   int device = 0;
@@ -153,6 +154,9 @@ struct knpemi_handle {
   double* d_stage = nullptr; size_t stage_len = 0;   // staging buffer for strided field I/O
   double* kry = nullptr; size_t kry_n = 0;           // Krylov workspace (kernels_krylov.hip)
   KnAmg amg_emi, amg_knp;
+  // captured iteration bodies of the Krylov loops (kernels_krylov.hip); key = configuration they were captured for
+  struct KnGraph { hipGraphExec_t exec = nullptr; uint64_t key = 0; };
+  KnGraph graph_emi, graph_knp;
   int pc_emi = KNPEMI_PC_AMG, pc_knp = KNPEMI_PC_AMG;
   // per-kernel event profiling (knpemi_profile)
   uint32_t prof_mask = 0;
