@@ -89,6 +89,15 @@ def _apply_bcs(A, b, bcs, offsets):
     return A.tocsr(), b
 
 
+def _push_sources(dp, f):
+    """ECS source terms of the solved ions (knpWeakForm.py:164-166) as nodal fields."""
+    for k, ion in enumerate(f.ion_list[:-1]):
+        if 'f_source' in ion:
+            src = ion['f_source']
+            arr = src.x._a if isinstance(src, Function) else np.full(int(dp.n_vert[0]), as_float(src))
+            dp.push_array(L.F_SOURCE, 0, k, arr)
+
+
 class LinearProblem:
     def __init__(self, system, a, Lf, u, subdomain_list, direct, p, bcs, atol, rtol, threshold, prefix):
         if a.system != system or Lf.system != system:
@@ -128,11 +137,7 @@ class LinearProblem:
             for tag in f.subdomain_list:
                 dp.push(L.F_PHI, dp.sub_index[tag], 0, f.phi[tag])
             _push_currents(dp, f)
-            for k, ion in enumerate(f.ion_list[:-1]):
-                if 'f_source' in ion:
-                    src = ion['f_source']
-                    arr = src.x._a if isinstance(src, Function) else np.full(int(dp.n_vert[0]), as_float(src))
-                    dp.push_array(L.F_SOURCE, 0, k, arr)
+            _push_sources(dp, f)
             dp.assemble_knp(splitting_scheme=f.splitting_scheme)
             self.A = dp.csr(L.A_KNP)
             self.P = self.A
@@ -188,6 +193,7 @@ class LinearProblem:
             for tag in f.subdomain_list:
                 dp.push(L.F_PHI, dp.sub_index[tag], 0, f.phi[tag])
             _push_currents(dp, f)
+            _push_sources(dp, f)
             dp.assemble_knp(splitting_scheme=f.splitting_scheme)
         its, relres = dp.solve(which, self.rtol, self.atol, maxit=1000)
         self.solver.iterations, self.solver.residual_norm = its, relres

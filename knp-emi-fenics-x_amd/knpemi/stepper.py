@@ -65,6 +65,10 @@ class DeviceStepper:
                     for k, ion in enumerate(a.ion_list):
                         dp.push(L.F_I_CH, s, j * L.MAX_IONS + k, mm['I_ch_k'][ion['name']])
 
+    def set_source(self, ion_index, values):
+        """Nodal ECS source term of solved ion `ion_index` (`ion['f_source']`, knpWeakForm.py:164-166)."""
+        self.dp.push_array(L.F_SOURCE, 0, int(ion_index), np.ascontiguousarray(values, np.float64))
+
     def add_membrane_model(self, ode_model, stimulus=None, stimulus_locator=None):
         """Register a bound MembraneModel: uploads its tables and stimulus once."""
         dp = self.dp

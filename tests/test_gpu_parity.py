@@ -1,4 +1,6 @@
 """GPU parity tests: HIP kernels (through the C ABI and the knpemi API) against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -585,3 +587,63 @@ def test_device_resident_time_loop_matches_oracle(hip_lib):
             assert rel_err(s.c_prev[t][k].x._a, run.c_all[t][k]) < 1e-8
     assert rel_err(ode.states, run.states) < 1e-6
     assert all(it[1] <= 1000 for it in st.iterations)
+
+
+def _load_stim_driver():
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "examples", "local_astrocyte_depolarization", "run_stim_duration.py")
+    spec = importlib.util.spec_from_file_location("run_stim_duration", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_ecs_source_term_matches_oracle(hip_lib):
+    """`ion['f_source']` on the ECS (knpWeakForm.py:164-166): b_knp with a nodal source field against the oracle."""
+    import adapters
+    from knpemi.fem import Function
+    from knpemi.pdeSolver import create_solver_knp
+    s = Setup("tet", 0)
+    s.perturb()
+    V0 = s.c_prev[0][0].function_space
+    rng = np.random.default_rng(11)
+    src = {}
+    for k, ion in enumerate(s.ion_list[:-1]):
+        f = Function(V0, name=f"f_source_{ion['name']}")
+        f.x.array[:] = 50.0 * rng.uniform(-1, 1, f.x.array.shape[0])
+        ion['f_source'] = f
+        src[k] = f.x._a.copy()
+    o, P, params, ions = adapters.oracle_problem(s)
+    c_all, phi, phiM, mm = adapters.oracle_fields(s)
+    knp = create_solver_knp(s.a_knp, s.L_knp, s.c, s.entity_maps, s.subdomain_list, None, p=s.p_knp)
+    Ak, bk = knp.assemble()
+    Ako, bko = o.assemble_knp(P, params, ions, c_all, phi, phiM, mm, s.dt, f_source=src)
+    _, bko0 = o.assemble_knp(P, params, ions, c_all, phi, phiM, mm, s.dt)
+    assert rel_err(bk, bko) < TOL and csr_rel_err(Ak, Ako) < TOL
+    assert rel_err(bko, bko0) > 1e-6          # the source is visible in the right-hand side
+
+
+def test_stim_duration_driver_device_resident_matches_dropin(hip_lib, tmp_path):
+    """The YAML-configured three-sub-domain driver (neuron HH-mV + glia + pulsed ECS source): twelve
+    steps through the drop-in API (host arrays authoritative, device Krylov solves) and through the device-resident
+    stepper give the same fields; the source switches on and off inside the run and raises ECS K+ in its region."""
+    drv = _load_stim_driver()
+    cfg = drv.load_config("baseline")
+    cfg.update(delay=0.2, period=0.6, pulse_width=0.3, end_time=5.0, save_frequency=1, f_value=97)
+    pa, ha = drv.solve_system(dict(cfg), n_steps=12, device_resident=False, outdir=str(tmp_path / "a"), quiet=True)
+    pb, hb = drv.solve_system(dict(cfg), n_steps=12, device_resident=True, outdir=str(tmp_path / "b"), quiet=True)
+    assert ha["source"] == hb["source"] and 0.0 in ha["source"] and 97.0 in ha["source"]
+    for tag in (0, 1, 2):
+        assert rel_err(pb.phi[tag].x._a - pb.phi[tag].x._a.mean() * 0, pa.phi[tag].x._a) < 1e-5
+        for k in range(2):
+            assert rel_err(pb.c_prev[tag][k].x._a, pa.c_prev[tag][k].x._a) < 1e-8
+    for tag in (1, 2):
+        assert rel_err(pb.phi_M_prev[tag].x._a, pa.phi_M_prev[tag].x._a) < 1e-6
+    # potassium accumulates where it is injected
+    K0 = drv.INIT["K"][0]
+    K = pa.c_prev[0][0].x._a
+    assert K[pa.region].mean() > K0 + 1.0 and abs(K[~pa.region].min() - K0) < 1.0
+    assert os.path.exists(tmp_path / "a" / "step_000011.npz") and os.path.exists(tmp_path / "b" / "step_000011.npz")
+    assert all(0 <= i <= 1000 for i in ha["its_emi"] + ha["its_knp"] + hb["its_emi"] + hb["its_knp"])
