@@ -5,7 +5,8 @@ One "step" = one pass of the hot path over one synthetic field state, device-res
 (SURVEY.md section 8d / BASELINE.md section 2): fused ODE launch (trace refresh + LSODA sweep +
 copy-back), EMI assembly (A, P, b in one pass), KNP assembly (A once, b incl. the membrane
 kernel), end-of-step update.  Krylov solves and file output are excluded.  At N > 1 the mesh is
-N times longer (weak scaling, x-slabs) and every step also exchanges the ghost-dof halos.
+N times longer (weak scaling, x-slabs) and every step also exchanges the ghost-dof halo of the bulk fields
+(stream-ordered RCCL point-to-point, no host synchronisation; ghost membrane dofs are integrated redundantly).
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -211,7 +212,7 @@ def main():
     if halo is not None:
         halo.attach(dp)
         halo.exchange_bulk()        # ghosts start from their owners' values
-        halo.exchange_membrane()
+        halo.exchange_membrane()    # once: afterwards the ghost membrane dofs are integrated redundantly
 
     def sync():
         if dist is not None:

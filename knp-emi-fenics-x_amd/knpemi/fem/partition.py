@@ -5,10 +5,12 @@ The reference is parallelised only through DOLFINx's MPI cell partition with
 `utils.py:100,199,204,254,293`).  Here every rank owns the vertex
 planes of its slab, keeps one layer of ghost cells on its low-x side plus the ghost vertex
 plane on its high-x side, and assembles all rows of its owned vertices locally
-(owner-computes: no matrix communication).  The only exchange is the forward halo of
-dof fields -- bulk fields (c_prev, c_eliminated, phi) after each update, membrane fields
-(phi_M, I_ch) after each ODE sweep -- sent point-to-point to the two x-neighbours with
-`torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+(owner-computes: no matrix communication).  The only exchange is the forward halo of the
+bulk dof fields (c_prev, c_eliminated, phi) after each update, sent point-to-point to the two
+x-neighbours with `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo"
+in the CPU tests).  The membrane dofs of the ghost layer are integrated redundantly (identical
+bits on both ranks), so phi_M / I_ch need no halo; `exchange_membrane` remains for drivers that
+skip ghost dofs.
 """
 from __future__ import annotations
 
@@ -123,6 +125,7 @@ class SlabHalo:
         dev = torch.device("cuda", dp.device)
         n_slots = int(dp.n_models.sum())
         self.width = {"bulk": 4, "mem": 1 + n_slots * L.MAX_IONS}
+        self._ext = torch.cuda.ExternalStream(dp.lib.knpemi_stream(dp.h), device=dev)
         self._dev = {}
         for kind in ("bulk", "mem"):
             for side, pl in self.plans[kind].items():
@@ -145,7 +148,19 @@ class SlabHalo:
             ops += [dist.P2POp(dist.isend, d["send_buf"], d["nb"]), dist.P2POp(dist.irecv, d["recv_buf"], d["nb"])]
         if not ops:
             return
-        dp.sync()                       # packed data is complete before RCCL reads it
+        if dist.get_backend() != "gloo":
+            # RCCL: torch's current stream is the library's stream (ExternalStream), so the send/recv kernels
+            # are ordered after the pack kernel and `wait()` orders the unpack kernel after them: no host
+            # synchronisation anywhere in the exchange (tools/check_async_halo.py rehearses this with real RCCL)
+            with self.torch.cuda.stream(self._ext):
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            for (kd, side), d in self._dev.items():
+                if kd == kind:
+                    L.check(dp.lib.knpemi_halo_unpack(dp.h, k, d["recv_idx"].data_ptr(), d["recv_idx"].numel(),
+                                                      d["recv_buf"].data_ptr()))
+            return
+        dp.sync()                       # packed data is complete before it is staged
         if dist.get_backend() == "gloo":   # single-GPU rehearsal: stage through host memory
             staged, ops = [], []
             for (kd, side), d in self._dev.items():

@@ -122,8 +122,9 @@ class DeviceStepper:
             L.check(lib.knpemi_ode_step(dp.h, m._sub, m._model, float(m.time), self.dt, m.rtol, m.atol,
                                         flags, L.iptr(m._ion_param), int(m.V_index)))
             m.time = m.time + self.dt
-        if halo is not None:
-            halo.exchange_membrane()
+        # Partitioned runs: the membrane dofs of the ghost cell layer are integrated redundantly on both ranks
+        # (same inputs after the bulk halo, deterministic LSODA => identical bits, tools/check_partition_steps.py),
+        # so phi_M / I_ch need no exchange of their own.
         if self.overlap:
             L.check(lib.knpemi_join(dp.h))
             L.check(lib.knpemi_assemble_emi_membrane_rhs(dp.h, self.flags_emi))

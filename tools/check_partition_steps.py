@@ -1,0 +1,134 @@
+"""Multi-step consistency of the x-slab partition on the GPU (rehearsal with gloo, 2+ ranks on one card):
+
+    torchrun --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/check_partition_steps.py [--no-mem-halo]
+
+Every rank steps its slab of the (32 * world) um box K times with the device-resident stepper (bench flow: no
+linear solves) and compares its OWNED membrane fields / ODE states with a single-rank run of the whole box.
+"""
+import argparse, contextlib, io, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "knp-emi-fenics-x_amd"))
+sys.path.insert(0, os.path.join(ROOT, "examples", "idealized_geometries"))
+
+
+def init_fields(s, L_x):
+    """Deterministic functions of the coordinates, so every rank and the global run start from the same state."""
+    for tag in s.subdomain_list:
+        x = s.subdomain_list[tag]['mesh_sub'].x
+        w = np.sin(2 * np.pi * x[:, 0] / L_x) * np.cos(3e6 * x[:, 1]) * np.cos(2e6 * x[:, 2])
+        for k in range(2):
+            s.c_prev[tag][k].x.array[:] *= 1.0 + 1e-3 * w * (1 + k)
+            s.c[tag][k].x.array[:] = s.c_prev[tag][k].x._a
+        s.ion_list[-1][f'c_{tag}'].x.array[:] = -(1.0 / s.ion_list[-1]['z']) * sum(
+            ion['z'] * f.x._a for ion, f in zip(s.ion_list[:-1], s.c_prev[tag]))
+        s.phi[tag].x.array[:] = (-0.0744 if tag > 0 else 0.0) + 1e-3 * w
+
+
+def run(s, K, halo, mem_halo):
+    from knpemi.stepper import DeviceStepper
+    st = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp), s.c, s.c_prev, s.phi, s.phi_M_prev)
+    for mm in s.mem_models:
+        st.add_membrane_model(mm['ode'], s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
+    if halo is not None:
+        halo.attach(st.dp)
+        halo.exchange_bulk()
+        halo.exchange_membrane()
+        if not mem_halo:
+            halo.exchange_membrane = lambda: None
+    for _ in range(K):
+        st.step(halo)
+    st.download()
+    ode = s.mem_models[0]['ode']
+    out = dict(x=ode.dof_locations.copy(), phiM=s.phi_M_prev[1].x._a.copy(), states=ode.states.copy())
+    for n, f in s.mem_models[0]['I_ch_k'].items():
+        out["I_" + n] = f.x._a.copy()
+    # right-hand sides of the last step (they see the ghost membrane dofs through the facets of ghost cells)
+    from knpemi import _lib as L
+    dp = st.dp
+    b_emi, b_knp = dp.rhs(L.B_EMI), dp.rhs(L.B_KNP)
+    rows = dict(x=[], b_emi=[], b_knp0=[], b_knp1=[])
+    off = koff = 0
+    for tag in s.subdomain_list:
+        xs = s.subdomain_list[tag]['mesh_sub'].x
+        n = len(xs)
+        rows["x"].append(np.hstack([xs, np.full((n, 1), float(tag))]))
+        rows["b_emi"].append(b_emi[off:off + n])
+        rows["b_knp0"].append(b_knp[koff:koff + n])
+        rows["b_knp1"].append(b_knp[koff + n:koff + 2 * n])
+        off += n
+        koff += 2 * n
+    out["rows"] = {k: np.concatenate(v) for k, v in rows.items()}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--no-mem-halo", action="store_true")
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--kind", default="tet")
+    a = ap.parse_args()
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    from knpemi.fem.partition import make_slab_problem
+    from knpemi.fem import make_mesh_3D
+    from setup_problem import Setup
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = make_slab_problem(a.kind, 0, rank, world, g_syn=10.0)
+    L_x = s.global_length
+    init_fields(s, L_x)
+    loc = run(s, a.steps, s.halo, not a.no_mem_halo)
+    lay = s.layout
+    hx = L_x / lay.nx
+    plane = np.rint(loc["x"][:, 0] / hx).astype(int)
+    own = (plane >= lay.own_lo) & (plane <= lay.own_hi)
+    rows = loc.pop("rows")
+    rplane = np.rint(rows["x"][:, 0] / hx).astype(int)
+    rown = (rplane >= lay.own_lo) & (rplane <= lay.own_hi)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, ({k: v[own] for k, v in loc.items()}, {k: v[rown] for k, v in rows.items()}))
+    if rank == 0:
+        with contextlib.redirect_stdout(io.StringIO()):
+            ctype = {"tet": "tetrahedron", "hex": "hexahedron"}[a.kind]
+            g = Setup(a.kind, 0, g_syn=10.0, mesh_data=make_mesh_3D(0, ctype, l=2 * world))
+        init_fields(g, L_x)
+        ref = run(g, a.steps, None, True)
+        ref_rows = ref.pop("rows")
+        key = lambda x: tuple(np.rint(x / (hx / 64)).astype(np.int64))
+        lookup = {key(x): i for i, x in enumerate(ref["x"])}
+        rlookup = {key(x): i for i, x in enumerate(ref_rows["x"])}
+        worst = {}
+        n = nr = 0
+        for _, part in gathered:
+            idx = np.array([rlookup[key(x)] for x in part["x"]])
+            nr += len(idx)
+            for k in part:
+                if k == "x":
+                    continue
+                d = np.abs(part[k] - ref_rows[k][idx]).max() / max(np.abs(ref_rows[k]).max(), 1e-300)
+                worst[k] = max(worst.get(k, 0.0), d)
+        print("matrix rows compared:", nr, "of", len(ref_rows["x"]))
+        assert nr == len(ref_rows["x"])
+        for part, _ in gathered:
+            idx = np.array([lookup[key(x)] for x in part["x"]])
+            n += len(idx)
+            for k in part:
+                if k == "x":
+                    continue
+                d = np.abs(part[k] - ref[k][idx]).max() / max(np.abs(ref[k]).max(), 1e-300)
+                worst[k] = max(worst.get(k, 0.0), d)
+        print("membrane dofs compared:", n, "of", len(ref["x"]), "mem halo:", not a.no_mem_halo)
+        print("max relative differences:", worst)
+        assert n == len(ref["x"])
+        assert max(worst.values()) < 1e-12, worst
+        print("PARTITION STEPS OK")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
