@@ -3,9 +3,9 @@
 // (src/knpemi/pdeSolver.py:24-35,99-110: pc_type hypre, boomeramg, one V-cycle per application); this is
 // the MI355X-side counterpart: a V(1,1) cycle with damped-Jacobi smoothing whose levels are CSR SpMVs.
 //
-// Set-up (host, once per hierarchy): strength graph |a_ij| >= theta sqrt(a_ii a_jj), greedy
+// Set-up (host, once per hierarchy): strength graph -a_ij >= theta sqrt(a_ii a_jj), greedy
 // aggregation, tentative piecewise-constant prolongator smoothed once with damped Jacobi
-// (P = (I - 4/(3 rho) D^-1 A) T, rho = the Gershgorin bound of D^-1 A), Galerkin products R A P, until the
+// (P = (I - 4/(3 rho) D^-1 A) T, rho from a few power iterations on D^-1 A), Galerkin products R A P, until the
 // level is small enough for an explicit dense inverse.  The idealized EMI geometries are 35:1 cables meshed with
 // 10:1 elements and sub-domains coupled only through the weak membrane capacitance: the strength graph
 // semi-coarsens the cross-sections and never aggregates across the membrane, which is what brings CG from
@@ -41,14 +41,17 @@ std::vector<double> diagonal(const HostCsr& A) {
 
 // greedy aggregation on the strength graph (three passes: roots with free neighbourhoods, attach
 // leftovers to a neighbouring aggregate, remaining isolated points become their own aggregates)
-int aggregate(const HostCsr& A, const std::vector<double>& d, double theta, std::vector<int>& agg) {
+int aggregate(const HostCsr& A, const std::vector<double>& d, double theta, bool negative_only, std::vector<int>& agg) {
   const int n = A.n;
   std::vector<int> srp(n + 1, 0), sci;
   sci.reserve(A.ci.size());
   for (int i = 0; i < n; ++i) {
     for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
       const int c = A.ci[j];
-      if (c != i && std::fabs(A.v[j]) >= theta * std::sqrt(std::fabs(d[i] * d[c]))) sci.push_back(c);
+      // negative_only: classical strength (-a_ij): the positive couplings of stretched Q1 cells do not carry
+      // smooth error and must not glue aggregates together along the weak direction
+      const double a = negative_only ? -A.v[j] : std::fabs(A.v[j]);
+      if (c != i && a > 0.0 && a >= theta * std::sqrt(std::fabs(d[i] * d[c]))) sci.push_back(c);
     }
     srp[i + 1] = (int)sci.size();
   }
@@ -120,14 +123,38 @@ HostCsr transpose(const HostCsr& A) {
   return T;
 }
 
-double gershgorin_rho(const HostCsr& A, const std::vector<double>& d) {
-  double rho = 0.0;
+// spectral radius of D^-1 A: 15 power iterations (x 1.1), capped by the Gershgorin bound
+double estimate_rho(const HostCsr& A, const std::vector<double>& d) {
+  double bound = 0.0;
   for (int i = 0; i < A.n; ++i) {
     double s = 0.0;
     for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) s += std::fabs(A.v[j]);
-    rho = std::max(rho, s / std::fabs(d[i]));
+    bound = std::max(bound, s / std::fabs(d[i]));
   }
-  return rho > 0 ? rho : 1.0;
+  if (!(bound > 0)) return 1.0;
+  std::vector<double> v(A.n), w(A.n);
+  uint64_t state = 0x9E3779B97F4A7C15ull;   // fixed seed: the hierarchy must be reproducible
+  for (int i = 0; i < A.n; ++i) {
+    state = state * 6364136223846793005ull + 1442695040888963407ull;
+    v[i] = (double)(state >> 11) / 9007199254740992.0 - 0.5;
+  }
+  double lam = bound;
+  for (int it = 0; it < 15; ++it) {
+    double nrm = 0.0;
+    for (int i = 0; i < A.n; ++i) {
+      double s = 0.0;
+      for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) s += A.v[j] * v[A.ci[j]];
+      w[i] = s / d[i];
+      nrm += w[i] * w[i];
+    }
+    nrm = std::sqrt(nrm);
+    if (!(nrm > 0)) return bound;
+    double dot = 0.0, vv = 0.0;
+    for (int i = 0; i < A.n; ++i) { dot += w[i] * v[i]; vv += v[i] * v[i]; }
+    lam = std::fabs(dot / vv);
+    for (int i = 0; i < A.n; ++i) v[i] = w[i] / nrm;
+  }
+  return std::min(bound, 1.1 * lam);
 }
 
 // P = (I - w D^-1 A) T for the piecewise-constant T of `agg`
@@ -318,7 +345,7 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
     KnAmgLevel L;
     L.n = cur.n;
     std::vector<double> d = diagonal(cur);
-    const double rho = gershgorin_rho(cur, d);
+    const double rho = estimate_rho(cur, d);
     L.omega = 4.0 / (3.0 * rho);
     L.avg_row = cur.n ? (int)(cur.ci.size() / (size_t)cur.n) : 0;
     if (l == 0) {   // the finest operator is the caller's CSR of the current step
@@ -334,15 +361,18 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
       // a threshold that leaves (almost) no strong connections stalls the coarsening: relax it for this level
       double th = theta;
       for (int attempt = 0; attempt < 6; ++attempt, th = attempt == 5 ? 0.0 : 0.5 * th) {
-        na = aggregate(cur, d, th, agg);
+        na = aggregate(cur, d, th, G.negative_strength, agg);
         if (na < cur.n * 0.7) break;
       }
     }
     if (cur.n <= n_dense || na >= cur.n * 0.9 || l == max_levels - 1) {
-      if (cur.n > 1024) { kn_set_error("AMG set-up: coarsening stagnated"); return KNPEMI_ESOLVE; }
-      std::vector<double> inv;
-      if (!dense_inverse(cur, singular, inv)) { kn_set_error("AMG set-up: singular coarsest operator"); return KNPEMI_ESOLVE; }
-      if ((rc = upload(G, inv, &L.dense_inv, st))) return rc;
+      // coarsening stalled on a large level (e.g. a mass-dominated operator with no strong connections):
+      // that level is well conditioned for Jacobi, which then stands in for the coarsest solve
+      if (cur.n <= 1024) {
+        std::vector<double> inv;
+        if (!dense_inverse(cur, singular, inv)) { kn_set_error("AMG set-up: singular coarsest operator"); return KNPEMI_ESOLVE; }
+        if ((rc = upload(G, inv, &L.dense_inv, st))) return rc;
+      }
       L.nc = 0;
       G.lev.push_back(L);
       work += 3 * (size_t)cur.n;
@@ -390,8 +420,14 @@ int kn_amg_apply(knpemi_handle* h, KnAmg& G, const double* vals, const double* d
     const double* Av = l == 0 ? vals : L.A.v;
     const double* dinv = l == 0 ? dinv0 : L.dinv;
     if (L.nc == 0) {
-      dim3 g(((size_t)L.n * 64 + 255) / 256);
-      hipLaunchKernelGGL(amg_dense_kernel, g, dim3(256), 0, st, L.n, L.dense_inv, rl, nl == 1 ? out : L.t);
+      double* dst = nl == 1 ? out : L.t;
+      if (L.dense_inv) {
+        dim3 g(((size_t)L.n * 64 + 255) / 256);
+        hipLaunchKernelGGL(amg_dense_kernel, g, dim3(256), 0, st, L.n, L.dense_inv, rl, dst);
+      } else {   // Jacobi level: two damped sweeps from a zero guess
+        launch_spmv<M_PRE>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, nullptr, rl, dinv, L.omega, xl == dst ? L.x : dst, xl);
+        launch_spmv<M_JAC>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, xl, rl, dinv, L.omega, dst);
+      }
       break;
     }
     launch_spmv<M_PRE>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, nullptr, rl, dinv, L.omega, L.t, xl);

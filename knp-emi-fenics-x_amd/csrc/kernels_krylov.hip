@@ -251,6 +251,7 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   KnAmg& G = h->amg_emi;
   const bool amg = h->pc_emi == KNPEMI_PC_AMG;
   if (amg && (!G.built || G.n != n)) {
+    G.negative_strength = true;
     if ((rc = kn_amg_setup(h, G, n, D.rowptr, D.colind, D.A_emi, true))) return rc;
     G.its_ref = -1;
     ++G.builds;
@@ -332,6 +333,7 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   KnAmg& G = h->amg_knp;
   const bool amg = h->pc_knp == KNPEMI_PC_AMG;
   if (amg && (!G.built || G.n != n)) {
+    G.negative_strength = true;
     if ((rc = kn_amg_setup(h, G, n, D.krowptr, D.kcolind, D.A_knp, false))) return rc;
     G.its_ref = -1;
     ++G.builds;

@@ -115,6 +115,7 @@ struct KnAmg {
   std::vector<KnAmgLevel> lev;
   std::vector<void*> allocs;
   bool built = false, singular = false;
+  bool negative_strength = false;    // strength of connection from -a_ij only (classical) instead of |a_ij|
   int n = 0;
   double theta = 0.08;               // strength threshold
   double op_complexity = 1.0;
