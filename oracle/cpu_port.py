@@ -21,6 +21,10 @@ def lib():
         so = os.path.join(HERE, "_build", "libknpemi_cpu.so")
         if not os.path.exists(so):
             subprocess.check_call(["make", "-C", HERE])
+        # keep the OpenMP team spinning between the parallel regions of a step: the regions are short and
+        # separated by Python work, and waking sleeping threads costs more than the regions themselves
+        os.environ.setdefault("OMP_WAIT_POLICY", "ACTIVE")
+        os.environ.setdefault("GOMP_SPINCOUNT", "2000000")   # a few ms, then sleep (do not starve later serial legs)
         _lib = C.CDLL(so)
         _lib.cpu_ode_sweep.restype = C.c_int
     return _lib

@@ -59,11 +59,22 @@ Geo simplex_geo(const double* x, const int* v, int gdim, int nv) {
   return g;
 }
 
+// Scatter-adds are atomic so that the element / facet loops can run under OpenMP (cpu_set_threads > 1: the
+// "all host cores" leg of the CPU baseline, standing in for `mpirun -n <cores>` of the reference).  With one thread
+// the summation order is the loop order.
+int g_threads = 1;
+
+inline void vec_add(double* dst, double v) {
+  if (g_threads == 1) { *dst += v; return; }
+#pragma omp atomic
+  *dst += v;
+}
+
 inline void csr_add(const int* rowptr, const int* colind, double* vals, int row, int col, double v) {
   const int* b = colind + rowptr[row];
   const int* e = colind + rowptr[row + 1];
   const int* p = std::lower_bound(b, e, col);
-  vals[p - colind] += v;
+  vec_add(vals + (p - colind), v);
 }
 
 double facet_measure(const double* x, const int* v, int gdim, int nf) {
@@ -85,6 +96,8 @@ double facet_measure(const double* x, const int* v, int gdim, int nf) {
 
 extern "C" {
 
+void cpu_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+
 // Per-sub-domain constants [S][3]: kap = F psi z^2 D, sig = F z D, D, zpsiD = z psi D, az2D = D z^2.
 // Fields are indexed by global vertex id (sub-domain offset + sub-mesh vertex).
 void cpu_assemble_emi(int gdim, int nv, int nc, const int* cells, const int* cell_sub, const double* x,
@@ -96,6 +109,7 @@ void cpu_assemble_emi(int gdim, int nv, int nc, const int* cells, const int* cel
   std::memset(P, 0, (size_t)nnz * sizeof(double));
   std::memset(b, 0, (size_t)ntot * sizeof(double));
   const double mfac = 1.0 / ((gdim + 1) * (gdim + 2));
+#pragma omp parallel for schedule(static) num_threads(g_threads)
   for (int c = 0; c < nc; ++c) {
     const int* v = cells + (size_t)c * nv;
     const int s = cell_sub[c];
@@ -114,10 +128,11 @@ void cpu_assemble_emi(int gdim, int nv, int nc, const int* cells, const int* cel
         csr_add(rowptr, colind, P, v[i], v[j], s > 0 ? a + g.vol * mfac * (i == j ? 2.0 : 1.0) : a);
         bi -= g.vol * sg[j] * g.G[i][j];
       }
-      b[v[i]] += bi;
+      vec_add(&b[v[i]], bi);
     }
   }
   const double ffac = 1.0 / (nf * (nf + 1));
+#pragma omp parallel for schedule(static) num_threads(g_threads)
   for (int f = 0; f < nF; ++f) {
     const int* E = fe + (size_t)f * nf; const int* I = fi + (size_t)f * nf; const int* Q = fq + (size_t)f * nf;
     const double m = facet_measure(x, E, gdim, nf) * ffac;
@@ -135,8 +150,8 @@ void cpu_assemble_emi(int gdim, int nv, int nc, const int* cells, const int* cel
           csr_add(rowptr, colind, mat, E[a], E[bb], val);
         }
       }
-      b[I[a]] += C_phi * gs;
-      b[E[a]] -= C_phi * gs;
+      vec_add(&b[I[a]], C_phi * gs);
+      vec_add(&b[E[a]], -C_phi * gs);
     }
   }
 }
@@ -155,6 +170,7 @@ void cpu_assemble_knp(int gdim, int nv, int nc, const int* cells, const int* cel
   std::memset(b, 0, (size_t)2 * ntot * sizeof(double));
   const double mfac = 1.0 / ((gdim + 1) * (gdim + 2));
   const double* cc[2] = {c0, c1};
+#pragma omp parallel for schedule(static) num_threads(g_threads)
   for (int c = 0; c < nc; ++c) {
     const int* v = cells + (size_t)c * nv;
     const int s = cell_sub[c];
@@ -172,10 +188,11 @@ void cpu_assemble_knp(int gdim, int nv, int nc, const int* cells, const int* cel
                   mm / dt + Dk[s * 3 + k] * g.vol * g.G[i][j] + zpsiD[s * 3 + k] * drift);
           bi += mm * cc[k][v[j]] / dt;
         }
-        b[ri] += bi;
+        vec_add(&b[ri], bi);
       }
     }
   }
+#pragma omp parallel for schedule(static) num_threads(g_threads)
   for (int f = 0; f < nF; ++f) {
     const int* E = fe + (size_t)f * nf; const int* I = fi + (size_t)f * nf; const int* Q = fq + (size_t)f * nf;
     const int si = f_isub[f];
@@ -200,8 +217,8 @@ void cpu_assemble_knp(int gdim, int nv, int nc, const int* cells, const int* cel
         if (splitting) { ge += dt / C_M * it; gi += dt / C_M * it; }
         for (int a = 0; a < nf; ++a) {
           const double N = qN[q * nf + a];
-          b[krow[(size_t)k * ntot + E[a]]] += w * N * (-Ce * ge + Ce * jump);
-          b[krow[(size_t)k * ntot + I[a]]] += w * N * (Ci * gi - Ci * jump);
+          vec_add(&b[krow[(size_t)k * ntot + E[a]]], w * N * (-Ce * ge + Ce * jump));
+          vec_add(&b[krow[(size_t)k * ntot + I[a]]], w * N * (Ci * gi - Ci * jump));
         }
       }
     }
@@ -212,6 +229,7 @@ void cpu_assemble_knp(int gdim, int nv, int nc, const int* cells, const int* cel
 void cpu_update(int ntot, const int* vsub, const double* cs0, const double* cs1, double* c0, double* c1, double* c2,
                 const double* rho_term, const double* elim, const double* phi, int NQ, const int* q2e, const int* q2i,
                 double* phiM) {
+#pragma omp parallel for schedule(static) num_threads(g_threads)
   for (int g = 0; g < ntot; ++g) {
     c0[g] = cs0[g];
     c1[g] = cs1[g];
@@ -230,6 +248,7 @@ int cpu_ode_sweep(int model, int nq, int ns, int np, double* states, double* par
   if (!init) { lsoda_fill_coef(&cf); init = true; }
   int failed = 0;
   int64_t nfe = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : failed, nfe) num_threads(g_threads)
   for (int q = 0; q < nq; ++q) {
     double* y = states + (size_t)q * ns;
     double* p = params + (size_t)q * np;
