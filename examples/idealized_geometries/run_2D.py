@@ -3,8 +3,8 @@
 
 Same structure as the reference's `examples/idealized_geometries/run_2D.py` (`solve_odes` :80-111,
 time loop :341-372): per step the membrane ODEs, the EMI solve, the KNP solve and the end-of-step
-update, through the knpemi API.  Mesh files (XDMF) and ADIOS2 checkpoints are replaced by the
-in-memory mesh generator and a compressed `.npz` of the final fields (I/O is outside the hot path).
+update, through the knpemi API.  The mesh comes from the in-memory generator or from the XDMF file `make_mesh_2D.py` writes (`--mesh-file`);
+ADIOS2 checkpoints are replaced by a compressed `.npz` of the final fields (I/O is outside the hot path).
 
     python run_2D.py [--res 1] [--steps 10] [--iterative]
 """
@@ -40,8 +40,19 @@ def solve_odes(s, k):
                 ode_model.get_parameter("I_ch_" + ion, I_ch_k)
 
 
-def solve_system(kind, res, n_steps, direct=True, g_syn=10.0, out=None):
-    s = Setup(kind, res, g_syn=g_syn)
+def read_mesh(mesh_file):
+    """run_2D.py:114-134 of the reference, through knpemi.fem.XDMFFile."""
+    from knpemi.fem import XDMFFile
+    with XDMFFile(None, mesh_file, 'r') as xdmf:
+        mesh = xdmf.read_mesh(ghost_mode=None)
+        ct = xdmf.read_meshtags(mesh, name='cell_marker')
+        ft = xdmf.read_meshtags(mesh, name='facet_marker')
+    xdmf.close()
+    return mesh, ct, ft
+
+
+def solve_system(kind, res, n_steps, direct=True, g_syn=10.0, out=None, mesh_file=None):
+    s = Setup(kind, res, g_syn=g_syn, mesh_data=read_mesh(mesh_file) if mesh_file else None)
     problem_emi = create_solver_emi(s.a_emi, s.L_emi, s.phi, s.entity_maps, s.subdomain_list, None,
                                     direct=direct, p=s.p_emi, atol=1e-40, rtol=1e-5)
     problem_knp = create_solver_knp(s.a_knp, s.L_knp, s.c, s.entity_maps, s.subdomain_list, None,
@@ -71,8 +82,9 @@ if __name__ == "__main__":
     ap.add_argument("--res", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--iterative", action="store_true")
+    ap.add_argument("--mesh-file", default=None, help="XDMF mesh written by make_mesh_2D.py (default: generate)")
     a = ap.parse_args()
-    s, it_emi, it_knp = solve_system("2d", a.res, a.steps, direct=not a.iterative,
+    s, it_emi, it_knp = solve_system("2d", a.res, a.steps, direct=not a.iterative, mesh_file=a.mesh_file,
                                      out=os.path.join(HERE, "results", f"2D_{a.res}.npz"))
     v = s.phi_M_prev[1].x._a
     print(f"phi_M after {a.steps} steps: min {v.min():.6f} V, max {v.max():.6f} V")

@@ -19,9 +19,10 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--tets", action="store_true")
     ap.add_argument("--iterative", action="store_true")
+    ap.add_argument("--mesh-file", default=None, help="XDMF mesh written by make_mesh_3D.py (default: generate)")
     a = ap.parse_args()
     s, it_emi, it_knp = solve_system("tet" if a.tets else "hex", a.res, a.steps, direct=not a.iterative,
-                                     g_syn=0.0, out=os.path.join(HERE, "results", f"3D_{a.res}.npz"))
+                                     g_syn=0.0, mesh_file=a.mesh_file, out=os.path.join(HERE, "results", f"3D_{a.res}.npz"))
     v = s.phi_M_prev[1].x._a
     print(f"phi_M after {a.steps} steps: min {v.min():.6f} V, max {v.max():.6f} V")
     print(it_emi)

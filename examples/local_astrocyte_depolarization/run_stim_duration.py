@@ -7,10 +7,11 @@ tag 1 with the HH-mV model, glia tag 2 with the Kir4.1 / pump model), tortuosity
 a source `f_value` in the box [x_L, x_U] x [y_L, y_U] x [z_L, z_U] that is on for `pulse_width` ms every
 `period` ms after `delay` until `end_time`, results every `save_frequency` steps.
 
-Differences (outside the hot path): the emimesh tetrahedral mesh of the reference is not shipped (and there is no
-HDF5 reader here), so `mesh` in the config selects the synthetic four-cell box of `knpemi.fem.make_mesh_3D` scaled
-to centimetres with cells 1,3 tagged neuron and 2,4 glia (or an `.npz` with x / cells / cell_tags / facets /
-facet_tags); XDMF + ADIOS2 output is replaced by one compressed `.npz` per saved step.  The source is a nodal
+Differences (outside the hot path): the emimesh tetrahedral mesh of the reference is not shipped, so unless the
+config names a `mesh_file` (XDMF + HDF5 with `cell_marker` / `facet_marker`, read with `knpemi.fem.XDMFFile`), `mesh`
+selects the synthetic four-cell box of `knpemi.fem.make_mesh_3D` scaled to centimetres with cells 1,3 tagged neuron
+and 2,4 glia; results are one compressed `.npz` per saved step (the ADIOS2 checkpoints' role) and, with `--xdmf`,
+the reference's `results_sub_<tag>.xdmf` / `results_mem_<tag>.xdmf` time series.  The source is a nodal
 P1 field on the ECS (the reference evaluates the UFL conditional at quadrature points: identical when the region
 is a union of cells, a one-cell ramp otherwise).
 
@@ -33,7 +34,6 @@ from knpemi import (create_functions_emi, create_functions_knp, create_solver_em
                     emi_system, knp_system, set_initial_conditions, setup_membrane_model,
                     update_ode_variables, update_pde_variables)
 from knpemi.fem import Constant, Function, extract_submesh, make_mesh_3D  # noqa: E402
-from knpemi.fem.mesh import Mesh, meshtags  # noqa: E402
 from setup_problem import load_model  # noqa: E402
 
 # physical parameters, run_stim_duration.py:215-243 (ms, cm, mM)
@@ -70,16 +70,13 @@ def load_config(name_or_path):
 
 def read_mesh(cfg):
     m = cfg["mesh"]
-    if m.get("file"):
-        d = np.load(m["file"])
-        ctype = {3: "triangle", 4: "tetrahedron", 8: "hexahedron"}[d["cells"].shape[1]] if d["x"].shape[1] == 3 \
-            else "triangle"
-        mesh = Mesh(d["x"], d["cells"], ctype)
-        ct = meshtags(mesh, mesh.gdim, np.arange(len(d["cell_tags"])), d["cell_tags"])
-        facets = mesh.facets
-        lookup = {tuple(sorted(f)): i for i, f in enumerate(facets.tolist())}
-        idx = np.array([lookup[tuple(sorted(f))] for f in d["facets"].tolist()], np.int64)
-        ft = meshtags(mesh, mesh.gdim - 1, idx, d["facet_tags"])
+    if cfg.get("mesh_file"):            # the reference's key: XDMF with cell_marker / facet_marker (:61-80)
+        from knpemi.fem import XDMFFile
+        path = cfg["mesh_file"] if os.path.isabs(cfg["mesh_file"]) else os.path.join(HERE, cfg["mesh_file"])
+        with XDMFFile(None, path, "r") as xdmf:
+            mesh = xdmf.read_mesh(ghost_mode=None)
+            ct = xdmf.read_meshtags(mesh, name="cell_marker")
+            ft = xdmf.read_meshtags(mesh, name="facet_marker")
         return mesh, ct, ft
     mesh, ct, ft = make_mesh_3D(int(m["resolution_factor"]), m["cell_type"], l=int(m["length"]),
                                 axon_tags=(1, 2, 1, 2))
@@ -115,7 +112,6 @@ class Problem:
                 sd.update(mesh_mem=g, mem_to_parent=g2p)
         self.dt = DT
         le, li = cfg["lambda_e"], cfg["lambda_i"]
-        idx = {"K": 0, "Na": 0, "Cl": 0}
         rho = {"z": -1}
         for tag in subs:
             rho[tag] = Constant(subs[tag]["mesh_sub"], INIT["Na"][tag] + INIT["K"][tag] - INIT["Cl"][tag])
@@ -123,7 +119,6 @@ class Problem:
             "dt": Constant(mesh, DT), "n_steps_ODE": Constant(mesh, DT), "F": Constant(mesh, FARADAY),
             "psi": Constant(mesh, PSI), "C_phi": Constant(mesh, C_M / DT), "C_M": Constant(mesh, C_M),
             "R": Constant(mesh, RGAS), "temperature": Constant(mesh, TEMPERATURE), "rho": rho}
-        del idx
 
         def per_sub(e, i):
             return {0: Constant(subs[0]["mesh_sub"], e), 1: Constant(subs[1]["mesh_sub"], i),
@@ -133,7 +128,6 @@ class Problem:
             return {t: Constant(subs[t]["mesh_sub"], INIT[name][t]) for t in subs}
 
         # ECS source fields (nodal): +f on K, -f on Na inside the region while the pulse is on
-        V0 = None
         self.region = source_region(subs[0]["mesh_sub"].x, cfg)
         Na = {"c_init": init("Na"), "z": 1.0, "name": "Na", "D": per_sub(D_NA / le ** 2, D_NA / li ** 2)}
         K = {"c_init": init("K"), "z": 1.0, "name": "K", "D": per_sub(D_K / le ** 2, D_K / li ** 2)}
@@ -187,6 +181,33 @@ def solve_odes(p, k):
                 ode_model.get_parameter("I_ch_" + ion, I_ch_k)
 
 
+class XdmfResults:
+    """results_sub_<tag>.xdmf / results_mem_<tag>.xdmf time series as the reference writes them
+    (run_stim_duration.py:36-90,442-463), through knpemi.fem.XDMFFile."""
+
+    def __init__(self, p, outdir):
+        from knpemi.fem import XDMFFile
+        self.sub, self.mem = {}, {}
+        for tag, sd in p.subdomain_list.items():
+            self.sub[tag] = XDMFFile(None, os.path.join(outdir, f"results_sub_{tag}.xdmf"), "w")
+            self.sub[tag].write_mesh(sd["mesh_sub"])
+            if tag > 0:
+                self.mem[tag] = XDMFFile(None, os.path.join(outdir, f"results_mem_{tag}.xdmf"), "w")
+                self.mem[tag].write_mesh(sd["mesh_mem"])
+
+    def write(self, p, t):
+        for tag in p.subdomain_list:
+            self.sub[tag].write_function(p.phi[tag], t)
+            for f in p.c[tag]:
+                self.sub[tag].write_function(f, t)
+            if tag > 0:
+                self.mem[tag].write_function(p.phi_M_prev[tag], t)
+
+    def close(self):
+        for f in list(self.sub.values()) + list(self.mem.values()):
+            f.close()
+
+
 def write_results(p, outdir, k, t):
     fields = {}
     for tag in p.subdomain_list:
@@ -199,13 +220,14 @@ def write_results(p, outdir, k, t):
     np.savez_compressed(os.path.join(outdir, f"step_{k:06d}.npz"), t=t, **fields)
 
 
-def solve_system(config, n_steps=None, device_resident=False, direct=False, outdir=None, quiet=False):
+def solve_system(config, n_steps=None, device_resident=False, direct=False, outdir=None, quiet=False, xdmf=False):
     p = Problem(config)
     n_total = int(round(config["Tstop"] / float(DT)))
     n_steps = n_total if n_steps is None else min(n_steps, n_total)
     if outdir is None:
         outdir = os.path.join(HERE, "results", str(config["fname"]))
     os.makedirs(outdir, exist_ok=True)
+    xdmf_out = XdmfResults(p, outdir) if xdmf else None
     history = dict(t=[], source=[], phi_M_neuron=[], phi_M_glia=[], K_ecs_max=[], its_emi=[], its_knp=[])
     t = 0.0
 
@@ -239,6 +261,8 @@ def solve_system(config, n_steps=None, device_resident=False, direct=False, outd
                 e, kk = st.iterations[-2][1], st.iterations[-1][1]
                 record(e, kk)
                 write_results(p, outdir, k, t)
+                if xdmf_out:
+                    xdmf_out.write(p, t)
                 if not quiet:
                     print(f"t = {t:.2f} ms  source {'on ' if history['source'][-1] else 'off'}  "
                           f"phi_M neuron {history['phi_M_neuron'][-1]:.4f} glia {history['phi_M_glia'][-1]:.4f} mV")
@@ -261,6 +285,10 @@ def solve_system(config, n_steps=None, device_resident=False, direct=False, outd
             if (k % config["save_frequency"]) == 0 or k == n_steps - 1:
                 record(problem_emi.solver.getIterationNumber(), problem_knp.solver.getIterationNumber())
                 write_results(p, outdir, k, t)
+                if xdmf_out:
+                    xdmf_out.write(p, t)
+    if xdmf_out:
+        xdmf_out.close()
     history["wall_s"] = time.perf_counter() - t_wall
     history["steps"] = n_steps
     return p, history
@@ -273,8 +301,10 @@ if __name__ == "__main__":
     parser.add_argument("--steps", type=int, default=None, help="stop after this many steps (default: Tstop / dt)")
     parser.add_argument("--device-resident", action="store_true", help="DeviceStepper + device Krylov solves")
     parser.add_argument("--direct", action="store_true", help="host LU solves (MUMPS stand-in)")
+    parser.add_argument("--xdmf", action="store_true", help="also write results_sub_/results_mem_ XDMF time series")
     args = parser.parse_args()
     cfg = load_config(args.c)
-    _, hist = solve_system(cfg, n_steps=args.steps, device_resident=args.device_resident, direct=args.direct)
+    _, hist = solve_system(cfg, n_steps=args.steps, device_resident=args.device_resident, direct=args.direct,
+                           xdmf=args.xdmf)
     print(f"{hist['steps']} steps in {hist['wall_s']:.2f} s; phi_M neuron {hist['phi_M_neuron'][-1]:.4f} mV, "
           f"glia {hist['phi_M_glia'][-1]:.4f} mV, max ECS K {hist['K_ecs_max'][-1]:.4f} mM")

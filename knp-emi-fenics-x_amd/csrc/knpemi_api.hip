@@ -419,6 +419,22 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
     h->lds_doubles_knp = std::max(h->lds_doubles_knp, rowptrL[g1] - rowptrL[g0]);
   }
 
+  if (getenv("KNPEMI_DEBUG_LDS")) {
+    // distribution of the per-block LDS needs (the launch uses the maxima)
+    std::vector<int> segs, uniq;
+    for (int b = 0; b < nblocks; ++b) {
+      int g0 = blk_row0[b], g1 = g0 + blk_nrows[b];
+      segs.push_back(rowptr[g1] - rowptr[g0]);
+      uniq.push_back(blk_info[(size_t)b * 16 + 13]);
+    }
+    std::sort(segs.begin(), segs.end());
+    std::sort(uniq.begin(), uniq.end());
+    auto pct = [&](const std::vector<int>& v, double p) { return v[(size_t)(p * (v.size() - 1))]; };
+    fprintf(stderr, "[knpemi] blocks %d lpr %d | EMI segment doubles: p50 %d p90 %d p99 %d max %d | distinct vertices: p50 %d p90 %d p99 %d max %d\n",
+            nblocks, LPR, pct(segs, .5), pct(segs, .9), pct(segs, .99), segs.back(), pct(uniq, .5), pct(uniq, .9), pct(uniq, .99),
+            uniq.back());
+  }
+
   // ---- upload --------------------------------------------------------------------------------------------
   KnDev& D = h->dev;
   D.Ntot = Ntot; D.nctot = nctot; D.NQtot = NQtot; D.nftot = nftot; D.nblocks = nblocks;

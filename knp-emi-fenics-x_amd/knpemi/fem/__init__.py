@@ -5,3 +5,4 @@ from .mesh import (CELL_INFO, CellType, EntityMap, Mesh, MeshTags, compute_inter
                    transfer_meshtags_to_submesh)
 from .function import Constant, Function, FunctionSpace, Vector, as_float, functionspace
 from .idealized import make_mesh_2D, make_mesh_3D, make_mesh_mms
+from .xdmf import XDMFFile

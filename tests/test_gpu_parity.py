@@ -633,7 +633,8 @@ def test_stim_duration_driver_device_resident_matches_dropin(hip_lib, tmp_path):
     cfg = drv.load_config("baseline")
     cfg.update(delay=0.2, period=0.6, pulse_width=0.3, end_time=5.0, save_frequency=1, f_value=97)
     pa, ha = drv.solve_system(dict(cfg), n_steps=12, device_resident=False, outdir=str(tmp_path / "a"), quiet=True)
-    pb, hb = drv.solve_system(dict(cfg), n_steps=12, device_resident=True, outdir=str(tmp_path / "b"), quiet=True)
+    pb, hb = drv.solve_system(dict(cfg), n_steps=12, device_resident=True, outdir=str(tmp_path / "b"), quiet=True,
+                              xdmf=True)
     assert ha["source"] == hb["source"] and 0.0 in ha["source"] and 97.0 in ha["source"]
     for tag in (0, 1, 2):
         assert rel_err(pb.phi[tag].x._a - pb.phi[tag].x._a.mean() * 0, pa.phi[tag].x._a) < 1e-5
@@ -646,4 +647,8 @@ def test_stim_duration_driver_device_resident_matches_dropin(hip_lib, tmp_path):
     K = pa.c_prev[0][0].x._a
     assert K[pa.region].mean() > K0 + 1.0 and abs(K[~pa.region].min() - K0) < 1.0
     assert os.path.exists(tmp_path / "a" / "step_000011.npz") and os.path.exists(tmp_path / "b" / "step_000011.npz")
+    # the XDMF time series holds the last saved membrane potential of the glial cell
+    from knpemi.fem import hdf5
+    with hdf5.File(str(tmp_path / "b" / "results_mem_2.h5"), "r") as h5:
+        assert np.array_equal(h5.read("/Function/phi_M_2/11").ravel(), pb.phi_M_prev[2].x._a)
     assert all(0 <= i <= 1000 for i in ha["its_emi"] + ha["its_knp"] + hb["its_emi"] + hb["its_knp"])
