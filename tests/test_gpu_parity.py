@@ -179,6 +179,16 @@ def test_abi_error_paths(hip_lib):
     assert hip_lib.knpemi_assemble_emi(None, 0) == L.EINVAL
     n, nnz = C.c_int64(), C.c_int64()
     assert hip_lib.knpemi_csr_dims(dp.h, 7, C.byref(n), C.byref(nnz)) == L.EINVAL
+    # solver entry points
+    assert hip_lib.knpemi_solver_setup(dp.h, 9, L.PC_AMG, 0.0) == L.EINVAL
+    assert hip_lib.knpemi_solver_setup(dp.h, L.B_EMI, 5, 0.0) == L.EINVAL
+    assert hip_lib.knpemi_solver_setup(None, L.B_EMI, L.PC_AMG, 0.0) == L.EINVAL
+    it, rr = C.c_int(), C.c_double()
+    assert hip_lib.knpemi_solve_emi(dp.h, -1.0, 0.0, 10, C.byref(it), C.byref(rr)) == L.EINVAL
+    assert hip_lib.knpemi_solve_knp(dp.h, 1e-5, 0.0, -3, C.byref(it), C.byref(rr)) == L.EINVAL
+    lev, b = C.c_int(), C.c_int()
+    assert hip_lib.knpemi_solver_info(dp.h, L.B_KNP, C.byref(lev), C.byref(rr), C.byref(b)) == L.OK
+    assert lev.value == 0 and b.value == 0           # nothing built before the first solve
 
 
 @pytest.mark.parametrize("kind,r", [("2d", 1), ("tet", 0), ("hex", 0)])
