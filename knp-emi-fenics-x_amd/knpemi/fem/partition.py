@@ -128,58 +128,55 @@ class SlabHalo:
         self._ext = torch.cuda.ExternalStream(dp.lib.knpemi_stream(dp.h), device=dev)
         self._dev = {}
         for kind in ("bulk", "mem"):
-            for side, pl in self.plans[kind].items():
-                w = self.width[kind]
-                self._dev[(kind, side)] = dict(
-                    nb=pl["nb"],
-                    send_idx=torch.from_numpy(pl["send"]).to(dev), recv_idx=torch.from_numpy(pl["recv"]).to(dev),
-                    send_buf=torch.empty(len(pl["send"]) * w, dtype=torch.float64, device=dev),
-                    recv_buf=torch.empty(len(pl["recv"]) * w, dtype=torch.float64, device=dev))
+            # one packed buffer per direction and kind: both neighbours' entries are packed / unpacked by a single
+            # kernel launch, the point-to-point operations work on slices of it
+            w = self.width[kind]
+            sides = list(self.plans[kind].values())
+            if not sides:
+                continue
+            send_idx = np.concatenate([pl["send"] for pl in sides]).astype(np.int32)
+            recv_idx = np.concatenate([pl["recv"] for pl in sides]).astype(np.int32)
+            d = dict(send_idx=torch.from_numpy(send_idx).to(dev), recv_idx=torch.from_numpy(recv_idx).to(dev),
+                     send_buf=torch.empty(len(send_idx) * w, dtype=torch.float64, device=dev),
+                     recv_buf=torch.empty(len(recv_idx) * w, dtype=torch.float64, device=dev), parts=[])
+            so = ro = 0
+            for pl in sides:
+                ns, nr = len(pl["send"]) * w, len(pl["recv"]) * w
+                d["parts"].append((pl["nb"], slice(so, so + ns), slice(ro, ro + nr)))
+                so, ro = so + ns, ro + nr
+            self._dev[kind] = d
 
     def _exchange(self, kind):
         L, dp, dist = self.L, self.dp, self.dist
-        k = 0 if kind == "bulk" else 1
-        ops = []
-        for (kd, side), d in self._dev.items():
-            if kd != kind:
-                continue
-            L.check(dp.lib.knpemi_halo_pack(dp.h, k, d["send_idx"].data_ptr(), d["send_idx"].numel(),
-                                            d["send_buf"].data_ptr()))
-            ops += [dist.P2POp(dist.isend, d["send_buf"], d["nb"]), dist.P2POp(dist.irecv, d["recv_buf"], d["nb"])]
-        if not ops:
+        d = self._dev.get(kind)
+        if d is None:
             return
+        k = 0 if kind == "bulk" else 1
+        L.check(dp.lib.knpemi_halo_pack(dp.h, k, d["send_idx"].data_ptr(), d["send_idx"].numel(),
+                                        d["send_buf"].data_ptr()))
         if dist.get_backend() != "gloo":
             # RCCL: torch's current stream is the library's stream (ExternalStream), so the send/recv kernels
             # are ordered after the pack kernel and `wait()` orders the unpack kernel after them: no host
             # synchronisation anywhere in the exchange (tools/check_async_halo.py rehearses this with real RCCL)
+            ops = []
+            for nb, ss, rs in d["parts"]:
+                ops += [dist.P2POp(dist.isend, d["send_buf"][ss], nb), dist.P2POp(dist.irecv, d["recv_buf"][rs], nb)]
             with self.torch.cuda.stream(self._ext):
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
-            for (kd, side), d in self._dev.items():
-                if kd == kind:
-                    L.check(dp.lib.knpemi_halo_unpack(dp.h, k, d["recv_idx"].data_ptr(), d["recv_idx"].numel(),
-                                                      d["recv_buf"].data_ptr()))
-            return
-        dp.sync()                       # packed data is complete before it is staged
-        if dist.get_backend() == "gloo":   # single-GPU rehearsal: stage through host memory
-            staged, ops = [], []
-            for (kd, side), d in self._dev.items():
-                if kd == kind:
-                    sb, rb = d["send_buf"].cpu(), self.torch.empty(d["recv_buf"].shape, dtype=self.torch.float64)
-                    staged.append((d, rb))
-                    ops += [dist.P2POp(dist.isend, sb, d["nb"]), dist.P2POp(dist.irecv, rb, d["nb"])]
+        else:                           # single-GPU rehearsal: stage through host memory
+            dp.sync()
+            sb = d["send_buf"].cpu()
+            rb = self.torch.empty(d["recv_buf"].shape, dtype=self.torch.float64)
+            ops = []
+            for nb, ss, rs in d["parts"]:
+                ops += [dist.P2POp(dist.isend, sb[ss], nb), dist.P2POp(dist.irecv, rb[rs], nb)]
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
-            for d, rb in staged:
-                d["recv_buf"].copy_(rb)
-        else:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        self.torch.cuda.current_stream().synchronize()
-        for (kd, side), d in self._dev.items():
-            if kd == kind:
-                L.check(dp.lib.knpemi_halo_unpack(dp.h, k, d["recv_idx"].data_ptr(), d["recv_idx"].numel(),
-                                                  d["recv_buf"].data_ptr()))
+            d["recv_buf"].copy_(rb)
+            self.torch.cuda.current_stream().synchronize()
+        L.check(dp.lib.knpemi_halo_unpack(dp.h, k, d["recv_idx"].data_ptr(), d["recv_idx"].numel(),
+                                          d["recv_buf"].data_ptr()))
 
     def exchange_bulk(self):
         self._exchange("bulk")
