@@ -113,11 +113,30 @@ inline void lsoda_fill_coef(LsodaCoef* c) {
 // the results are bit-identical to LANES = 1), the right-hand side is evaluated component-wise by
 // `F::rhs_lane` after an all-gather of the state, and the N x N iteration matrix is gathered and
 // factorised redundantly by every lane.
+#if defined(__HIP_DEVICE_COMPILE__)
+// Exchange inside an aligned group of four lanes as a DPP quad permute on the two halves of the double: a
+// register-to-register move (two v_mov_b32_dpp), where __shfl / __shfl_xor go through the LDS crossbar
+// (ds_bpermute, ~100 cycles).  CTRL = quad_perm[0] | [1] << 2 | [2] << 4 | [3] << 6.  All lanes of a group are
+// active together (they take identical decisions), so no lane ever reads a disabled neighbour.
+template <int CTRL>
+__device__ __forceinline__ double kn_dpp_quad(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+#endif
+
 template <int L>
 KN_HD double kn_group_max(double v) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (L == 2 || L == 4) {
+    v = fmax(v, kn_dpp_quad<0xB1>(v));                      // lanes 1 0 3 2
+    if constexpr (L == 4) v = fmax(v, kn_dpp_quad<0x4E>(v));   // lanes 2 3 0 1
+  } else {
 #pragma unroll
-  for (int m = 1; m < L; m <<= 1) v = fmax(v, __shfl_xor(v, m));
+    for (int m = 1; m < L; m <<= 1) v = fmax(v, __shfl_xor(v, m));
+  }
 #endif
   return v;
 }
@@ -125,7 +144,16 @@ KN_HD double kn_group_max(double v) {
 template <int L>
 KN_HD double kn_group_get(double v, int k) {   // value held by lane k of this lane's group
 #if defined(__HIP_DEVICE_COMPILE__)
-  return __shfl(v, (int)((__lane_id() & ~(unsigned)(L - 1)) | (unsigned)k));
+  if constexpr (L == 4) {
+    switch (k) {   // k is a compile-time constant at every call site (unrolled loops)
+      case 0: return kn_dpp_quad<0x00>(v);
+      case 1: return kn_dpp_quad<0x55>(v);
+      case 2: return kn_dpp_quad<0xAA>(v);
+      default: return kn_dpp_quad<0xFF>(v);
+    }
+  } else {
+    return __shfl(v, (int)((__lane_id() & ~(unsigned)(L - 1)) | (unsigned)k));
+  }
 #else
   (void)k;
   return v;
