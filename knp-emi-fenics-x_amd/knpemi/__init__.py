@@ -1,27 +1,18 @@
 """knpemi -- MI355X-native hot path of the KNP-EMI solver (drop-in for `src/knpemi`).
 
-Exports the names the reference's package imports (`src/knpemi/__init__.py:1-16`);
-its `__all__` lists names that do not exist and is not reproduced.
+Re-exports the twelve public names of the reference package (`src/knpemi/__init__.py:1-16`).  The reference's
+`__all__` names several functions that do not exist; the list below is the set that can actually be imported
+from it.  The device-resident loop of this implementation lives in `knpemi.stepper`.
 """
-from knpemi.odeSolver import MembraneModel
+from .emiWeakForm import create_functions_emi, emi_system
+from .knpWeakForm import create_functions_knp, knp_system
+from .odeSolver import MembraneModel
+from .pdeSolver import create_solver_emi, create_solver_knp
+from .utils import (interpolate_to_membrane, set_initial_conditions, setup_membrane_model, update_ode_variables,
+                    update_pde_variables)
 
-from knpemi.emiWeakForm import emi_system
-from knpemi.emiWeakForm import create_functions_emi
-
-from knpemi.knpWeakForm import knp_system
-from knpemi.knpWeakForm import create_functions_knp
-
-from knpemi.utils import set_initial_conditions
-from knpemi.utils import setup_membrane_model
-from knpemi.utils import interpolate_to_membrane
-from knpemi.utils import update_ode_variables
-from knpemi.utils import update_pde_variables
-
-from knpemi.pdeSolver import create_solver_emi
-from knpemi.pdeSolver import create_solver_knp
-
-__all__ = [
-    "MembraneModel", "emi_system", "create_functions_emi", "knp_system", "create_functions_knp",
-    "set_initial_conditions", "setup_membrane_model", "interpolate_to_membrane",
-    "update_ode_variables", "update_pde_variables", "create_solver_emi", "create_solver_knp",
-]
+__all__ = sorted([
+    "MembraneModel", "create_functions_emi", "create_functions_knp", "create_solver_emi", "create_solver_knp",
+    "emi_system", "interpolate_to_membrane", "knp_system", "set_initial_conditions", "setup_membrane_model",
+    "update_ode_variables", "update_pde_variables",
+])
