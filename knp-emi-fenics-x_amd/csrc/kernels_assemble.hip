@@ -88,6 +88,71 @@ __device__ __forceinline__ void facet_mass_row(const Rec (&p)[NF], int a, double
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Membrane part of an EMI row: coupling C_phi (u_i - u_e)(v_i - v_e) and Robin RHS
+// (emiWeakForm.py:160-165,228-239).  Everything static about the (row, facet) entries e0 .. e0 + ne - 1 was
+// flattened at set-up -- model slot, the facet-mass row (computed once on the device by
+// `membrane_mass_kernel`, same `facet_mass_row` as before), the Q dofs and the byte-packed CSR slots -- so the
+// row needs one level of loads for the matrix and one more (phi_M) for the right-hand side, instead of the
+// former chain row -> list pointer -> entry -> facet -> vertex ids -> vertex records.
+// ---------------------------------------------------------------------------------------------
+template <int NF>
+__device__ __forceinline__ double emi_membrane_entry_rhs(const KnDev& D, const KnConsts& C, int e, int ms, int splitting) {
+  double gs = 0.0;
+#pragma unroll
+  for (int bb = 0; bb < NF; ++bb) {
+    const int q = D.me_q[(size_t)e * NF + bb];
+    double gq = D.phiM[q];
+    if (!(splitting & 1)) {
+      double it = 0.0;
+      for (int k = 0; k < KN_MAXK; ++k) it += D.Ich[((size_t)ms * KN_MAXK + k) * D.NQtot + q];
+      gq -= it / C.C_phi;
+    }
+    gs += D.me_mass[(size_t)e * NF + bb] * gq;
+  }
+  return gs;
+}
+
+template <int NF>
+__device__ __forceinline__ void emi_membrane_row(const KnDev& D, const KnConsts& C, int e0, int ne, bool cell_side,
+                                                 int rowbase, double* accA, double* accP, bool acc_p, int splitting,
+                                                 double& gam) {
+  for (int e = e0; e < e0 + ne; ++e) {
+    const int ms = D.me_model[e];
+    if (ms < 0) continue;
+    const uint64_t sl = D.mslots[e];
+#pragma unroll
+    for (int bb = 0; bb < NF; ++bb) {
+      const double val = C.C_phi * D.me_mass[(size_t)e * NF + bb];
+      const int io = rowbase + (int)((sl >> (8 * bb)) & 255);
+      const int it2 = rowbase + (int)((sl >> (8 * (4 + bb))) & 255);
+      unsafeAtomicAdd(&accA[io], val);
+      unsafeAtomicAdd(&accA[it2], -val);
+      if (acc_p) { unsafeAtomicAdd(&accP[io], val); unsafeAtomicAdd(&accP[it2], -val); }
+    }
+    if (!(splitting & 2))
+      gam += (cell_side ? 1.0 : -1.0) * C.C_phi * emi_membrane_entry_rhs<NF>(D, C, e, ms, splitting);
+  }
+}
+
+// one-time fill of the facet-mass rows of the membrane entries (set-up; geometry is static)
+template <int NF>
+__global__ void membrane_mass_kernel(KnDev D, int n_entries, int v_cells, const int* __restrict__ entry_row,
+                                     double* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_entries) return;
+  const int ent = D.mentry[e];
+  const int fg = ent >> 3, a = ent & 7;
+  const int* fown = entry_row[e] >= v_cells ? D.fi : D.fe;
+  Rec p[NF];
+#pragma unroll
+  for (int bb = 0; bb < NF; ++bb) p[bb] = load_rec(D.VR, fown[(size_t)fg * NF + bb]);
+  double Mr[NF];
+  facet_mass_row<NF>(p, a, Mr);
+#pragma unroll
+  for (int bb = 0; bb < NF; ++bb) out[(size_t)e * NF + bb] = Mr[bb];
+}
+
 // =============================================================================================
 // Simplex row kernels, version 2: neighbour records staged in LDS.
 //
@@ -246,7 +311,7 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
   const bool cell_side = s > 0;
   double bacc = 0.0, gam = 0.0;   // volume part / membrane Robin part of b_emi
   if (valid) {
-    const int rowbase = ri.x, lap = ri.y, rL = ri.z;
+    const int rowbase = ri.x, lap = ri.y & 0xFFFF, ne = (unsigned)ri.y >> 16, rL = ri.z;
     // The diagonal entry receives a term from every pair: keep it in registers and add it once.
     // P differs from A only on cell-side rows (ICS mass), so ECS rows accumulate A alone.
     const bool acc_p = want_p && cell_side;
@@ -291,42 +356,7 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
       unsafeAtomicAdd(&accA[lap + diag], dA);
       if (acc_p) unsafeAtomicAdd(&accP[lap + diag], dP);
     }
-    // membrane coupling C_phi (u_i - u_e)(v_i - v_e) and Robin RHS (emiWeakForm.py:160-165,228-239)
-    const int m = sub == 0 ? ri.w : -1;
-    if (m >= 0) {
-      const int* fown = cell_side ? D.fi : D.fe;
-      for (int e = D.mptr[m]; e < D.mptr[m + 1]; ++e) {
-        const int ent = D.mentry[e];
-        const int fg = ent >> 3, a = ent & 7;
-        const int ms = D.fmodel[fg];
-        if (ms < 0) continue;
-        const uint64_t sl = D.mslots[e];
-        Rec p[NF];
-#pragma unroll
-        for (int bb = 0; bb < NF; ++bb) p[bb] = load_rec(D.VR, fown[(size_t)fg * NF + bb]);
-        double Mr[NF];
-        facet_mass_row<NF>(p, a, Mr);
-        double gs = 0.0;
-#pragma unroll
-        for (int bb = 0; bb < NF; ++bb) {
-          const int q = D.fq[(size_t)fg * NF + bb];
-          double gq = D.phiM[q];
-          if (!(splitting & 1)) {
-            double it = 0.0;
-            for (int k = 0; k < KN_MAXK; ++k) it += D.Ich[((size_t)ms * KN_MAXK + k) * D.NQtot + q];
-            gq -= it / C.C_phi;
-          }
-          gs += Mr[bb] * gq;
-          const double val = C.C_phi * Mr[bb];
-          const int io = rowbase + (int)((sl >> (8 * bb)) & 255);
-          const int it2 = rowbase + (int)((sl >> (8 * (4 + bb))) & 255);
-          unsafeAtomicAdd(&accA[io], val);
-          unsafeAtomicAdd(&accA[it2], -val);
-          if (acc_p) { unsafeAtomicAdd(&accP[io], val); unsafeAtomicAdd(&accP[it2], -val); }
-        }
-        if (!(splitting & 2)) gam += (cell_side ? 1.0 : -1.0) * C.C_phi * gs;
-      }
-    }
+    if (sub == 0 && ne > 0) emi_membrane_row<NF>(D, C, ri.w, ne, cell_side, rowbase, accA, accP, acc_p, splitting, gam);
   }
 #pragma unroll
   for (int m = 1; m < LPR; m <<= 1) bacc += __shfl_xor(bacc, m);
@@ -341,7 +371,7 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
 
 template <int GDIM, int LPR>
 __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n, int rec_n) {
-  constexpr int NV = GDIM + 1, NF = GDIM;
+  constexpr int NV = GDIM + 1;
   const KnConsts& C = *Cp;
   extern __shared__ __align__(16) double lds[];
   double* acc0 = lds;
@@ -412,17 +442,13 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
       unsafeAtomicAdd(&acc0[rL + diag], d0);
       unsafeAtomicAdd(&acc1[rL + diag], d1);
     }
-    // membrane Robin/coupling contributions, precomputed per (facet, side) by knp_membrane_kernel
-    const int m = sub == 0 ? ri.w : -1;
-    if (m >= 0) {
-      const int side = s > 0 ? 1 : 0;
-      for (int e = D.mptr[m]; e < D.mptr[m + 1]; ++e) {
-        const int ent = D.mentry[e];
-        const int fg = ent >> 3, a = ent & 7;
-        if (D.fmodel[fg] < 0) continue;
-        const double* cg = D.gam_contrib + ((size_t)(fg * 2 + side) * NF + a) * 2;
-        b0 += cg[0];
-        b1 += cg[1];
+    // membrane Robin/coupling contributions, written per (row, facet) entry by knp_membrane_kernel
+    if (sub == 0) {
+      const int ne = (unsigned)ri.y >> 16;
+      for (int e = ri.w; e < ri.w + ne; ++e) {
+        const double2 gc = *reinterpret_cast<const double2*>(D.gam_e + 2 * (size_t)e);
+        b0 += gc.x;
+        b1 += gc.y;
       }
     }
   }
@@ -698,7 +724,7 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
   const bool cell_side = s > 0;
   double bacc = 0.0, gam = 0.0;
   if (valid) {
-    const int rowbase = ri.x, lap = ri.y, rL = ri.z;
+    const int rowbase = ri.x, lap = ri.y & 0xFFFF, ne = (unsigned)ri.y >> 16, rL = ri.z;
     const bool acc_p = want_p && cell_side;
     auto do_pair = [&](int pc, uint2 sl) {
       const int li = pc & 7;
@@ -723,42 +749,7 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
       const int pc = D.pair_cell[ent];
       if (pc >= 0) do_pair(pc, *reinterpret_cast<const uint2*>(D.pair_slots + 2 * ent));
     }
-    // membrane coupling C_phi (u_i - u_e)(v_i - v_e) and Robin RHS (emiWeakForm.py:160-165,228-239)
-    const int m = sub == 0 ? ri.w : -1;
-    if (m >= 0) {
-      const int* fown = cell_side ? D.fi : D.fe;
-      for (int e = D.mptr[m]; e < D.mptr[m + 1]; ++e) {
-        const int ent = D.mentry[e];
-        const int fg = ent >> 3, a = ent & 7;
-        const int ms = D.fmodel[fg];
-        if (ms < 0) continue;
-        const uint64_t sl = D.mslots[e];
-        Rec p[NF];
-#pragma unroll
-        for (int bb = 0; bb < NF; ++bb) p[bb] = load_rec(D.VR, fown[(size_t)fg * NF + bb]);
-        double Mr[NF];
-        facet_mass_row<NF>(p, a, Mr);
-        double gs = 0.0;
-#pragma unroll
-        for (int bb = 0; bb < NF; ++bb) {
-          const int q = D.fq[(size_t)fg * NF + bb];
-          double gq = D.phiM[q];
-          if (!(splitting & 1)) {
-            double it = 0.0;
-            for (int k = 0; k < KN_MAXK; ++k) it += D.Ich[((size_t)ms * KN_MAXK + k) * D.NQtot + q];
-            gq -= it / C.C_phi;
-          }
-          gs += Mr[bb] * gq;
-          const double val = C.C_phi * Mr[bb];
-          const int io = rowbase + (int)((sl >> (8 * bb)) & 255);
-          const int it2 = rowbase + (int)((sl >> (8 * (4 + bb))) & 255);
-          unsafeAtomicAdd(&accA[io], val);
-          unsafeAtomicAdd(&accA[it2], -val);
-          if (acc_p) { unsafeAtomicAdd(&accP[io], val); unsafeAtomicAdd(&accP[it2], -val); }
-        }
-        if (!(splitting & 2)) gam += (cell_side ? 1.0 : -1.0) * C.C_phi * gs;
-      }
-    }
+    if (sub == 0 && ne > 0) emi_membrane_row<NF>(D, C, ri.w, ne, cell_side, rowbase, accA, accP, acc_p, splitting, gam);
   }
 #pragma unroll
   for (int m = 1; m < LPR; m <<= 1) bacc += __shfl_xor(bacc, m);
@@ -773,7 +764,6 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
 
 template <int LPR, bool AFFINE>
 __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n, int rec_n) {
-  constexpr int NF = 4;
   const KnConsts& C = *Cp;
   extern __shared__ __align__(16) double lds[];
   double* acc0 = lds;
@@ -830,16 +820,12 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDe
       const int pc = D.pair_cell[ent];
       if (pc >= 0) do_pair(pc, *reinterpret_cast<const uint2*>(D.pair_slots + 2 * ent));
     }
-    const int m = sub == 0 ? ri.w : -1;
-    if (m >= 0) {
-      const int side = s > 0 ? 1 : 0;
-      for (int e = D.mptr[m]; e < D.mptr[m + 1]; ++e) {
-        const int ent = D.mentry[e];
-        const int fg = ent >> 3, a = ent & 7;
-        if (D.fmodel[fg] < 0) continue;
-        const double* cg = D.gam_contrib + ((size_t)(fg * 2 + side) * NF + a) * 2;
-        b0 += cg[0];
-        b1 += cg[1];
+    if (sub == 0) {
+      const int ne = (unsigned)ri.y >> 16;
+      for (int e = ri.w; e < ri.w + ne; ++e) {
+        const double2 gc = *reinterpret_cast<const double2*>(D.gam_e + 2 * (size_t)e);
+        b0 += gc.x;
+        b1 += gc.y;
       }
     }
   }
@@ -880,10 +866,10 @@ __global__ __launch_bounds__(256) void knp_membrane_kernel(KnDev D, const KnCons
   const int fg = t >> 1;
   const bool cell_side = t & 1;
   const int ms = D.fmodel[fg];
-  double* out = D.gam_contrib + (size_t)t * NF * 2;
+  const int* pos = D.gam_pos + (size_t)t * NF;   // entry of (facet, side, local vertex) in the membrane row lists
   if (ms < 0) {
 #pragma unroll
-    for (int i = 0; i < NF * 2; ++i) out[i] = 0.0;
+    for (int a = 0; a < NF; ++a) *reinterpret_cast<double2*>(D.gam_e + 2 * (size_t)pos[a]) = double2{0.0, 0.0};
     return;
   }
   Rec pe[NF], pi[NF];
@@ -959,7 +945,7 @@ __global__ __launch_bounds__(256) void knp_membrane_kernel(KnDev D, const KnCons
     }
   }
 #pragma unroll
-  for (int a = 0; a < NF; ++a) { out[2 * a] = acc0[a]; out[2 * a + 1] = acc1[a]; }
+  for (int a = 0; a < NF; ++a) *reinterpret_cast<double2*>(D.gam_e + 2 * (size_t)pos[a]) = double2{acc0[a], acc1[a]};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1042,31 +1028,11 @@ __global__ __launch_bounds__(256) void emi_membrane_rhs_kernel(KnDev D, const Kn
   if (m >= D.M) return;
   const int g = D.mrow[m];
   const bool cell_side = g >= C.voff[1];
-  const int* fown = cell_side ? D.fi : D.fe;
   double gam = 0.0;
   for (int e = D.mptr[m]; e < D.mptr[m + 1]; ++e) {
-    const int ent = D.mentry[e];
-    const int fg = ent >> 3, a = ent & 7;
-    const int ms = D.fmodel[fg];
+    const int ms = D.me_model[e];
     if (ms < 0) continue;
-    Rec p[NF];
-#pragma unroll
-    for (int bb = 0; bb < NF; ++bb) p[bb] = load_rec(D.VR, fown[(size_t)fg * NF + bb]);
-    double Mr[NF];
-    facet_mass_row<NF>(p, a, Mr);
-    double gs = 0.0;
-#pragma unroll
-    for (int bb = 0; bb < NF; ++bb) {
-      const int q = D.fq[(size_t)fg * NF + bb];
-      double gq = D.phiM[q];
-      if (!splitting) {
-        double it = 0.0;
-        for (int k = 0; k < KN_MAXK; ++k) it += D.Ich[((size_t)ms * KN_MAXK + k) * D.NQtot + q];
-        gq -= it / C.C_phi;
-      }
-      gs += Mr[bb] * gq;
-    }
-    gam += (cell_side ? 1.0 : -1.0) * C.C_phi * gs;
+    gam += (cell_side ? 1.0 : -1.0) * C.C_phi * emi_membrane_entry_rhs<NF>(D, C, e, ms, splitting);
   }
   D.b_emi[g] = D.b_emi[g] + gam;
 }
@@ -1200,6 +1166,17 @@ int kn_launch_knp_rows(knpemi_handle* h, int flags) {
   if (D.nblocks == 0) return KNPEMI_OK;
   if (h->NV == 8) return launch_knp_hex_v2(h);
   return h->gdim == 2 ? launch_knp_v2<2>(h) : launch_knp_v2<3>(h);
+}
+
+int kn_launch_membrane_mass(knpemi_handle* h, int n_entries, const int* d_entry_row, double* d_out) {
+  if (n_entries == 0) return KNPEMI_OK;
+  const KnDev& D = h->dev;
+  dim3 grid((n_entries + 255) / 256), block(256);
+  const int v_cells = h->voff[1];
+  if (h->NF == 2) hipLaunchKernelGGL(membrane_mass_kernel<2>, grid, block, 0, h->stream, D, n_entries, v_cells, d_entry_row, d_out);
+  else if (h->NF == 3) hipLaunchKernelGGL(membrane_mass_kernel<3>, grid, block, 0, h->stream, D, n_entries, v_cells, d_entry_row, d_out);
+  else hipLaunchKernelGGL(membrane_mass_kernel<4>, grid, block, 0, h->stream, D, n_entries, v_cells, d_entry_row, d_out);
+  return check_launch("membrane_mass_kernel");
 }
 
 int kn_launch_knp_membrane(knpemi_handle* h, int flags) {

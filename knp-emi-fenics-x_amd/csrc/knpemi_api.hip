@@ -348,6 +348,7 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
 
   // ---- membrane rows ----------------------------------------------------------------------------------
   std::vector<int> gam_idx(Ntot, -1), mptr(1, 0), mentry, mrow;
+  std::vector<int> me_model, me_q, me_row, gam_pos((size_t)std::max(1, nftot) * 2 * NF, 0);
   std::vector<uint64_t> mslots;
   for (size_t i = 0; i < ment.size();) {
     int g = ment[i].first;
@@ -367,8 +368,12 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
         sl |= so << (8 * b);
         sl |= st << (8 * (4 + b));
       }
+      gam_pos[((size_t)fg * 2 + (ecs ? 0 : 1)) * NF + (ment[i].second & 7)] = (int)mentry.size();
       mentry.push_back(ment[i].second);
       mslots.push_back(sl);
+      me_model.push_back(fmodel[fg]);
+      me_row.push_back(g);
+      for (int b = 0; b < NF; ++b) me_q.push_back(fq[(size_t)fg * NF + b]);
     }
     mptr.push_back((int)mentry.size());
   }
@@ -405,10 +410,14 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
     }
     for (int g = g0; g < g1; ++g) {
       int* ri = &row_info[(size_t)g * 4];
+      const int m = gam_idx[g];
+      const int ne = m < 0 ? 0 : mptr[m + 1] - mptr[m];
       ri[0] = rowptr[g] - rowptr[g0];
       ri[1] = ri[0] + lapoff[g];
+      if (ri[1] > 0xFFFF || ne > 0x7FFF) return fail(KNPEMI_EINVAL, "row block too large for the packed row descriptor");
+      ri[1] |= ne << 16;
       ri[2] = rowptrL[g] - rowptrL[g0];
-      ri[3] = gam_idx[g];
+      ri[3] = m < 0 ? 0 : mptr[m];
     }
   }
 
@@ -466,11 +475,13 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   if ((rc = dev_upload(h, lapoff, &D.lapoff))) return rc;
   if ((rc = dev_upload(h, rowptrL, &D.rowptrL))) return rc;
   if ((rc = dev_upload(h, colindL, &D.colindL))) return rc;
-  if ((rc = dev_upload(h, gam_idx, &D.gam_idx))) return rc;
   if ((rc = dev_upload(h, mptr, &D.mptr))) return rc;
   if ((rc = dev_upload(h, mentry, &D.mentry))) return rc;
   if ((rc = dev_upload(h, mslots, &D.mslots))) return rc;
   if ((rc = dev_upload(h, mrow, &D.mrow))) return rc;
+  if ((rc = dev_upload(h, me_model, &D.me_model))) return rc;
+  if ((rc = dev_upload(h, me_q, &D.me_q))) return rc;
+  if ((rc = dev_upload(h, gam_pos, &D.gam_pos))) return rc;
   if ((rc = dev_upload(h, fe, &D.fe))) return rc;
   if ((rc = dev_upload(h, fi, &D.fi))) return rc;
   if ((rc = dev_upload(h, fq, &D.fq))) return rc;
@@ -485,7 +496,7 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   if ((rc = dev_zeros(h, (size_t)(K - 1) * D.nnzL, &D.A_knp))) return rc;
   if ((rc = dev_zeros(h, (size_t)(K - 1) * Ntot, &D.b_knp))) return rc;
   if ((rc = dev_zeros(h, (size_t)NQtot, &D.phiM))) return rc;
-  if ((rc = dev_zeros(h, (size_t)std::max(1, nftot) * 2 * NF * 2, &D.gam_contrib))) return rc;
+  if ((rc = dev_zeros(h, std::max<size_t>(1, mentry.size()) * 2, &D.gam_e))) return rc;
   if ((rc = dev_zeros(h, (size_t)std::max(1, h->moff[S]) * K * std::max(1, NQtot), &D.Ich))) return rc;
   {
     std::vector<int> krp((size_t)(K - 1) * Ntot + 1, 0), kci((size_t)(K - 1) * colindL.size());
@@ -510,6 +521,17 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
     std::vector<double> qt;
     D.nq_gamma = kn_gamma_quadrature(NF, &qt);
     if ((rc = dev_upload(h, qt, &D.qtab))) return rc;
+  }
+
+  {   // facet-mass rows of the membrane entries: static geometry, computed once by the device code the kernels share
+    const int n_entries = (int)mentry.size();
+    double* mass = nullptr;
+    if ((rc = dev_zeros(h, std::max<size_t>(1, (size_t)n_entries * NF), &mass))) return rc;
+    D.me_mass = mass;
+    const int* d_rows = nullptr;
+    if ((rc = dev_upload(h, me_row, &d_rows))) return rc;
+    if ((rc = kn_launch_membrane_mass(h, n_entries, d_rows, mass))) return rc;
+    KN_HIP(hipStreamSynchronize(h->stream));
   }
 
   KnConsts& C = h->consts;

@@ -51,7 +51,8 @@ struct KnDev {
                               //   {4 x uint8 slice steps, #distinct vertices, 0, 0}
   const int* blk_uverts;      // concatenated per-block sorted lists of the distinct vertices its rows touch
   const uint16_t* ent_loc;    // [nnzL] position of every Laplacian entry's vertex in its block's list
-  const int4* row_info;       // [Ntot]: {rowptr[g] - seg0, that + lapoff[g], rowptrL[g] - segL0, gam_idx[g]}
+  const int4* row_info;       // [Ntot]: {rowptr[g] - seg0, (that + lapoff[g]) | n_membrane_entries << 16, rowptrL[g] - segL0,
+                              //          first membrane entry}
   double* VR;                 // [Ntot][KN_REC]
   double* csol;               // [K-1][Ntot]  solver output c (block order handled by offsets)
   double* fsrc;               // [K-1][N_0] optional ECS source term (NULL when unused)
@@ -72,15 +73,19 @@ struct KnDev {
   const int* krowptr; const int* kcolind; // monolithic block-diagonal KNP pattern (Krylov solve, export)
   int64_t nnz, nnzL;
   // membrane
-  const int* gam_idx;         // [Ntot] membrane-row index or -1
   const int* mptr;            // [M+1]
   const int* mentry;          // facet*8 + local vertex a
   const uint64_t* mslots;     // bytes 0..3 own-side slot of col b, bytes 4..7 other-side slot
   const int* mrow;            // [M] global row of each membrane row
+  // per membrane entry e = (row, facet, local vertex): model slot (-1: none), Q dofs of the facet, facet-mass row
+  const int* me_model;        // [E]
+  const int* me_q;            // [E][NF]
+  const double* me_mass;      // [E][NF], filled once by membrane_mass_kernel
+  const int* gam_pos;         // [nftot][2 sides][NF] -> entry e
   const int* fe; const int* fi; const int* fq;   // [nftot][NF] global ids
   const int* fmodel;          // [nftot] global model slot or -1
   const int* q2e; const int* q2i;                // [NQtot] global vertex ids
-  double* gam_contrib;        // [nftot][2 sides][NF][2 ions] membrane partial integrals of b_knp
+  double* gam_e;              // [E][2 ions] membrane partial integrals of b_knp, in entry order
   double* phiM;               // [NQtot]
   double* Ich;                // [n_model_slots][K][stride NQtot] (indexed by global q)
   int M;
@@ -201,6 +206,7 @@ int kn_launch_emi_rows(knpemi_handle* h, int flags);
 int kn_launch_knp_rows(knpemi_handle* h, int flags);
 int kn_launch_emi_membrane_rhs(knpemi_handle* h, int flags);
 int kn_launch_knp_membrane(knpemi_handle* h, int flags);
+int kn_launch_membrane_mass(knpemi_handle* h, int n_entries, const int* d_entry_row, double* d_out);
 int kn_launch_ode_step(knpemi_handle* h, int slot, double t0, double dt, double rtol, double atol,
                        int flags, const int32_t* ion_param, int v_index);
 int kn_launch_update_pde(knpemi_handle* h);
