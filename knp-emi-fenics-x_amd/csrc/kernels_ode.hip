@@ -44,6 +44,15 @@ __global__ __launch_bounds__(ODE_BLOCK) void ode_step_kernel(KnDev D, OdeArgs a,
   // LSODA's dynamically indexed state (Nordsieck history, method coefficients, and for LANES = 1 the
   // iteration matrix) lives in LDS, one column per lane; the rest stays in registers.
   __shared__ double work[Integrator::WORK * ODE_BLOCK];
+  // LSODA's coefficient tables (3.9 kB) are consulted at every step with a per-lane order index: keep the
+  // workgroup's copy in LDS instead of paying a global-memory round trip each time
+  __shared__ LsodaCoef scf;
+  {
+    const double* src = reinterpret_cast<const double*>(cf);
+    double* dst = reinterpret_cast<double*>(&scf);
+    for (int i = threadIdx.x; i < (int)(sizeof(LsodaCoef) / sizeof(double)); i += ODE_BLOCK) dst[i] = src[i];
+    __syncthreads();
+  }
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
   const int q = gt / LANES, comp = gt % LANES;
   if (q >= a.nq) return;
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(ODE_BLOCK) void ode_step_kernel(KnDev D, OdeArgs a,
     for (int i = 0; i < a.n_stim; ++i) p[a.stim_idx[i]] = a.stim_val[i];
   Integrator s;
   s.f.prepare(p);
-  const int rc = s.integrate(cf, work + threadIdx.x, y, a.t0, a.t0 + a.dt, a.rtol, a.atol, 10000, comp);
+  const int rc = s.integrate(&scf, work + threadIdx.x, y, a.t0, a.t0 + a.dt, a.rtol, a.atol, 10000, comp);
   // 3. write back: state row, phi_M_prev <- V; the lane that owns V stores the currents (the reference's
   //    RHS side effect) into the parameter row and the I_ch_k fields
 #pragma unroll
