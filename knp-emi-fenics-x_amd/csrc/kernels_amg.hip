@@ -336,7 +336,7 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
     if (!(x == x)) { kn_set_error("AMG set-up: operator contains NaN"); return KNPEMI_EINVAL; }
 
   const double theta = G.theta;
-  const int n_dense = 256, max_levels = 12;
+  const int n_dense = 640, max_levels = 12;
   int rc;
   G.singular = singular;
   size_t work = 0;

@@ -19,11 +19,12 @@ constexpr int RED_BLOCKS = 512, RED_THREADS = 256;
 // sc[] layout (device scalars)
 enum { S_RHO = 0, S_RHO_OLD, S_PAP, S_ALPHA, S_BETA, S_OMEGA, S_RR, S_BB, S_TS, S_TT, S_MEAN, S_TMP, S_N };
 
-// y = A * (x .* dinv?) : 16 lanes per row
+// y = A * (x .* dinv?), or (dinv == NULL, b != NULL) the residual y = b - A x : 16 lanes per row
 template <bool SCALED>
 __global__ __launch_bounds__(256) void spmv_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ colind,
                                                    const double* __restrict__ vals, const double* __restrict__ x,
-                                                   const double* __restrict__ dinv, double* __restrict__ y) {
+                                                   const double* __restrict__ dinv, double* __restrict__ y,
+                                                   const double* __restrict__ b = nullptr) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int row = t >> 4, l = t & 15;
   double acc = 0.0;
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void spmv_kernel(int n, const int* __restrict_
   }
 #pragma unroll
   for (int m = 8; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
-  if (row < n && l == 0) y[row] = acc;
+  if (row < n && l == 0) y[row] = (!SCALED && b) ? b[row] - acc : acc;
 }
 
 __global__ void diag_inv_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ colind,
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(RED_THREADS) void dots_kernel(int n, int nd, const 
   switch (op) {
     case OP_STORE3: sc[d0] = v0; if (nd > 1) sc[d1] = v1; if (nd > 2) sc[d2] = v2; break;
     case OP_MEAN: sc[S_MEAN] = v0 * scale; break;
-    case OP_CG_INIT: sc[S_RHO] = v0; sc[S_RR] = v1; break;                                  // r.z, r.r
+    case OP_CG_INIT: sc[S_RHO] = v0; sc[S_RR] = v1; if (nd > 2) sc[S_BB] = v2; break;          // r.z, r.r[, b.b]
     case OP_CG_PAP: sc[S_PAP] = v0; sc[S_ALPHA] = sc[S_RHO] / v0; break;                     // p.Ap
     case OP_CG_RHO: sc[S_BETA] = v0 / sc[S_RHO]; sc[S_RHO] = v0; sc[S_RR] = v1; break;       // r.z, r.r
     case OP_BI_RHO:                                                                          // rhat.r
@@ -146,6 +147,21 @@ __global__ void bicg_update_kernel(int n, const double* __restrict__ sc, double*
   r[i] = sres[i] - sc[S_OMEGA] * t[i];
 }
 
+// KNP unknowns: `csol` is ion-major over the global vertex numbering ([k][g]); the solver works in the
+// reference's block order [sub-domain][ion][vertex] (pdeSolver.py:117).  to_blocks: x = csol, else csol = x.
+__global__ void knp_order_kernel(int ntot, int ks, int n_sub, const KnConsts* __restrict__ Cp, double* __restrict__ x,
+                                 double* __restrict__ csol, int to_blocks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ks * ntot) return;
+  const int k = i / ntot, g = i - k * ntot;
+  int sd = 0;
+  for (int t = 1; t < n_sub; ++t) sd += g >= Cp->voff[t];
+  const int v0 = Cp->voff[sd], nv = Cp->voff[sd + 1] - v0;
+  const size_t xb = (size_t)ks * v0 + (size_t)k * nv + (g - v0);
+  if (to_blocks) x[xb] = csol[i];
+  else csol[i] = x[xb];
+}
+
 struct Ctx {
   knpemi_handle* h;
   int n;
@@ -155,10 +171,11 @@ struct Ctx {
 
 inline dim3 grid1(int n) { return dim3((n + 255) / 256); }
 
-void spmv(const Ctx& c, const double* x, double* y, const double* dinv) {
+void spmv(const Ctx& c, const double* x, double* y, const double* dinv, const double* b = nullptr) {
   dim3 g(((size_t)c.n * 16 + 255) / 256);
-  if (dinv) hipLaunchKernelGGL((spmv_kernel<true>), g, dim3(256), 0, c.h->stream, c.n, c.rowptr, c.colind, c.vals, x, dinv, y);
-  else hipLaunchKernelGGL((spmv_kernel<false>), g, dim3(256), 0, c.h->stream, c.n, c.rowptr, c.colind, c.vals, x, dinv, y);
+  if (dinv) hipLaunchKernelGGL((spmv_kernel<true>), g, dim3(256), 0, c.h->stream, c.n, c.rowptr, c.colind, c.vals, x, dinv, y,
+                               (const double*)nullptr);
+  else hipLaunchKernelGGL((spmv_kernel<false>), g, dim3(256), 0, c.h->stream, c.n, c.rowptr, c.colind, c.vals, x, dinv, y, b);
 }
 
 void dots(const Ctx& c, int nd, const double* a0, const double* b0, const double* a1, const double* b1, const double* a2,
@@ -261,13 +278,11 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     vec(c, V_JACOBI, z, nullptr, r, dinv);
     return KNPEMI_OK;
   };
-  const int chunk = amg ? 2 : 8;
-  spmv(c, x, q, nullptr);
-  vec(c, V_RESID, r, nullptr, b, q);
+  const int chunk = amg ? 1 : 8;   // a V-cycle costs ~15 launches: test convergence after every iteration
+  spmv(c, x, r, nullptr, b);                                   // r = b - A x
   if ((rc = precond())) return rc;
   vec(c, V_COPY, p, nullptr, z, nullptr);
-  dots(c, 2, r, z, r, r, nullptr, nullptr, OP_CG_INIT);
-  dots(c, 1, b, b, nullptr, nullptr, nullptr, nullptr, OP_STORE3, S_BB);
+  dots(c, 3, r, z, r, r, b, b, OP_CG_INIT);                    // r.z, r.r and b.b in one launch
   double sc[S_N];
   if ((rc = read_scalars(c, sc, S_N))) return rc;
   const double bnorm = std::sqrt(sc[S_BB]);
@@ -322,13 +337,7 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   double *phat = h->kry + 8 * N, *shat = h->kry + 9 * N;
   Ctx c{h, n, D.krowptr, D.kcolind, D.A_knp, h->kry + 11 * N, h->kry + 11 * N + 64};
   // x0 = previous concentrations in the block order [c[0][0], c[0][1], c[1][0], ...]
-  for (int sd = 0; sd < h->n_sub; ++sd)
-    for (int k = 0; k < KS; ++k) {
-      const size_t nv = h->n_vert[sd];
-      if (!nv) continue;
-      KN_HIP(hipMemcpyAsync(x + (size_t)KS * h->voff[sd] + k * nv, D.csol + (size_t)k * D.Ntot + h->voff[sd],
-                            nv * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    }
+  hipLaunchKernelGGL(knp_order_kernel, grid1(n), dim3(256), 0, h->stream, D.Ntot, KS, h->n_sub, h->d_consts, x, D.csol, 1);
   hipLaunchKernelGGL(diag_inv_kernel, grid1(n), dim3(256), 0, h->stream, n, c.rowptr, c.colind, c.vals, dinv);
   KnAmg& G = h->amg_knp;
   const bool amg = h->pc_knp == KNPEMI_PC_AMG;
@@ -338,15 +347,13 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     G.its_ref = -1;
     ++G.builds;
   }
-  spmv(c, x, v, nullptr);
-  vec(c, V_RESID, r, nullptr, D.b_knp, v);
+  spmv(c, x, r, nullptr, D.b_knp);                             // r = b - A x
   vec(c, V_COPY, rhat, nullptr, r, nullptr);
   KN_HIP(hipMemsetAsync(p, 0, (size_t)n * sizeof(double), h->stream));
   KN_HIP(hipMemsetAsync(v, 0, (size_t)n * sizeof(double), h->stream));
   double init[S_N] = {0};
   init[S_RHO] = init[S_ALPHA] = init[S_OMEGA] = 1.0;
   KN_HIP(hipMemcpyAsync(c.sc, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
-  KN_HIP(hipStreamSynchronize(h->stream));
   dots(c, 2, r, r, D.b_knp, D.b_knp, nullptr, nullptr, OP_STORE3, S_RR, S_BB);
   double sc[S_N];
   if ((rc = read_scalars(c, sc, S_N))) return rc;
@@ -389,13 +396,7 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     rn = std::sqrt(sc[S_RR]);
     if (!(rn == rn)) { kn_set_error("KNP BiCGStab broke down (NaN residual)"); return KNPEMI_EINVAL; }
   }
-  for (int sd = 0; sd < h->n_sub; ++sd)
-    for (int k = 0; k < KS; ++k) {
-      const size_t nv = h->n_vert[sd];
-      if (!nv) continue;
-      KN_HIP(hipMemcpyAsync(D.csol + (size_t)k * D.Ntot + h->voff[sd], x + (size_t)KS * h->voff[sd] + k * nv,
-                            nv * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    }
+  hipLaunchKernelGGL(knp_order_kernel, grid1(n), dim3(256), 0, h->stream, D.Ntot, KS, h->n_sub, h->d_consts, x, D.csol, 0);
   if (iters) *iters = it;
   if (relres) *relres = bnorm > 0 ? rn / bnorm : rn;
   hipError_t e = hipGetLastError();
