@@ -115,8 +115,7 @@ __device__ __forceinline__ double emi_membrane_entry_rhs(const KnDev& D, const K
 
 template <int NF>
 __device__ __forceinline__ void emi_membrane_row(const KnDev& D, const KnConsts& C, int e0, int ne, bool cell_side,
-                                                 int rowbase, double* accA, double* accP, bool acc_p, int splitting,
-                                                 double& gam) {
+                                                 int rowbase, double* accA, int splitting, double& gam) {
   for (int e = e0; e < e0 + ne; ++e) {
     const int ms = D.me_model[e];
     if (ms < 0) continue;
@@ -128,7 +127,6 @@ __device__ __forceinline__ void emi_membrane_row(const KnDev& D, const KnConsts&
       const int it2 = rowbase + (int)((sl >> (8 * (4 + bb))) & 255);
       unsafeAtomicAdd(&accA[io], val);
       unsafeAtomicAdd(&accA[it2], -val);
-      if (acc_p) { unsafeAtomicAdd(&accP[io], val); unsafeAtomicAdd(&accP[it2], -val); }
     }
     if (!(splitting & 2))
       gam += (cell_side ? 1.0 : -1.0) * C.C_phi * emi_membrane_entry_rhs<NF>(D, C, e, ms, splitting);
@@ -284,8 +282,7 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
   const KnConsts& C = *Cp;
   extern __shared__ __align__(16) double lds[];
   double* accA = lds;
-  double* accP = lds + acc_n;
-  double* recs = lds + 2 * (size_t)acc_n;
+  double* recs = lds + (size_t)acc_n;
   uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + 6 * (size_t)rec_n);
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
@@ -303,7 +300,7 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
     slr[p] = (valid && p < np) ? D.pair_sl[base + (int64_t)p * KN_SLICE] : 0xFFFFFFFFu;
   const int4 ri = D.row_info[g];
   // phase A: zero accumulators, stage the records of the block's Laplacian entries
-  for (int i = tid; i < seglen; i += KN_BLOCK) { accA[i] = 0.0; accP[i] = 0.0; }
+  for (int i = tid; i < seglen; i += KN_BLOCK) accA[i] = 0.0;
   stage_records<false>(D, B, recs, eloc, tid, 0.0, nullptr, 0);
   __syncthreads();
 
@@ -313,10 +310,8 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
   if (valid) {
     const int rowbase = ri.x, lap = ri.y & 0xFFFF, ne = (unsigned)ri.y >> 16, rL = ri.z;
     // The diagonal entry receives a term from every pair: keep it in registers and add it once.
-    // P differs from A only on cell-side rows (ICS mass), so ECS rows accumulate A alone.
-    const bool acc_p = want_p && cell_side;
     int diag = -1;
-    double dA = 0.0, dP = 0.0;
+    double dA = 0.0;
     Rec6 r[NV];
     auto do_pair = [&](uint32_t sl) {
       int slot[NV];
@@ -334,16 +329,10 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
         sd += (sc.sig[0] * r[j].a + sc.sig[1] * r[j].b + sc.sig[2] * r[j].c) * d[j];
       }
       const double kbar = (sc.kap[0] * cb0 + sc.kap[1] * cb1 + sc.kap[2] * cb2) * (1.0 / NV);
-      const double m = vol * (1.0 / ((GDIM + 1) * (GDIM + 2)));
       bacc -= vol * sd;
       dA += vol * kbar * d[0];
-      dP += vol * kbar * d[0] + 2.0 * m;
 #pragma unroll
-      for (int j = 1; j < NV; ++j) {
-        const double a = vol * kbar * d[j];
-        unsafeAtomicAdd(&accA[lap + slot[j]], a);
-        if (acc_p) unsafeAtomicAdd(&accP[lap + slot[j]], a + m);
-      }
+      for (int j = 1; j < NV; ++j) unsafeAtomicAdd(&accA[lap + slot[j]], vol * kbar * d[j]);
     };
 #pragma unroll
     for (int p = 0; p < KN_PREFETCH; ++p)
@@ -352,11 +341,8 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
       const uint32_t sl = D.pair_sl[base + (int64_t)p * KN_SLICE];
       if (sl != 0xFFFFFFFFu) do_pair(sl);
     }
-    if (diag >= 0) {
-      unsafeAtomicAdd(&accA[lap + diag], dA);
-      if (acc_p) unsafeAtomicAdd(&accP[lap + diag], dP);
-    }
-    if (sub == 0 && ne > 0) emi_membrane_row<NF>(D, C, ri.w, ne, cell_side, rowbase, accA, accP, acc_p, splitting, gam);
+    if (diag >= 0) unsafeAtomicAdd(&accA[lap + diag], dA);
+    if (sub == 0 && ne > 0) emi_membrane_row<NF>(D, C, ri.w, ne, cell_side, rowbase, accA, splitting, gam);
   }
 #pragma unroll
   for (int m = 1; m < LPR; m <<= 1) bacc += __shfl_xor(bacc, m);
@@ -365,7 +351,7 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
   for (int i = tid; i < seglen; i += KN_BLOCK) {
     const double a = accA[i];
     D.A_emi[seg0 + i] = a;
-    if (want_p) D.P_emi[seg0 + i] = cell_side ? accP[i] : a;
+    if (want_p) D.P_emi[seg0 + i] = cell_side ? a + D.P_mass[seg0 + i - D.pmass0] : a;
   }
 }
 
@@ -628,17 +614,17 @@ __device__ __forceinline__ double hex_interp(const hexq::Point& P, const double 
   return s;
 }
 
-// Row l of the EMI element matrices of one hexahedron: ra = kappa-stiffness, rm = mass (ICS rows), and
-// the volume right-hand side (emiWeakForm.py:138-241).
-template <bool MASS, bool AFFINE>
+// Row l of the EMI element matrix of one hexahedron: ra = kappa-stiffness, and the volume right-hand side
+// (emiWeakForm.py:138-241).  The ICS mass of P_emi is static and added at write-out (D.P_mass).
+template <bool AFFINE>
 __device__ __forceinline__ void hex_emi_row(const Rec6 (&r)[8], int li, const KnSubConst& sc, double (&ra)[8],
-                                            double (&rm)[8], double& bvol) {
+                                            double& bvol) {
   double kv[8], sv[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     kv[j] = sc.kap[0] * r[j].a + sc.kap[1] * r[j].b + sc.kap[2] * r[j].c;
     sv[j] = sc.sig[0] * r[j].a + sc.sig[1] * r[j].b + sc.sig[2] * r[j].c;
-    ra[j] = 0.0; rm[j] = 0.0;
+    ra[j] = 0.0;
   }
   double ds[3][4];
   hex_edge_diffs(sv, ds);
@@ -658,7 +644,6 @@ __device__ __forceinline__ void hex_emi_row(const Rec6 (&r)[8], int li, const Kn
     const double wk = G.wd * kq;
     const double v[3] = {G.w[0] * wk, G.w[1] * wk, G.w[2] * wk};
     hex_add_grad_dot(P, ra, v);
-    if (MASS) hex_add_shape(P, rm, G.wd * G.Nl);
   }
 }
 
@@ -696,8 +681,7 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
   const KnConsts& C = *Cp;
   extern __shared__ __align__(16) double lds[];
   double* accA = lds;
-  double* accP = lds + acc_n;
-  double* recs = lds + 2 * (size_t)acc_n;
+  double* recs = lds + (size_t)acc_n;
   uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + 6 * (size_t)rec_n);
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
@@ -716,7 +700,7 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
     sl0 = *reinterpret_cast<const uint2*>(D.pair_slots + 2 * base);
   }
   const int4 ri = D.row_info[g];
-  for (int i = tid; i < seglen; i += KN_BLOCK) { accA[i] = 0.0; accP[i] = 0.0; }
+  for (int i = tid; i < seglen; i += KN_BLOCK) accA[i] = 0.0;
   stage_records<false>(D, B, recs, eloc, tid, 0.0, nullptr, 0);
   __syncthreads();
 
@@ -725,7 +709,6 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
   double bacc = 0.0, gam = 0.0;
   if (valid) {
     const int rowbase = ri.x, lap = ri.y & 0xFFFF, ne = (unsigned)ri.y >> 16, rL = ri.z;
-    const bool acc_p = want_p && cell_side;
     auto do_pair = [&](int pc, uint2 sl) {
       const int li = pc & 7;
       int slot[8];
@@ -734,14 +717,10 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
       Rec6 r[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) r[j] = lds_rec(recs, eloc[rL + slot[j]]);
-      double ra[8], rm[8];
-      if (acc_p) hex_emi_row<true, AFFINE>(r, li, sc, ra, rm, bacc);
-      else hex_emi_row<false, AFFINE>(r, li, sc, ra, rm, bacc);
+      double ra[8];
+      hex_emi_row<AFFINE>(r, li, sc, ra, bacc);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        unsafeAtomicAdd(&accA[lap + slot[j]], ra[j]);
-        if (acc_p) unsafeAtomicAdd(&accP[lap + slot[j]], ra[j] + rm[j]);
-      }
+      for (int j = 0; j < 8; ++j) unsafeAtomicAdd(&accA[lap + slot[j]], ra[j]);
     };
     if (pc0 >= 0) do_pair(pc0, sl0);
     for (int p = 1; p < np; ++p) {
@@ -749,7 +728,7 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
       const int pc = D.pair_cell[ent];
       if (pc >= 0) do_pair(pc, *reinterpret_cast<const uint2*>(D.pair_slots + 2 * ent));
     }
-    if (sub == 0 && ne > 0) emi_membrane_row<NF>(D, C, ri.w, ne, cell_side, rowbase, accA, accP, acc_p, splitting, gam);
+    if (sub == 0 && ne > 0) emi_membrane_row<NF>(D, C, ri.w, ne, cell_side, rowbase, accA, splitting, gam);
   }
 #pragma unroll
   for (int m = 1; m < LPR; m <<= 1) bacc += __shfl_xor(bacc, m);
@@ -758,7 +737,7 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
   for (int i = tid; i < seglen; i += KN_BLOCK) {
     const double a = accA[i];
     D.A_emi[seg0 + i] = a;
-    if (want_p) D.P_emi[seg0 + i] = cell_side ? accP[i] : a;
+    if (want_p) D.P_emi[seg0 + i] = cell_side ? a + D.P_mass[seg0 + i - D.pmass0] : a;
   }
 }
 
@@ -1065,7 +1044,7 @@ template <int GDIM>
 static int launch_emi_v2(knpemi_handle* h, int want_p, int split) {
   const KnDev& D = h->dev;
   const int acc_n = (h->lds_doubles_emi + 1) & ~1, rec_n = h->lds_uniq_max;
-  const size_t lds = ((size_t)2 * acc_n + 6 * (size_t)rec_n) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
+  const size_t lds = ((size_t)acc_n + 6 * (size_t)rec_n) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
   if (lds > 160 * 1024) { kn_set_error("EMI row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   dim3 grid(D.nblocks), block(KN_BLOCK);
   int rc = 0;
@@ -1107,7 +1086,7 @@ static int launch_knp_v2(knpemi_handle* h) {
 static int launch_emi_hex_v2(knpemi_handle* h, int want_p, int split) {
   const KnDev& D = h->dev;
   const int acc_n = (h->lds_doubles_emi + 1) & ~1, rec_n = h->lds_uniq_max;
-  const size_t lds = ((size_t)2 * acc_n + 6 * (size_t)rec_n) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
+  const size_t lds = ((size_t)acc_n + 6 * (size_t)rec_n) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
   if (lds > 160 * 1024) { kn_set_error("EMI row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   dim3 grid(D.nblocks), block(KN_BLOCK);
   int rc = 0;

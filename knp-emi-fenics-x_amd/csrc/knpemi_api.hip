@@ -282,6 +282,64 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
     h->hex_affine = affine && getenv("KNPEMI_HEX_GENERAL") == nullptr;
   }
 
+  // ---- static ICS mass of the preconditioner: P_emi = A_emi + int u v dx on the cell sub-domains ---------
+  // (emiWeakForm.py:169-198).  The geometry never changes, so the mass entries are tabulated once (P1: closed
+  // form; Q1: the 2x2x2 Gauss rule) in the layout of the cell-side CSR rows and added when P is written.
+  const int64_t pmass0 = rowptr[h->voff[1]];
+  std::vector<double> pmass((size_t)(rowptr[Ntot] - pmass0), 0.0);
+  for (int sdm = 1; sdm < S; ++sdm)
+    for (int c = h->coff[sdm]; c < h->coff[sdm + 1]; ++c) {
+      const int* cv = &cells[(size_t)c * NV];
+      double X[8][3] = {};
+      for (int a = 0; a < NV; ++a)
+        for (int t = 0; t < d->gdim; ++t) X[a][t] = VR[(size_t)cv[a] * KN_REC + t];
+      double Me[8][8] = {};
+      if (NV == 3 || NV == 4) {
+        double det;
+        if (NV == 3) {
+          det = (X[1][0] - X[0][0]) * (X[2][1] - X[0][1]) - (X[1][1] - X[0][1]) * (X[2][0] - X[0][0]);
+        } else {
+          const double ax = X[1][0] - X[0][0], ay = X[1][1] - X[0][1], az = X[1][2] - X[0][2];
+          const double bx = X[2][0] - X[0][0], by = X[2][1] - X[0][1], bz = X[2][2] - X[0][2];
+          const double cx = X[3][0] - X[0][0], cy = X[3][1] - X[0][1], cz = X[3][2] - X[0][2];
+          det = ax * (by * cz - bz * cy) + ay * (bz * cx - bx * cz) + az * (bx * cy - by * cx);
+        }
+        const double vol = std::fabs(det) / (NV == 3 ? 2.0 : 6.0), m = vol / ((d->gdim + 1) * (d->gdim + 2));
+        for (int i = 0; i < NV; ++i)
+          for (int j = 0; j < NV; ++j) Me[i][j] = i == j ? 2.0 * m : m;
+      } else {
+        const double g0 = 0.5 - 0.28867513459481287, g1 = 0.5 + 0.28867513459481287;
+        for (int q = 0; q < 8; ++q) {
+          double N[8], dN[8][3], J[3][3] = {};
+          for (int v = 0; v < 8; ++v) {
+            double f[3], df[3];
+            for (int ax = 0; ax < 3; ++ax) {
+              const double xq = ((q >> ax) & 1) ? g1 : g0;
+              const bool hi = (v >> ax) & 1;
+              f[ax] = hi ? xq : 1.0 - xq;
+              df[ax] = hi ? 1.0 : -1.0;
+            }
+            N[v] = f[0] * f[1] * f[2];
+            dN[v][0] = df[0] * f[1] * f[2]; dN[v][1] = f[0] * df[1] * f[2]; dN[v][2] = f[0] * f[1] * df[2];
+            for (int a = 0; a < 3; ++a)
+              for (int t = 0; t < 3; ++t) J[a][t] += X[v][a] * dN[v][t];
+          }
+          const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) + J[0][1] * (J[1][2] * J[2][0] - J[1][0] * J[2][2]) +
+                             J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+          const double wd = 0.125 * std::fabs(det);
+          for (int i = 0; i < 8; ++i)
+            for (int j = 0; j < 8; ++j) Me[i][j] += wd * N[i] * N[j];
+        }
+      }
+      for (int i = 0; i < NV; ++i) {
+        const int g = cv[i];
+        const int* rb = &colindL[rowptrL[g]];
+        const int* re = &colindL[rowptrL[g + 1]];
+        const int64_t base = (int64_t)rowptr[g] + lapoff[g] - pmass0;
+        for (int j = 0; j < NV; ++j) pmass[(size_t)(base + (std::lower_bound(rb, re, cv[j]) - rb))] += Me[i][j];
+      }
+    }
+
   // ---- lanes per row: enough workgroups to fill 256 CUs several times over on small meshes --------
   {
     // simplices (v2 kernels stage 48 B per Laplacian entry in LDS): 64-row blocks for tetrahedra,
@@ -482,6 +540,8 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   if ((rc = dev_upload(h, me_model, &D.me_model))) return rc;
   if ((rc = dev_upload(h, me_q, &D.me_q))) return rc;
   if ((rc = dev_upload(h, gam_pos, &D.gam_pos))) return rc;
+  if ((rc = dev_upload(h, pmass, &D.P_mass))) return rc;
+  D.pmass0 = pmass0;
   if ((rc = dev_upload(h, fe, &D.fe))) return rc;
   if ((rc = dev_upload(h, fi, &D.fi))) return rc;
   if ((rc = dev_upload(h, fq, &D.fq))) return rc;

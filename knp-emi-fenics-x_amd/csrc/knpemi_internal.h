@@ -85,6 +85,8 @@ struct KnDev {
   const int* fe; const int* fi; const int* fq;   // [nftot][NF] global ids
   const int* fmodel;          // [nftot] global model slot or -1
   const int* q2e; const int* q2i;                // [NQtot] global vertex ids
+  const double* P_mass;       // [nnz - pmass0] static ICS mass entries of P_emi (rows of the cell sub-domains)
+  int64_t pmass0;             // rowptr[first cell-side row]
   double* gam_e;              // [E][2 ions] membrane partial integrals of b_knp, in entry order
   double* phiM;               // [NQtot]
   double* Ich;                // [n_model_slots][K][stride NQtot] (indexed by global q)
