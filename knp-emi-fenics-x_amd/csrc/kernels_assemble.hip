@@ -174,8 +174,8 @@ __device__ __forceinline__ Rec6 lds_rec(const double* recs, int i) {
   return Rec6{u.x, u.y, v.x, v.y, w.x, w.y};
 }
 
-template <int GDIM>
-__device__ __forceinline__ double simplex_row0(const Rec6 (&r)[GDIM + 1], double (&d)[GDIM + 1]) {
+template <int GDIM, class R>
+__device__ __forceinline__ double simplex_row0(const R (&r)[GDIM + 1], double (&d)[GDIM + 1]) {
   // gradient dot products of lambda_0 with all lambda_j, and the cell measure
   if constexpr (GDIM == 2) {
     const double e1x = r[1].x - r[0].x, e1y = r[1].y - r[0].y;
@@ -231,9 +231,20 @@ __device__ __forceinline__ BlkInfo load_blk(const KnDev& D, int b, int wave) {
 
 // Phase A of the v2 kernels: the 48-byte records of the block's distinct vertices go to `recs`, the
 // 2-byte local index of every Laplacian entry to `eloc`.
+// EMI records are 5 doubles: x y z | kappa = sum_k kap_k c_k | sigma = sum_k sig_k c_k (the two combinations of
+// the concentrations the forms need; every staged vertex belongs to the block's sub-domain, so its constants
+// apply).  KNP records are 6: x y z | f0 f1 | phi.
+struct Rec5 { double x, y, z, k, s; };
+
+__device__ __forceinline__ Rec5 lds_rec5(const double* recs, int i) {
+  const double* p = recs + (size_t)i * 5;
+  return Rec5{p[0], p[1], p[2], p[3], p[4]};
+}
+
 template <bool KNP>
 __device__ __forceinline__ void stage_records(const KnDev& D, const BlkInfo& B, double* recs, uint16_t* eloc, int tid,
-                                              double inv_dt, const double* fs0, int nvs) {
+                                              double inv_dt, const double* fs0, int nvs,
+                                              const KnSubConst* scp = nullptr) {
   int vv[KN_STAGE];
 #pragma unroll
   for (int k = 0; k < KN_STAGE; ++k) {
@@ -257,7 +268,11 @@ __device__ __forceinline__ void stage_records(const KnDev& D, const BlkInfo& B, 
         if (fs0) { f0 += fs0[vv[k]]; f1 += fs0[nvs + vv[k]]; }
         dst[0] = u[k][0]; dst[1] = double2{u[k][1].x, f0}; dst[2] = double2{f1, u[k][3].y};
       } else {
-        dst[0] = u[k][0]; dst[1] = double2{u[k][1].x, u[k][2].x}; dst[2] = double2{u[k][2].y, u[k][3].x};
+        double* d5 = recs + (size_t)(tid + k * KN_BLOCK) * 5;
+        const double c0 = u[k][2].x, c1 = u[k][2].y, c2 = u[k][3].x;
+        d5[0] = u[k][0].x; d5[1] = u[k][0].y; d5[2] = u[k][1].x;
+        d5[3] = scp->kap[0] * c0 + scp->kap[1] * c1 + scp->kap[2] * c2;
+        d5[4] = scp->sig[0] * c0 + scp->sig[1] * c1 + scp->sig[2] * c2;
       }
     }
   for (int i = tid + KN_STAGE * KN_BLOCK; i < B.nuniq; i += KN_BLOCK) {   // oversized blocks only
@@ -270,7 +285,10 @@ __device__ __forceinline__ void stage_records(const KnDev& D, const BlkInfo& B, 
       if (fs0) { f0 += fs0[v]; f1 += fs0[nvs + v]; }
       dst[0] = u0; dst[1] = double2{u1.x, f0}; dst[2] = double2{f1, u3.y};
     } else {
-      dst[0] = u0; dst[1] = double2{u1.x, u2.x}; dst[2] = double2{u2.y, u3.x};
+      double* d5 = recs + (size_t)i * 5;
+      d5[0] = u0.x; d5[1] = u0.y; d5[2] = u1.x;
+      d5[3] = scp->kap[0] * u2.x + scp->kap[1] * u2.y + scp->kap[2] * u3.x;
+      d5[4] = scp->sig[0] * u2.x + scp->sig[1] * u2.y + scp->sig[2] * u3.x;
     }
   }
 }
@@ -283,7 +301,7 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
   extern __shared__ __align__(16) double lds[];
   double* accA = lds;
   double* recs = lds + (size_t)acc_n;
-  uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + 6 * (size_t)rec_n);
+  uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + 5 * (size_t)rec_n + (rec_n & 1));
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
   const BlkInfo B = load_blk(D, b, tid >> 6);
@@ -301,10 +319,10 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
   const int4 ri = D.row_info[g];
   // phase A: zero accumulators, stage the records of the block's Laplacian entries
   for (int i = tid; i < seglen; i += KN_BLOCK) accA[i] = 0.0;
-  stage_records<false>(D, B, recs, eloc, tid, 0.0, nullptr, 0);
+  const KnSubConst& sc = C.sc[s];
+  stage_records<false>(D, B, recs, eloc, tid, 0.0, nullptr, 0, &sc);
   __syncthreads();
 
-  const KnSubConst& sc = C.sc[s];
   const bool cell_side = s > 0;
   double bacc = 0.0, gam = 0.0;   // volume part / membrane Robin part of b_emi
   if (valid) {
@@ -312,23 +330,23 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
     // The diagonal entry receives a term from every pair: keep it in registers and add it once.
     int diag = -1;
     double dA = 0.0;
-    Rec6 r[NV];
+    Rec5 r[NV];
     auto do_pair = [&](uint32_t sl) {
       int slot[NV];
 #pragma unroll
       for (int j = 0; j < NV; ++j) slot[j] = (sl >> (8 * j)) & 255;
-      if (diag < 0) { diag = slot[0]; r[0] = lds_rec(recs, eloc[rL + diag]); }   // the row's own vertex, once
+      if (diag < 0) { diag = slot[0]; r[0] = lds_rec5(recs, eloc[rL + diag]); }   // the row's own vertex, once
 #pragma unroll
-      for (int j = 1; j < NV; ++j) r[j] = lds_rec(recs, eloc[rL + slot[j]]);
+      for (int j = 1; j < NV; ++j) r[j] = lds_rec5(recs, eloc[rL + slot[j]]);
       double d[NV];
       const double vol = simplex_row0<GDIM>(r, d);
-      double cb0 = 0, cb1 = 0, cb2 = 0, sd = 0;
+      double ksum = 0, sd = 0;
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
-        cb0 += r[j].a; cb1 += r[j].b; cb2 += r[j].c;
-        sd += (sc.sig[0] * r[j].a + sc.sig[1] * r[j].b + sc.sig[2] * r[j].c) * d[j];
+        ksum += r[j].k;
+        sd += r[j].s * d[j];
       }
-      const double kbar = (sc.kap[0] * cb0 + sc.kap[1] * cb1 + sc.kap[2] * cb2) * (1.0 / NV);
+      const double kbar = ksum * (1.0 / NV);
       bacc -= vol * sd;
       dA += vol * kbar * d[0];
 #pragma unroll
@@ -502,7 +520,8 @@ struct HexGeo {   // geometry of the row vertex l at one Gauss point
 // edge vectors of the cell: e[t][k] = x[v | 1 << t] - x[v], v = lo(t, k)
 struct HexEdges { double x[3][4], y[3][4], z[3][4]; };
 
-__device__ __forceinline__ HexEdges hex_edges(const Rec6 (&r)[8]) {
+template <class R>
+__device__ __forceinline__ HexEdges hex_edges(const R (&r)[8]) {
   HexEdges e;
 #pragma unroll
   for (int t = 0; t < 3; ++t)
@@ -617,15 +636,10 @@ __device__ __forceinline__ double hex_interp(const hexq::Point& P, const double 
 // Row l of the EMI element matrix of one hexahedron: ra = kappa-stiffness, and the volume right-hand side
 // (emiWeakForm.py:138-241).  The ICS mass of P_emi is static and added at write-out (D.P_mass).
 template <bool AFFINE>
-__device__ __forceinline__ void hex_emi_row(const Rec6 (&r)[8], int li, const KnSubConst& sc, double (&ra)[8],
-                                            double& bvol) {
+__device__ __forceinline__ void hex_emi_row(const Rec5 (&r)[8], int li, double (&ra)[8], double& bvol) {
   double kv[8], sv[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    kv[j] = sc.kap[0] * r[j].a + sc.kap[1] * r[j].b + sc.kap[2] * r[j].c;
-    sv[j] = sc.sig[0] * r[j].a + sc.sig[1] * r[j].b + sc.sig[2] * r[j].c;
-    ra[j] = 0.0;
-  }
+  for (int j = 0; j < 8; ++j) { kv[j] = r[j].k; sv[j] = r[j].s; ra[j] = 0.0; }
   double ds[3][4];
   hex_edge_diffs(sv, ds);
   const HexEdges e = hex_edges(r);
@@ -682,7 +696,7 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
   extern __shared__ __align__(16) double lds[];
   double* accA = lds;
   double* recs = lds + (size_t)acc_n;
-  uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + 6 * (size_t)rec_n);
+  uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + 5 * (size_t)rec_n + (rec_n & 1));
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
   const BlkInfo B = load_blk(D, b, tid >> 6);
@@ -701,10 +715,10 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
   }
   const int4 ri = D.row_info[g];
   for (int i = tid; i < seglen; i += KN_BLOCK) accA[i] = 0.0;
-  stage_records<false>(D, B, recs, eloc, tid, 0.0, nullptr, 0);
+  const KnSubConst& sc = C.sc[s];
+  stage_records<false>(D, B, recs, eloc, tid, 0.0, nullptr, 0, &sc);
   __syncthreads();
 
-  const KnSubConst& sc = C.sc[s];
   const bool cell_side = s > 0;
   double bacc = 0.0, gam = 0.0;
   if (valid) {
@@ -714,11 +728,11 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
       int slot[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) { slot[j] = (sl.x >> (8 * j)) & 255; slot[4 + j] = (sl.y >> (8 * j)) & 255; }
-      Rec6 r[8];
+      Rec5 r[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) r[j] = lds_rec(recs, eloc[rL + slot[j]]);
+      for (int j = 0; j < 8; ++j) r[j] = lds_rec5(recs, eloc[rL + slot[j]]);
       double ra[8];
-      hex_emi_row<AFFINE>(r, li, sc, ra, bacc);
+      hex_emi_row<AFFINE>(r, li, ra, bacc);
 #pragma unroll
       for (int j = 0; j < 8; ++j) unsafeAtomicAdd(&accA[lap + slot[j]], ra[j]);
     };
@@ -1044,7 +1058,7 @@ template <int GDIM>
 static int launch_emi_v2(knpemi_handle* h, int want_p, int split) {
   const KnDev& D = h->dev;
   const int acc_n = (h->lds_doubles_emi + 1) & ~1, rec_n = h->lds_uniq_max;
-  const size_t lds = ((size_t)acc_n + 6 * (size_t)rec_n) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
+  const size_t lds = ((size_t)acc_n + 5 * (size_t)rec_n + 1) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
   if (lds > 160 * 1024) { kn_set_error("EMI row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   dim3 grid(D.nblocks), block(KN_BLOCK);
   int rc = 0;
@@ -1086,7 +1100,7 @@ static int launch_knp_v2(knpemi_handle* h) {
 static int launch_emi_hex_v2(knpemi_handle* h, int want_p, int split) {
   const KnDev& D = h->dev;
   const int acc_n = (h->lds_doubles_emi + 1) & ~1, rec_n = h->lds_uniq_max;
-  const size_t lds = ((size_t)acc_n + 6 * (size_t)rec_n) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
+  const size_t lds = ((size_t)acc_n + 5 * (size_t)rec_n + 1) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
   if (lds > 160 * 1024) { kn_set_error("EMI row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   dim3 grid(D.nblocks), block(KN_BLOCK);
   int rc = 0;
