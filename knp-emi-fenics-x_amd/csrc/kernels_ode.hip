@@ -37,8 +37,11 @@ constexpr int ODE_BLOCK = 64;
 
 // LANES = M::NS: lane c of every group of NS adjacent lanes integrates component c of one membrane dof
 // (lsoda_core.h); LANES = 1: one thread per dof.
-template <class M, int LANES>
-__global__ __launch_bounds__(ODE_BLOCK) void ode_step_kernel(KnDev D, OdeArgs a, const LsodaCoef* __restrict__ cf) {
+// WAVES = 2 caps the register budget at 256 per lane so that two waves share a SIMD: slower per wave (a few
+// spills) but the stalls of one wave are filled by the other.  It pays once there are more waves than SIMDs
+// (large membranes); small sweeps run one wave per SIMD with the full register file.
+template <class M, int LANES, int WAVES = 1>
+__global__ __launch_bounds__(ODE_BLOCK, WAVES) void ode_step_kernel(KnDev D, OdeArgs a, const LsodaCoef* __restrict__ cf) {
   using Integrator = Lsoda<M::NS, M, ODE_BLOCK, LANES>;
   constexpr int NI = Integrator::NI;
   // LSODA's dynamically indexed state (Nordsieck history, method coefficients, and for LANES = 1 the
@@ -137,14 +140,19 @@ int kn_launch_ode_step(knpemi_handle* h, int slot, double t0, double dt, double 
   const bool one_lane = lanes_env && atoi(lanes_env) == 1;
   const int lanes = (m.n_states == 4 && !one_lane) ? 4 : 1;
   dim3 grid(((size_t)m.nq * lanes + ODE_BLOCK - 1) / ODE_BLOCK), block(ODE_BLOCK);
+  // more waves than 1.5 x the chip's 1024 SIMDs: trade registers for a second resident wave per SIMD
+  bool dense = (size_t)grid.x > 1536;
+  if (const char* env = getenv("KNPEMI_ODE_WAVES")) dense = atoi(env) == 2;
   KnProfScope prof(h, KNPEMI_K_ODE);
   switch (m.model_id) {
     case KNPEMI_MODEL_HH_SI:
-      if (lanes == 4) hipLaunchKernelGGL((ode_step_kernel<ModelHHSI, 4>), grid, block, 0, h->stream, h->dev, a, cf);
+      if (lanes == 4 && dense) hipLaunchKernelGGL((ode_step_kernel<ModelHHSI, 4, 2>), grid, block, 0, h->stream, h->dev, a, cf);
+      else if (lanes == 4) hipLaunchKernelGGL((ode_step_kernel<ModelHHSI, 4>), grid, block, 0, h->stream, h->dev, a, cf);
       else hipLaunchKernelGGL((ode_step_kernel<ModelHHSI, 1>), grid, block, 0, h->stream, h->dev, a, cf);
       break;
     case KNPEMI_MODEL_HH_MV:
-      if (lanes == 4) hipLaunchKernelGGL((ode_step_kernel<ModelHHMV, 4>), grid, block, 0, h->stream, h->dev, a, cf);
+      if (lanes == 4 && dense) hipLaunchKernelGGL((ode_step_kernel<ModelHHMV, 4, 2>), grid, block, 0, h->stream, h->dev, a, cf);
+      else if (lanes == 4) hipLaunchKernelGGL((ode_step_kernel<ModelHHMV, 4>), grid, block, 0, h->stream, h->dev, a, cf);
       else hipLaunchKernelGGL((ode_step_kernel<ModelHHMV, 1>), grid, block, 0, h->stream, h->dev, a, cf);
       break;
     default:

@@ -368,6 +368,27 @@ def test_all_membrane_models_match_golden_trajectories(hip_lib, key):
     assert np.all(ode.states == ode.states[0])      # identical inputs -> identical bits on every dof
 
 
+def test_two_waves_per_simd_ode_variant_is_bit_identical(hip_lib, monkeypatch):
+    """Large sweeps (more waves than SIMDs) run a register-capped build of the ODE kernel so that two waves share a
+    SIMD (KNPEMI_ODE_WAVES forces it here): spills change no arithmetic, so states, currents and counts are
+    identical to the default build."""
+    from knpemi.utils import update_ode_variables
+    out = []
+    for waves in ("1", "2"):
+        monkeypatch.setenv("KNPEMI_ODE_WAVES", waves)
+        s = Setup("2d", 2, g_syn=10.0)
+        s.perturb()
+        s.phi_M_prev[1].x.array[:] = -0.0744
+        ode = s.mem_models[0]['ode']
+        for k in range(3):
+            update_ode_variables(ode, s.c_prev, s.phi_M_prev[1], s.ion_list, s.subdomain_list, s.mesh, s.ct, 1, k)
+            ode.step_lsoda(s.dt, s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
+            ode.get_membrane_potential(s.phi_M_prev[1])
+        out.append((ode.states.copy(), ode.parameters.copy(), dict(ode.last_stats)))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert all(out[0][2][k] == out[1][2][k] for k in ("n_rhs", "n_steps"))
+
+
 def test_lane_parallel_lsoda_matches_one_thread_per_dof(hip_lib, monkeypatch):
     """The 4-lanes-per-dof integrator (one lane per state component) follows the sequential one: states
     agree to rounding (the compiler contracts multiply-adds differently in the two RHS code shapes, so
