@@ -192,6 +192,10 @@ int knpemi_ode_set_stimulus(knpemi_handle* h, int sub, int model, const uint8_t*
  * ion (ode.parameter_indices), v_index = ode.state_indices('V'). */
 #define KNPEMI_ODE_SET_V 1
 #define KNPEMI_ODE_SET_TRACES 2
+/* run the sweep on the auxiliary stream (fork after what is queued on the main stream; knpemi_join waits for it):
+ * lets a caller keep the LONGER of {ODE sweep, EMI matrix assembly} on the main stream, so that the work that follows
+ * the join does not pay the cross-stream signal latency */
+#define KNPEMI_ODE_ON_AUX_STREAM 4
 int knpemi_ode_step(knpemi_handle* h, int sub, int model, double t0, double dt, double rtol,
                     double atol, int flags, const int32_t* ion_param, int v_index);
 /* RHS evaluations / internal steps / failed dofs summed over all knpemi_ode_step launches since

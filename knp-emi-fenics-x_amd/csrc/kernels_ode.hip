@@ -146,17 +146,17 @@ int kn_launch_ode_step(knpemi_handle* h, int slot, double t0, double dt, double 
   KnProfScope prof(h, KNPEMI_K_ODE);
   switch (m.model_id) {
     case KNPEMI_MODEL_HH_SI:
-      if (lanes == 4 && dense) hipLaunchKernelGGL((ode_step_kernel<ModelHHSI, 4, 2>), grid, block, 0, h->stream, h->dev, a, cf);
-      else if (lanes == 4) hipLaunchKernelGGL((ode_step_kernel<ModelHHSI, 4>), grid, block, 0, h->stream, h->dev, a, cf);
-      else hipLaunchKernelGGL((ode_step_kernel<ModelHHSI, 1>), grid, block, 0, h->stream, h->dev, a, cf);
+      if (lanes == 4 && dense) hipLaunchKernelGGL((ode_step_kernel<ModelHHSI, 4, 2>), grid, block, 0, h->cur, h->dev, a, cf);
+      else if (lanes == 4) hipLaunchKernelGGL((ode_step_kernel<ModelHHSI, 4>), grid, block, 0, h->cur, h->dev, a, cf);
+      else hipLaunchKernelGGL((ode_step_kernel<ModelHHSI, 1>), grid, block, 0, h->cur, h->dev, a, cf);
       break;
     case KNPEMI_MODEL_HH_MV:
-      if (lanes == 4 && dense) hipLaunchKernelGGL((ode_step_kernel<ModelHHMV, 4, 2>), grid, block, 0, h->stream, h->dev, a, cf);
-      else if (lanes == 4) hipLaunchKernelGGL((ode_step_kernel<ModelHHMV, 4>), grid, block, 0, h->stream, h->dev, a, cf);
-      else hipLaunchKernelGGL((ode_step_kernel<ModelHHMV, 1>), grid, block, 0, h->stream, h->dev, a, cf);
+      if (lanes == 4 && dense) hipLaunchKernelGGL((ode_step_kernel<ModelHHMV, 4, 2>), grid, block, 0, h->cur, h->dev, a, cf);
+      else if (lanes == 4) hipLaunchKernelGGL((ode_step_kernel<ModelHHMV, 4>), grid, block, 0, h->cur, h->dev, a, cf);
+      else hipLaunchKernelGGL((ode_step_kernel<ModelHHMV, 1>), grid, block, 0, h->cur, h->dev, a, cf);
       break;
     default:
-      hipLaunchKernelGGL((ode_step_kernel<ModelGlial, 1>), grid, block, 0, h->stream, h->dev, a, cf);
+      hipLaunchKernelGGL((ode_step_kernel<ModelGlial, 1>), grid, block, 0, h->cur, h->dev, a, cf);
       break;
   }
   hipError_t e = hipGetLastError();

@@ -1116,6 +1116,16 @@ extern "C" int knpemi_ode_step(knpemi_handle* h, int sub, int model, double t0, 
   if (!(dt > 0) || !(rtol >= 0) || !(atol >= 0) || (rtol == 0 && atol == 0))
     return fail(KNPEMI_EINVAL, "knpemi_ode_step: bad dt / tolerances");
   KN_HIP(hipSetDevice(h->device));
+  if (flags & KNPEMI_ODE_ON_AUX_STREAM) {
+    KN_HIP(hipEventRecord(h->ev_fork, h->stream));
+    KN_HIP(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+    h->cur = h->aux;
+    int rc = kn_launch_ode_step(h, slot, t0, dt, rtol, atol, flags, ion_param, v_index);
+    h->cur = h->stream;
+    if (rc) return rc;
+    KN_HIP(hipEventRecord(h->ev_join, h->aux));
+    return KNPEMI_OK;
+  }
   return kn_launch_ode_step(h, slot, t0, dt, rtol, atol, flags, ion_param, v_index);
 }
 
@@ -1174,6 +1184,7 @@ extern "C" int knpemi_profile_read(knpemi_handle* h, int kernel, int64_t* launch
     return fail(KNPEMI_EINVAL, "knpemi_profile_read: bad argument");
   KN_HIP(hipSetDevice(h->device));
   KN_HIP(hipStreamSynchronize(h->stream));
+  KN_HIP(hipStreamSynchronize(h->aux));
   double sum = 0.0;
   for (size_t i = 0; i + 1 < h->prof_used[kernel]; i += 2) {
     float f = 0.f;

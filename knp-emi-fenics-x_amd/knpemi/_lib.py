@@ -22,7 +22,7 @@ F_PHI, F_C, F_C_PREV, F_C_ELIM, F_PHI_M, F_I_CH, F_SOURCE = range(7)
 A_EMI, P_EMI, A_KNP = 0, 1, 2
 B_EMI, B_KNP = 0, 1
 WANT_P, NO_SPLITTING, SKIP_MEMBRANE_RHS, ON_AUX_STREAM = 1, 2, 4, 8
-ODE_SET_V, ODE_SET_TRACES = 1, 2
+ODE_SET_V, ODE_SET_TRACES, ODE_ON_AUX = 1, 2, 4
 K_ODE, K_EMI_ROWS, K_KNP_ROWS, K_KNP_MEMBRANE, K_UPDATE = range(5)
 KERNEL_NAMES = ["ode_step_kernel", "emi_rows_kernel", "knp_rows_kernel", "knp_membrane_kernel", "update_pde_kernel"]
 

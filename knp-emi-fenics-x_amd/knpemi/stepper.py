@@ -38,6 +38,10 @@ class DeviceStepper:
         self.solve_emi, self.solve_knp = solve_emi, solve_knp
         self.assemble_knp_twice = assemble_knp_twice
         self.overlap = overlap
+        # Which of the two overlapped kernels runs on the auxiliary stream: the one that finishes first, so that the
+        # kernels after the join follow the longer one on the same stream without a cross-stream signal (~15 us).
+        # Decided from their measured durations at the first step (None = not yet known).
+        self.ode_on_aux = None
         self.k = 0
         self.models = []   # (MembraneModel, stimulus, locator)
         dp = self.dp
@@ -114,20 +118,36 @@ class DeviceStepper:
     def step(self, halo=None):
         dp, lib = self.dp, self.lib
         flags = L.ODE_SET_TRACES | (L.ODE_SET_V if self.k > 0 else 0)
-        if self.overlap:
+        calibrate = self.overlap and self.ode_on_aux is None and self.models
+        if calibrate:
+            L.check(lib.knpemi_profile(dp.h, (1 << L.KERNEL_NAMES.index("ode_step_kernel"))
+                                       | (1 << L.KERNEL_NAMES.index("emi_rows_kernel"))))
+        ode_aux = bool(self.overlap and self.ode_on_aux)
+        if self.overlap and not ode_aux:
             # the EMI matrix (A, P, volume part of b) does not depend on the ODE output: assemble it on the
             # auxiliary stream while the ODE sweep runs on the main one
             L.check(lib.knpemi_assemble_emi(dp.h, self.flags_emi | L.SKIP_MEMBRANE_RHS | L.ON_AUX_STREAM))
         for m in self.models:
             L.check(lib.knpemi_ode_step(dp.h, m._sub, m._model, float(m.time), self.dt, m.rtol, m.atol,
-                                        flags, L.iptr(m._ion_param), int(m.V_index)))
+                                        flags | (L.ODE_ON_AUX if ode_aux else 0), L.iptr(m._ion_param),
+                                        int(m.V_index)))
             m.time = m.time + self.dt
+        if ode_aux:     # the assembly is the longer kernel here: it stays on the main stream
+            L.check(lib.knpemi_assemble_emi(dp.h, self.flags_emi | L.SKIP_MEMBRANE_RHS))
         # Partitioned runs: the membrane dofs of the ghost cell layer are integrated redundantly on both ranks
         # (same inputs after the bulk halo, deterministic LSODA => identical bits, tools/check_partition_steps.py),
         # so phi_M / I_ch need no exchange of their own.
         if self.overlap:
             L.check(lib.knpemi_join(dp.h))
             L.check(lib.knpemi_assemble_emi_membrane_rhs(dp.h, self.flags_emi))
+            if calibrate:
+                us = {}
+                for name in ("ode_step_kernel", "emi_rows_kernel"):
+                    n, ms = C.c_int64(), C.c_double()
+                    L.check(lib.knpemi_profile_read(dp.h, L.KERNEL_NAMES.index(name), C.byref(n), C.byref(ms)))
+                    us[name] = ms.value
+                L.check(lib.knpemi_profile(dp.h, 0))
+                self.ode_on_aux = us["emi_rows_kernel"] > us["ode_step_kernel"]
         else:
             L.check(lib.knpemi_assemble_emi(dp.h, self.flags_emi))
         if self.solve_emi is not None:
