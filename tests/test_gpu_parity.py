@@ -218,7 +218,7 @@ def test_device_stepper_matches_dropin_path(hip_lib):
     from knpemi.pdeSolver import create_solver_emi, create_solver_knp
     from knpemi.stepper import DeviceStepper
     res = []
-    for mode in ("dropin", "stepper", "stepper_no_overlap"):
+    for mode in ("dropin", "stepper", "stepper_ode_on_aux", "stepper_no_overlap"):
         s = Setup("tet", 0, g_syn=10.0)
         s.perturb()
         # physically sensible "solution" fields: c close to c_prev, phi_i - phi_e close to rest
@@ -229,7 +229,9 @@ def test_device_stepper_matches_dropin_path(hip_lib):
         ode = s.mem_models[0]['ode']
         if mode.startswith("stepper"):
             st = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp), s.c, s.c_prev, s.phi,
-                               s.phi_M_prev, overlap=(mode == "stepper"))
+                               s.phi_M_prev, overlap=(mode != "stepper_no_overlap"))
+            if mode == "stepper_ode_on_aux":
+                st.ode_on_aux = True          # roles swapped: ODE sweep on the auxiliary stream, assembly on the main one
             st.add_membrane_model(ode, s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
             for _ in range(3):
                 st.step()
