@@ -685,3 +685,85 @@ def test_stim_duration_driver_device_resident_matches_dropin(hip_lib, tmp_path):
     with hdf5.File(str(tmp_path / "b" / "results_mem_2.h5"), "r") as h5:
         assert np.array_equal(h5.read("/Function/phi_M_2/11").ravel(), pb.phi_M_prev[2].x._a)
     assert all(0 <= i <= 1000 for i in ha["its_emi"] + ha["its_knp"] + hb["its_emi"] + hb["its_knp"])
+
+
+@pytest.mark.parametrize("kind,r,label", [("tet", 1, "config 2: 124 416 tetrahedra"),
+                                          ("hex", 2, "config 2h: 165 888 hexahedra"),
+                                          ("tet", 2, "config 3 mesh: 995 328 tetrahedra")])
+def test_full_size_properties(hip_lib, kind, r, label):
+    """BASELINE-size meshes, checked through properties that need no oracle: sorted CSR rows,
+    symmetry and constant null space of A_emi, P = A on the ECS rows, zero-sum
+    membrane right-hand side, A_knp row sums = volume / dt at constant phi, linearity of A_emi in the concentrations,
+    identical bits on re-assembly, and an ODE sweep whose equal inputs give equal outputs."""
+    import hashlib
+    from knpemi import update_ode_variables
+    from knpemi.pdeSolver import create_solver_emi, create_solver_knp
+    s = Setup(kind, r, g_syn=10.0)
+    n0 = s.phi[0].x.array.shape[0]
+    dt = s.dt
+    emi = create_solver_emi(s.a_emi, s.L_emi, s.phi, s.entity_maps, s.subdomain_list, None, p=s.p_emi, direct=False)
+    knp = create_solver_knp(s.a_knp, s.L_knp, s.c, s.entity_maps, s.subdomain_list, None, p=s.p_knp)
+    # uniform concentrations (the initial state), constant potentials
+    s.phi[0].x.array[:] = 0.0
+    s.phi[1].x.array[:] = -0.0744
+    s.phi_M_prev[1].x.array[:] = -0.0744
+    A, b = emi.assemble()
+    P = emi.P
+    Ak, bk = knp.assemble()
+    n = A.shape[0]
+    scale = np.abs(A.data).max()
+    # structure
+    assert np.all(np.diff(A.indptr) > 0) and all(np.all(np.diff(A.indices[A.indptr[i]:A.indptr[i + 1]]) > 0)
+                                                  for i in range(0, n, max(1, n // 2000)))
+    # symmetry and the constant null space (pdeSolver.py:74-78)
+    assert csr_rel_err(A, A.T.tocsr()) < 1e-13
+    assert np.abs(A @ np.ones(n)).max() < 1e-11 * scale
+    # P = A bit for bit on the ECS rows (on the cell rows P - A is the ICS mass, which in SI units sits at the
+    # rounding level of A, ~1e-23 against ~1e-7, and cannot be recovered from the difference)
+    M = (P - A).tocsr()
+    assert M[:n0].nnz == 0 or np.abs(M[:n0].data).max() == 0.0
+    # uniform concentrations: the volume part of b_emi vanishes, the membrane part (C_phi phi_M on both sides of every
+    # facet with opposite signs) is there and sums to zero
+    area = 4 * (4 * 22e-6 * 0.2e-6 + 2 * 0.2e-6 * 0.2e-6)
+    assert abs(np.abs(b).sum() - 2 * (0.02 / dt) * 0.0744 * area) < 1e-9 * np.abs(b).sum()
+    assert abs(b.sum()) < 1e-9 * np.abs(b).sum()
+    # A_knp 1 at constant phi = lumped mass / dt: per ion the volume of the whole box
+    vol = 32e-6 * 0.9e-6 * 0.9e-6
+    rs = Ak @ np.ones(Ak.shape[0])
+    assert abs(rs.sum() - 2 * vol / dt) < 1e-9 * (2 * vol / dt)
+    # identical bits on re-assembly (checksum of checksums)
+    def digest(*arrays):
+        h = hashlib.sha256()
+        for a in arrays:
+            h.update(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest())
+        return h.hexdigest()
+    d1 = digest(A.data, P.data, b, Ak.data, bk)
+    A2, b2 = emi.assemble()
+    Ak2, bk2 = knp.assemble()
+    assert digest(A2.data, emi.P.data, b2, Ak2.data, bk2) == d1
+    # linearity of A_emi in the concentrations: second difference of A(c), A(2c), A(3c) vanishes
+    base = {(t, k): s.c_prev[t][k].x._a.copy() for t in s.subdomain_list for k in range(2)}
+    elim = {t: s.ion_list[-1][f'c_{t}'].x._a.copy() for t in s.subdomain_list}
+    mats = []
+    for f in (1.0, 2.0, 3.0):
+        for (t, k), v in base.items():
+            s.c_prev[t][k].x.array[:] = f * v
+        for t, v in elim.items():
+            s.ion_list[-1][f'c_{t}'].x.array[:] = f * v
+        mats.append(emi.assemble()[0].copy())
+    assert np.abs(mats[2].data - 2.0 * mats[1].data + mats[0].data).max() < 1e-12 * np.abs(mats[2].data).max()
+    for (t, k), v in base.items():
+        s.c_prev[t][k].x.array[:] = v
+    for t, v in elim.items():
+        s.ion_list[-1][f'c_{t}'].x.array[:] = v
+    # ODE sweep at full size: dofs with equal inputs (same stimulus flag, uniform traces) end in equal states
+    ode = s.mem_models[0]['ode']
+    s.phi_M_prev[1].x.array[:] = -0.0744
+    for k in range(2):
+        update_ode_variables(ode, s.c_prev, s.phi_M_prev[1], s.ion_list, s.subdomain_list, s.mesh, s.ct, 1, k)
+        ode.step_lsoda(dt, s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
+    stim = np.fromiter(map(s.stim_params['stimulus_locator'], ode.dof_locations), dtype=bool)
+    for sel in (stim, ~stim):
+        assert sel.any() and np.all(ode.states[sel] == ode.states[sel][0])
+    assert not np.array_equal(ode.states[stim][0], ode.states[~stim][0])
+    assert ode.last_stats["n_failed"] == 0
