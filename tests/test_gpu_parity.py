@@ -541,6 +541,27 @@ def test_empty_cell_subdomain(hip_lib):
     ode.step_lsoda(1e-4, None)
 
 
+def test_vertex_valence_limit_is_reported(hip_lib):
+    """Maximum sizes: CSR rows are addressed with one byte per slot (<= 255 entries).  A fan of 300 triangles around
+    one vertex exceeds that and must be refused with a message, not assembled wrongly; 200 triangles pass."""
+    from knpemi.fem import Mesh, meshtags
+    from knpemi import _lib as L
+
+    def fan(n):
+        ang = 2 * np.pi * np.arange(n) / n
+        x = np.vstack([[0.0, 0.0], np.c_[np.cos(ang), np.sin(ang)] * 1e-6])
+        cells = np.array([[0, 1 + i, 1 + (i + 1) % n] for i in range(n)], np.int32)
+        mesh = Mesh(x, cells, "triangle")
+        ct = meshtags(mesh, 2, np.arange(n), np.zeros(n, np.int32))
+        ft = meshtags(mesh, 1, np.zeros(0, np.int32), np.zeros(0, np.int32))
+        return mesh, ct, ft
+    with pytest.raises(L.KnpemiError, match="255"):
+        _custom_problem(*fan(300), {1: [(1, "hh_si")]})
+    s = _custom_problem(*fan(200), {1: [(1, "hh_si")]})
+    errs = _compare_with_oracle(s, {0: [], 1: [1]})
+    assert max(errs.values()) < TOL, errs
+
+
 @pytest.mark.parametrize("kind,r", [("2d", 1), ("tet", 0), ("hex", 0)])
 def test_device_krylov_solves_match_direct_solves(hip_lib, kind, r):
     """`direct=False`: Jacobi-PCG (EMI, constant null space) and Jacobi-BiCGStab (KNP) on the device against
