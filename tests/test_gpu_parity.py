@@ -152,6 +152,23 @@ def test_ode_sweep_matches_scipy_lsoda(hip_lib, g_syn):
     assert abs(ode.time - 3 * s.dt) < 1e-15
 
 
+def test_lsoda_failure_is_reported(hip_lib):
+    """`assert success` after every LSODA call (odeSolver.py:121): a dof whose state is NaN cannot be integrated; the
+    sweep must say so (KNPEMI_EODE -> AssertionError, failure count) instead of returning silently, and the healthy
+    dofs of the same launch are still integrated."""
+    from knpemi import update_ode_variables
+    s = Setup("2d", 1, g_syn=10.0)
+    ode = s.mem_models[0]['ode']
+    update_ode_variables(ode, s.c_prev, s.phi_M_prev[1], s.ion_list, s.subdomain_list, s.mesh, s.ct, 1, 0)
+    good = ode.states.copy()
+    ode.states[5, 3] = np.nan
+    with pytest.raises(AssertionError, match="LSODA failed"):
+        ode.step_lsoda(s.dt, s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
+    assert ode.last_stats["n_failed"] == 1
+    ok = np.arange(ode.nodes) != 5
+    assert np.all(np.isfinite(ode.states[ok])) and np.all((ode.states[ok] != good[ok]).any(axis=1))
+
+
 def test_ode_sweep_is_bit_reproducible(hip_lib):
     from knpemi.utils import update_ode_variables
     out = []
