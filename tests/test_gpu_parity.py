@@ -558,6 +558,55 @@ def test_empty_cell_subdomain(hip_lib):
     ode.step_lsoda(1e-4, None)
 
 
+def test_mms_knp_convergence(hip_lib):
+    """Manufactured KNP problem of tests/mms_knp_problem.py through the knpemi API: GPU-assembled mass / dt +
+    diffusion + drift operator and source right-hand side, device BiCGStab + AMG solve; second order in L2."""
+    import contextlib
+    import io
+    import mms_knp_problem as K
+    from knpemi import create_functions_emi, create_functions_knp, emi_system, knp_system, set_initial_conditions
+    from knpemi.fem import Constant, Function, create_unit_square, extract_submesh, meshtags
+    from knpemi.pdeSolver import create_solver_knp
+    errs = []
+    for M in (8, 16, 32):
+        mesh = create_unit_square(None, M, M)
+        ct = meshtags(mesh, 2, np.arange(mesh.num_cells), np.zeros(mesh.num_cells, np.int32))
+        ft = meshtags(mesh, 1, np.zeros(0, np.int32), np.zeros(0, np.int32))
+        subs = {}
+        for t in (0, 1):
+            sm, e2p, v2p, _, _ = extract_submesh(mesh, ct, t)
+            subs[t] = dict(tag=t, name=f"sub{t}", mesh_sub=sm, sub_to_parent=e2p, sub_vertex_to_parent=v2p)
+        g, g2p, _, _, _ = extract_submesh(mesh, ft, [1])
+        subs[1].update(mesh_mem=g, mem_to_parent=g2p, membrane_tags=[1], mem_models=[])
+        s0 = subs[0]['mesh_sub']
+        cst = lambda v: {0: Constant(s0, v), 1: Constant(subs[1]['mesh_sub'], v)}
+        pp = {'dt': Constant(mesh, K.DT), 'F': Constant(mesh, 1.0), 'psi': Constant(mesh, K.PSI),
+              'C_phi': Constant(mesh, 1.0 / K.DT), 'C_M': Constant(mesh, 1.0), 'rho': {'z': -1, **cst(0.0)}}
+        ions = [dict(name=n, z=z, D=cst(K.D), c_init=cst(1.0)) for n, z in zip("abc", K.Z)]
+        with contextlib.redirect_stdout(io.StringIO()):
+            phi, phi_M_prev = create_functions_emi(subs, degree=1)
+            c, c_prev = create_functions_knp(subs, ions, degree=1)
+            set_initial_conditions(ions, subs, c_prev)
+        X0 = s0.x.T
+        for k in range(2):
+            c_prev[0][k].x.array[:] = K.C_EXACT[k](X0)
+            c[0][k].x.array[:] = c_prev[0][k].x._a            # initial guess of the iterative solve
+            f = Function(c_prev[0][k].function_space, name=f"f_{k}")
+            f.x.array[:] = K.F_SOURCE[k](X0)
+            ions[k]['f_source'] = f
+        ions[2]['c_0'].x.array[:] = K.C_ELIM(X0)
+        phi[0].x.array[:] = K.PHI(X0)
+        emi_system(mesh, ct, ft, pp, ions, subs, phi, phi_M_prev, c_prev, K.DT)
+        a_knp, p_knp, L_knp = knp_system(mesh, ct, ft, pp, ions, subs, phi, phi_M_prev, c, c_prev, K.DT)
+        knp = create_solver_knp(a_knp, L_knp, c, [], subs, None, direct=False, p=p_knp, rtol=1e-12, atol=1e-40)
+        knp.solve()
+        errs.append([K.l2_error_p1(s0, c[0][k].x._a, K.C_EXACT[k]) for k in range(2)])
+    errs = np.array(errs)
+    rates = np.log2(errs[:-1] / errs[1:])
+    print("KNP MMS L2 errors:", errs, "rates:", rates)
+    assert np.all(rates > 1.9) and np.all(errs[-1] < 2e-2), (errs, rates)
+
+
 def test_vertex_valence_limit_is_reported(hip_lib):
     """Maximum sizes: CSR rows are addressed with one byte per slot (<= 255 entries).  A fan of 300 triangles around
     one vertex exceeds that and must be refused with a message, not assembled wrongly; 200 triangles pass."""

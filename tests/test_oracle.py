@@ -162,3 +162,32 @@ def test_oracle_mms_emi_convergence():
     errs = np.array(errs)
     rates = np.log2(errs[:-1] / errs[1:])
     assert np.all(rates > 1.85) and np.all(errs[-1] < 2e-3), (errs, rates)
+
+
+def test_oracle_mms_knp_convergence():
+    """Analytic known answer for the oracle's KNP volume forms (mass / dt, diffusion, drift, source): the
+    manufactured steady state of tests/mms_knp_problem.py is recovered at second order in L2."""
+    import scipy.sparse.linalg as spla
+    from knpemi.fem import create_unit_square
+    import mms_knp_problem as K
+    errs = []
+    for M in (8, 16, 32):
+        mesh = create_unit_square(None, M, M)
+        ct = np.zeros(mesh.num_cells, np.int32)
+        P = o.OracleProblem(mesh.x, mesh.cells, mesh.cell_type, ct, np.zeros((0, 2), np.int32), np.zeros(0, np.int32),
+                            {0: [], 1: [1]})
+        params = dict(dt=K.DT, F=1.0, psi=K.PSI, C_M=1.0, C_phi=1.0 / K.DT)
+        ions = [dict(name=n, z=z, D={0: K.D, 1: K.D}) for n, z in zip("abc", K.Z)]
+        X0 = P.sub[0]["x"].T
+        empty = np.zeros(0)
+        c_all = {0: [K.C_EXACT[0](X0), K.C_EXACT[1](X0), K.C_ELIM(X0)], 1: [empty, empty, empty]}
+        phi = {0: K.PHI(X0), 1: empty}
+        src = {k: K.F_SOURCE[k](X0) for k in range(2)}
+        Ak, bk = o.assemble_knp(P, params, ions, c_all, phi, {1: empty}, {1: []}, K.DT, f_source=src)
+        xs = spla.splu(Ak.tocsc()).solve(bk)
+        n0 = P.N[0]
+        sub = type("S", (), dict(x=P.sub[0]["x"], cells=P.sub[0]["cells"]))
+        errs.append([K.l2_error_p1(sub, xs[k * n0:(k + 1) * n0], K.C_EXACT[k]) for k in range(2)])
+    errs = np.array(errs)
+    rates = np.log2(errs[:-1] / errs[1:])
+    assert np.all(rates > 1.9) and np.all(errs[-1] < 2e-2), (errs, rates)
