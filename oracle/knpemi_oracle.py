@@ -18,8 +18,9 @@ numbalsoda, numba are absent).  The only
 reference-supplied known answers are the analytic MMS solutions
 (`tests/run_mms_emi.py:166-176`) and the calibrated ODE initial state
 (`examples/idealized_geometries/mm_hh.py:12-16`); `tests/test_oracle.py` checks
-the oracle against those, against a manufactured KNP solution of this repo
-(`tests/mms_knp_problem.py`) and against form-independent invariants.
+the oracle against those, against two manufactured KNP solutions of this repo
+(`tests/mms_knp_problem.py`: volume terms; membrane terms in both splitting
+modes) and against form-independent invariants.
 
 Third-party algorithm restated here (un-vendored, un-pinned in the reference:
 `pyproject.toml:13-18`): DOLFINx 0.10-era `assemble_matrix/vector` over FFCx

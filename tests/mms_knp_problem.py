@@ -50,3 +50,69 @@ def l2_error_p1(mesh, values, exact):
         uh = values[mesh.cells] @ lam
         err += w * np.sum(det * (uh - exact(xq.T)) ** 2)
     return float(np.sqrt(err))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Membrane variant: the unit square with ICS = [0.25, 0.75]^2 (make_mesh_mms).  u = cos(2 pi x) cos(2 pi y) has a
+# vanishing gradient at the four corners of the ICS, so the normal fluxes below are single-valued at every Q node.
+#   c_k = A_k + B_k u on both sides, phi_i = P u, phi_e = P u - PHI0   ([phi] = PHI0),
+#   phi_M(previous step) = PHI0 + delta(x),
+#   membrane law  F z_k J_k . n_i = I_ch_k + alpha_k C_M ([phi] - phi_M_prev) / dt     (knpWeakForm.py:178-214)
+#     => I_ch_k = F z_k J_k . n_i + alpha_k C_M delta / dt,    alpha_k = D z_k^2 c_k / sum_j D z_j^2 c_j,
+#   (alpha_k evaluated with the previous-step fields, as the forms do) and c_prev = c + dt div J_k absorbs the volume source on both sides (the forms have no ICS source term).
+# One implicit Euler step must return c: this pins the rational membrane terms (alpha, C, g, the signs on either
+# side) of b_knp.  Splitting scheme: the potential handed over is the one the ODE step has already advanced,
+# phi_M_prev - (dt / C_M) sum_k I_ch_k (all three ions).
+# ---------------------------------------------------------------------------------------------------------------
+F_CONST = C_M = 1.0
+DT_M = 0.01                       # small enough for c_prev = c + dt div J to stay positive
+A_M = (2.0, 4.0)
+B_M = (0.5, -0.7)
+PHI0 = 0.3
+DELTA0 = 0.2
+um = sp.cos(2 * sp.pi * x) * sp.cos(2 * sp.pi * y)
+phim = P0 * um
+cm = [A_M[0] + B_M[0] * um, A_M[1] + B_M[1] * um]
+cm.append(-(Z[0] * cm[0] + Z[1] * cm[1]) / Z[2])
+delta = DELTA0 * (1 + sp.cos(2 * sp.pi * x) ** 2 + sp.cos(2 * sp.pi * y) ** 2) / 3
+Jm = [[-D * sp.diff(cm[k], v) - Z[k] * PSI * D * cm[k] * sp.diff(phim, v) for v in (x, y)] for k in range(3)]
+divJ = [sp.diff(Jm[k][0], x) + sp.diff(Jm[k][1], y) for k in range(3)]
+# the forms evaluate alpha with the fields of the previous step (c_prev of the solved ions, the eliminated ion as given)
+cprev = [cm[0] + DT_M * divJ[0], cm[1] + DT_M * divJ[1], cm[2]]
+asum = sum(D * Z[k] ** 2 * cprev[k] for k in range(3))
+alpha = [D * Z[k] ** 2 * cprev[k] / asum for k in range(3)]
+
+M_C = [_fn(ck) for ck in cm]
+M_CPREV = [_fn(cprev[k]) for k in range(2)]
+M_PHI = _fn(phim)
+M_DELTA = _fn(delta)
+_Jx = [_fn(Jm[k][0]) for k in range(3)]
+_Jy = [_fn(Jm[k][1]) for k in range(3)]
+_AL = [_fn(alpha[k]) for k in range(3)]
+
+
+def ics_normals(X):
+    """Outward unit normal of [0.25, 0.75]^2 at boundary points X [2, n] (corners: either side, the fluxes vanish)."""
+    d = np.stack([np.abs(X[0] - 0.25), np.abs(X[0] - 0.75), np.abs(X[1] - 0.25), np.abs(X[1] - 0.75)])
+    side = np.argmin(d, axis=0)
+    n = np.zeros_like(X)
+    n[0] = np.where(side == 0, -1.0, np.where(side == 1, 1.0, 0.0))
+    n[1] = np.where(side == 2, -1.0, np.where(side == 3, 1.0, 0.0))
+    return n
+
+
+def channel_currents(XQ):
+    """I_ch_k (k = 0, 1, 2) at the membrane points XQ [2, n]."""
+    n = ics_normals(XQ)
+    out = []
+    for k in range(3):
+        jn = _Jx[k](XQ) * n[0] + _Jy[k](XQ) * n[1]
+        out.append(F_CONST * Z[k] * jn + _AL[k](XQ) * C_M * M_DELTA(XQ) / DT_M)
+    return out
+
+
+def membrane_potential_prev(XQ, splitting):
+    pm = PHI0 + M_DELTA(XQ)
+    if splitting:
+        pm = pm - (DT_M / C_M) * sum(channel_currents(XQ))
+    return pm

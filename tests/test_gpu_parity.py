@@ -607,6 +607,66 @@ def test_mms_knp_convergence(hip_lib):
     assert np.all(rates > 1.9) and np.all(errs[-1] < 2e-2), (errs, rates)
 
 
+@pytest.mark.parametrize("splitting", [False, True])
+def test_mms_knp_membrane_convergence(hip_lib, splitting):
+    """Membrane variant of the manufactured KNP problem (tests/mms_knp_problem.py): the rational Robin terms of b_knp
+    (alpha fractions, C, g, signs on both sides, with and without the splitting correction) assembled by
+    knp_membrane_kernel + knp_rows and solved on the device; second order in L2 on both sub-domains."""
+    import contextlib
+    import io
+    import mms_knp_problem as K
+    from mms_problem import MMSMembraneModel
+    from knpemi import create_functions_emi, create_functions_knp, emi_system, knp_system, set_initial_conditions
+    from knpemi.fem import Constant, Function, extract_submesh, make_mesh_mms
+    from knpemi.pdeSolver import create_solver_knp
+    errs = []
+    for M in (16, 32, 64):
+        mesh, ct, ft = make_mesh_mms(M)
+        s0, e2p, ev2p, _, _ = extract_submesh(mesh, ct, 0)
+        s1, i2p, iv2p, _, _ = extract_submesh(mesh, ct, 1)
+        g, g2p, _, _, _ = extract_submesh(mesh, ft, 1)
+        subs = {0: dict(name="ECS", mesh_sub=s0, sub_to_parent=e2p, sub_vertex_to_parent=ev2p),
+                1: dict(name="cell", mesh_sub=s1, sub_to_parent=i2p, sub_vertex_to_parent=iv2p, mesh_mem=g,
+                        mem_to_parent=g2p)}
+        cst = lambda v: {0: Constant(s0, v), 1: Constant(s1, v)}
+        pp = {'dt': Constant(mesh, K.DT_M), 'F': Constant(mesh, K.F_CONST), 'psi': Constant(mesh, K.PSI),
+              'C_phi': Constant(mesh, K.C_M / K.DT_M), 'C_M': Constant(mesh, K.C_M), 'rho': {'z': -1, **cst(0.0)}}
+        ions = [dict(name=n, z=z, D=cst(K.D), c_init=cst(1.0)) for n, z in zip("abc", K.Z)]
+        with contextlib.redirect_stdout(io.StringIO()):
+            phi, phi_M_prev = create_functions_emi(subs, degree=1)
+            c, c_prev = create_functions_knp(subs, ions, degree=1)
+            set_initial_conditions(ions, subs, c_prev)
+        Q = phi_M_prev[1].function_space
+        XQ = g.x.T
+        I = K.channel_currents(XQ)
+        I_ch_k = {}
+        for k, n in enumerate("abc"):
+            I_ch_k[n] = Function(Q, name=f"I_ch_{n}")
+            I_ch_k[n].x.array[:] = I[k]
+        mm = MMSMembraneModel()
+        mm.tag = 1
+        subs[1]['mem_models'] = [{'ode': mm, 'I_ch_k': I_ch_k}]
+        phi_M_prev[1].x.array[:] = K.membrane_potential_prev(XQ, splitting)
+        for t, sm in ((0, s0), (1, s1)):
+            X = sm.x.T
+            for k in range(2):
+                c_prev[t][k].x.array[:] = K.M_CPREV[k](X)
+                c[t][k].x.array[:] = K.M_C[k](X) * 1.01          # initial guess, off the answer
+            ions[2][f'c_{t}'].x.array[:] = K.M_C[2](X)
+            phi[t].x.array[:] = K.M_PHI(X) - (K.PHI0 if t == 0 else 0.0)
+        emi_system(mesh, ct, ft, pp, ions, subs, phi, phi_M_prev, c_prev, K.DT_M)
+        a_knp, p_knp, L_knp = knp_system(mesh, ct, ft, pp, ions, subs, phi, phi_M_prev, c, c_prev, K.DT_M)
+        for f in (a_knp, L_knp):
+            f.shared['splitting_scheme'] = splitting
+        knp = create_solver_knp(a_knp, L_knp, c, [], subs, None, direct=False, p=p_knp, rtol=1e-12, atol=1e-40)
+        knp.solve()
+        errs.append([K.l2_error_p1(sm, c[t][k].x._a, K.M_C[k]) for t, sm in ((0, s0), (1, s1)) for k in range(2)])
+    errs = np.array(errs)
+    rates = np.log2(errs[:-1] / errs[1:])
+    print("KNP membrane MMS L2 errors:", errs, "rates:", rates)
+    assert np.all(rates > 1.85) and np.all(errs[-1] < 1e-2), (errs, rates)
+
+
 def test_vertex_valence_limit_is_reported(hip_lib):
     """Maximum sizes: CSR rows are addressed with one byte per slot (<= 255 entries).  A fan of 300 triangles around
     one vertex exceeds that and must be refused with a message, not assembled wrongly; 200 triangles pass."""

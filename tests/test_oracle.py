@@ -191,3 +191,39 @@ def test_oracle_mms_knp_convergence():
     errs = np.array(errs)
     rates = np.log2(errs[:-1] / errs[1:])
     assert np.all(rates > 1.9) and np.all(errs[-1] < 2e-2), (errs, rates)
+
+
+@pytest.mark.parametrize("splitting", [False, True])
+def test_oracle_mms_knp_membrane_convergence(splitting):
+    """Analytic known answer for the oracle's membrane terms of b_knp (alpha fractions, C, g, signs on both sides,
+    with and without the splitting correction): tests/mms_knp_problem.py, membrane variant; second order in L2."""
+    import scipy.sparse.linalg as spla
+    from knpemi.fem import make_mesh_mms
+    import mms_knp_problem as K
+    errs = []
+    for M in (16, 32, 64):
+        mesh, ct, ft = make_mesh_mms(M)
+        P = o.OracleProblem(mesh.x, mesh.cells, mesh.cell_type, ct.dense(), mesh.facets[ft.indices], ft.values,
+                            {0: [], 1: [1]})
+        params = dict(dt=K.DT_M, F=K.F_CONST, psi=K.PSI, C_M=K.C_M, C_phi=K.C_M / K.DT_M)
+        ions = [dict(name=n, z=z, D={0: K.D, 1: K.D}) for n, z in zip("abc", K.Z)]
+        X = {t: P.sub[t]["x"].T for t in (0, 1)}
+        c_all = {t: [K.M_CPREV[0](X[t]), K.M_CPREV[1](X[t]), K.M_C[2](X[t])] for t in (0, 1)}
+        phi = {0: K.M_PHI(X[0]) - K.PHI0, 1: K.M_PHI(X[1])}
+        XQ = P.mem[1]["x"].T
+        I = K.channel_currents(XQ)
+        mm = {1: [dict(tag=1, I_ch_k={n: I[k] for k, n in enumerate("abc")})]}
+        phiM = {1: K.membrane_potential_prev(XQ, splitting)}
+        Ak, bk = o.assemble_knp(P, params, ions, c_all, phi, phiM, mm, K.DT_M, splitting_scheme=splitting)
+        xs = spla.splu(Ak.tocsc()).solve(bk)
+        boff, _ = o.knp_block_offsets(P, 2)
+        e = []
+        for t in (0, 1):
+            sub = type("S", (), dict(x=P.sub[t]["x"], cells=P.sub[t]["cells"]))
+            for k in range(2):
+                e.append(K.l2_error_p1(sub, xs[boff[(t, k)]:boff[(t, k)] + P.N[t]], K.M_C[k]))
+        errs.append(e)
+    errs = np.array(errs)
+    rates = np.log2(errs[:-1] / errs[1:])
+    print("oracle KNP membrane MMS: errors", errs[-1], "rates", rates[-1])
+    assert np.all(rates > 1.85) and np.all(errs[-1] < 1e-2), (errs, rates)
