@@ -303,7 +303,9 @@ def main():
         }
         if args.solve_steps > 0 and world == 1:
             out["with_solves"] = with_solves(s, stepper, args.solve_steps, torch)
-        if args.cpu_steps > 0 and world == 1:
+        if args.cpu_steps > 0 and world == 1 and kind == "hex":
+            out["cpu_baseline"] = None    # the C++ port covers P1 simplices (the BASELINE configs) only
+        elif args.cpu_steps > 0 and world == 1:
             avail = len(os.sched_getaffinity(0))
             n1 = max(1, int(0.4 * args.cpu_steps))
             with contextlib.redirect_stdout(quiet):
