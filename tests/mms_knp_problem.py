@@ -116,3 +116,35 @@ def membrane_potential_prev(XQ, splitting):
     if splitting:
         pm = pm - (DT_M / C_M) * sum(channel_currents(XQ))
     return pm
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 3D volume variant (tetrahedra and Q1 hexahedra): the same steady state on the unit cube,
+# u = cos(pi x) cos(pi y) cos(pi z), no-flux boundary.
+# ---------------------------------------------------------------------------------------------------------------
+zz = sp.symbols("z")
+u3 = sp.cos(sp.pi * x) * sp.cos(sp.pi * y) * sp.cos(sp.pi * zz)
+phi3 = P0 * u3
+c3 = [A[k] + B[k] * u3 for k in range(2)]
+c3_elim = -(Z[0] * c3[0] + Z[1] * c3[1]) / Z[2]
+
+
+def _fn3(expr):
+    f = sp.lambdify((x, y, zz), expr, "numpy")
+    return lambda X: f(X[0], X[1], X[2]) + 0.0 * X[0]
+
+
+def _div_flux3(ck, zk):
+    J = [-D * sp.diff(ck, v) - zk * PSI * D * ck * sp.diff(phi3, v) for v in (x, y, zz)]
+    return sum(sp.diff(J[i], v) for i, v in enumerate((x, y, zz)))
+
+
+PHI3 = _fn3(phi3)
+C3_EXACT = [_fn3(ck) for ck in c3]
+C3_ELIM = _fn3(c3_elim)
+F3_SOURCE = [_fn3(_div_flux3(c3[k], Z[k])) for k in range(2)]
+
+
+def nodal_rms_error(values, exact_values):
+    """Root mean square of the nodal error (uniform grids: a discrete L2 norm)."""
+    return float(np.sqrt(np.mean((values - exact_values) ** 2)))

@@ -607,6 +607,56 @@ def test_mms_knp_convergence(hip_lib):
     assert np.all(rates > 1.9) and np.all(errs[-1] < 2e-2), (errs, rates)
 
 
+@pytest.mark.parametrize("cell_type", ["tetrahedron", "hexahedron"])
+def test_mms_knp_convergence_3d(hip_lib, cell_type):
+    """The manufactured KNP steady state on the unit cube: an analytic check of the 3D row kernels (P1 tetrahedra,
+    Q1 hexahedra) -- mass / dt, diffusion, drift, source -- with the device solve; second order."""
+    import contextlib
+    import io
+    import mms_knp_problem as K
+    from knpemi import create_functions_emi, create_functions_knp, emi_system, knp_system, set_initial_conditions
+    from knpemi.fem import Constant, Function, create_box, extract_submesh, meshtags
+    from knpemi.pdeSolver import create_solver_knp
+    errs = []
+    for M in (4, 8, 16):
+        mesh = create_box(None, [np.zeros(3), np.ones(3)], (M, M, M), cell_type)
+        ct = meshtags(mesh, 3, np.arange(mesh.num_cells), np.zeros(mesh.num_cells, np.int32))
+        ft = meshtags(mesh, 2, np.zeros(0, np.int32), np.zeros(0, np.int32))
+        subs = {}
+        for t in (0, 1):
+            sm, e2p, v2p, _, _ = extract_submesh(mesh, ct, t)
+            subs[t] = dict(tag=t, name=f"sub{t}", mesh_sub=sm, sub_to_parent=e2p, sub_vertex_to_parent=v2p)
+        g, g2p, _, _, _ = extract_submesh(mesh, ft, [1])
+        subs[1].update(mesh_mem=g, mem_to_parent=g2p, membrane_tags=[1], mem_models=[])
+        s0 = subs[0]['mesh_sub']
+        cst = lambda v: {0: Constant(s0, v), 1: Constant(subs[1]['mesh_sub'], v)}
+        pp = {'dt': Constant(mesh, K.DT), 'F': Constant(mesh, 1.0), 'psi': Constant(mesh, K.PSI),
+              'C_phi': Constant(mesh, 1.0 / K.DT), 'C_M': Constant(mesh, 1.0), 'rho': {'z': -1, **cst(0.0)}}
+        ions = [dict(name=n, z=z, D=cst(K.D), c_init=cst(1.0)) for n, z in zip("abc", K.Z)]
+        with contextlib.redirect_stdout(io.StringIO()):
+            phi, phi_M_prev = create_functions_emi(subs, degree=1)
+            c, c_prev = create_functions_knp(subs, ions, degree=1)
+            set_initial_conditions(ions, subs, c_prev)
+        X0 = s0.x.T
+        for k in range(2):
+            c_prev[0][k].x.array[:] = K.C3_EXACT[k](X0)
+            c[0][k].x.array[:] = c_prev[0][k].x._a
+            f = Function(c_prev[0][k].function_space, name=f"f_{k}")
+            f.x.array[:] = K.F3_SOURCE[k](X0)
+            ions[k]['f_source'] = f
+        ions[2]['c_0'].x.array[:] = K.C3_ELIM(X0)
+        phi[0].x.array[:] = K.PHI3(X0)
+        emi_system(mesh, ct, ft, pp, ions, subs, phi, phi_M_prev, c_prev, K.DT)
+        a_knp, p_knp, L_knp = knp_system(mesh, ct, ft, pp, ions, subs, phi, phi_M_prev, c, c_prev, K.DT)
+        knp = create_solver_knp(a_knp, L_knp, c, [], subs, None, direct=False, p=p_knp, rtol=1e-12, atol=1e-40)
+        knp.solve()
+        errs.append([K.nodal_rms_error(c[0][k].x._a, K.C3_EXACT[k](X0)) for k in range(2)])
+    errs = np.array(errs)
+    rates = np.log2(errs[:-1] / errs[1:])
+    print("3D KNP MMS nodal errors:", errs, "rates:", rates)
+    assert np.all(rates[-1] > 1.8) and np.all(errs[-1] < 5e-2), (errs, rates)
+
+
 @pytest.mark.parametrize("splitting", [False, True])
 def test_mms_knp_membrane_convergence(hip_lib, splitting):
     """Membrane variant of the manufactured KNP problem (tests/mms_knp_problem.py): the rational Robin terms of b_knp
