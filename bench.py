@@ -303,11 +303,11 @@ def main():
         }
         if args.solve_steps > 0 and world == 1:
             out["with_solves"] = with_solves(s, stepper, args.solve_steps, torch)
-        if args.cpu_steps > 0 and world == 1 and kind == "hex":
-            out["cpu_baseline"] = None    # the C++ port covers P1 simplices (the BASELINE configs) only
-        elif args.cpu_steps > 0 and world == 1:
+        if args.cpu_steps > 0 and world == 1:
             avail = len(os.sched_getaffinity(0))
-            n1 = max(1, int(0.4 * args.cpu_steps))
+            # bounded sample: --cpu-steps refers to the config-2 size and shrinks with the problem size
+            n_all = max(3, int(round(args.cpu_steps * min(1.0, 79251.0 / dofs_total))))
+            n1 = max(2, int(0.4 * n_all))
             with contextlib.redirect_stdout(quiet):
                 t_one, a_one, o_one, _ = cpu_baseline(s, n1, threads=1)     # before any OpenMP team exists
                 # thread count: a fully subscribed host can be slower than a partly subscribed one (spinning OpenMP
@@ -315,13 +315,13 @@ def main():
                 cand = sorted({min(avail, c) for c in (4, 8, 16, 32, avail)})
                 probes = {c: cpu_baseline(s, 3, threads=c)[0] for c in cand}
                 cores = min(probes, key=probes.get)
-                t_all, a_all, o_all, nrows = cpu_baseline(s, args.cpu_steps, threads=cores)
+                t_all, a_all, o_all, nrows = cpu_baseline(s, n_all, threads=cores)
             what = ("whole steps of the C++ port (oracle/knpemi_cpu.cpp) on the same mesh: EMI (A, P, b) + KNP (A, b) "
                     "assembly and update {a:.0f} ms/step, LSODA sweep over all {n} membrane dofs {o:.0f} ms/step; "
                     "the reference itself cannot run here")
             out["cpu_baseline"] = {
                 "value": dofs_total / t_all, "unit": "dofs/s", "cores": cores, "kind": "port",
-                "sample": f"{args.cpu_steps} " + what.format(a=a_all * 1e3, o=o_all * 1e3, n=nrows)
+                "sample": f"{n_all} " + what.format(a=a_all * 1e3, o=o_all * 1e3, n=nrows)
                           + f"; OpenMP over cells / facets / membrane dofs, {cores} threads (fastest of "
                             f"{cand} on the {avail} cores visible to this process)"}
             out["cpu_baseline_1core"] = {

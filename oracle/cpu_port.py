@@ -80,8 +80,9 @@ class CpuPort:
         pts, wts = o.quadrature(P.facet_type, 6)
         phi, _ = o.tabulate(P.facet_type, pts)
         ref = 1.0 if self.nf == 2 else 0.5
-        self.qw = np.ascontiguousarray(wts / ref * (1.0 if self.nf == 2 else 0.5))
+        self.qw = np.ascontiguousarray(wts if self.nf == 4 else wts / ref * (1.0 if self.nf == 2 else 0.5))
         self.qN = np.ascontiguousarray(phi)
+        self.qxi = np.ascontiguousarray(pts if self.nf == 4 else np.zeros((len(wts), 2)))
         self.A = np.zeros(A.nnz); self.Pm = np.zeros(A.nnz); self.b = np.zeros(self.ntot)
         self.Ak = np.zeros(Ak.nnz); self.bk = np.zeros(2 * self.ntot)
 
@@ -113,7 +114,7 @@ class CpuPort:
             _p(self.kci), C.c_int64(len(self.Ak)), C.c_int(self.ntot), _p(self.Ak), _p(self.bk), C.c_double(self.params["dt"]),
             C.c_int(len(self.fe)), C.c_int(self.nf), _p(self.fe), _p(self.fi), _p(self.fq), _p(self.fsub), _p(pm), _p(Ich),
             C.c_int(self.NQ), C.c_double(self.params["C_M"]), C.c_double(self.params["F"]), _p(self.z),
-            C.c_int(len(self.qw)), _p(self.qw), _p(self.qN), C.c_int(int(splitting)))
+            C.c_int(len(self.qw)), _p(self.qw), _p(self.qN), _p(self.qxi), C.c_int(int(splitting)))
         return self.Ak, self.bk
 
     def ode_sweep(self, model_id, states, params, t0, dt, mask, stim_idx, stim_val):

@@ -1,4 +1,4 @@
-// CPU port of the knpemi hot path for simplicial meshes -- TEST INFRASTRUCTURE / TIMED CPU BASELINE.
+// CPU port of the knpemi hot path (P1 simplices and Q1 hexahedra) -- TEST INFRASTRUCTURE / TIMED CPU BASELINE.
 //
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load this library; the product
 // never does.  It restates, as scalar C++ loops of the kind DOLFINx + FFCx + PETSc execute, what the
@@ -92,6 +92,79 @@ double facet_measure(const double* x, const int* v, int gdim, int nf) {
   return 0.5 * std::sqrt(n0 * n0 + n1 * n1 + n2 * n2);
 }
 
+// Q1 hexahedron (tensor-product vertex order): basis values, physical gradients and weight * |det J| at the
+// 2x2x2 Gauss points (the rule FFCx picks for these integrands)
+struct HexElem {
+  double N[8][8];       // [q][a]
+  double G[8][8][3];    // [q][a][d]
+  double wd[8];
+};
+
+HexElem hex_elem(const double* x, const int* v) {
+  HexElem E;
+  const double g0 = 0.5 - 0.28867513459481287, g1 = 0.5 + 0.28867513459481287;
+  for (int q = 0; q < 8; ++q) {
+    double dN[8][3], J[3][3] = {{0}};
+    for (int a = 0; a < 8; ++a) {
+      double f[3], df[3];
+      for (int ax = 0; ax < 3; ++ax) {
+        const double xq = ((q >> ax) & 1) ? g1 : g0;
+        const bool hi = (a >> ax) & 1;
+        f[ax] = hi ? xq : 1.0 - xq;
+        df[ax] = hi ? 1.0 : -1.0;
+      }
+      E.N[q][a] = f[0] * f[1] * f[2];
+      dN[a][0] = df[0] * f[1] * f[2]; dN[a][1] = f[0] * df[1] * f[2]; dN[a][2] = f[0] * f[1] * df[2];
+      for (int d = 0; d < 3; ++d)
+        for (int t = 0; t < 3; ++t) J[d][t] += x[(size_t)v[a] * 3 + d] * dN[a][t];
+    }
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1], c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2],
+                 c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+    double Ji[3][3];   // Ji[t][d] = d xi_t / d x_d
+    Ji[0][0] = c00 / det; Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det; Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det;
+    Ji[1][0] = c01 / det; Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det; Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+    Ji[2][0] = c02 / det; Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det; Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+    for (int a = 0; a < 8; ++a)
+      for (int d = 0; d < 3; ++d) E.G[q][a][d] = dN[a][0] * Ji[0][d] + dN[a][1] * Ji[1][d] + dN[a][2] * Ji[2][d];
+    E.wd[q] = 0.125 * std::fabs(det);
+  }
+  return E;
+}
+
+// surface Jacobian of a bilinear quadrilateral facet (tensor-product vertex order) at (xi, eta)
+double quad_jacobian(const double* x, const int* v, double xi, double eta) {
+  double u[3], w[3];
+  for (int d = 0; d < 3; ++d) {
+    const double p0 = x[(size_t)v[0] * 3 + d], p1 = x[(size_t)v[1] * 3 + d], p2 = x[(size_t)v[2] * 3 + d], p3 = x[(size_t)v[3] * 3 + d];
+    u[d] = (1 - eta) * (p1 - p0) + eta * (p3 - p2);
+    w[d] = (1 - xi) * (p2 - p0) + xi * (p3 - p1);
+  }
+  const double n0 = u[1] * w[2] - u[2] * w[1], n1 = u[2] * w[0] - u[0] * w[2], n2 = u[0] * w[1] - u[1] * w[0];
+  return std::sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+}
+
+// facet mass matrix M[a][b] (P1 facets: closed form; Q1 quadrilaterals: 2x2 Gauss)
+void facet_mass(const double* x, const int* v, int gdim, int nf, double M[4][4]) {
+  if (nf != 4) {
+    const double m = facet_measure(x, v, gdim, nf) / (nf * (nf + 1));
+    for (int a = 0; a < nf; ++a)
+      for (int b = 0; b < nf; ++b) M[a][b] = m * (a == b ? 2.0 : 1.0);
+    return;
+  }
+  const double g0 = 0.5 - 0.28867513459481287, g1 = 0.5 + 0.28867513459481287;
+  for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 4; ++b) M[a][b] = 0.0;
+  for (int qj = 0; qj < 2; ++qj)
+    for (int qi = 0; qi < 2; ++qi) {
+      const double xi = qi ? g1 : g0, eta = qj ? g1 : g0;
+      const double N[4] = {(1 - xi) * (1 - eta), xi * (1 - eta), (1 - xi) * eta, xi * eta};
+      const double w = 0.25 * quad_jacobian(x, v, xi, eta);
+      for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) M[a][b] += w * N[a] * N[b];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -113,6 +186,33 @@ void cpu_assemble_emi(int gdim, int nv, int nc, const int* cells, const int* cel
   for (int c = 0; c < nc; ++c) {
     const int* v = cells + (size_t)c * nv;
     const int s = cell_sub[c];
+    if (nv == 8) {   // Q1 hexahedron: Gauss quadrature with the interpolated conductivity
+      const HexElem E = hex_elem(x, v);
+      double kv[8], sg8[8];
+      for (int a = 0; a < 8; ++a) {
+        kv[a] = kap[s * 3] * c0[v[a]] + kap[s * 3 + 1] * c1[v[a]] + kap[s * 3 + 2] * c2[v[a]];
+        sg8[a] = sig[s * 3] * c0[v[a]] + sig[s * 3 + 1] * c1[v[a]] + sig[s * 3 + 2] * c2[v[a]];
+      }
+      for (int i = 0; i < 8; ++i) {
+        double bi = 0;
+        for (int j = 0; j < 8; ++j) {
+          double a = 0, m = 0, sij = 0;
+          for (int q = 0; q < 8; ++q) {
+            double kq = 0;
+            for (int t = 0; t < 8; ++t) kq += E.N[q][t] * kv[t];
+            const double gg = E.G[q][i][0] * E.G[q][j][0] + E.G[q][i][1] * E.G[q][j][1] + E.G[q][i][2] * E.G[q][j][2];
+            a += E.wd[q] * kq * gg;
+            m += E.wd[q] * E.N[q][i] * E.N[q][j];
+            sij += E.wd[q] * gg;
+          }
+          csr_add(rowptr, colind, A, v[i], v[j], a);
+          csr_add(rowptr, colind, P, v[i], v[j], s > 0 ? a + m : a);
+          bi -= sg8[j] * sij;
+        }
+        vec_add(&b[v[i]], bi);
+      }
+      continue;
+    }
     const Geo g = simplex_geo(x, v, gdim, nv);
     double kbar = 0, sg[4];
     for (int a = 0; a < nv; ++a) {
@@ -131,15 +231,15 @@ void cpu_assemble_emi(int gdim, int nv, int nc, const int* cells, const int* cel
       vec_add(&b[v[i]], bi);
     }
   }
-  const double ffac = 1.0 / (nf * (nf + 1));
 #pragma omp parallel for schedule(static) num_threads(g_threads)
   for (int f = 0; f < nF; ++f) {
     const int* E = fe + (size_t)f * nf; const int* I = fi + (size_t)f * nf; const int* Q = fq + (size_t)f * nf;
-    const double m = facet_measure(x, E, gdim, nf) * ffac;
+    double Mf[4][4];
+    facet_mass(x, E, gdim, nf, Mf);
     for (int a = 0; a < nf; ++a) {
       double gs = 0;
       for (int bb = 0; bb < nf; ++bb) {
-        const double M = m * (a == bb ? 2.0 : 1.0), val = C_phi * M;
+        const double M = Mf[a][bb], val = C_phi * M;
         double gq = phiM[Q[bb]];
         if (!splitting) gq -= Isum[Q[bb]] / C_phi;
         gs += M * gq;
@@ -158,14 +258,14 @@ void cpu_assemble_emi(int gdim, int nv, int nc, const int* cells, const int* cel
 
 // KNP: monolithic block-diagonal CSR in the order [c[0][0], c[0][1], c[1][0], ...]; `krow[k * ntot + g]` is
 // the row of unknown (ion k, global vertex g).  qw / qN: degree-6 facet rule (nq weights incl. the
-// reference measure, nq x nf shape values).
+// reference measure, nq x nf shape values); qxi: its points (quadrilateral facets: surface Jacobian per point).
 void cpu_assemble_knp(int gdim, int nv, int nc, const int* cells, const int* cell_sub, const double* x,
                       const double* c0, const double* c1, const double* c2, const double* phi, const double* Dk,
                       const double* zpsiD, const double* az2D, const int* krow, const int* rowptr, const int* colind,
                       int64_t nnz, int ntot, double* A, double* b, double dt, int nF, int nf, const int* fe,
                       const int* fi, const int* fq, const int* f_isub, const double* phiM, const double* Ich,
                       int NQ, double C_M, double F, const double* z, int nq, const double* qw, const double* qN,
-                      int splitting) {
+                      const double* qxi, int splitting) {
   std::memset(A, 0, (size_t)nnz * sizeof(double));
   std::memset(b, 0, (size_t)2 * ntot * sizeof(double));
   const double mfac = 1.0 / ((gdim + 1) * (gdim + 2));
@@ -174,6 +274,32 @@ void cpu_assemble_knp(int gdim, int nv, int nc, const int* cells, const int* cel
   for (int c = 0; c < nc; ++c) {
     const int* v = cells + (size_t)c * nv;
     const int s = cell_sub[c];
+    if (nv == 8) {
+      const HexElem E = hex_elem(x, v);
+      double gphi[8][3];
+      for (int q = 0; q < 8; ++q)
+        for (int d = 0; d < 3; ++d) {
+          gphi[q][d] = 0;
+          for (int a = 0; a < 8; ++a) gphi[q][d] += phi[v[a]] * E.G[q][a][d];
+        }
+      for (int i = 0; i < 8; ++i)
+        for (int k = 0; k < 2; ++k) {
+          const int ri = krow[(size_t)k * ntot + v[i]];
+          double bi = 0;
+          for (int j = 0; j < 8; ++j) {
+            double m = 0, st = 0, dr = 0;
+            for (int q = 0; q < 8; ++q) {
+              m += E.wd[q] * E.N[q][i] * E.N[q][j];
+              st += E.wd[q] * (E.G[q][i][0] * E.G[q][j][0] + E.G[q][i][1] * E.G[q][j][1] + E.G[q][i][2] * E.G[q][j][2]);
+              dr += E.wd[q] * E.N[q][j] * (gphi[q][0] * E.G[q][i][0] + gphi[q][1] * E.G[q][i][1] + gphi[q][2] * E.G[q][i][2]);
+            }
+            csr_add(rowptr, colind, A, ri, krow[(size_t)k * ntot + v[j]], m / dt + Dk[s * 3 + k] * st + zpsiD[s * 3 + k] * dr);
+            bi += m * cc[k][v[j]] / dt;
+          }
+          vec_add(&b[ri], bi);
+        }
+      continue;
+    }
     const Geo g = simplex_geo(x, v, gdim, nv);
     for (int i = 0; i < nv; ++i) {
       double gp = 0;
@@ -196,7 +322,7 @@ void cpu_assemble_knp(int gdim, int nv, int nc, const int* cells, const int* cel
   for (int f = 0; f < nF; ++f) {
     const int* E = fe + (size_t)f * nf; const int* I = fi + (size_t)f * nf; const int* Q = fq + (size_t)f * nf;
     const int si = f_isub[f];
-    const double meas = facet_measure(x, E, gdim, nf) * (nf == 2 ? 1.0 : 2.0);
+    const double meas = nf == 4 ? 0.0 : facet_measure(x, E, gdim, nf) * (nf == 2 ? 1.0 : 2.0);
     for (int q = 0; q < nq; ++q) {
       double ce[3] = {0, 0, 0}, ci[3] = {0, 0, 0}, pe = 0, pi = 0, pm = 0, ik[3] = {0, 0, 0};
       for (int a = 0; a < nf; ++a) {
@@ -209,7 +335,8 @@ void cpu_assemble_knp(int gdim, int nv, int nc, const int* cells, const int* cel
       const double it = ik[0] + ik[1] + ik[2];
       const double ase = az2D[0] * ce[0] + az2D[1] * ce[1] + az2D[2] * ce[2];
       const double asi = az2D[si * 3] * ci[0] + az2D[si * 3 + 1] * ci[1] + az2D[si * 3 + 2] * ci[2];
-      const double w = qw[q] * meas, jump = pi - pe;
+      const double w = nf == 4 ? qw[q] * quad_jacobian(x, E, qxi[2 * q], qxi[2 * q + 1]) : qw[q] * meas;
+      const double jump = pi - pe;
       for (int k = 0; k < 2; ++k) {
         const double ae = az2D[k] * ce[k] / ase, ai = az2D[si * 3 + k] * ci[k] / asi;
         const double Ce = ae * C_M / (F * z[k] * dt), Ci = ai * C_M / (F * z[k] * dt);

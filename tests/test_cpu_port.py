@@ -11,7 +11,7 @@ import knpemi_oracle as o
 from helpers import Setup, rel_err
 
 
-@pytest.mark.parametrize("kind,r", [("2d", 1), ("tet", 0)])
+@pytest.mark.parametrize("kind,r", [("2d", 1), ("tet", 0), ("hex", 0)])
 @pytest.mark.parametrize("splitting", [True, False])
 def test_cpu_port_matches_numpy_oracle(kind, r, splitting):
     with contextlib.redirect_stdout(io.StringIO()):
