@@ -14,6 +14,8 @@ skip ghost dofs.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from .idealized import make_mesh_3D_slab
@@ -125,7 +127,11 @@ class SlabHalo:
         dev = torch.device("cuda", dp.device)
         n_slots = int(dp.n_models.sum())
         self.width = {"bulk": 4, "mem": 1 + n_slots * L.MAX_IONS}
-        self._ext = torch.cuda.ExternalStream(dp.lib.knpemi_stream(dp.h), device=dev)
+        self._stream_ordered = os.environ.get("KNPEMI_HALO_SYNC") is None
+        try:
+            self._ext = torch.cuda.ExternalStream(dp.lib.knpemi_stream(dp.h), device=dev)
+        except (RuntimeError, TypeError):
+            self._ext, self._stream_ordered = None, False
         self._dev = {}
         for kind in ("bulk", "mem"):
             # one packed buffer per direction and kind: both neighbours' entries are packed / unpacked by a single
@@ -155,15 +161,27 @@ class SlabHalo:
         L.check(dp.lib.knpemi_halo_pack(dp.h, k, d["send_idx"].data_ptr(), d["send_idx"].numel(),
                                         d["send_buf"].data_ptr()))
         if dist.get_backend() != "gloo":
-            # RCCL: torch's current stream is the library's stream (ExternalStream), so the send/recv kernels
-            # are ordered after the pack kernel and `wait()` orders the unpack kernel after them: no host
-            # synchronisation anywhere in the exchange (tools/check_async_halo.py rehearses this with real RCCL)
             ops = []
             for nb, ss, rs in d["parts"]:
                 ops += [dist.P2POp(dist.isend, d["send_buf"][ss], nb), dist.P2POp(dist.irecv, d["recv_buf"][rs], nb)]
-            with self.torch.cuda.stream(self._ext):
+            if self._stream_ordered:
+                # RCCL: torch's current stream is the library's stream (ExternalStream), so the send/recv kernels
+                # are ordered after the pack kernel and `wait()` orders the unpack kernel after them: no host
+                # synchronisation anywhere in the exchange (tools/check_async_halo.py rehearses this with real RCCL)
+                try:
+                    with self.torch.cuda.stream(self._ext):
+                        for req in dist.batch_isend_irecv(ops):
+                            req.wait()
+                except RuntimeError as exc:      # fall back to the host-synchronised exchange for the rest of the run
+                    import warnings
+                    warnings.warn(f"stream-ordered halo exchange failed ({exc}); using host synchronisation")
+                    self._stream_ordered = False
+                    return self._exchange(kind)
+            else:
+                dp.sync()                        # packed data is complete before RCCL reads it
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
+                self.torch.cuda.current_stream().synchronize()
         else:                           # single-GPU rehearsal: stage through host memory
             dp.sync()
             sb = d["send_buf"].cpu()
