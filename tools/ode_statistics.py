@@ -1,4 +1,4 @@
-"""LSODA work per membrane dof and PDE step at the bench state (debug aid)."""
+"""LSODA work per membrane dof and PDE step at the bench state (diagnostic)."""
 import sys, os, contextlib, io, ctypes as C
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 import numpy as np

@@ -1,4 +1,4 @@
-"""Iteration counts / timings of the device Krylov solves (debug aid)."""
+"""Iteration counts / timings of the device Krylov solves (diagnostic)."""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 import numpy as np
