@@ -2,14 +2,13 @@
 // hot path).  The reference hands its systems to PETSc (src/knpemi/pdeSolver.py:13-38,88-113): CG +
 // hypre BoomerAMG for the symmetric positive semi-definite EMI system with the constant null space
 // attached (:74-78), GMRES + BoomerAMG for the non-symmetric block-diagonal KNP system, both with a
-// non-zero initial guess (the previous solution).  Here: CG preconditioned with a smoothed-aggregation
-// V-cycle (kernels_amg.hip; Jacobi selectable) with the right-hand side and the solution projected onto
-// zero mean, and Jacobi-preconditioned BiCGStab (the KNP blocks are mass-dominated at the reference's
-// dt), working in place on the assembled device CSR.
+// non-zero initial guess (the previous solution).  Here: CG with the right-hand side and the solution
+// projected onto zero mean, and right-preconditioned BiCGStab, both preconditioned with a smoothed-aggregation
+// V-cycle (kernels_amg.hip; Jacobi selectable), working in place on the assembled device CSR.
 //
-// All vectors and scalars stay on the device; the host reads back one residual norm every few
-// iterations to test convergence.  Reductions are two-stage with a fixed summation order, so the solves
-// are bit-reproducible.
+// All vectors and scalars stay on the device; the host reads back one residual norm per chunk of iterations
+// (one iteration with AMG) to test convergence.  A dot product, its block partials and the scalar update it
+// feeds are one launch with a fixed summation order, so the solves are bit-reproducible.
 #include "knpemi_internal.h"
 
 namespace {
