@@ -121,14 +121,19 @@ def with_solves(s, stepper, n_steps, torch):
     from knpemi import _lib as L
     dp = stepper.dp
     its = {"emi": [], "knp": []}
-    stepper.solve_emi = lambda d: its["emi"].append(d.solve(L.B_EMI, 1e-5, 1e-40, 1000)[0])
-    stepper.solve_knp = lambda d: its["knp"].append(d.solve(L.B_KNP, 1e-7, 2e-40, 1000)[0])
+
+    def solver(which, key, rtol, atol):
+        def run(d):
+            L.check(d.lib.knpemi_extrapolate_guess(d.h, which))     # start from 2 x_n - x_(n-1)
+            its[key].append(d.solve(which, rtol, atol, 1000)[0])
+        return run
+    stepper.solve_emi = solver(L.B_EMI, "emi", 1e-5, 1e-40)
+    stepper.solve_knp = solver(L.B_KNP, "knp", 1e-7, 2e-40)
     for _ in range(3):
         stepper.step()           # builds the AMG hierarchies
     torch.cuda.synchronize()
-    its = {"emi": [], "knp": []}
-    stepper.solve_emi = lambda d: its["emi"].append(d.solve(L.B_EMI, 1e-5, 1e-40, 1000)[0])
-    stepper.solve_knp = lambda d: its["knp"].append(d.solve(L.B_KNP, 1e-7, 2e-40, 1000)[0])
+    its["emi"].clear()
+    its["knp"].clear()
     t0 = time.perf_counter()
     for _ in range(n_steps):
         stepper.step()
@@ -137,7 +142,7 @@ def with_solves(s, stepper, n_steps, torch):
     ms = (time.perf_counter() - t0) / n_steps * 1e3
     stepper.solve_emi = stepper.solve_knp = None
     info = {k: dp.solver_info(w) for k, w in (("emi", L.B_EMI), ("knp", L.B_KNP))}
-    return {"ms_per_step": ms, "steps": n_steps,
+    return {"ms_per_step": ms, "steps": n_steps, "initial_guess": "2 x_n - x_(n-1) (knpemi_extrapolate_guess)",
             "emi": {"solver": "CG + SA-AMG V(1,1), rtol 1e-5", "iterations_avg": sum(its["emi"]) / n_steps, **info["emi"]},
             "knp": {"solver": "BiCGStab + SA-AMG V(1,1), rtol 1e-7", "iterations_avg": sum(its["knp"]) / n_steps,
                     **info["knp"]}}

@@ -220,7 +220,8 @@ def write_results(p, outdir, k, t):
     np.savez_compressed(os.path.join(outdir, f"step_{k:06d}.npz"), t=t, **fields)
 
 
-def solve_system(config, n_steps=None, device_resident=False, direct=False, outdir=None, quiet=False, xdmf=False):
+def solve_system(config, n_steps=None, device_resident=False, direct=False, outdir=None, quiet=False, xdmf=False,
+                 extrapolate_guess=True):
     p = Problem(config)
     n_total = int(round(config["Tstop"] / float(DT)))
     n_steps = n_total if n_steps is None else min(n_steps, n_total)
@@ -246,7 +247,7 @@ def solve_system(config, n_steps=None, device_resident=False, direct=False, outd
         from knpemi import _lib as L
         from knpemi.stepper import DeviceStepper
         st = DeviceStepper((p.a_emi, p.p_emi, p.L_emi), (p.a_knp, p.p_knp, p.L_knp), p.c, p.c_prev, p.phi,
-                           p.phi_M_prev, device_solves=(1e-6, 1e-7))
+                           p.phi_M_prev, device_solves=(1e-6, 1e-7), extrapolate_guess=extrapolate_guess)
         for tag in (1, 2):
             for mm in p.subdomain_list[tag]["mem_models"]:
                 st.add_membrane_model(mm["ode"], p.stim_params["stimulus"], p.stim_params["stimulus_locator"])

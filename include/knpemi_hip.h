@@ -166,6 +166,10 @@ int knpemi_get_solution(knpemi_handle* h, int which, double* x);
 enum { KNPEMI_PC_JACOBI = 0, KNPEMI_PC_AMG = 1 };
 int knpemi_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* iters, double* relres);
 int knpemi_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* iters, double* relres);
+/* Replace the initial guess of the next solve of `which` (the current phi / c, i.e. the previous solution:
+ * ksp_initial_guess_nonzero, pdeSolver.py:26,101) by the linear extrapolation 2 x_n - x_(n-1) of the last two
+ * solutions; the first call only records x_n.  Call once per time step, before the solve. */
+int knpemi_extrapolate_guess(knpemi_handle* h, int which);
 /* Preconditioner of the device solve of system `which` (KNPEMI_B_EMI / KNPEMI_B_KNP): the counterpart of
  * pc_type / pc_hypre_type in pdeSolver.py:27-34,102-109.  KNPEMI_PC_AMG: smoothed-aggregation V(1,1) cycle,
  * strength threshold `theta` (<= 0: default 0.08); the hierarchy is (re)built at the next solve and kept for

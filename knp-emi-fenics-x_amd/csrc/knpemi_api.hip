@@ -832,6 +832,13 @@ extern "C" int knpemi_solve_knp(knpemi_handle* h, double rtol, double atol, int 
   return kn_solve_knp(h, rtol, atol, maxit, iters, relres);
 }
 
+extern "C" int knpemi_extrapolate_guess(knpemi_handle* h, int which) {
+  if (!h) return fail(KNPEMI_EINVAL, "null handle");
+  if (which != KNPEMI_B_EMI && which != KNPEMI_B_KNP) return fail(KNPEMI_EINVAL, "knpemi_extrapolate_guess: unknown system");
+  KN_HIP(hipSetDevice(h->device));
+  return kn_extrapolate_guess(h, which);
+}
+
 extern "C" int knpemi_solver_setup(knpemi_handle* h, int which, int precond, double theta) {
   if (!h) return fail(KNPEMI_EINVAL, "null handle");
   if (which != KNPEMI_B_EMI && which != KNPEMI_B_KNP) return fail(KNPEMI_EINVAL, "knpemi_solver_setup: unknown system");

@@ -161,6 +161,8 @@ struct knpemi_handle {
   std::vector<int> h_rowptr, h_colind, h_rowptrL, h_colindL;
   double* d_stage = nullptr; size_t stage_len = 0;   // staging buffer for strided field I/O
   double* kry = nullptr; size_t kry_n = 0;           // Krylov workspace (kernels_krylov.hip)
+  double* guess_old[2] = {nullptr, nullptr};         // previous solutions (EMI, KNP) for knpemi_extrapolate_guess
+  bool guess_have[2] = {false, false};
   KnAmg amg_emi, amg_knp;
   // captured iteration bodies of the Krylov loops (kernels_krylov.hip); key = configuration they were captured for
   struct KnGraph { hipGraphExec_t exec = nullptr; uint64_t key = 0; };
@@ -214,6 +216,7 @@ int kn_launch_ode_step(knpemi_handle* h, int slot, double t0, double dt, double 
 int kn_launch_update_pde(knpemi_handle* h);
 int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* iters, double* relres);
 int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* iters, double* relres);
+int kn_extrapolate_guess(knpemi_handle* h, int which);
 int kn_launch_halo(knpemi_handle* h, int kind, int pack, const int32_t* idx, int n, double* buf);
 int kn_launch_field_scatter(knpemi_handle* h, const double* src, double* dst, int n, int dst_stride);
 int kn_launch_field_gather(knpemi_handle* h, const double* src, int src_stride, double* dst, int n);

@@ -78,6 +78,7 @@ SIGNATURES = {
     "knpemi_join": (C.c_int, [C.c_void_p]),
     "knpemi_solve_emi": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int), c_dbl_p]),
     "knpemi_solve_knp": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int), c_dbl_p]),
+    "knpemi_extrapolate_guess": (C.c_int, [C.c_void_p, C.c_int]),
     "knpemi_solver_setup": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double]),
     "knpemi_solver_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), c_dbl_p, C.POINTER(C.c_int)]),
     "knpemi_csr_dims": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

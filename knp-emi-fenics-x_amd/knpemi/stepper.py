@@ -23,7 +23,7 @@ from . import _lib as L
 
 class DeviceStepper:
     def __init__(self, forms_emi, forms_knp, c, c_prev, phi, phi_M_prev, solve_emi=None, solve_knp=None,
-                 assemble_knp_twice=False, overlap=True, device_solves=None):
+                 assemble_knp_twice=False, overlap=True, device_solves=None, extrapolate_guess=True):
         a = forms_emi[0]
         self.dp = a.dp
         self.a = a
@@ -31,10 +31,16 @@ class DeviceStepper:
         self.c, self.c_prev, self.phi, self.phi_M_prev = c, c_prev, phi, phi_M_prev
         if device_solves is not None:
             # (rtol_emi, rtol_knp): Krylov solves on the device between the assemblies (knpemi_solve_emi/knp)
+            # extrapolate_guess: start each solve from 2 x_n - x_(n-1) instead of x_n (knpemi_extrapolate_guess)
             rtol_emi, rtol_knp = device_solves
             self.iterations = []
-            solve_emi = lambda dp: self.iterations.append(("emi",) + dp.solve(L.B_EMI, rtol_emi, 1e-40))
-            solve_knp = lambda dp: self.iterations.append(("knp",) + dp.solve(L.B_KNP, rtol_knp, 2e-40))
+
+            def _solve(dp, which, name, rtol, atol):
+                if extrapolate_guess:
+                    L.check(dp.lib.knpemi_extrapolate_guess(dp.h, which))
+                self.iterations.append((name,) + dp.solve(which, rtol, atol))
+            solve_emi = lambda dp: _solve(dp, L.B_EMI, "emi", rtol_emi, 1e-40)
+            solve_knp = lambda dp: _solve(dp, L.B_KNP, "knp", rtol_knp, 2e-40)
         self.solve_emi, self.solve_knp = solve_emi, solve_knp
         self.assemble_knp_twice = assemble_knp_twice
         self.overlap = overlap
