@@ -288,15 +288,18 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   };
   const int chunk = amg ? 1 : 8;   // a V-cycle costs ~15 launches: test convergence after every iteration
   spmv(c, x, r, nullptr, b);                                   // r = b - A x
-  if ((rc = precond())) return rc;
-  vec(c, V_COPY, p, nullptr, z, nullptr);
-  dots(c, 3, r, z, r, r, b, b, OP_CG_INIT);                    // r.z, r.r and b.b in one launch
+  dots(c, 2, r, r, b, b, nullptr, nullptr, OP_STORE3, S_RR, S_BB);
   double sc[S_N];
   if ((rc = read_scalars(c, sc, S_N))) return rc;
   const double bnorm = std::sqrt(sc[S_BB]);
   const double target = std::max(atol, rtol * (bnorm > 0 ? bnorm : 1.0));
   int it = 0;
   double rn = std::sqrt(sc[S_RR]);
+  if (rn > target) {   // the (extrapolated) initial guess is not good enough: first search direction
+    if ((rc = precond())) return rc;
+    vec(c, V_COPY, p, nullptr, z, nullptr);
+    dots(c, 2, r, z, r, r, nullptr, nullptr, OP_CG_INIT);      // r.z, r.r
+  }
   auto iteration = [&]() -> int {
     spmv(c, p, q, nullptr);
     dots(c, 1, p, q, nullptr, nullptr, nullptr, nullptr, OP_CG_PAP);
