@@ -148,3 +148,22 @@ F3_SOURCE = [_fn3(_div_flux3(c3[k], Z[k])) for k in range(2)]
 def nodal_rms_error(values, exact_values):
     """Root mean square of the nodal error (uniform grids: a discrete L2 norm)."""
     return float(np.sqrt(np.mean((values - exact_values) ** 2)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# EMI volume check without a source term: with c_2, c_3 constant and c_1 = C exp(-psi phi) - (D_2 c_2 + D_3 c_3) / D_1
+# (z_k^2 = 1) the identity  F sum_k z_k D_k grad c_k = -kappa grad phi,  kappa = F psi sum_k z_k^2 D_k c_k,  holds
+# pointwise, so the EMI equation  div(kappa grad phi) + F sum_k z_k div(D_k grad c_k) = 0  (emiWeakForm.py:138-241)
+# is satisfied by phi itself, natural boundary condition included: assembling A_emi, b_emi from these
+# concentrations and solving must return phi up to a constant at second order.
+# ---------------------------------------------------------------------------------------------------------------
+EMI_C = 10.0
+EMI_C23 = (2.0, 2.0)
+
+
+def emi_exact(X):
+    """(phi, [c_1, c_2, c_3]) at points X [d, n] (d = 2 or 3)."""
+    u_ = np.prod(np.cos(np.pi * X), axis=0)
+    ph = P0 * u_
+    c1 = EMI_C * np.exp(-PSI * ph) - (EMI_C23[0] + EMI_C23[1])
+    return ph, [c1, np.full_like(ph, EMI_C23[0]), np.full_like(ph, EMI_C23[1])]

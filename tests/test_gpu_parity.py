@@ -657,6 +657,56 @@ def test_mms_knp_convergence_3d(hip_lib, cell_type):
     assert np.all(rates[-1] > 1.8) and np.all(errs[-1] < 5e-2), (errs, rates)
 
 
+@pytest.mark.parametrize("cell_type", ["triangle", "tetrahedron", "hexahedron"])
+def test_emi_volume_terms_recover_boltzmann_potential(hip_lib, cell_type):
+    """Analytic check of the EMI volume kernels (kappa-stiffness and the all-ion diffusive right-hand side) in 2D and
+    3D: concentrations in Boltzmann equilibrium with a given potential (tests/mms_knp_problem.py) make that potential
+    the solution of the assembled system; device CG + AMG with the constant null space; second order."""
+    import contextlib
+    import io
+    import mms_knp_problem as K
+    from knpemi import create_functions_emi, create_functions_knp, emi_system, set_initial_conditions
+    from knpemi.fem import Constant, create_box, create_unit_square, extract_submesh, meshtags
+    from knpemi.pdeSolver import create_solver_emi
+    errs = []
+    for M in ((16, 32, 64) if cell_type == "triangle" else (4, 8, 16)):
+        if cell_type == "triangle":
+            mesh = create_unit_square(None, M, M)
+        else:
+            mesh = create_box(None, [np.zeros(3), np.ones(3)], (M, M, M), cell_type)
+        ct = meshtags(mesh, mesh.tdim, np.arange(mesh.num_cells), np.zeros(mesh.num_cells, np.int32))
+        ft = meshtags(mesh, mesh.tdim - 1, np.zeros(0, np.int32), np.zeros(0, np.int32))
+        subs = {}
+        for t in (0, 1):
+            sm, e2p, v2p, _, _ = extract_submesh(mesh, ct, t)
+            subs[t] = dict(tag=t, name=f"sub{t}", mesh_sub=sm, sub_to_parent=e2p, sub_vertex_to_parent=v2p)
+        g, g2p, _, _, _ = extract_submesh(mesh, ft, [1])
+        subs[1].update(mesh_mem=g, mem_to_parent=g2p, membrane_tags=[1], mem_models=[])
+        s0 = subs[0]['mesh_sub']
+        cst = lambda v: {0: Constant(s0, v), 1: Constant(subs[1]['mesh_sub'], v)}
+        pp = {'dt': Constant(mesh, 1.0), 'F': Constant(mesh, 1.0), 'psi': Constant(mesh, K.PSI),
+              'C_phi': Constant(mesh, 1.0), 'C_M': Constant(mesh, 1.0), 'rho': {'z': -1, **cst(0.0)}}
+        ions = [dict(name=n, z=z, D=cst(K.D), c_init=cst(1.0)) for n, z in zip("abc", K.Z)]
+        with contextlib.redirect_stdout(io.StringIO()):
+            phi, phi_M_prev = create_functions_emi(subs, degree=1)
+            c, c_prev = create_functions_knp(subs, ions, degree=1)
+            set_initial_conditions(ions, subs, c_prev)
+        ph, cs = K.emi_exact(s0.x.T)
+        # ion order [a (z=+1), b (z=-1), c (z=+1, eliminated)]: the varying species must carry z = +1
+        c_prev[0][0].x.array[:] = cs[0]
+        c_prev[0][1].x.array[:] = cs[1]
+        ions[2]['c_0'].x.array[:] = cs[2]
+        a_emi, p_emi, L_emi = emi_system(mesh, ct, ft, pp, ions, subs, phi, phi_M_prev, c_prev, 1.0)
+        emi = create_solver_emi(a_emi, L_emi, phi, [], subs, None, direct=False, p=p_emi, rtol=1e-12, atol=1e-40)
+        emi.solve()
+        x = phi[0].x._a
+        errs.append(K.nodal_rms_error(x - x.mean(), ph - ph.mean()))
+    errs = np.array(errs)
+    rates = np.log2(errs[:-1] / errs[1:])
+    print(cell_type, "EMI Boltzmann check: errors", errs, "rates", rates)
+    assert rates[-1] > 1.8 and errs[-1] < 2e-2, (errs, rates)
+
+
 @pytest.mark.parametrize("splitting", [False, True])
 def test_mms_knp_membrane_convergence(hip_lib, splitting):
     """Membrane variant of the manufactured KNP problem (tests/mms_knp_problem.py): the rational Robin terms of b_knp

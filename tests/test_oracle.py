@@ -227,3 +227,28 @@ def test_oracle_mms_knp_membrane_convergence(splitting):
     rates = np.log2(errs[:-1] / errs[1:])
     print("oracle KNP membrane MMS: errors", errs[-1], "rates", rates[-1])
     assert np.all(rates > 1.85) and np.all(errs[-1] < 1e-2), (errs, rates)
+
+
+@pytest.mark.parametrize("cell_type", ["triangle", "tetrahedron", "hexahedron"])
+def test_oracle_emi_volume_terms_recover_boltzmann_potential(cell_type):
+    """Analytic known answer for the oracle's EMI volume forms in 2D and 3D (tests/mms_knp_problem.py, `emi_exact`):
+    concentrations in Boltzmann equilibrium with a potential make that potential the solution; second order."""
+    from knpemi.fem import create_box, create_unit_square
+    import driver
+    import mms_knp_problem as K
+    errs = []
+    for M in ((8, 16, 32) if cell_type == "triangle" else (4, 8)):
+        mesh = create_unit_square(None, M, M) if cell_type == "triangle" else \
+            create_box(None, [np.zeros(3), np.ones(3)], (M, M, M), cell_type)
+        nvf = {"triangle": 2, "tetrahedron": 3, "hexahedron": 4}[cell_type]
+        P = o.OracleProblem(mesh.x, mesh.cells, mesh.cell_type, np.zeros(mesh.num_cells, np.int32),
+                            np.zeros((0, nvf), np.int32), np.zeros(0, np.int32), {0: [], 1: [1]})
+        params = dict(dt=1.0, F=1.0, psi=K.PSI, C_M=1.0, C_phi=1.0)
+        ions = [dict(name=n, z=z, D={0: K.D, 1: K.D}) for n, z in zip("abc", K.Z)]
+        ph, cs = K.emi_exact(P.sub[0]["x"].T)
+        empty = np.zeros(0)
+        A, _, b = o.assemble_emi(P, params, ions, {0: cs, 1: [empty] * 3}, {1: empty}, {1: []})
+        x = driver.solve_singular(A, b)
+        errs.append(K.nodal_rms_error(x - x.mean(), ph - ph.mean()))
+    rates = np.log2(np.array(errs[:-1]) / np.array(errs[1:]))
+    assert rates[-1] > 1.8 and errs[-1] < 2e-2, (errs, rates)
