@@ -167,3 +167,54 @@ def emi_exact(X):
     ph = P0 * u_
     c1 = EMI_C * np.exp(-PSI * ph) - (EMI_C23[0] + EMI_C23[1])
     return ph, [c1, np.full_like(ph, EMI_C23[0]), np.full_like(ph, EMI_C23[1])]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 3D membrane variant: unit cube, ICS = [0.25, 0.75]^3, u = cos(2 pi x) cos(2 pi y) cos(2 pi z) (its gradient vanishes
+# on the edges and corners of the inner cube, so the normal fluxes are single-valued at every membrane vertex).
+# Same construction as the 2D membrane variant; checks the triangular (tetrahedra) and quadrilateral (hexahedra)
+# membrane-facet kernels.
+# ---------------------------------------------------------------------------------------------------------------
+um3 = sp.cos(2 * sp.pi * x) * sp.cos(2 * sp.pi * y) * sp.cos(2 * sp.pi * zz)
+phim3 = P0 * um3
+cm3 = [A_M[0] + B_M[0] * um3, A_M[1] + B_M[1] * um3]
+cm3.append(-(Z[0] * cm3[0] + Z[1] * cm3[1]) / Z[2])
+delta3 = DELTA0 * (1 + sp.cos(2 * sp.pi * x) ** 2 + sp.cos(2 * sp.pi * y) ** 2 + sp.cos(2 * sp.pi * zz) ** 2) / 4
+DT_M3 = 0.005
+Jm3 = [[-D * sp.diff(cm3[k], v) - Z[k] * PSI * D * cm3[k] * sp.diff(phim3, v) for v in (x, y, zz)] for k in range(3)]
+divJ3 = [sum(sp.diff(Jm3[k][i], v) for i, v in enumerate((x, y, zz))) for k in range(3)]
+cprev3 = [cm3[0] + DT_M3 * divJ3[0], cm3[1] + DT_M3 * divJ3[1], cm3[2]]
+asum3 = sum(D * Z[k] ** 2 * cprev3[k] for k in range(3))
+alpha3 = [D * Z[k] ** 2 * cprev3[k] / asum3 for k in range(3)]
+M3_C = [_fn3(ck) for ck in cm3]
+M3_CPREV = [_fn3(cprev3[k]) for k in range(2)]
+M3_PHI = _fn3(phim3)
+M3_DELTA = _fn3(delta3)
+_J3 = [[_fn3(Jm3[k][i]) for i in range(3)] for k in range(3)]
+_AL3 = [_fn3(alpha3[k]) for k in range(3)]
+
+
+def ics_normals3(X):
+    """Outward unit normal of [0.25, 0.75]^3 at boundary points X [3, n] (edges / corners: any adjacent face)."""
+    d = np.stack([np.abs(X[a] - v) for a in range(3) for v in (0.25, 0.75)])
+    side = np.argmin(d, axis=0)
+    n = np.zeros_like(X)
+    for a in range(3):
+        n[a] = np.where(side == 2 * a, -1.0, np.where(side == 2 * a + 1, 1.0, 0.0))
+    return n
+
+
+def channel_currents3(XQ):
+    n = ics_normals3(XQ)
+    out = []
+    for k in range(3):
+        jn = sum(_J3[k][i](XQ) * n[i] for i in range(3))
+        out.append(F_CONST * Z[k] * jn + _AL3[k](XQ) * C_M * M3_DELTA(XQ) / DT_M3)
+    return out
+
+
+def membrane_potential_prev3(XQ, splitting):
+    pm = PHI0 + M3_DELTA(XQ)
+    if splitting:
+        pm = pm - (DT_M3 / C_M) * sum(channel_currents3(XQ))
+    return pm

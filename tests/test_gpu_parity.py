@@ -767,6 +767,66 @@ def test_mms_knp_membrane_convergence(hip_lib, splitting):
     assert np.all(rates > 1.85) and np.all(errs[-1] < 1e-2), (errs, rates)
 
 
+@pytest.mark.parametrize("cell_type", ["tetrahedron", "hexahedron"])
+def test_mms_knp_membrane_convergence_3d(hip_lib, cell_type):
+    """3D membrane variant of the manufactured KNP problem: the triangular (tetrahedra) and quadrilateral (hexahedra)
+    membrane-facet kernels with their degree-6 rules, the 3D row kernels' membrane sums and the device solve; second
+    order on both sub-domains (splitting scheme on)."""
+    import contextlib
+    import io
+    import mms_knp_problem as K
+    from mms_problem import MMSMembraneModel
+    from knpemi import create_functions_emi, create_functions_knp, emi_system, knp_system, set_initial_conditions
+    from knpemi.fem import Constant, Function, create_box, extract_submesh
+    from knpemi.fem.idealized import _tag
+    from knpemi.pdeSolver import create_solver_knp
+    errs = []
+    for M in (8, 16, 32) if cell_type == "hexahedron" else (8, 16):
+        mesh = create_box(None, [np.zeros(3), np.ones(3)], (M, M, M), cell_type)
+        ct, ft = _tag(mesh, [([0.25] * 3, [0.75] * 3)], [1], full_facet_tags=False)
+        s0, e2p, ev2p, _, _ = extract_submesh(mesh, ct, 0)
+        s1, i2p, iv2p, _, _ = extract_submesh(mesh, ct, 1)
+        g, g2p, _, _, _ = extract_submesh(mesh, ft, 1)
+        subs = {0: dict(name="ECS", mesh_sub=s0, sub_to_parent=e2p, sub_vertex_to_parent=ev2p),
+                1: dict(name="cell", mesh_sub=s1, sub_to_parent=i2p, sub_vertex_to_parent=iv2p, mesh_mem=g,
+                        mem_to_parent=g2p)}
+        cst = lambda v: {0: Constant(s0, v), 1: Constant(s1, v)}
+        pp = {'dt': Constant(mesh, K.DT_M3), 'F': Constant(mesh, K.F_CONST), 'psi': Constant(mesh, K.PSI),
+              'C_phi': Constant(mesh, K.C_M / K.DT_M3), 'C_M': Constant(mesh, K.C_M), 'rho': {'z': -1, **cst(0.0)}}
+        ions = [dict(name=n, z=z, D=cst(K.D), c_init=cst(1.0)) for n, z in zip("abc", K.Z)]
+        with contextlib.redirect_stdout(io.StringIO()):
+            phi, phi_M_prev = create_functions_emi(subs, degree=1)
+            c, c_prev = create_functions_knp(subs, ions, degree=1)
+            set_initial_conditions(ions, subs, c_prev)
+        Q = phi_M_prev[1].function_space
+        XQ = g.x.T
+        I = K.channel_currents3(XQ)
+        I_ch_k = {}
+        for k, n in enumerate("abc"):
+            I_ch_k[n] = Function(Q, name=f"I_ch_{n}")
+            I_ch_k[n].x.array[:] = I[k]
+        mm = MMSMembraneModel()
+        mm.tag = 1
+        subs[1]['mem_models'] = [{'ode': mm, 'I_ch_k': I_ch_k}]
+        phi_M_prev[1].x.array[:] = K.membrane_potential_prev3(XQ, True)
+        for t, sm in ((0, s0), (1, s1)):
+            X = sm.x.T
+            for k in range(2):
+                c_prev[t][k].x.array[:] = K.M3_CPREV[k](X)
+                c[t][k].x.array[:] = K.M3_C[k](X) * 1.01
+            ions[2][f'c_{t}'].x.array[:] = K.M3_C[2](X)
+            phi[t].x.array[:] = K.M3_PHI(X) - (K.PHI0 if t == 0 else 0.0)
+        emi_system(mesh, ct, ft, pp, ions, subs, phi, phi_M_prev, c_prev, K.DT_M3)
+        a_knp, p_knp, L_knp = knp_system(mesh, ct, ft, pp, ions, subs, phi, phi_M_prev, c, c_prev, K.DT_M3)
+        knp = create_solver_knp(a_knp, L_knp, c, [], subs, None, direct=False, p=p_knp, rtol=1e-12, atol=1e-40)
+        knp.solve()
+        errs.append([K.nodal_rms_error(c[t][k].x._a, K.M3_C[k](sm.x.T)) for t, sm in ((0, s0), (1, s1)) for k in range(2)])
+    errs = np.array(errs)
+    rates = np.log2(errs[:-1] / errs[1:])
+    print(cell_type, "3D KNP membrane MMS: errors", errs[-1], "rates", rates[-1])
+    assert np.all(rates[-1] > 1.7) and np.all(errs[-1] < 1e-1), (errs, rates)
+
+
 def test_vertex_valence_limit_is_reported(hip_lib):
     """Maximum sizes: CSR rows are addressed with one byte per slot (<= 255 entries).  A fan of 300 triangles around
     one vertex exceeds that and must be refused with a message, not assembled wrongly; 200 triangles pass."""
