@@ -827,6 +827,68 @@ def test_mms_knp_membrane_convergence_3d(hip_lib, cell_type):
     assert np.all(rates[-1] > 1.7) and np.all(errs[-1] < 1e-1), (errs, rates)
 
 
+@pytest.mark.parametrize("cell_type", ["triangle", "tetrahedron", "hexahedron"])
+def test_emi_membrane_coupling_recovers_jump(hip_lib, cell_type):
+    """Analytic check of the EMI membrane terms (coupling C_phi [u][v] with the facet mass of intervals, triangles and
+    quadrilaterals, Robin right-hand side) in 2D and 3D: Boltzmann-equilibrium concentrations on both sides (zero
+    total current) and phi_M_prev = PHI0 make phi_e = P u, phi_i = P u + PHI0 the solution; the jump across the membrane
+    and both potentials come back at second order from the device CG + AMG solve."""
+    import contextlib
+    import io
+    import mms_knp_problem as K
+    from mms_problem import MMSMembraneModel
+    from knpemi import create_functions_emi, create_functions_knp, emi_system, set_initial_conditions
+    from knpemi.fem import Constant, Function, create_box, create_unit_square, extract_submesh
+    from knpemi.fem.idealized import _tag
+    from knpemi.pdeSolver import create_solver_emi
+    errs = []
+    d = 2 if cell_type == "triangle" else 3
+    for M in ((16, 32, 64) if d == 2 else (8, 16)):
+        mesh = create_unit_square(None, M, M) if d == 2 else create_box(None, [np.zeros(3), np.ones(3)], (M, M, M), cell_type)
+        ct, ft = _tag(mesh, [([0.25] * d, [0.75] * d)], [1], full_facet_tags=False)
+        s0, e2p, ev2p, _, _ = extract_submesh(mesh, ct, 0)
+        s1, i2p, iv2p, _, _ = extract_submesh(mesh, ct, 1)
+        g, g2p, _, _, _ = extract_submesh(mesh, ft, 1)
+        subs = {0: dict(name="ECS", mesh_sub=s0, sub_to_parent=e2p, sub_vertex_to_parent=ev2p),
+                1: dict(name="cell", mesh_sub=s1, sub_to_parent=i2p, sub_vertex_to_parent=iv2p, mesh_mem=g,
+                        mem_to_parent=g2p)}
+        cst = lambda v: {0: Constant(s0, v), 1: Constant(s1, v)}
+        pp = {'dt': Constant(mesh, 1.0), 'F': Constant(mesh, 1.0), 'psi': Constant(mesh, K.PSI),
+              'C_phi': Constant(mesh, 1.0), 'C_M': Constant(mesh, 1.0), 'rho': {'z': -1, **cst(0.0)}}
+        ions = [dict(name=n, z=z, D=cst(K.D), c_init=cst(1.0)) for n, z in zip("abc", K.Z)]
+        with contextlib.redirect_stdout(io.StringIO()):
+            phi, phi_M_prev = create_functions_emi(subs, degree=1)
+            c, c_prev = create_functions_knp(subs, ions, degree=1)
+            set_initial_conditions(ions, subs, c_prev)
+        Q = phi_M_prev[1].function_space
+        zero = {}
+        for n in "abc":
+            zero[n] = Function(Q, name=f"I_ch_{n}")
+        mm = MMSMembraneModel()
+        mm.tag = 1
+        subs[1]['mem_models'] = [{'ode': mm, 'I_ch_k': zero}]
+        phi_M_prev[1].x.array[:] = K.PHI0
+        exact = {}
+        for t, sm in ((0, s0), (1, s1)):
+            ph, cs = K.emi_exact(sm.x.T)
+            exact[t] = ph + (K.PHI0 if t == 1 else 0.0)
+            c_prev[t][0].x.array[:] = cs[0]
+            c_prev[t][1].x.array[:] = cs[1]
+            ions[2][f'c_{t}'].x.array[:] = cs[2]
+        a_emi, p_emi, L_emi = emi_system(mesh, ct, ft, pp, ions, subs, phi, phi_M_prev, c_prev, 1.0)
+        emi = create_solver_emi(a_emi, L_emi, phi, [], subs, None, direct=False, p=p_emi, rtol=1e-12, atol=1e-40)
+        emi.solve()
+        x = np.concatenate([phi[0].x._a, phi[1].x._a])
+        xe = np.concatenate([exact[0], exact[1]])
+        shift = (x - xe).mean()                       # the system fixes the potentials up to one common constant
+        jump = phi[1].x._a.mean() - exact[1].mean() - (phi[0].x._a.mean() - exact[0].mean())
+        errs.append([K.nodal_rms_error(x - shift, xe), abs(jump)])
+    errs = np.array(errs)
+    rates = np.log2(errs[:-1] / errs[1:])
+    print(cell_type, "EMI membrane check: errors", errs[-1], "rates", rates[-1])
+    assert rates[-1][0] > 1.8 and errs[-1][0] < 2e-2 and errs[-1][1] < 5e-3, (errs, rates)
+
+
 def test_vertex_valence_limit_is_reported(hip_lib):
     """Maximum sizes: CSR rows are addressed with one byte per slot (<= 255 entries).  A fan of 300 triangles around
     one vertex exceeds that and must be refused with a message, not assembled wrongly; 200 triangles pass."""
