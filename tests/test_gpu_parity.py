@@ -878,6 +878,13 @@ def test_emi_membrane_coupling_recovers_jump(hip_lib, cell_type):
         a_emi, p_emi, L_emi = emi_system(mesh, ct, ft, pp, ions, subs, phi, phi_M_prev, c_prev, 1.0)
         emi = create_solver_emi(a_emi, L_emi, phi, [], subs, None, direct=False, p=p_emi, rtol=1e-12, atol=1e-40)
         emi.solve()
+        # P_emi - A_emi is the mass matrix of the cell (tabulated once at set-up): nothing on the ECS rows, entries
+        # that sum to the volume of [0.25, 0.75]^d, symmetric
+        A, _ = emi.assemble()
+        Mm = (emi.P - A).tocsr()
+        n0 = phi[0].x.array.shape[0]
+        assert Mm[:n0].nnz == 0 or np.abs(Mm[:n0].data).max() == 0.0
+        assert abs(Mm.sum() - 0.5 ** d) < 1e-10 and abs(Mm - Mm.T).max() < 1e-13
         x = np.concatenate([phi[0].x._a, phi[1].x._a])
         xe = np.concatenate([exact[0], exact[1]])
         shift = (x - xe).mean()                       # the system fixes the potentials up to one common constant
