@@ -827,8 +827,9 @@ def test_mms_knp_membrane_convergence_3d(hip_lib, cell_type):
     assert np.all(rates[-1] > 1.7) and np.all(errs[-1] < 1e-1), (errs, rates)
 
 
+@pytest.mark.parametrize("splitting", [True, False])
 @pytest.mark.parametrize("cell_type", ["triangle", "tetrahedron", "hexahedron"])
-def test_emi_membrane_coupling_recovers_jump(hip_lib, cell_type):
+def test_emi_membrane_coupling_recovers_jump(hip_lib, cell_type, splitting):
     """Analytic check of the EMI membrane terms (coupling C_phi [u][v] with the facet mass of intervals, triangles and
     quadrilaterals, Robin right-hand side) in 2D and 3D: Boltzmann-equilibrium concentrations on both sides (zero
     total current) and phi_M_prev = PHI0 make phi_e = P u, phi_i = P u + PHI0 the solution; the jump across the membrane
@@ -868,6 +869,13 @@ def test_emi_membrane_coupling_recovers_jump(hip_lib, cell_type):
         mm.tag = 1
         subs[1]['mem_models'] = [{'ode': mm, 'I_ch_k': zero}]
         phi_M_prev[1].x.array[:] = K.PHI0
+        if not splitting:
+            # emiWeakForm.py:236: g = phi_M_prev - I_ch / C_phi; a non-zero channel current compensated in phi_M_prev
+            # leaves the same solution and exercises that branch
+            I_tot = 0.3 + 0.2 * np.cos(2 * np.pi * g.x[:, 0])
+            zero["a"].x.array[:] = 0.7 * I_tot
+            zero["c"].x.array[:] = 0.3 * I_tot
+            phi_M_prev[1].x.array[:] = K.PHI0 + I_tot / 1.0
         exact = {}
         for t, sm in ((0, s0), (1, s1)):
             ph, cs = K.emi_exact(sm.x.T)
@@ -876,6 +884,7 @@ def test_emi_membrane_coupling_recovers_jump(hip_lib, cell_type):
             c_prev[t][1].x.array[:] = cs[1]
             ions[2][f'c_{t}'].x.array[:] = cs[2]
         a_emi, p_emi, L_emi = emi_system(mesh, ct, ft, pp, ions, subs, phi, phi_M_prev, c_prev, 1.0)
+        a_emi.shared['splitting_scheme'] = splitting
         emi = create_solver_emi(a_emi, L_emi, phi, [], subs, None, direct=False, p=p_emi, rtol=1e-12, atol=1e-40)
         emi.solve()
         # P_emi - A_emi is the mass matrix of the cell (tabulated once at set-up): nothing on the ECS rows, entries
