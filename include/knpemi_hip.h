@@ -207,6 +207,12 @@ int knpemi_ode_step(knpemi_handle* h, int sub, int model, double t0, double dt, 
 int knpemi_ode_stats(knpemi_handle* h, int sub, int model, int64_t* n_rhs, int64_t* n_steps,
                      int32_t* n_failed);
 
+/* Diagnostics (no reference counterpart): with KNPEMI_ODE_STAMPS=1 in the environment the sweep runs a stamped build of
+ * the kernel; per workgroup 12 cycle sums (loop head, TOP, PRED, RHS, CORR, ERR up to the order selection, prologue, -,
+ * order selection, new coefficients + rescaling, rest of ERR, -) and 12 counts.  Returns
+ * the number of workgroups copied (<= max_blocks). */
+int knpemi_debug_ode_stamps(knpemi_handle* h, int sub, int model, uint64_t* out, int max_blocks);
+
 /* End-of-step update: update_pde_variables (utils.py:238-295): c_prev <- c, eliminated ion from
  * electroneutrality, phi_M_prev <- tr(phi_i) - tr(phi_e). */
 int knpemi_update_pde(knpemi_handle* h);

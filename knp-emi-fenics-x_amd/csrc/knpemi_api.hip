@@ -1029,7 +1029,8 @@ extern "C" int knpemi_ode_bind(knpemi_handle* h, int sub, int model, int model_i
   int rc;
   if ((rc = dev_zeros(h, (size_t)n_states * m.nq, &m.d_states))) return rc;
   if ((rc = dev_zeros(h, (size_t)n_params * m.nq, &m.d_params))) return rc;
-  if ((rc = dev_zeros(h, 3, &m.d_stats))) return rc;
+  m.n_stat_blocks = (int)(((size_t)m.nq * n_states + 63) / 64) + 1;   // one slot per workgroup of the sweep
+  if ((rc = dev_zeros(h, 3 * (size_t)m.n_stat_blocks, &m.d_stats))) return rc;
   m.bound = 1;
   return KNPEMI_OK;
 }
@@ -1139,16 +1140,33 @@ extern "C" int knpemi_ode_step(knpemi_handle* h, int sub, int model, double t0, 
 extern "C" int knpemi_ode_stats(knpemi_handle* h, int sub, int model, int64_t* n_rhs, int64_t* n_steps, int32_t* n_failed) {
   int slot = ode_slot(h, sub, model, 1);
   if (slot < 0) return KNPEMI_EINVAL;
-  unsigned long long st[3];
+  unsigned long long st[3] = {0, 0, 0};
   KN_HIP(hipSetDevice(h->device));
-  KN_HIP(hipMemcpyAsync(st, h->ode[slot].d_stats, sizeof(st), hipMemcpyDeviceToHost, h->stream));
-  KN_HIP(hipMemsetAsync(h->ode[slot].d_stats, 0, sizeof(st), h->stream));
+  KnOdeModel& mo = h->ode[slot];
+  std::vector<unsigned long long> part(3 * (size_t)mo.n_stat_blocks);
+  KN_HIP(hipStreamSynchronize(h->aux));   // the sweep may run on the auxiliary stream
+  KN_HIP(hipMemcpyAsync(part.data(), mo.d_stats, part.size() * sizeof(part[0]), hipMemcpyDeviceToHost, h->stream));
+  KN_HIP(hipMemsetAsync(mo.d_stats, 0, part.size() * sizeof(part[0]), h->stream));
   KN_HIP(hipStreamSynchronize(h->stream));
+  for (size_t i = 0; i < part.size(); ++i) st[i % 3] += part[i];
   if (n_rhs) *n_rhs = (int64_t)st[0];
   if (n_steps) *n_steps = (int64_t)st[1];
   if (n_failed) *n_failed = (int32_t)st[2];
   if (st[2]) return fail(KNPEMI_EODE, "LSODA failed on at least one membrane dof (odeSolver.py:121 `assert success`)");
   return KNPEMI_OK;
+}
+
+extern "C" int knpemi_debug_ode_stamps(knpemi_handle* h, int sub, int model, uint64_t* out, int max_blocks) {
+  int slot = ode_slot(h, sub, model, 1);
+  if (slot < 0) return KNPEMI_EINVAL;
+  KnOdeModel& m = h->ode[slot];
+  if (!m.d_stamps || !out) return fail(KNPEMI_EINVAL, "knpemi_debug_ode_stamps: run with KNPEMI_ODE_STAMPS=1");
+  const int nb = std::min(max_blocks, m.n_stat_blocks - 1);
+  KN_HIP(hipSetDevice(h->device));
+  KN_HIP(hipStreamSynchronize(h->aux));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  KN_HIP(hipMemcpy(out, m.d_stamps, (size_t)nb * 24 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return nb;
 }
 
 extern "C" int knpemi_update_pde(knpemi_handle* h) {

@@ -104,7 +104,9 @@ struct KnOdeModel {
   int n_stim = 0;
   int stim_idx[8];
   double stim_val[8];
-  unsigned long long* d_stats = nullptr; // [3]: rhs evals, steps, failures
+  unsigned long long* d_stats = nullptr; // [n_stat_blocks][3]: rhs evals, steps, failures per workgroup of the sweep
+  int n_stat_blocks = 0;
+  unsigned long long* d_stamps = nullptr;   // diagnostic phase stamps (KNPEMI_ODE_STAMPS)
 };
 
 // Algebraic multigrid hierarchy (kernels_amg.hip)

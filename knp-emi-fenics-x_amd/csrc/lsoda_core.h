@@ -1,5 +1,5 @@
-// LSODA (Livermore Solver for ODEs with Automatic method switching) for tiny systems, written so
-// that one GPU thread integrates one membrane dof entirely out of its own private memory.
+// LSODA (Livermore Solver for ODEs with Automatic method switching) for tiny systems on gfx950,
+// written as a flat phase machine so that the lanes of a wavefront never serialise each other.
 //
 // The reference calls numbalsoda's C++ LSODA once per membrane dof and step
 // (src/knpemi/odeSolver.py:116-120: `lsoda(addr, state, [t, t+dt], data=params, rtol=1e-8,
@@ -10,8 +10,25 @@
 // detection, istate = 1 / itask = 1 semantics (fresh start at every call, overshoot tout and
 // interpolate back).
 //
+// Shape of the code.  ODEPACK's DLSODA -> DSTODA -> corrector nest is four loops deep (time loop, retry after
+// a failed error test, retry after a corrector failure, corrector iterations).  On a GPU every lane of a
+// wavefront would wait for the slowest lane at each level: a wave pays the SUM over steps of the MAXIMUM
+// number of retries / iterations, and the compiler keeps a copy of the right-hand side per call site.  Here one
+// trip of a single loop is one right-hand-side evaluation for every lane, whatever that lane is doing:
+//
+//     TOP (checks before a step, DSTODA prologue) -> PRED (predict, start the corrector) -> [RHS] ->
+//     CORR (one corrector iteration, convergence test) -> ERR (error test, order / step / method selection)
+//
+// and each lane carries its phase.  A wave therefore runs max-over-lanes(RHS evaluations) trips, there is ONE
+// right-hand-side call site in the loop, and all integrator state -- the Nordsieck array included -- is held in
+// registers: loops over the rows of the Nordsieck array are unrolled over the 13 possible rows and cut at a
+// wave-uniform bound `lhi` >= every lane's order + 1, rows above a lane's own order are kept at zero so that
+// these loops need no per-lane predicate (x + 0 = x exactly).  The arithmetic of every formula is ODEPACK's;
+// tests/ check the host build of this file against scipy's ODEPACK LSODA (same step, evaluation and Jacobian
+// counts) and, bit for bit, against the plain sequential restatement in oracle/lsoda_seq.h.
+//
 // Compiles for the device (hipcc) and for the host (g++, used only by tests/ to check this very
-// code against scipy's ODEPACK LSODA on the CPU -- it is not a CPU fallback of the product).
+// code on the CPU -- it is not a CPU fallback of the product).
 #pragma once
 
 #include <math.h>
@@ -26,13 +43,22 @@
 
 #define KN_ETA 2.2204460492503131e-16
 
+// true when the predicate holds on any active lane of the wavefront (a scalar branch condition on the device)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KN_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
+#else
+#define KN_ANY(c) (c)
+#endif
+
 // Method coefficients (ODEPACK CFODE), 1-based like the original: elco[meth-1][nq][i],
-// tesco[meth-1][nq][k]; cm1/cm2 = tesco[.][2] * elco[.][nq+1] used by the method switch.
+// tesco[meth-1][nq][k]; cm1/cm2 = tesco[.][2] * elco[.][nq+1] used by the method switch; sm1 = the
+// stability-region bounds of the Adams methods (DSTODA's data statement).
 struct LsodaCoef {
   double elco[2][13][14];
   double tesco[2][13][4];
   double cm1[13];
   double cm2[6];
+  double sm1[13];
 };
 
 // Host-side construction of the coefficient tables (exact restatement of CFODE).
@@ -96,23 +122,16 @@ inline void lsoda_fill_coef(LsodaCoef* c) {
   c->cm2[0] = 0.0;
   for (int i = 1; i <= 12; ++i) c->cm1[i] = c->tesco[0][i][2] * c->elco[0][i][i + 1];
   for (int i = 1; i <= 5; ++i) c->cm2[i] = c->tesco[1][i][2] * c->elco[1][i][i + 1];
+  static const double sm1[13] = {0.0, 0.5, 0.575, 0.55, 0.45, 0.35, 0.25, 0.2, 0.15, 0.1, 0.075, 0.05, 0.025};
+  for (int i = 0; i < 13; ++i) c->sm1[i] = sm1[i];
 }
 
-// N = number of states (1..8); F provides `static void rhs(double t, const double* y, double* dy,
-// double* p)` where p is the (in/out) parameter row, exactly the numba cfunc signature
-// `rhs_numba(t, states, values, parameters)` of the reference's membrane modules.
-// STRIDE: distance (in doubles) between consecutive elements of the dynamically indexed work arrays
-// (Nordsieck history, method coefficients, iteration matrix).  The host build uses 1 (a private
-// array); the HIP kernel points `work` at LDS with STRIDE = workgroup size so that lane l owns the
-// column l: conflict-free, and an order of magnitude lower latency than scratch memory.
-//
 // LANES: number of GPU lanes that share one ODE system.  LANES = 1: one thread integrates all N
 // components (host build, and N = 1 models).  LANES = N (device only): lane c of a group of N adjacent
 // lanes owns component c -- every vector operation of the algorithm becomes one scalar operation per
-// lane, norms become a max over the group (exact, so all lanes of a group take identical decisions and
-// the results are bit-identical to LANES = 1), the right-hand side is evaluated component-wise by
-// `F::rhs_lane` after an all-gather of the state, and the N x N iteration matrix is gathered and
-// factorised redundantly by every lane.
+// lane, norms become a max over the group (exact, so all lanes of a group take identical decisions),
+// the right-hand side is evaluated component-wise by `F::rhs_lane` after an all-gather of the state,
+// and the N x N iteration matrix is gathered and factorised redundantly by every lane.
 #if defined(__HIP_DEVICE_COMPILE__)
 // Exchange inside an aligned group of four lanes as a DPP quad permute on the two halves of the double: a
 // register-to-register move (two v_mov_b32_dpp), where __shfl / __shfl_xor go through the LDS crossbar
@@ -151,48 +170,73 @@ KN_HD double kn_group_get(double v, int k) {   // value held by lane k of this l
       case 2: return kn_dpp_quad<0xAA>(v);
       default: return kn_dpp_quad<0xFF>(v);
     }
-  } else {
+  } else if constexpr (L > 1) {
     return __shfl(v, (int)((__lane_id() & ~(unsigned)(L - 1)) | (unsigned)k));
   }
 #else
   (void)k;
-  return v;
 #endif
+  return v;
 }
 
-template <int N, class F, int STRIDE = 1, int LANES = 1>
+// x^e for x >= 0, e > 0 (the step-ratio formulas of DSTODA): exp(e log x), under half the instructions of
+// the general pow() on gfx950 and accurate to a few ulp, far inside what these heuristics resolve.
+KN_HD double kn_powr(double x, double e) { return exp(log(x) * e); }
+
+// N = number of states (1..8); F is a model functor (membrane_models.h): `rhs(t, y, dy)` evaluates all
+// components, `rhs_lane(c, t, y)` component c.
+// STAMPS: diagnostic build only (KNPEMI_ODE_STAMPS=1, never the timed kernel) -- s_memtime stamps between the phases of
+// a trip, summed per phase.
+// STRIDE: distance (in doubles) between consecutive entries of the work storage that holds the factorised iteration
+// matrix of the BDF method and its pivots (only the stiff method touches it): 1 on the host (a private array), the
+// workgroup size on the device, where `work` points into LDS and lane t owns column t.
+template <int N, class F, int LANES = 1, bool STAMPS = false, int STRIDE = 1>
 struct Lsoda {
   static constexpr int MXORDN = 12, MXORDS = 5, MAXCOR = 3, MSBP = 20, MXNCF = 10;
   static constexpr int NI = N / LANES;               // components held by one lane
-  static constexpr int WORK = 15 * NI + 14 + (LANES == 1 ? N * N : 0);   // doubles of strided work storage
+  static constexpr int WORK = N * N + N;             // doubles of strided work storage (iteration matrix, pivots)
+  static constexpr int ROWS = 13;                    // Nordsieck rows 1..13
   static_assert(LANES == 1 || LANES == N, "one lane per system or one lane per component");
+  enum Phase { PH_TOP = 0, PH_PRED = 1, PH_CORR = 2, PH_ERR = 3, PH_RESTART = 4, PH_DONE = 5 };
 
   const LsodaCoef* cf;
   F f;        // model functor: caches the parameter row, keeps the side-effect currents
   double rtol, atol;
-  double* work;
-  // YH(1..13, N): Nordsieck array (row 14 only bounds a dead branch of methodswitch)
-  KN_HD double& YH(int j, int i) { return work[(j * NI + i) * STRIDE]; }
-  KN_HD double& EL(int i) { return work[(15 * NI + i) * STRIDE]; }
-  KN_HD double& WM(int i, int j) { return work[(15 * NI + 14 + i * N + j) * STRIDE]; }
-  int ipvt[N];
+  double yh[ROWS + 1][NI];   // Nordsieck array, rows 1..13; rows above l are kept at +0
+  double ysave[NI];          // ODEPACK's YH(lmax) slot: the correction saved for the order-increase test
+  double el[ROWS + 1];       // method coefficients of the current (meth, nq); entries above l are 0
+  double tq1, tq2, tq3;      // tesco(nq, 1..3) of the current (meth, nq)
   double ewt[NI], savf[NI], acor[NI], y[NI];
-  double lu[LANES == 1 ? 1 : N][LANES == 1 ? 1 : N];   // LANES = N: factorised iteration matrix (registers)
+  double* work;
+  KN_HD double& WM(int i, int j) const { return work[(i * N + j) * STRIDE]; }   // iteration matrix / its LU factors
+  KN_HD double& PIV(int k) const { return work[(N * N + k) * STRIDE]; }         // pivot rows (stored as doubles)
   int comp = 0;                                         // LANES = N: the component this lane owns
-  double h, hu, tn, hold, rc, crate, conit, el0, rmax, pdest, pdlast, pdnorm, ratio, tsw;
+  double h, hu, tn, hold, rcr, crate, conit, el0, rmax, pdest, pdlast, pdnorm, ratio, tsw;
+  double told, delp, pdh, rh, del, pnorm, rate;         // DSTODA / corrector locals that live across phases
   int nq, l, meth, mused, miter, ialth, ipup, jcur, jstart, kflag, icount, irflag, nslp, nst, nfe,
       nje, lmax, maxord, nqu, ierpj;
+  int m, ncf, ph, ret;
+  int lhi;    // wave-uniform bound: l <= lhi on every running lane when a trip starts
+  unsigned long long st_last = 0, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned st_cnt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-  KN_HD double sm1(int i) const {
-    switch (i) {
-      case 1: return 0.5; case 2: return 0.575; case 3: return 0.55; case 4: return 0.45;
-      case 5: return 0.35; case 6: return 0.25; case 7: return 0.2; case 8: return 0.15;
-      case 9: return 0.1; case 10: return 0.075; case 11: return 0.05; case 12: return 0.025;
-      default: return 0.0;
+  KN_HD void stamp(int i, bool ran) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (STAMPS) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_sched_barrier(0);
+      st_acc[i] += t - st_last;
+      st_last = t;
+      st_cnt[i] += ran ? 1u : 0u;
     }
+#else
+    (void)i; (void)ran;
+#endif
   }
-  KN_HD double elco(int q, int i) const { return cf->elco[meth - 1][q][i]; }
-  KN_HD double tesco(int q, int i) const { return cf->tesco[meth - 1][q][i]; }
+
+  KN_HD double sm1(int i) const { return cf->sm1[i]; }
 
   KN_HD double vmnorm(const double* v) const {
     double vm = 0.0;
@@ -200,10 +244,43 @@ struct Lsoda {
     return kn_group_max<LANES>(vm);
   }
 
-  KN_HD double vmnorm_yh(int j) {
-    double vm = 0.0;
-    _Pragma("unroll") for (int i = 0; i < NI; ++i) vm = fmax(vm, fabs(YH(j, i)) * ewt[i]);
-    return kn_group_max<LANES>(vm);
+  // ---- loops over the rows of the Nordsieck array ---------------------------------------------------------
+  // fn(j) for j = FIRST .. cap, cap = the class (4, 6, 8 or 13) of the wave-uniform bound lb >= l.  Every body is
+  // harmless on the rows between a lane's own l and the cap (zero rows, masked selects), so no row costs a branch.
+  template <int FIRST, int CAP, class Fn>
+  KN_HD void rows_to(Fn&& fn) {
+    _Pragma("unroll") for (int j = FIRST; j <= CAP; ++j) fn(j);
+  }
+  template <int FIRST, class Fn>
+  KN_HD void for_rows(int lb, Fn&& fn) {
+    if (lb <= 4) rows_to<FIRST, 4>(fn);
+    else if (lb <= 6) rows_to<FIRST, 6>(fn);
+    else if (lb <= 8) rows_to<FIRST, 8>(fn);
+    else rows_to<FIRST, ROWS>(fn);
+  }
+  template <int CAP, class Fn>
+  KN_HD void rows_down(Fn&& fn) {
+    _Pragma("unroll") for (int j = CAP; j >= 1; --j) fn(j);
+  }
+  template <class Fn>
+  KN_HD void for_rows_down(int lb, Fn&& fn) {
+    if (lb <= 4) rows_down<4>(fn);
+    else if (lb <= 6) rows_down<6>(fn);
+    else if (lb <= 8) rows_down<8>(fn);
+    else rows_down<ROWS>(fn);
+  }
+
+  // row j of the Nordsieck array, j <= jb (jb wave-uniform)
+  KN_HD void get_row(int j, int jb, double* out) {
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) out[i] = 0.0;
+    for_rows<1>(jb, [&](int jj) {
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) out[i] = (jj == j) ? yh[jj][i] : out[i];
+    });
+  }
+  KN_HD void set_row(int j, int jb, const double* in) {
+    for_rows<1>(jb, [&](int jj) {
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) yh[jj][i] = (jj == j) ? in[i] : yh[jj][i];
+    });
   }
 
   // right-hand side: all components (LANES = 1) or this lane's component after an all-gather
@@ -227,65 +304,115 @@ struct Lsoda {
     return kn_group_max<LANES>(bad) == 0.0;
   }
 
-  KN_HD void resetcoeff() {
-    for (int i = 1; i <= l; ++i) EL(i) = elco(nq, i);
-    rc = rc * EL(1) / el0;
-    el0 = EL(1);
+  // three step-ratio powers at once; with four lanes per system each of three lanes evaluates one of them
+  KN_HD void pow3(double b0, double e0, double b1, double e1, double b2, double e2, double& r0, double& r1,
+                  double& r2) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (LANES >= 4) {
+      const int c = comp & 3;
+      const double b = c == 0 ? b0 : (c == 1 ? b1 : b2), e = c == 0 ? e0 : (c == 1 ? e1 : e2);
+      const double r = kn_powr(b, e);
+      if constexpr (LANES == 4) {
+        r0 = kn_group_get<4>(r, 0); r1 = kn_group_get<4>(r, 1); r2 = kn_group_get<4>(r, 2);
+      } else {
+        const int base = (int)(__lane_id() & ~(unsigned)(LANES - 1));
+        r0 = __shfl(r, base); r1 = __shfl(r, base + 1); r2 = __shfl(r, base + 2);
+      }
+      return;
+    }
+#endif
+    r0 = kn_powr(b0, e0); r1 = kn_powr(b1, e1); r2 = kn_powr(b2, e2);
+  }
+
+  // coefficients of the current (meth, nq): el(1..l), tesco(nq, 1..3)   [DSTODA label 150]
+  KN_HD void resetcoeff(int lb) {
+    for_rows<1>(lb, [&](int i) { el[i] = (i <= l) ? cf->elco[meth - 1][nq][i] : 0.0; });
+    tq1 = cf->tesco[meth - 1][nq][1];
+    tq2 = cf->tesco[meth - 1][nq][2];
+    tq3 = cf->tesco[meth - 1][nq][3];
+    rcr = rcr * el[1] / el0;
+    el0 = el[1];
     conit = 0.5 / (double)(nq + 2);
   }
 
-  KN_HD void scaleh(double* rh, double* pdh) {
-    *rh = fmin(*rh, rmax);
+  // new order: rows above the new l are dead in ODEPACK; here they return to zero
+  KN_HD void set_order(int newq, int lb) {
+    nq = newq;
+    l = nq + 1;
+    for_rows<2>(lb, [&](int j) {
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) yh[j][i] = (j > l) ? 0.0 : yh[j][i];
+    });
+  }
+
+  KN_HD void scaleh(int lb) {
+    rh = fmin(rh, rmax);
     // hmxi = 0 (no maximum step): rh / max(1, |h| * hmxi * rh) == rh
     if (meth == 1) {
       irflag = 0;
-      *pdh = fmax(fabs(h) * pdlast, 0.000001);
-      if ((*rh * *pdh * 1.00001) >= sm1(nq)) {
-        *rh = sm1(nq) / *pdh;
+      pdh = fmax(fabs(h) * pdlast, 0.000001);
+      const double s = sm1(nq);
+      if ((rh * pdh * 1.00001) >= s) {
+        rh = s / pdh;
         irflag = 1;
       }
     }
     double r = 1.0;
-    for (int j = 2; j <= l; ++j) {
-      r *= *rh;
-      _Pragma("unroll") for (int i = 0; i < NI; ++i) YH(j, i) *= r;
-    }
-    h *= *rh;
-    rc *= *rh;
+    for_rows<2>(lb, [&](int j) {
+      r *= rh;
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) yh[j][i] *= r;
+    });
+    h *= rh;
+    rcr *= rh;
     ialth = l;
   }
 
-  KN_HD void retract(double told) {
+  // Pascal-triangle products of the Nordsieck array: SIGN = +1 predicts, -1 retracts.  qb >= nq is wave-uniform;
+  // the triangle runs to the class of qb (rows above a lane's order are zero: x +- 0 = x).
+  template <int SIGN, int Q>
+  KN_HD void triangle_to() {
+    _Pragma("unroll") for (int j = Q; j >= 1; --j)
+      _Pragma("unroll") for (int i1 = j; i1 <= Q; ++i1)
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) {
+          if constexpr (SIGN > 0) yh[i1][i] += yh[i1 + 1][i];
+          else yh[i1][i] -= yh[i1 + 1][i];
+        }
+  }
+  template <int SIGN>
+  KN_HD void triangle(int qb) {
+    if (qb <= 3) triangle_to<SIGN, 3>();
+    else if (qb <= 5) triangle_to<SIGN, 5>();
+    else if (qb <= 7) triangle_to<SIGN, 7>();
+    else triangle_to<SIGN, ROWS - 1>();
+  }
+
+  KN_HD void retract(int lb) {
     tn = told;
-    for (int j = nq; j >= 1; --j)
-      for (int i1 = j; i1 <= nq; ++i1)
-        _Pragma("unroll") for (int i = 0; i < NI; ++i) YH(i1, i) -= YH(i1 + 1, i);
+    triangle<-1>(lb - 1);
   }
 
-  KN_HD void corfailure(double told, double* rh, int* ncf, int* corflag) {
-    (*ncf)++;
+  // corrector failure [DSTODA label 410]: returns 1 (retry with a quarter of the step) or 2 (give up)
+  KN_HD int corfailure(int lb) {
+    ncf++;
     rmax = 2.0;
-    retract(told);
-    if (fabs(h) <= 0.0 || *ncf == MXNCF) {  // hmin = 0
-      *corflag = 2;
-      return;
-    }
-    *corflag = 1;
-    *rh = 0.25;
+    retract(lb);
+    if (fabs(h) <= 0.0 || ncf == MXNCF) return 2;   // hmin = 0
+    rh = 0.25;
     ipup = miter;
+    return 1;
   }
 
-  // Finite-difference Jacobian, P = I - h*el0*J, LU factorisation (PRJA with miter = 2).
+  // Finite-difference Jacobian, P = I - h*el0*J, LU factorisation (PRJA with miter = 2).  The factors and the pivots
+  // go to the work storage (LDS on the device): only the stiff method ever reads them.
   KN_HDN void prja(double t) {
+    nje++;
+    ierpj = 0;
+    jcur = 1;
+    const double hl0 = h * el0;
+    double fac = vmnorm(savf);
+    double r0 = 1000.0 * fabs(h) * KN_ETA * (double)N * fac;
+    if (r0 == 0.0) r0 = 1.0;
+    const double sqrteta = 1.4901161193847656e-08;
     if constexpr (LANES == 1) {
-      nje++;
-      ierpj = 0;
-      jcur = 1;
-      const double hl0 = h * el0;
-      double fac = vmnorm(savf);
-      double r0 = 1000.0 * fabs(h) * KN_ETA * (double)N * fac;
-      if (r0 == 0.0) r0 = 1.0;
-      const double sqrteta = 1.4901161193847656e-08;
   #pragma unroll
       for (int j = 0; j < N; ++j) {
         const double yj = y[j];
@@ -312,7 +439,7 @@ struct Lsoda {
         double mx = fabs(WM(k, k));
         for (int i = k + 1; i < N; ++i)
           if (fabs(WM(i, k)) > mx) { mx = fabs(WM(i, k)); piv = i; }
-        ipvt[k] = piv;
+        PIV(k) = (double)piv;
         if (WM(piv, k) == 0.0) { ierpj = 1; continue; }
         if (piv != k) { const double t2 = WM(piv, k); WM(piv, k) = WM(k, k); WM(k, k) = t2; }
         const double tinv = -1.0 / WM(k, k);
@@ -323,18 +450,10 @@ struct Lsoda {
           for (int i = k + 1; i < N; ++i) WM(i, j) += t2 * WM(i, k);
         }
       }
-      ipvt[N - 1] = N - 1;  // (ipvt is only indexed with unrolled constants)
+      PIV(N - 1) = (double)(N - 1);
       if (WM(N - 1, N - 1) == 0.0) ierpj = 1;
     }
     else {
-      nje++;
-      ierpj = 0;
-      jcur = 1;
-      const double hl0 = h * el0;
-      double fac = vmnorm(savf);
-      double r0 = 1000.0 * fabs(h) * KN_ETA * (double)N * fac;
-      if (r0 == 0.0) r0 = 1.0;
-      const double sqrteta = 1.4901161193847656e-08;
       double ya[N], ea[N], row[N];
 #pragma unroll
       for (int k = 0; k < N; ++k) { ya[k] = kn_group_get<LANES>(y[0], k); ea[k] = kn_group_get<LANES>(ewt[0], k); }
@@ -355,7 +474,10 @@ struct Lsoda {
       pdnorm = kn_group_max<LANES>(sum * ewt[0]) / fabs(hl0);
 #pragma unroll
       for (int j = 0; j < N; ++j) row[j] += (j == comp) ? 1.0 : 0.0;
-      // every lane gathers the whole matrix and factorises it (dgefa, selects instead of dynamic indices)
+      // every lane gathers the whole matrix and factorises it in registers (dgefa, selects instead of dynamic
+      // indices), then parks the factors in its column of the work storage
+      double lu[N][N];
+      int ipvt[N];
 #pragma unroll
       for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -392,12 +514,25 @@ struct Lsoda {
       }
       ipvt[N - 1] = N - 1;
       if (lu[N - 1][N - 1] == 0.0) ierpj = 1;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        PIV(i) = (double)ipvt[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) WM(i, j) = lu[i][j];
+      }
     }
   }
 
   KN_HD void solsy(double* b) {  // dgesl, job = 0 (selects instead of b[piv]: b stays in registers)
     if constexpr (LANES > 1) {
-      double ba[N];
+      double ba[N], lu[N][N];
+      int ipvt[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        ipvt[i] = (int)PIV(i);
+#pragma unroll
+        for (int j = 0; j < N; ++j) lu[i][j] = WM(i, j);
+      }
 #pragma unroll
       for (int k = 0; k < N; ++k) ba[k] = kn_group_get<LANES>(b[0], k);
 #pragma unroll
@@ -425,105 +560,34 @@ struct Lsoda {
       for (int k = 1; k < N; ++k) own = (k == comp) ? ba[k] : own;
       b[0] = own;
       return;
-    }
+    } else {
 #pragma unroll
-    for (int k = 0; k < N - 1; ++k) {
-      const int piv = ipvt[k];
-      double t2 = b[k];
+      for (int k = 0; k < N - 1; ++k) {
+        const int piv = (int)PIV(k);
+        double t2 = b[k];
 #pragma unroll
-      for (int i = k + 1; i < N; ++i) t2 = (i == piv) ? b[i] : t2;
-      const double bk = b[k];
+        for (int i = k + 1; i < N; ++i) t2 = (i == piv) ? b[i] : t2;
+        const double bk = b[k];
 #pragma unroll
-      for (int i = k + 1; i < N; ++i) b[i] = (i == piv) ? bk : b[i];
-      b[k] = t2;
+        for (int i = k + 1; i < N; ++i) b[i] = (i == piv) ? bk : b[i];
+        b[k] = t2;
 #pragma unroll
-      for (int i = k + 1; i < N; ++i) b[i] += t2 * WM(i, k);
-    }
-#pragma unroll
-    for (int k = N - 1; k >= 0; --k) {
-      b[k] /= WM(k, k);
-      const double t2 = -b[k];
-#pragma unroll
-      for (int i = 0; i < k; ++i) b[i] += t2 * WM(i, k);
-    }
-  }
-
-  KN_HDN void correction(double pnorm, double* del, double* delp, double told, int* ncf, double* rh,
-                         int* m, int* corflag) {
-    double rate = 0.0;
-    *m = 0;
-    *corflag = 0;
-    *del = 0.0;
-    _Pragma("unroll") for (int i = 0; i < NI; ++i) y[i] = YH(1, i);
-    eval_rhs(tn, y, savf);
-    nfe++;
-    while (true) {
-      if (*m == 0) {
-        if (ipup > 0) {
-          prja(tn);
-          ipup = 0;
-          rc = 1.0;
-          nslp = nst;
-          crate = 0.7;
-          if (ierpj != 0) { corfailure(told, rh, ncf, corflag); return; }
-        }
-        _Pragma("unroll") for (int i = 0; i < NI; ++i) acor[i] = 0.0;
+        for (int i = k + 1; i < N; ++i) b[i] += t2 * WM(i, k);
       }
-      if (miter == 0) {
-        _Pragma("unroll") for (int i = 0; i < NI; ++i) {
-          savf[i] = h * savf[i] - YH(2, i);
-          y[i] = savf[i] - acor[i];
-        }
-        *del = vmnorm(y);
-        _Pragma("unroll") for (int i = 0; i < NI; ++i) {
-          y[i] = YH(1, i) + EL(1) * savf[i];
-          acor[i] = savf[i];
-        }
-      } else {
-        _Pragma("unroll") for (int i = 0; i < NI; ++i) y[i] = h * savf[i] - (YH(2, i) + acor[i]);
-        solsy(y);
-        *del = vmnorm(y);
-        _Pragma("unroll") for (int i = 0; i < NI; ++i) {
-          acor[i] += y[i];
-          y[i] = YH(1, i) + EL(1) * acor[i];
-        }
-      }
-      if (*del <= 100.0 * pnorm * KN_ETA) break;
-      if (*m != 0 || meth != 1) {
-        if (*m != 0) {
-          double rm = 1024.0;
-          if (*del <= (1024.0 * *delp)) rm = *del / *delp;
-          rate = fmax(rate, rm);
-          crate = fmax(0.2 * crate, rm);
-        }
-        const double dcon = *del * fmin(1.0, 1.5 * crate) / (tesco(nq, 2) * conit);
-        if (dcon <= 1.0) {
-          pdest = fmax(pdest, rate / fabs(h * EL(1)));
-          if (pdest != 0.0) pdlast = pdest;
-          break;
-        }
-      }
-      (*m)++;
-      if (*m == MAXCOR || (*m >= 2 && *del > 2.0 * *delp)) {
-        if (miter == 0 || jcur == 1) { corfailure(told, rh, ncf, corflag); return; }
-        ipup = miter;
-        *m = 0;
-        rate = 0.0;
-        *del = 0.0;
-        _Pragma("unroll") for (int i = 0; i < NI; ++i) y[i] = YH(1, i);
-        eval_rhs(tn, y, savf);
-        nfe++;
-      } else {
-        *delp = *del;
-        eval_rhs(tn, y, savf);
-        nfe++;
+#pragma unroll
+      for (int k = N - 1; k >= 0; --k) {
+        b[k] /= WM(k, k);
+        const double t2 = -b[k];
+#pragma unroll
+        for (int i = 0; i < k; ++i) b[i] += t2 * WM(i, k);
       }
     }
   }
 
-  KN_HDN void methodswitch(double dsm, double pnorm, double* pdh, double* rh) {
+  KN_HDN void methodswitch(double dsm, double* rhp) {
     int nqm1, nqm2;
     double rh1, rh2, rh1it, exm2, dm2, exm1, dm1, alpha, exsm;
+    double row[NI];
     if (meth == 1) {
       if (nq > 5) return;
       if (dsm <= (100.0 * pnorm * KN_ETA) || pdest == 0.0) {
@@ -532,31 +596,31 @@ struct Lsoda {
         nqm2 = nq < MXORDS ? nq : MXORDS;
       } else {
         exsm = 1.0 / (double)l;
-        rh1 = 1.0 / (1.2 * pow(dsm, exsm) + 0.0000012);
+        rh1 = 1.0 / (1.2 * kn_powr(dsm, exsm) + 0.0000012);
         rh1it = 2.0 * rh1;
-        *pdh = pdlast * fabs(h);
-        if ((*pdh * rh1) > 0.00001) rh1it = sm1(nq) / *pdh;
+        pdh = pdlast * fabs(h);
+        if ((pdh * rh1) > 0.00001) rh1it = sm1(nq) / pdh;
         rh1 = fmin(rh1, rh1it);
-        if (nq > MXORDS) {
+        if (nq > MXORDS) {   // (unreachable behind `nq > 5` above; kept as in DSTODA)
           nqm2 = MXORDS;
           const int lm2 = MXORDS + 1;
           exm2 = 1.0 / (double)lm2;
-          dm2 = vmnorm_yh(lm2 + 1) / cf->cm2[MXORDS];
-          rh2 = 1.0 / (1.2 * pow(dm2, exm2) + 0.0000012);
+          get_row(lm2 + 1, ROWS, row);
+          dm2 = vmnorm(row) / cf->cm2[MXORDS];
+          rh2 = 1.0 / (1.2 * kn_powr(dm2, exm2) + 0.0000012);
         } else {
           dm2 = dsm * (cf->cm1[nq] / cf->cm2[nq]);
-          rh2 = 1.0 / (1.2 * pow(dm2, exsm) + 0.0000012);
+          rh2 = 1.0 / (1.2 * kn_powr(dm2, exsm) + 0.0000012);
           nqm2 = nq;
         }
         if (rh2 < ratio * rh1) return;
       }
-      *rh = rh2;
+      *rhp = rh2;
       icount = 20;
       meth = 2;
       miter = 2;
       pdlast = 0.0;
-      nq = nqm2;
-      l = nq + 1;
+      set_order(nqm2, ROWS);
       return;
     }
     exsm = 1.0 / (double)l;
@@ -564,102 +628,119 @@ struct Lsoda {
       nqm1 = MXORDN;
       const int lm1 = MXORDN + 1;
       exm1 = 1.0 / (double)lm1;
-      dm1 = vmnorm_yh(lm1 + 1) / cf->cm1[MXORDN];
-      rh1 = 1.0 / (1.2 * pow(dm1, exm1) + 0.0000012);
+      get_row(lm1 + 1 > ROWS ? ROWS : lm1 + 1, ROWS, row);
+      dm1 = vmnorm(row) / cf->cm1[MXORDN];
+      rh1 = 1.0 / (1.2 * kn_powr(dm1, exm1) + 0.0000012);
     } else {
       dm1 = dsm * (cf->cm2[nq] / cf->cm1[nq]);
-      rh1 = 1.0 / (1.2 * pow(dm1, exsm) + 0.0000012);
+      rh1 = 1.0 / (1.2 * kn_powr(dm1, exsm) + 0.0000012);
       nqm1 = nq;
       exm1 = exsm;
     }
     rh1it = 2.0 * rh1;
-    *pdh = pdnorm * fabs(h);
-    if ((*pdh * rh1) > 0.00001) rh1it = sm1(nqm1) / *pdh;
+    pdh = pdnorm * fabs(h);
+    if ((pdh * rh1) > 0.00001) rh1it = sm1(nqm1) / pdh;
     rh1 = fmin(rh1, rh1it);
-    rh2 = 1.0 / (1.2 * pow(dsm, exsm) + 0.0000012);
+    rh2 = 1.0 / (1.2 * kn_powr(dsm, exsm) + 0.0000012);
     if ((rh1 * ratio) < (5.0 * rh2)) return;
     alpha = fmax(0.001, rh1);
-    dm1 *= pow(alpha, exm1);
+    dm1 *= kn_powr(alpha, exm1);
     if (dm1 <= 1000.0 * KN_ETA * pnorm) return;
-    *rh = rh1;
+    *rhp = rh1;
     icount = 20;
     meth = 1;
     miter = 0;
     pdlast = 0.0;
-    nq = nqm1;
-    l = nq + 1;
+    set_order(nqm1, ROWS);
   }
 
-  KN_HDN void orderswitch(double* rhup, double dsm, double* pdh, double* rh, int* orderflag) {
+  // Order selection [DSTODA labels 520-620].  want_up: the step was accepted and the order may rise (rhup from the
+  // saved correction); after a failed error test rhup = 0.  Returns ODEPACK's orderflag.
+  KN_HDN int orderswitch(bool want_up, double dsm, int lb) {
     int newq;
-    *orderflag = 0;
     const double exsm = 1.0 / (double)l;
-    double rhsm = 1.0 / (1.2 * pow(dsm, exsm) + 0.0000012);
-    double rhdn = 0.0;
-    if (nq != 1) {
-      const double ddn = vmnorm_yh(l) / tesco(nq, 1);
-      const double exdn = 1.0 / (double)nq;
-      rhdn = 1.0 / (1.3 * pow(ddn, exdn) + 0.0000013);
+    // the three candidates' error norms, then their roots in one go
+    const bool up = want_up && l != lmax, dn = nq != 1;
+    double dup = 1.0, ddn = 1.0;
+    if (up) {
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) savf[i] = acor[i] - ysave[i];
+      dup = vmnorm(savf) / tq3;
     }
+    if (dn) {
+      double row[NI];
+      get_row(l, lb, row);
+      ddn = vmnorm(row) / tq1;
+    }
+    double psm, pdn, pup;
+    pow3(dsm, exsm, ddn, 1.0 / (double)nq, dup, 1.0 / (double)(l + 1), psm, pdn, pup);
+    double rhup = up ? 1.0 / (1.4 * pup + 0.0000014) : 0.0;
+    double rhsm = 1.0 / (1.2 * psm + 0.0000012);
+    double rhdn = dn ? 1.0 / (1.3 * pdn + 0.0000013) : 0.0;
     if (meth == 1) {
-      *pdh = fmax(fabs(h) * pdlast, 0.000001);
-      if (l < lmax) *rhup = fmin(*rhup, sm1(l) / *pdh);
-      rhsm = fmin(rhsm, sm1(nq) / *pdh);
-      if (nq > 1) rhdn = fmin(rhdn, sm1(nq - 1) / *pdh);
+      pdh = fmax(fabs(h) * pdlast, 0.000001);
+      if (l < lmax) rhup = fmin(rhup, sm1(l) / pdh);
+      rhsm = fmin(rhsm, sm1(nq) / pdh);
+      if (nq > 1) rhdn = fmin(rhdn, sm1(nq - 1) / pdh);
       pdest = 0.0;
     }
-    if (rhsm >= *rhup) {
+    if (rhsm >= rhup) {
       if (rhsm >= rhdn) {
         newq = nq;
-        *rh = rhsm;
+        rh = rhsm;
       } else {
         newq = nq - 1;
-        *rh = rhdn;
-        if (kflag < 0 && *rh > 1.0) *rh = 1.0;
+        rh = rhdn;
+        if (kflag < 0 && rh > 1.0) rh = 1.0;
       }
     } else {
-      if (*rhup <= rhdn) {
+      if (rhup <= rhdn) {
         newq = nq - 1;
-        *rh = rhdn;
-        if (kflag < 0 && *rh > 1.0) *rh = 1.0;
+        rh = rhdn;
+        if (kflag < 0 && rh > 1.0) rh = 1.0;
       } else {
-        *rh = *rhup;
-        if (*rh >= 1.1) {
-          const double r = EL(l) / (double)l;
+        rh = rhup;
+        if (rh >= 1.1) {
+          const double r = el[0] / (double)l;   // el[0] holds el(l), refreshed below before every call
           nq = l;
           l = nq + 1;
-          _Pragma("unroll") for (int i = 0; i < NI; ++i) YH(l, i) = acor[i] * r;
-          *orderflag = 2;
-          return;
+          double row[NI];
+          _Pragma("unroll") for (int i = 0; i < NI; ++i) row[i] = acor[i] * r;
+          set_row(l, lb, row);
+          return 2;
         }
         ialth = 3;
-        return;
+        return 0;
       }
     }
     if (meth == 1) {
-      if ((*rh * *pdh * 1.00001) < sm1(newq))
-        if (kflag == 0 && *rh < 1.1) { ialth = 3; return; }
+      if ((rh * pdh * 1.00001) < sm1(newq))
+        if (kflag == 0 && rh < 1.1) { ialth = 3; return 0; }
     } else {
-      if (kflag == 0 && *rh < 1.1) { ialth = 3; return; }
+      if (kflag == 0 && rh < 1.1) { ialth = 3; return 0; }
     }
-    if (kflag <= -2) *rh = fmin(*rh, 0.2);
-    if (newq == nq) { *orderflag = 1; return; }
-    nq = newq;
-    l = nq + 1;
-    *orderflag = 2;
+    if (kflag <= -2) rh = fmin(rh, 0.2);
+    if (newq == nq) return 1;
+    set_order(newq, lb);
+    return 2;
   }
 
-  KN_HD void endstoda() {
-    const double r = 1.0 / tesco(nqu, 2);
-    _Pragma("unroll") for (int i = 0; i < NI; ++i) acor[i] *= r;
-    hold = h;
-    jstart = 1;
+  // el(l) of the current coefficients (a per-lane row index: one select chain, only where it is needed)
+  KN_HD void load_el_l(int lb) {
+    double v = 0.0;
+    for_rows<1>(lb, [&](int j) { v = (j == l) ? el[j] : v; });
+    el[0] = v;
   }
 
-  // One internal step (DSTODA).
-  KN_HDN void stoda() {
-    int corflag, orderflag, m, ncf;
-    double del, delp, dsm, dup, exup, r, rh, rhup, told, pdh, pnorm;
+  // ---- phases -----------------------------------------------------------------------------------
+  // before a step: DLSODA's checks at the top of its loop (label 250) and DSTODA's prologue
+  KN_HDN void phase_top(int mxstep) {
+    if (nst > 0) {
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) y[i] = yh[1][i];
+      if (!ewset(y)) { ret = -6; ph = PH_DONE; return; }
+    }
+    if (nst >= mxstep) { ret = -1; ph = PH_DONE; return; }
+    const double tolsf = KN_ETA * vmnorm(yh[1]);
+    if (tolsf > 0.01) { ret = -2; ph = PH_DONE; return; }
     kflag = 0;
     told = tn;
     ncf = 0;
@@ -674,7 +755,7 @@ struct Lsoda {
       l = 2;
       ialth = 2;
       rmax = 10000.0;
-      rc = 0.0;
+      rcr = 0.0;
       el0 = 1.0;
       crate = 0.7;
       hold = h;
@@ -685,7 +766,7 @@ struct Lsoda {
       pdest = 0.0;
       pdlast = 0.0;
       ratio = 5.0;
-      resetcoeff();
+      resetcoeff(lhi);
     }
     if (jstart == -1) {
       ipup = miter;
@@ -693,142 +774,221 @@ struct Lsoda {
       if (ialth == 1) ialth = 2;
       if (meth != mused) {
         ialth = l;
-        resetcoeff();
+        resetcoeff(lhi);
       }
       if (h != hold) {
         rh = h / hold;
         h = hold;
-        scaleh(&rh, &pdh);
+        scaleh(lhi);
       }
     }
     if (jstart > 0 && h != hold) {
       rh = h / hold;
       h = hold;
-      scaleh(&rh, &pdh);
+      scaleh(lhi);
     }
-    while (true) {
-      while (true) {
-        if (fabs(rc - 1.0) > 0.3) ipup = miter;
-        if (nst >= nslp + MSBP) ipup = miter;
-        tn += h;
-        for (int j = nq; j >= 1; --j)
-          for (int i1 = j; i1 <= nq; ++i1)
-            _Pragma("unroll") for (int i = 0; i < NI; ++i) YH(i1, i) += YH(i1 + 1, i);
-        pnorm = vmnorm_yh(1);
-        correction(pnorm, &del, &delp, told, &ncf, &rh, &m, &corflag);
-        if (corflag == 0) break;
-        if (corflag == 1) {
-          rh = fmax(rh, 0.0);
-          scaleh(&rh, &pdh);
-          continue;
-        }
-        kflag = -2;
-        hold = h;
-        jstart = 1;
+    ph = PH_PRED;
+  }
+
+  // predict, start the corrector [DSTODA label 200 and the head of the corrector loop]
+  KN_HD void phase_pred() {
+    if (fabs(rcr - 1.0) > 0.3) ipup = miter;
+    if (nst >= nslp + MSBP) ipup = miter;
+    tn += h;
+    triangle<1>(lhi - 1);
+    pnorm = vmnorm(yh[1]);
+    rate = 0.0;
+    m = 0;
+    del = 0.0;
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) y[i] = yh[1][i];
+    ph = PH_CORR;
+  }
+
+  // one corrector iteration on the right-hand side just evaluated at (tn, y) [DSTODA labels 220-430]
+  KN_HDN void phase_corr() {
+    if (m == 0) {
+      if (ipup > 0) {
+        prja(tn);
+        ipup = 0;
+        rcr = 1.0;
+        nslp = nst;
+        crate = 0.7;
+        if (ierpj != 0) { corr_failed(); return; }
+      }
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) acor[i] = 0.0;
+    }
+    if (miter == 0) {
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) {
+        savf[i] = h * savf[i] - yh[2][i];
+        y[i] = savf[i] - acor[i];
+      }
+      del = vmnorm(y);
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) {
+        y[i] = yh[1][i] + el[1] * savf[i];
+        acor[i] = savf[i];
+      }
+    } else {
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) y[i] = h * savf[i] - (yh[2][i] + acor[i]);
+      solsy(y);
+      del = vmnorm(y);
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) {
+        acor[i] += y[i];
+        y[i] = yh[1][i] + el[1] * acor[i];
+      }
+    }
+    if (del <= 100.0 * pnorm * KN_ETA) { ph = PH_ERR; return; }
+    if (m != 0 || meth != 1) {
+      if (m != 0) {
+        double rm = 1024.0;
+        if (del <= (1024.0 * delp)) rm = del / delp;
+        rate = fmax(rate, rm);
+        crate = fmax(0.2 * crate, rm);
+      }
+      const double dcon = del * fmin(1.0, 1.5 * crate) / (tq2 * conit);
+      if (dcon <= 1.0) {
+        pdest = fmax(pdest, rate / fabs(h * el[1]));
+        if (pdest != 0.0) pdlast = pdest;
+        ph = PH_ERR;
         return;
       }
-      jcur = 0;
-      if (m == 0) dsm = del / tesco(nq, 2);
-      else dsm = vmnorm(acor) / tesco(nq, 2);
-      if (dsm <= 1.0) {
-        kflag = 0;
-        nst++;
-        hu = h;
-        nqu = nq;
-        mused = meth;
-        for (int j = 1; j <= l; ++j) {
-          r = EL(j);
-          _Pragma("unroll") for (int i = 0; i < NI; ++i) YH(j, i) += r * acor[i];
+    }
+    m++;
+    if (m == MAXCOR || (m >= 2 && del > 2.0 * delp)) {
+      if (miter == 0 || jcur == 1) { corr_failed(); return; }
+      // the Jacobian is out of date: restart the corrector with a fresh one
+      ipup = miter;
+      m = 0;
+      rate = 0.0;
+      del = 0.0;
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) y[i] = yh[1][i];
+    } else {
+      delp = del;
+    }
+  }
+
+  KN_HD void corr_failed() {
+    const int corflag = corfailure(lhi);
+    if (corflag == 2) {   // kflag = -2: repeated corrector failures
+      ret = -5;
+      ph = PH_DONE;
+      return;
+    }
+    rh = fmax(rh, 0.0);
+    scaleh(lhi);
+    ph = PH_PRED;
+  }
+
+  // after a converged corrector: error test, then order / step / method selection [labels 450-700], and back in
+  // DLSODA the method-switch bookkeeping and the test for tout
+  KN_HDN void phase_err(double tout, double* y0) {
+    const int lb = lhi + 1 > ROWS ? ROWS : lhi + 1;   // an order increase in this phase can reach lhi + 1
+    jcur = 0;
+    double dsm;
+    if (m == 0) dsm = del / tq2;
+    else dsm = vmnorm(acor) / tq2;
+    if (dsm <= 1.0) {
+      kflag = 0;
+      nst++;
+      hu = h;
+      nqu = nq;
+      mused = meth;
+      for_rows<1>(lb, [&](int j) {
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) yh[j][i] += el[j] * acor[i];
+      });
+      const double tq2u = tq2;   // tesco(nqu, 2) of the method that took the step (used by "endstoda")
+      icount--;
+      bool ended = false;
+      if (icount < 0) {
+        methodswitch(dsm, &rh);
+        if (meth != mused) {
+          rh = fmax(rh, 0.0);
+          scaleh(ROWS);
+          rmax = 10.0;
+          ended = true;
         }
-        icount--;
-        if (icount < 0) {
-          methodswitch(dsm, pnorm, &pdh, &rh);
-          if (meth != mused) {
-            rh = fmax(rh, 0.0);
-            scaleh(&rh, &pdh);
-            rmax = 10.0;
-            // endstoda() uses the coefficients of the method that took the step
-            const double rr = 1.0 / cf->tesco[mused - 1][nqu][2];
-            _Pragma("unroll") for (int i = 0; i < NI; ++i) acor[i] *= rr;
-            hold = h;
-            jstart = 1;
-            break;
-          }
-        }
+      }
+      if (!ended) {
         ialth--;
         if (ialth == 0) {
-          rhup = 0.0;
-          if (l != lmax) {
-            _Pragma("unroll") for (int i = 0; i < NI; ++i) savf[i] = acor[i] - YH(lmax, i);
-            dup = vmnorm(savf) / tesco(nq, 3);
-            exup = 1.0 / (double)(l + 1);
-            rhup = 1.0 / (1.4 * pow(dup, exup) + 0.0000014);
-          }
-          orderswitch(&rhup, dsm, &pdh, &rh, &orderflag);
-          if (orderflag == 0) { endstoda(); break; }
-          if (orderflag == 1) {
+          stamp(5, true);
+          load_el_l(lb);
+          const int orderflag = orderswitch(true, dsm, lb);
+          stamp(8, true);
+          if (orderflag != 0) {
+            if (orderflag == 2) resetcoeff(lb);
             rh = fmax(rh, 0.0);
-            scaleh(&rh, &pdh);
+            scaleh(lb);
             rmax = 10.0;
-            endstoda();
-            break;
           }
-          resetcoeff();
-          rh = fmax(rh, 0.0);
-          scaleh(&rh, &pdh);
-          rmax = 10.0;
-          endstoda();
-          break;
+          stamp(9, true);
+        } else if (!(ialth > 1 || l == lmax)) {
+          _Pragma("unroll") for (int i = 0; i < NI; ++i) ysave[i] = acor[i];
         }
-        if (ialth > 1 || l == lmax) { endstoda(); break; }
-        _Pragma("unroll") for (int i = 0; i < NI; ++i) YH(lmax, i) = acor[i];
-        endstoda();
-        break;
       }
-      // error test failed
-      kflag--;
-      retract(told);
-      rmax = 2.0;
-      if (fabs(h) <= 0.0) {
-        kflag = -1;
+      {   // "endstoda"
+        const double r = 1.0 / tq2u;
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) acor[i] *= r;
         hold = h;
         jstart = 1;
-        break;
       }
-      if (kflag > -3) {
-        rhup = 0.0;
-        orderswitch(&rhup, dsm, &pdh, &rh, &orderflag);
-        if (orderflag == 1 || orderflag == 0) {
-          if (orderflag == 0) rh = fmin(rh, 0.2);
-          rh = fmax(rh, 0.0);
-          scaleh(&rh, &pdh);
-        }
-        if (orderflag == 2) {
-          resetcoeff();
-          rh = fmax(rh, 0.0);
-          scaleh(&rh, &pdh);
-        }
-        continue;
+      // DLSODA after a successful return of DSTODA
+      if (meth != mused) {
+        tsw = tn;
+        maxord = meth == 2 ? MXORDS : MXORDN;
+        jstart = -1;
       }
-      if (kflag == -10) {
-        kflag = -1;
-        hold = h;
-        jstart = 1;
-        break;
-      }
-      rh = 0.1;
-      h *= rh;
-      _Pragma("unroll") for (int i = 0; i < NI; ++i) y[i] = YH(1, i);
-      eval_rhs(tn, y, savf);
-      nfe++;
-      _Pragma("unroll") for (int i = 0; i < NI; ++i) YH(2, i) = h * savf[i];
-      ipup = miter;
-      ialth = 5;
-      if (nq == 1) continue;
-      nq = 1;
-      l = 2;
-      resetcoeff();
+      if ((tn - tout) * h < 0.0) { ph = PH_TOP; return; }
+      // intdy, k = 0: Horner from row l down
+      const double s = (tout - tn) / h;
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) y0[i] = 0.0;
+      for_rows_down(lb, [&](int j) {
+        _Pragma("unroll") for (int i = 0; i < NI; ++i)
+          y0[i] = (j < l) ? yh[j][i] + s * y0[i] : ((j == l) ? yh[j][i] : y0[i]);
+      });
+      ret = 0;
+      ph = PH_DONE;
+      return;
     }
+    // error test failed
+    kflag--;
+    retract(lb);
+    rmax = 2.0;
+    if (fabs(h) <= 0.0) {   // hmin = 0
+      ret = -4;
+      ph = PH_DONE;
+      return;
+    }
+    if (kflag > -3) {
+      load_el_l(lb);
+      const int orderflag = orderswitch(false, dsm, lb);
+      if (orderflag == 2) resetcoeff(lb);
+      if (orderflag == 0) rh = fmin(rh, 0.2);
+      rh = fmax(rh, 0.0);
+      scaleh(lb);
+      ph = PH_PRED;
+      return;
+    }
+    if (kflag == -10) {
+      ret = -4;
+      ph = PH_DONE;
+      return;
+    }
+    // three failures in a row: drop to order 1 with a tenth of the step and a fresh derivative
+    rh = 0.1;
+    h *= rh;
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) y[i] = yh[1][i];
+    ph = PH_RESTART;
+  }
+
+  KN_HD void phase_restart() {
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) yh[2][i] = h * savf[i];
+    ipup = miter;
+    ialth = 5;
+    if (nq != 1) {
+      set_order(1, lhi);
+      resetcoeff(lhi);
+    }
+    ph = PH_PRED;
   }
 
   // Integrate y0 from t0 to tout (istate = 1, itask = 1).  Returns 0 on success, a negative
@@ -840,62 +1000,76 @@ struct Lsoda {
     comp = comp_;
     rtol = rtol_;
     atol = atol_;
-    for (int j = 0; j < 15; ++j)
-      _Pragma("unroll") for (int i = 0; i < NI; ++i) YH(j, i) = 0.0;
+    _Pragma("unroll") for (int j = 0; j <= ROWS; ++j) {
+      el[j] = 0.0;
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) yh[j][i] = 0.0;
+    }
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) ysave[i] = 0.0;
+    tq1 = tq2 = tq3 = 0.0;
     tn = t0;
     tsw = t0;
     maxord = MXORDN;
     jstart = 0;
     nst = 0; nje = 0; nslp = 0;
     hu = 0.0; nqu = 0; mused = 0; miter = 0; meth = 1;
-    nq = 1; l = 2;
+    nq = 1; l = 2; lhi = 2;
+    ret = 0;
+    ph = PH_TOP;
     _Pragma("unroll") for (int i = 0; i < NI; ++i) y[i] = y0[i];
     eval_rhs(t0, y, savf);
     nfe = 1;
-    _Pragma("unroll") for (int i = 0; i < NI; ++i) { YH(1, i) = y[i]; YH(2, i) = savf[i]; }
-    if (!ewset(y)) return -6;
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) { yh[1][i] = y[i]; yh[2][i] = savf[i]; }
+    if (!ewset(y)) { ret = -6; ph = PH_DONE; }
     // initial step size (DLSODA block c)
     const double tdist = fabs(tout - t0);
     const double w0 = fmax(fabs(t0), fabs(tout));
-    if (tdist < 2.0 * KN_ETA * w0) return -3;
+    if (ph != PH_DONE && tdist < 2.0 * KN_ETA * w0) { ret = -3; ph = PH_DONE; }
     double tol = rtol;
     if (tol <= 0.0) {
       _Pragma("unroll") for (int i = 0; i < NI; ++i) {
         const double ayi = fabs(y[i]);
         if (ayi != 0.0) tol = fmax(tol, atol / ayi);
       }
+      tol = kn_group_max<LANES>(tol);
     }
     tol = fmax(tol, 100.0 * KN_ETA);
     tol = fmin(tol, 0.001);
-    double sum = vmnorm_yh(2);
+    double sum = vmnorm(yh[2]);
     sum = 1.0 / (tol * w0 * w0) + tol * sum * sum;
     double h0 = 1.0 / sqrt(sum);
     h0 = fmin(h0, tdist);
     h0 = (tout - t0) >= 0.0 ? h0 : -h0;
     h = h0;
-    _Pragma("unroll") for (int i = 0; i < NI; ++i) YH(2, i) *= h0;
-    while (true) {
-      if (nst > 0) {
-        _Pragma("unroll") for (int i = 0; i < NI; ++i) y[i] = YH(1, i);
-        if (!ewset(y)) return -6;
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) yh[2][i] *= h0;
+
+    // one trip = one right-hand-side evaluation for every lane that is still integrating
+    const long trips_max = 16L * (long)mxstep + 64;
+    stamp(6, true);
+    for (long trip = 0; KN_ANY(ph != PH_DONE); ++trip) {
+      if (trip >= trips_max) {   // cannot happen (mxstep bounds every path); never leave a wave spinning
+        if (ph != PH_DONE) { ret = -7; ph = PH_DONE; }
+        break;
       }
-      if (nst >= mxstep) return -1;
-      double tolsf = KN_ETA * vmnorm_yh(1);
-      if (tolsf > 0.01) return -2;
-      stoda();
-      if (kflag != 0) return kflag == -1 ? -4 : -5;
-      if (meth != mused) {
-        tsw = tn;
-        maxord = meth == 2 ? MXORDS : MXORDN;
-        jstart = -1;
+      // keep l <= lhi on every running lane (an order rises by one per trip at most), let lhi fall when it can
+      if (KN_ANY(ph != PH_DONE && l > lhi)) ++lhi;
+      else if (lhi > 2 && !KN_ANY(ph != PH_DONE && l >= lhi)) --lhi;
+      bool ran = false;
+      if constexpr (STAMPS) { stamp(0, true); ran = KN_ANY(ph == PH_TOP); }
+      if (ph == PH_TOP) phase_top(mxstep);
+      if constexpr (STAMPS) { stamp(1, ran); ran = KN_ANY(ph == PH_PRED); }
+      if (ph == PH_PRED) phase_pred();
+      if constexpr (STAMPS) { stamp(2, ran); ran = KN_ANY(ph == PH_CORR || ph == PH_RESTART); }
+      if (ph == PH_CORR || ph == PH_RESTART) {
+        eval_rhs(tn, y, savf);
+        nfe++;
       }
-      if ((tn - tout) * h < 0.0) continue;
-      // intdy, k = 0
-      const double s = (tout - tn) / h;
-      _Pragma("unroll") for (int i = 0; i < NI; ++i) y0[i] = YH(l, i);
-      for (int jj = l - 1; jj >= 1; --jj)
-        _Pragma("unroll") for (int i = 0; i < NI; ++i) y0[i] = YH(jj, i) + s * y0[i];
-      return 0;
+      if constexpr (STAMPS) { stamp(3, ran); ran = KN_ANY(ph == PH_CORR || ph == PH_RESTART); }
+      if (ph == PH_RESTART) phase_restart();
+      else if (ph == PH_CORR) phase_corr();
+      if constexpr (STAMPS) { stamp(4, ran); ran = KN_ANY(ph == PH_ERR); }
+      if (ph == PH_ERR) phase_err(tout, y0);
+      if constexpr (STAMPS) stamp(10, ran);
     }
+    return ret;
   }
 };

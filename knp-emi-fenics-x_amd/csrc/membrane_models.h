@@ -19,6 +19,14 @@
 // current); `rhs` is the cfunc body and keeps the side-effect currents in members; `finish(p)` stores
 // them into the parameter row, which is what the reference's in-place writes amount to after the
 // last call.
+// fmod(t, period) for the periodic stimulus: inside the first period the remainder is t itself (fmod is exact, so
+// this returns the same bits) and the ~70-instruction reduction loop is skipped -- by the whole wavefront, since all
+// membrane dofs of a sweep integrate the same time interval.
+KN_HD double kn_fmod_period(double t, double period) {
+  if (t >= 0.0 && t < period) return t;
+  return fmod(t, period);
+}
+
 template <int S>
 struct StridedRow {   // p[j] of dof q in a [column][dof] table: base + j * S
   double* b;
@@ -51,7 +59,7 @@ struct ModelHHSI {
     dy[0] = (1 - m) * am - m * bm;
     dy[1] = (1 - h) * ah - h * bh;
     dy[2] = (1 - n) * an - n * bn;
-    const double i_stim = stim * exp(-fmod(t, 0.03) / 0.002) * (t < 125e-3 ? 1.0 : 0.0);
+    const double i_stim = stim * exp(-kn_fmod_period(t, 0.03) / 0.002) * (t < 125e-3 ? 1.0 : 0.0);
     const double i_Na = (glNa + gNa * h * (m * m * m) + i_stim) * (V - E_Na) + 3 * i_pump;
     const double n2 = n * n;
     const double i_K = (glK + gK * (n2 * n2)) * (V - E_K) - 2 * i_pump;
@@ -68,7 +76,7 @@ struct ModelHHSI {
   KN_HD double rhs_lane(int c, double t, const double* y) const {
     const double m = y[0], h = y[1], n = y[2], V = y[3];
     const double u = 1.0e3 * (V + 65.0e-3);
-    const double n1 = c == 0 ? (25. - u) : (c == 1 ? -u : (c == 2 ? (10. - u) : -fmod(t, 0.03)));
+    const double n1 = c == 0 ? (25. - u) : (c == 1 ? -u : (c == 2 ? (10. - u) : -kn_fmod_period(t, 0.03)));
     const double d1 = c == 1 ? 20. : (c == 3 ? 0.002 : 10.);
     const double n2 = c == 1 ? (30. - u) : -u;
     const double d2 = c == 0 ? 18. : (c == 1 ? 10. : 80.);
@@ -116,7 +124,7 @@ struct ModelHHMV {
     dy[0] = (1 - m) * am - m * bm;
     dy[1] = (1 - h) * ah - h * bh;
     dy[2] = (1 - n) * an - n * bn;
-    const double i_stim = stim * exp(-fmod(t, 30.0) / 2.0) * (t < 125 ? 1.0 : 0.0);
+    const double i_stim = stim * exp(-kn_fmod_period(t, 30.0) / 2.0) * (t < 125 ? 1.0 : 0.0);
     const double i_Na = (glNa + gNa * h * (m * m * m) + i_stim) * (V - E_Na) + 3 * i_pump;
     const double n2 = n * n;
     const double i_K = (glK + gK * (n2 * n2)) * (V - E_K) - 2 * i_pump;
@@ -129,7 +137,7 @@ struct ModelHHMV {
   KN_HD double rhs_lane(int c, double t, const double* y) const {
     const double m = y[0], h = y[1], n = y[2], V = y[3];
     const double u = V + 65.0;
-    const double n1 = c == 0 ? (25. - u) : (c == 1 ? -u : (c == 2 ? (10. - u) : -fmod(t, 30.0)));
+    const double n1 = c == 0 ? (25. - u) : (c == 1 ? -u : (c == 2 ? (10. - u) : -kn_fmod_period(t, 30.0)));
     const double d1 = c == 1 ? 20. : (c == 3 ? 2.0 : 10.);
     const double n2 = c == 1 ? (30. - u) : -u;
     const double d2 = c == 0 ? 18. : (c == 1 ? 10. : 80.);

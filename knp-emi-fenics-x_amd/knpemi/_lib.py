@@ -98,6 +98,7 @@ SIGNATURES = {
                                   C.c_double, C.c_int, c_int_p, C.c_int]),
     "knpemi_ode_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64),
                                    C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "knpemi_debug_ode_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_int]),
     "knpemi_update_pde": (C.c_int, [C.c_void_p]),
     "knpemi_trace": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p]),
     "knpemi_halo_width": (C.c_int, [C.c_void_p, C.c_int]),

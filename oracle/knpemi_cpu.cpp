@@ -17,6 +17,7 @@
 #include <cstring>
 
 #include "../knp-emi-fenics-x_amd/csrc/membrane_models.h"
+#include "lsoda_seq.h"   // sequential ODEPACK restatement (this directory)
 
 namespace {
 
@@ -383,13 +384,13 @@ int cpu_ode_sweep(int model, int nq, int ns, int np, double* states, double* par
       for (int i = 0; i < n_stim; ++i) p[stim_idx[i]] = stim_val[i];
     int rc;
     if (model == 0) {
-      Lsoda<4, ModelHHSI> s; double w[Lsoda<4, ModelHHSI>::WORK];
+      LsodaSeq<4, ModelHHSI> s; double w[LsodaSeq<4, ModelHHSI>::WORK];
       s.f.prepare(p); rc = s.integrate(&cf, w, y, t0, t0 + dt, rtol, atol, 10000); s.f.finish(p); nfe += s.nfe;
     } else if (model == 1) {
-      Lsoda<4, ModelHHMV> s; double w[Lsoda<4, ModelHHMV>::WORK];
+      LsodaSeq<4, ModelHHMV> s; double w[LsodaSeq<4, ModelHHMV>::WORK];
       s.f.prepare(p); rc = s.integrate(&cf, w, y, t0, t0 + dt, rtol, atol, 10000); s.f.finish(p); nfe += s.nfe;
     } else {
-      Lsoda<1, ModelGlial> s; double w[Lsoda<1, ModelGlial>::WORK];
+      LsodaSeq<1, ModelGlial> s; double w[LsodaSeq<1, ModelGlial>::WORK];
       s.f.prepare(p); rc = s.integrate(&cf, w, y, t0, t0 + dt, rtol, atol, 10000); s.f.finish(p); nfe += s.nfe;
     }
     failed += rc != 0;

@@ -2,6 +2,10 @@
 // `pytest -m "not gpu"` can check it against scipy's ODEPACK LSODA on the CPU.  Not shipped, not a
 // fallback: the product's ODE sweep only exists as the HIP kernel in csrc/kernels_ode.hip.
 #include "../../knp-emi-fenics-x_amd/csrc/membrane_models.h"
+// the sequential restatement of ODEPACK (oracle/, test infrastructure), here with the product's root function so
+// that the two integrators can be compared bit for bit
+#define KN_SEQ_POW kn_powr
+#include "../../oracle/lsoda_seq.h"
 
 static LsodaCoef g_cf;
 static bool g_init = false;
@@ -23,6 +27,26 @@ extern "C" int lsoda_host(int model, double* y, double* p, double t0, double t1,
   if (model == 0) return run<ModelHHSI>(y, p, t0, t1, rtol, atol, stats);
   if (model == 1) return run<ModelHHMV>(y, p, t0, t1, rtol, atol, stats);
   if (model == 2) return run<ModelGlial>(y, p, t0, t1, rtol, atol, stats);
+  return -100;
+}
+
+template <class M>
+static int run_seq(double* y, double* p, double t0, double t1, double rtol, double atol, int* stats) {
+  LsodaSeq<M::NS, M> s;
+  double work[LsodaSeq<M::NS, M>::WORK];
+  s.f.prepare(p);
+  int rc = s.integrate(&g_cf, work, y, t0, t1, rtol, atol, 10000);
+  s.f.finish(p);
+  if (stats) { stats[0] = s.nfe; stats[1] = s.nst; stats[2] = s.nje; stats[3] = s.mused; stats[4] = s.nqu; }
+  return rc;
+}
+
+extern "C" int lsoda_seq_host(int model, double* y, double* p, double t0, double t1, double rtol,
+                              double atol, int* stats) {
+  if (!g_init) { lsoda_fill_coef(&g_cf); g_init = true; }
+  if (model == 0) return run_seq<ModelHHSI>(y, p, t0, t1, rtol, atol, stats);
+  if (model == 1) return run_seq<ModelHHMV>(y, p, t0, t1, rtol, atol, stats);
+  if (model == 2) return run_seq<ModelGlial>(y, p, t0, t1, rtol, atol, stats);
   return -100;
 }
 

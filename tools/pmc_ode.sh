@@ -1,0 +1,16 @@
+#!/bin/bash
+# PMC passes for the ODE sweep at the bench state (one counter group per rocprofv3 run, kernel trace only).
+# usage: tools/pmc_ode.sh <workload> <outdir under gpurun_out>
+set -e
+W=${1:-config2}; OUT=${2:-pmc_ode}
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+i=0
+for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+           "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/$OUT/p$i -- \
+      python3 $R/bench.py --workload $W --steps 5 --warmup 2 --cpu-steps 0 --solve-steps 0 > $R/gpurun_out/$OUT.p$i.log 2>&1
+  echo "pass $i ($grp) done"
+done
+python3 $R/tools/pmc_summary.py $R/gpurun_out/$OUT
