@@ -1,12 +1,18 @@
 #!/usr/bin/env python3
 """bench.py -- assembled dofs/s of the KNP-EMI per-time-step hot path on MI355X.
 
-One "step" = one pass of the hot path over one synthetic field state, device-resident
-(SURVEY.md section 8d / BASELINE.md section 2): fused ODE launch (trace refresh + LSODA sweep +
-copy-back), EMI assembly (A, P, b in one pass), KNP assembly (A once, b incl. the membrane
-kernel), end-of-step update.  Krylov solves and file output are excluded.  At N > 1 the mesh is
-N times longer (weak scaling, x-slabs) and every step also exchanges the ghost-dof halo of the bulk fields
-(stream-ordered RCCL point-to-point, no host synchronisation; ghost membrane dofs are integrated redundantly).
+One "step" = one pass of the hot path over one field state, device-resident (SURVEY.md section 8d /
+BASELINE.md section 2): fused ODE launch (trace refresh + LSODA sweep + copy-back), EMI assembly (A, P, b in one
+pass), KNP assembly (A once, b incl. the membrane kernel), end-of-step update.  Krylov solves and file output are
+excluded from the timed region -- but the state the timed steps run on is a REAL trajectory: an untimed pass first
+integrates the same problem with the device Krylov solves and records the solution of every step; the timed steps
+start again from t = 0 and paste the recorded solution where the solve would write it (one launch per system, as the
+solve's own write-back).  The membrane therefore depolarises and fires as in a real run and the ODE sweep does the
+work a real run gives it (`ode_rhs_evals_per_dof_per_step`).
+
+At N > 1 the mesh is partitioned into x-slabs (weak: N times longer box; --scaling strong: the fixed config-3 box),
+every step exchanges the ghost-dof halo of the bulk fields (stream-ordered RCCL point-to-point; ghost membrane dofs
+are integrated redundantly) and the fields are held at their initial state (no recorded trajectory).
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -21,26 +27,78 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (os.path.join(ROOT, "knp-emi-fenics-x_amd"), os.path.join(ROOT, "examples", "idealized_geometries")):
+for p in (os.path.join(ROOT, "knp-emi-fenics-x_amd"), os.path.join(ROOT, "examples", "idealized_geometries"),
+          os.path.join(ROOT, "examples", "local_astrocyte_depolarization")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+LAUNCH_FLOOR_US = 5.0      # duration of a trivial streaming kernel in the same event brackets on this stack
+PROFILE_STEPS = 5
 
 WORKLOADS = {
-    # name: (mesh kind, resolution factor) -- geometry of make_mesh_3D.py, 6 tets per hexahedron
-    "config2": ("tet", 1),     # BASELINE.json configs[1]: 124 416 tets, 79 251 dofs/step
-    "config2h": ("hex", 2),    # reference-faithful Q1 hexahedra, 165 888 cells
-    "config3": ("tet", 2),     # 995 328 tets on ONE GPU (the 8-GPU mesh of configs[2])
-    "r3": ("tet", 3),          # 7.96 M tets
-    "2d": ("2d", 3),
+    # name: (family, mesh kind, resolution factor) -- geometry of make_mesh_3D.py, 6 tets per hexahedron
+    "config2": ("idealized", "tet", 1),     # BASELINE.json configs[1]: 124 416 tets, 79 251 dofs/step
+    "config2h": ("idealized", "hex", 2),    # reference-faithful Q1 hexahedra, 165 888 cells
+    "config3": ("idealized", "tet", 2),     # 995 328 tets on ONE GPU (the 8-GPU mesh of configs[2])
+    "r3": ("idealized", "tet", 3),          # 7.96 M tets
+    "2d": ("idealized", "2d", 3),
+    # BASELINE.json configs[4] stand-in (the emimesh mesh needs a network fetch): three sub-domains -- ECS, neuron
+    # (cells 1, 3: HH, mV / ms units), glia (cells 2, 4: Kir4.1 + pump) -- with the pulsed ECS K+ source of
+    # examples/local_astrocyte_depolarization/run_stim_duration.py on the box mesh
+    "config5s": ("astro", "tet", 2),        # 995 328 tets, 3 sub-domains, two membrane models
+    "config5s_r3": ("astro", "tet", 3),     # 7.96 M tets
 }
 
 
-def algorithmic_bytes(s, dp):
-    """compulsory bytes per launch, every array counted once."""
-    import numpy as np
+class Case:
+    """What the bench needs from a driver set-up, whichever example builds it."""
+
+    def __init__(self, workload, rank=0, world=1, scaling="weak"):
+        family, kind, r = WORKLOADS[workload]
+        self.family, self.kind, self.r = family, kind, r
+        quiet = io.StringIO()
+        with contextlib.redirect_stdout(quiet):
+            if family == "astro":
+                import run_stim_duration as rsd
+                cfg = dict(rsd.DEFAULTS)
+                cfg["mesh"] = dict(kind="box3d", resolution_factor=r, cell_type="tetrahedron", length=2)
+                # a source box like the reference's (0.8 x 0.8 x 0.4 um there), placed in an ECS corner of this box
+                # (cm), on from the first step for 1 ms
+                cfg.update(delay=0.0, pulse_width=1.0, period=10.0, end_time=100.0, x_L=15e-4, x_U=17e-4, y_L=-1.0,
+                           y_U=0.2e-4, z_L=-1.0, z_U=0.2e-4)
+                if world > 1:
+                    raise SystemExit("config5s runs on one GPU (the slab partitioner builds the idealized set-up)")
+                s = rsd.Problem(cfg)
+                s.set_source(0.0)
+                self.models = [(mm["ode"], s.stim_params["stimulus"], s.stim_params["stimulus_locator"])
+                               for tag in (1, 2) for mm in s.subdomain_list[tag]["mem_models"]]
+                self.solver_rtol = (1e-6, 1e-7)      # run_stim_duration.py:424-437
+                self.source = s.f_source_K.x._a
+                self.describe = ("HH (mV/ms) on cells 1,3 + glial Kir4.1/pump on cells 2,4, pulsed ECS K+ source on, "
+                                 "dt=0.1 ms")
+            else:
+                from setup_problem import Setup
+                if world > 1:
+                    from knpemi.fem.partition import make_slab_problem
+                    s = make_slab_problem(kind, r, rank, world, g_syn=10.0, length=2 if scaling == "strong" else None)
+                else:
+                    s = Setup(kind, r, g_syn=10.0)
+                self.models = [(mm["ode"], s.stim_params["stimulus"], s.stim_params["stimulus_locator"])
+                               for mm in s.mem_models]
+                self.solver_rtol = (1e-5, 1e-7)      # run_3D.py:296-305
+                self.source = None
+                self.describe = "HH, g_syn=10 for x<20um, dt=1e-4"
+        self.s = s
+        self.dt = s.dt
+
+
+def algorithmic_bytes(case, dp):
+    """Compulsory bytes per launch, every array counted once: `survey` = the accounting of SURVEY.md section 8(d)
+    (FEniCSx-style dofmap + element scatter-slot map), `design` = the arrays this implementation reads and writes
+    (4-byte pair entries, 2-byte entry map, distinct-vertex lists, 64-byte vertex records)."""
     from knpemi import _lib as L
+    s = case.s
     nv = s.mesh.cells.shape[1]
     gdim = s.mesh.gdim
     nc = int(dp.n_cell.sum())
@@ -50,10 +108,11 @@ def algorithmic_bytes(s, dp):
     NQ = int(dp.n_q.sum())
     nnz = dp._pattern(L.A_EMI)[1]
     nnzL = dp._pattern(L.A_KNP)[1] // 2
+    n_slots = int(dp.n_models.sum())
     idx = nc * (4 * nv + 4 * nv * nv)          # dofmap + scatter-slot map
     geo = 8 * gdim * N
     gam_idx = nF * (16 + 4 * (2 * nf) ** 2 + 2 * nf * 4)
-    out = {
+    survey = {
         # A and P (two matrices, one pass), b_emi, 3 coefficient fields, membrane coupling + Robin RHS
         "emi_rows_kernel": idx + geo + 8 * N * 3 + 2 * 8 * nnz + 8 * N + gam_idx + 8 * NQ + 8 * 2 * NQ,
         # two ion blocks, phi + 2 c_prev coefficients, 2 RHS vectors
@@ -62,10 +121,37 @@ def algorithmic_bytes(s, dp):
         "knp_membrane_kernel": nF * (16 + 2 * nf * 4) + 8 * NQ * 12 + 2 * 8 * 2 * NQ * 2,
         "update_pde_kernel": 8 * N * (2 * 2 + 3) + 8 * NQ * 3,
     }
-    for m in s.mem_models:
-        ns, npar = m['ode'].states.shape[1], m['ode'].parameters.shape[1]
-        out["ode_step_kernel"] = out.get("ode_step_kernel", 0) + 2 * 8 * NQ * (ns + npar) + 8 * NQ * 6 + 8 * NQ * 4
-    return out
+    # what the kernels touch: per (row, cell) pair 4 bytes (simplices) or 12 (hexahedra), 2 bytes per Laplacian
+    # entry, 4 bytes per distinct vertex of a row block (~7 per row on these meshes, measured through lds_uniq),
+    # one 64-byte record per distinct vertex of a block, 16-byte row descriptor
+    pair_b = 4 if nv != 8 else 12
+    # distinct vertices per row block, summed (rows per block: 256 threads / lanes per row, blocks do not straddle
+    # sub-domains), from the Laplacian pattern (first ion block of every sub-domain of A_knp)
+    import numpy as np
+    _, _, krp, kci = dp._pattern(L.A_KNP)
+    rpb = 128 if nv == 3 else 64
+    uniq = 0
+    for sd in range(len(dp.n_vert)):
+        r0, nvs = 2 * int(dp.voff[sd]), int(dp.n_vert[sd])
+        for a in range(0, nvs, rpb):
+            b = min(nvs, a + rpb)
+            uniq += np.unique(kci[krp[r0 + a]:krp[r0 + b]]).size
+    design = {
+        "emi_rows_kernel": nc * nv * pair_b + 2 * nnzL + 4 * uniq + 64 * uniq + 16 * N + 2 * 8 * nnz + 8 * (nnz - nnzL)
+                           + 8 * N + 2 * nF * nf * (8 + 4 + 4 * nf + 8 * nf),
+        "knp_rows_kernel": nc * nv * pair_b + 2 * nnzL + 4 * uniq + 64 * uniq + 16 * N + 2 * 8 * nnzL + 2 * 8 * N
+                           + 2 * nF * nf * 16,
+        # per (facet, side): 3 index triples, 2 nf 64-byte records, phi_M and the model's K currents on nf dofs,
+        # nf x 16 bytes of partial integrals out + their positions
+        "knp_membrane_kernel": 2 * nF * (3 * 4 * nf + 4 + 2 * nf * 64 + 8 * nf * (1 + 3) + nf * (16 + 4)),
+        "update_pde_kernel": 8 * N * 2 + 24 * N + 8 * NQ * 3 + 8 * NQ,
+    }
+    ode = 0
+    for m, _, _ in case.models:
+        ns, npar = m.states.shape[1], m.parameters.shape[1]
+        ode += 2 * 8 * m.nodes * (ns + npar) + 8 * m.nodes * 6 + 8 * m.nodes * 4
+    survey["ode_step_kernel"] = design["ode_step_kernel"] = ode
+    return survey, design, dict(nc=nc, N=N, nF=nF, NQ=NQ, nnz=nnz, nnzL=nnzL, n_model_slots=n_slots)
 
 
 def cpu_baseline(s, n_steps, threads=1):
@@ -114,23 +200,61 @@ def cpu_baseline(s, n_steps, threads=1):
     return (t_asm + t_ode) / n_steps, t_asm / n_steps, t_ode / n_steps, ode.nodes
 
 
-def with_solves(s, stepper, n_steps, torch):
-    """Whole time steps of run_3D.py:345-368 on the device, Krylov solves included (SURVEY section 8 f1): the
-    same stepper with `knpemi_solve_emi` (CG + AMG, rtol 1e-5) and `knpemi_solve_knp` (BiCGStab + AMG, rtol 1e-7)
-    between the assemblies.  Not part of `value`."""
+def device_solvers(case, its, maxit=1000):
+    """Solve callbacks of the stepper: knpemi_solve_emi (CG + AMG) / knpemi_solve_knp (BiCGStab + AMG) at the
+    reference's tolerances, starting from 2 x_n - x_(n-1)."""
     from knpemi import _lib as L
-    dp = stepper.dp
-    its = {"emi": [], "knp": []}
+    rtol_emi, rtol_knp = case.solver_rtol
 
     def solver(which, key, rtol, atol):
         def run(d):
-            L.check(d.lib.knpemi_extrapolate_guess(d.h, which))     # start from 2 x_n - x_(n-1)
-            its[key].append(d.solve(which, rtol, atol, 1000)[0])
+            L.check(d.lib.knpemi_extrapolate_guess(d.h, which))
+            its[key].append(d.solve(which, rtol, atol, maxit)[0])
         return run
-    stepper.solve_emi = solver(L.B_EMI, "emi", 1e-5, 1e-40)
-    stepper.solve_knp = solver(L.B_KNP, "knp", 1e-7, 2e-40)
-    for _ in range(3):
-        stepper.step()           # builds the AMG hierarchies
+    return solver(L.B_EMI, "emi", rtol_emi, 1e-40), solver(L.B_KNP, "knp", rtol_knp, 2e-40)
+
+
+def record_trajectory(case, stepper, n_steps, torch):
+    """Untimed: n_steps whole time steps with the device Krylov solves; returns the solutions (phi, c in the unknown
+    order of the two systems) of every step as device tensors [n_steps, n]."""
+    import numpy as np
+    from knpemi import _lib as L
+    dp = stepper.dp
+    n_emi = dp._pattern(L.A_EMI)[0]
+    n_knp = dp._pattern(L.A_KNP)[0]
+    phi_t = np.empty((n_steps, n_emi))
+    c_t = np.empty((n_steps, n_knp))
+    its = {"emi": [], "knp": []}
+    solve_emi, solve_knp = device_solvers(case, its)
+    k = [0]
+
+    def emi(d):
+        solve_emi(d)
+        L.check(d.lib.knpemi_get_solution(d.h, L.B_EMI, L.dptr(phi_t[k[0]])))
+
+    def knp(d):
+        solve_knp(d)
+        L.check(d.lib.knpemi_get_solution(d.h, L.B_KNP, L.dptr(c_t[k[0]])))
+        k[0] += 1
+    stepper.solve_emi, stepper.solve_knp = emi, knp
+    for _ in range(n_steps):
+        stepper.step()
+    dp.sync()
+    stepper.solve_emi = stepper.solve_knp = None
+    dev = torch.device("cuda", dp.device)
+    return torch.from_numpy(phi_t).to(dev), torch.from_numpy(c_t).to(dev), its
+
+
+def with_solves(case, stepper, n_steps, torch):
+    """Whole time steps of run_3D.py:345-368 on the device, Krylov solves included (SURVEY section 8 f1): the
+    same stepper with `knpemi_solve_emi` (CG + AMG) and `knpemi_solve_knp` (BiCGStab + AMG) between the assemblies,
+    continuing from the end of the timed trajectory.  Not part of `value`."""
+    from knpemi import _lib as L
+    dp = stepper.dp
+    its = {"emi": [], "knp": []}
+    stepper.solve_emi, stepper.solve_knp = device_solvers(case, its)
+    for _ in range(2):
+        stepper.step()
     torch.cuda.synchronize()
     its["emi"].clear()
     its["knp"].clear()
@@ -142,9 +266,10 @@ def with_solves(s, stepper, n_steps, torch):
     ms = (time.perf_counter() - t0) / n_steps * 1e3
     stepper.solve_emi = stepper.solve_knp = None
     info = {k: dp.solver_info(w) for k, w in (("emi", L.B_EMI), ("knp", L.B_KNP))}
+    re, rk = case.solver_rtol
     return {"ms_per_step": ms, "steps": n_steps, "initial_guess": "2 x_n - x_(n-1) (knpemi_extrapolate_guess)",
-            "emi": {"solver": "CG + SA-AMG V(1,1), rtol 1e-5", "iterations_avg": sum(its["emi"]) / n_steps, **info["emi"]},
-            "knp": {"solver": "BiCGStab + SA-AMG V(1,1), rtol 1e-7", "iterations_avg": sum(its["knp"]) / n_steps,
+            "emi": {"solver": f"CG + SA-AMG V(1,1), rtol {re:g}", "iterations_avg": sum(its["emi"]) / n_steps, **info["emi"]},
+            "knp": {"solver": f"BiCGStab + SA-AMG V(1,1), rtol {rk:g}", "iterations_avg": sum(its["knp"]) / n_steps,
                     **info["knp"]}}
 
 
@@ -154,12 +279,18 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = box length proportional to N (config 2 per GPU), strong = the fixed config-3 box "
+                         "(995 328 tets at --workload config3) cut into N slabs")
     ap.add_argument("--cpu-steps", type=int, default=100,
                     help="CPU-port steps timed for cpu_baseline on all host cores; the 1-core leg runs 0.4 x as many "
                          "(0 = skip)")
     ap.add_argument("--solve-steps", type=int, default=20,
-                    help="extra untimed-for-`value` pass: whole time steps including the device Krylov solves "
-                         "(rtol 1e-5 / 1e-7 as run_3D.py:296-305), reported as `with_solves` (0 = skip; N = 1 only)")
+                    help="extra untimed-for-`value` pass: whole time steps including the device Krylov solves, reported "
+                         "as `with_solves` (0 = skip; N = 1 only)")
+    ap.add_argument("--frozen-state", action="store_true",
+                    help="hold the fields at their initial state instead of replaying a recorded trajectory (the "
+                         "round-1 measurement: phi_M is reset every step and the cell never fires)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the EMI matrix assembly after the ODE sweep instead of beside it (aux stream)")
     ap.add_argument("--knp-twice", action="store_true",
@@ -187,35 +318,33 @@ def main():
 
     from knpemi import _lib as L
     from knpemi.stepper import DeviceStepper
-    from setup_problem import Setup
 
-    kind, r = WORKLOADS[args.workload]
-    quiet = io.StringIO()
-    with contextlib.redirect_stdout(quiet):
-        if world > 1:
-            from knpemi.fem.partition import make_slab_problem
-            s = make_slab_problem(kind, r, rank, world, g_syn=10.0)
-        else:
-            s = Setup(kind, r, g_syn=10.0)
-    s.perturb(seed=12345 + rank)
-    # synthetic "solution" state: c = c_prev, so the end-of-step update keeps the fields stationary
-    for tag in s.subdomain_list:
-        for k in range(2):
-            s.c[tag][k].x.array[:] = s.c_prev[tag][k].x._a
-        s.ion_list[-1][f'c_{tag}'].x.array[:] = -(1.0 / s.ion_list[-1]['z']) * sum(
-            ion['z'] * f.x._a for ion, f in zip(s.ion_list[:-1], s.c_prev[tag]))
-    # potentials: rest potential across the membrane plus a smooth perturbation
-    L_x = s.mesh.x[:, 0].max() if world == 1 else s.global_length
-    for tag in s.subdomain_list:
-        x = s.subdomain_list[tag]['mesh_sub'].x
-        s.phi[tag].x.array[:] = (-0.0744 if tag > 0 else 0.0) + 1e-3 * np.sin(2 * np.pi * x[:, 0] / L_x)
+    if world > 1 and args.scaling == "strong" and args.workload == "config2":
+        args.workload = "config3"       # the fixed mesh of BASELINE.json configs[2]
+    case = Case(args.workload, rank, world, args.scaling)
+    s = case.s
+    frozen = args.frozen_state or world > 1
+    if frozen and case.family == "idealized":
+        # synthetic stationary state: c = c_prev (the update keeps the fields), rest potential + a smooth perturbation
+        s.perturb(seed=12345 + rank)
+        for tag in s.subdomain_list:
+            for k in range(2):
+                s.c[tag][k].x.array[:] = s.c_prev[tag][k].x._a
+            s.ion_list[-1][f'c_{tag}'].x.array[:] = -(1.0 / s.ion_list[-1]['z']) * sum(
+                ion['z'] * f.x._a for ion, f in zip(s.ion_list[:-1], s.c_prev[tag]))
+        L_x = s.mesh.x[:, 0].max() if world == 1 else s.global_length
+        for tag in s.subdomain_list:
+            x = s.subdomain_list[tag]['mesh_sub'].x
+            s.phi[tag].x.array[:] = (-0.0744 if tag > 0 else 0.0) + 1e-3 * np.sin(2 * np.pi * x[:, 0] / L_x)
 
     stepper = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp),
                             s.c, s.c_prev, s.phi, s.phi_M_prev, assemble_knp_twice=args.knp_twice,
-                            overlap=not args.no_overlap)
+                            overlap=not args.no_overlap, fuse_update=not (args.frozen_state or world > 1))
     dp = stepper.dp
-    for mm in s.mem_models:
-        stepper.add_membrane_model(mm['ode'], s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
+    for m, stim, loc in case.models:
+        stepper.add_membrane_model(m, stim, loc)
+    if case.source is not None:
+        stepper.set_source(0, case.source)
     halo = getattr(s, "halo", None)
     if halo is not None:
         halo.attach(dp)
@@ -228,12 +357,37 @@ def main():
         torch.cuda.synchronize()
 
     lib = dp.lib
+    n_traj = args.warmup + PROFILE_STEPS + args.steps
+    traj_its = None
+    if not frozen:
+        phi_t, c_t, traj_its = record_trajectory(case, stepper, n_traj, torch)
+        stepper.reset()
+        if case.source is not None:
+            stepper.set_source(0, case.source)
+        cursor = [0]
+
+        def paste_emi(d):
+            L.check(d.lib.knpemi_set_solution(d.h, L.B_EMI, phi_t[cursor[0]].data_ptr(), 1))
+
+        def paste_knp(d):
+            L.check(d.lib.knpemi_set_solution(d.h, L.B_KNP, c_t[cursor[0]].data_ptr(), 1))
+            cursor[0] += 1
+        stepper.solve_emi, stepper.solve_knp = paste_emi, paste_knp
+
+    def ode_stats():
+        nr = ns = nf = 0
+        for m, _, _ in case.models:
+            a, b, c = C.c_int64(), C.c_int64(), C.c_int32()
+            lib.knpemi_ode_stats(dp.h, m._sub, m._model, C.byref(a), C.byref(b), C.byref(c))
+            nr, ns, nf = nr + a.value, ns + b.value, nf + c.value
+        return nr, ns, nf
+
     for _ in range(args.warmup):
         stepper.step(halo)
     sync()
     # untimed profiling pass: every kernel bracketed by HIP events -> per-kernel averages, dominant kernel
-    L.check(lib.knpemi_profile(dp.h, 0x1F))
-    for _ in range(5):
+    L.check(lib.knpemi_profile(dp.h, (1 << len(L.KERNEL_NAMES)) - 1))
+    for _ in range(PROFILE_STEPS):
         stepper.step(halo)
     sync()
     per_kernel = {}
@@ -241,23 +395,28 @@ def main():
         n, ms = C.c_int64(), C.c_double()
         L.check(lib.knpemi_profile_read(dp.h, kid, C.byref(n), C.byref(ms)))
         if n.value:
-            per_kernel[name] = ms.value / n.value * 1e3   # us per launch
-    asm = {k: v for k, v in per_kernel.items() if k != "ode_step_kernel"}
-    dominant = max(asm, key=asm.get) if asm else "emi_rows_kernel"
+            per_kernel[name] = ms.value / n.value * 1e3 * (n.value / PROFILE_STEPS)   # us per step (all launches)
+    rows = {k: v for k, v in per_kernel.items() if k in ("emi_rows_kernel", "knp_rows_kernel")}
+    dominant = max(rows, key=rows.get) if rows else "emi_rows_kernel"
     dom_id = L.KERNEL_NAMES.index(dominant)
-    # timed region: only the dominant assembly kernel stays bracketed by HIP events
-    L.check(lib.knpemi_profile(dp.h, 1 << dom_id))
+    mem_id = L.KERNEL_NAMES.index("knp_membrane_kernel")
+    # timed region: only the dominant row kernel and the membrane-facet kernel stay bracketed by HIP events
+    L.check(lib.knpemi_profile(dp.h, (1 << dom_id) | (1 << mem_id)))
+    ode_stats()                                 # reset the counters
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stepper.step(halo)
     sync()
     elapsed = time.perf_counter() - t0
+    n_rhs, n_lsoda_steps, n_failed = ode_stats()
     n, ms = C.c_int64(), C.c_double()
     L.check(lib.knpemi_profile_read(dp.h, dom_id, C.byref(n), C.byref(ms)))
     dom_us = ms.value / max(n.value, 1) * 1e3
+    L.check(lib.knpemi_profile_read(dp.h, mem_id, C.byref(n), C.byref(ms)))
+    mem_us = ms.value / max(n.value, 1) * 1e3
     L.check(lib.knpemi_profile(dp.h, 0))
-    if stepper.ode_failures():
+    if n_failed:
         raise SystemExit("LSODA failed on the device")
     if dist is not None:
         red_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
@@ -277,42 +436,69 @@ def main():
     value = dofs_total / (elapsed / args.steps)
 
     if rank == 0:
-        bytes_alg = algorithmic_bytes(s, dp)
-        achieved = bytes_alg[dominant] / (dom_us * 1e-6) / 1e9
-        # HBM bytes per launch measured with rocprofv3 PMC counters (committed, profiles/r01_traffic.json):
-        # PMC collection needs its own profiler passes and cannot run inside this process
-        traffic = None
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))[args.workload][dominant]
-            if world == 1:
-                traffic = (2.0 * tr["FETCH_SIZE_KiB"] + tr["WRITE_SIZE_KiB"]) * 1024.0
-        except (OSError, KeyError, ValueError):
-            pass
+        survey_b, design_b, sizes = algorithmic_bytes(case, dp)
+        n_ode_dofs = sum(m.nodes for m, _, _ in case.models)
+
+        def roof(kernel, us):
+            # HBM bytes per launch measured with rocprofv3 PMC counters on THIS build, if they were collected
+            # (tools/collect_traffic.sh -> profiles/r02_traffic.json); PMC collection needs its own profiler passes
+            traffic = None
+            try:
+                tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))[args.workload][kernel]
+                if world == 1:
+                    traffic = (2.0 * tr["FETCH_SIZE_KiB"] + tr["WRITE_SIZE_KiB"]) * 1024.0
+            except (OSError, KeyError, ValueError):
+                pass
+            ach = survey_b[kernel] / (us * 1e-6) / 1e9
+            return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": survey_b[kernel], "avg_launch_us": us,
+                    "bytes_this_design_touches": design_b[kernel],
+                    "frac_of_design_bytes": design_b[kernel] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                    # a launch cannot be shorter than the launch floor: the fraction of peak a perfect kernel would
+                    # reach at this size (1.0 = large enough for HBM to be the bound)
+                    "launch_floor_us": LAUNCH_FLOOR_US,
+                    "frac_at_launch_floor": min(1.0, survey_b[kernel] / (LAUNCH_FLOOR_US * 1e-6) / 1e9 / HBM_PEAK_GBS)}
         out = {
             "metric": "assembled dofs/s (volume + membrane-facet assembly + membrane ODE sweep) per timestep; "
                       "3D idealized mesh, fp64",
             "value": value, "unit": "dofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: make_mesh_3D geometry r={r}, {kind}, "
-                                   f"{int(dp.n_cell.sum())} cells/GPU, {int(dp.n_vert.sum())} sub-mesh vertices/GPU, "
-                                   f"{int(dp.n_q.sum())} membrane ODE dofs/GPU, 3 ions (K, Cl, Na eliminated), HH, "
-                                   f"g_syn=10 for x<20um, dt=1e-4",
+            "config": {"workload": f"{args.workload}: make_mesh_3D geometry r={case.r}, {case.kind}, "
+                                   f"{sizes['nc']} cells/GPU, {sizes['N']} sub-mesh vertices/GPU in "
+                                   f"{len(s.subdomain_list)} sub-domains, {n_ode_dofs} membrane ODE dofs/GPU, 3 ions "
+                                   f"(K, Cl, Na eliminated), {case.describe}",
                        "dofs_per_step": dofs_total, "A_knp_assemblies_per_step": 2 if args.knp_twice else 1,
-                       "emi_matrix_beside_ode_sweep": not args.no_overlap,
+                       "emi_matrix_beside_ode_sweep": bool(stepper.overlap),
+                       "update_fused_into_knp_write_back": bool(stepper.fuse_update),
+                       "state": ("fields frozen at the initial state (phi_M reset every step)" if frozen else
+                                 f"recorded trajectory of the first {n_traj} time steps from t = 0 (device Krylov solves, "
+                                 f"untimed); the timed steps replay it, pasting each recorded solution where the solve "
+                                 f"writes it"),
                        "partition": "x-slabs" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bytes_alg[dominant], "avg_launch_us": dom_us},
-            "kernels_us": per_kernel,
+            "roofline": roof(dominant, dom_us),
+            "roofline_membrane_facet_kernel": roof("knp_membrane_kernel", mem_us),
+            "kernels_us_per_step": per_kernel,
+            "ode": {"rhs_evals_per_dof_per_step": n_rhs / max(1, n_ode_dofs) / args.steps,
+                    "lsoda_steps_per_dof_per_step": n_lsoda_steps / max(1, n_ode_dofs) / args.steps,
+                    "kernel_us_per_step": per_kernel.get("ode_step_kernel"),
+                    "share_of_step": per_kernel.get("ode_step_kernel", 0.0) / (ms_per_step * 1e3)},
         }
+        if halo is not None:
+            out["config"]["halo"] = halo.mode
+        if traj_its is not None:
+            out["config"]["trajectory_iterations_avg"] = {k: sum(v) / max(1, len(v)) for k, v in traj_its.items()}
         if args.solve_steps > 0 and world == 1:
-            out["with_solves"] = with_solves(s, stepper, args.solve_steps, torch)
-        if args.cpu_steps > 0 and world == 1:
+            stepper.solve_emi = stepper.solve_knp = None
+            out["with_solves"] = with_solves(case, stepper, args.solve_steps, torch)
+        if args.cpu_steps > 0 and world == 1 and case.family == "idealized":
             avail = len(os.sched_getaffinity(0))
             # bounded sample: --cpu-steps refers to the config-2 size and shrinks with the problem size
             n_all = max(3, int(round(args.cpu_steps * min(1.0, 79251.0 / dofs_total))))
             n1 = max(2, int(0.4 * n_all))
+            quiet = io.StringIO()
             with contextlib.redirect_stdout(quiet):
                 t_one, a_one, o_one, _ = cpu_baseline(s, n1, threads=1)     # before any OpenMP team exists
                 # thread count: a fully subscribed host can be slower than a partly subscribed one (spinning OpenMP
@@ -321,8 +507,9 @@ def main():
                 probes = {c: cpu_baseline(s, 3, threads=c)[0] for c in cand}
                 cores = min(probes, key=probes.get)
                 t_all, a_all, o_all, nrows = cpu_baseline(s, n_all, threads=cores)
-            what = ("whole steps of the C++ port (oracle/knpemi_cpu.cpp) on the same mesh: EMI (A, P, b) + KNP (A, b) "
-                    "assembly and update {a:.0f} ms/step, LSODA sweep over all {n} membrane dofs {o:.0f} ms/step; "
+            what = ("whole steps of the C++ port (oracle/knpemi_cpu.cpp, sequential ODEPACK restatement "
+                    "oracle/lsoda_seq.h) on the same mesh from the initial state: EMI (A, P, b) + KNP (A, b) assembly "
+                    "and update {a:.0f} ms/step, LSODA sweep over all {n} membrane dofs {o:.0f} ms/step; "
                     "the reference itself cannot run here")
             out["cpu_baseline"] = {
                 "value": dofs_total / t_all, "unit": "dofs/s", "cores": cores, "kind": "port",

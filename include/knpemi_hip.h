@@ -153,7 +153,8 @@ int knpemi_device_csr(knpemi_handle* h, int which, const int32_t** rowptr, const
                       const double** vals);
 int knpemi_device_rhs(knpemi_handle* h, int which, const double** b);
 /* Write a solver result back into the bulk fields: x has the unknown order of the system
- * (`which` = KNPEMI_B_EMI -> phi, KNPEMI_B_KNP -> c).  on_device != 0: x is a device pointer. */
+ * (`which` = KNPEMI_B_EMI -> phi, KNPEMI_B_KNP -> c).  on_device != 0: x is a device pointer (one launch, nothing
+ * synchronised). */
 int knpemi_set_solution(knpemi_handle* h, int which, const double* x, int on_device);
 int knpemi_get_solution(knpemi_handle* h, int which, double* x);
 
@@ -200,6 +201,9 @@ int knpemi_ode_set_stimulus(knpemi_handle* h, int sub, int model, const uint8_t*
  * lets a caller keep the LONGER of {ODE sweep, EMI matrix assembly} on the main stream, so that the work that follows
  * the join does not pay the cross-stream signal latency */
 #define KNPEMI_ODE_ON_AUX_STREAM 4
+/* the same on a second auxiliary stream: the sweeps of different membrane models (neuron, glia, ...) are independent
+ * of each other and each fills a fraction of the chip only, so they run side by side */
+#define KNPEMI_ODE_ON_AUX2_STREAM 8
 int knpemi_ode_step(knpemi_handle* h, int sub, int model, double t0, double dt, double rtol,
                     double atol, int flags, const int32_t* ion_param, int v_index);
 /* RHS evaluations / internal steps / failed dofs summed over all knpemi_ode_step launches since
@@ -216,6 +220,14 @@ int knpemi_debug_ode_stamps(knpemi_handle* h, int sub, int model, uint64_t* out,
 /* End-of-step update: update_pde_variables (utils.py:238-295): c_prev <- c, eliminated ion from
  * electroneutrality, phi_M_prev <- tr(phi_i) - tr(phi_e). */
 int knpemi_update_pde(knpemi_handle* h);
+
+/* Options of a handle (device-resident loops).
+ * KNPEMI_OPT_FUSE_UPDATE (0/1): update_pde_variables follows problem_knp.solve() directly in the reference's loop
+ *   (run_3D.py:356,362); with this option the write-back kernel of knpemi_solve_knp -- and of
+ *   knpemi_set_solution(KNPEMI_B_KNP, device pointer) -- also performs that update (same arithmetic, one launch
+ *   fewer per step), and the caller does not call knpemi_update_pde. */
+#define KNPEMI_OPT_FUSE_UPDATE 1
+int knpemi_set_option(knpemi_handle* h, int option, int value);
 
 /* Nodal trace of an (ECS, cell) pair of bulk functions onto Q_sub: interpolate_to_membrane
  * (utils.py:150-207).  u_e has n_vert[0] entries, u_i n_vert[sub]; q_e, q_i receive n_q[sub]. */
@@ -241,7 +253,8 @@ int knpemi_halo_unpack(knpemi_handle* h, int kind, const int32_t* idx_dev, int n
 #define KNPEMI_K_KNP_ROWS 2      /* knp_rows_kernel      */
 #define KNPEMI_K_KNP_MEMBRANE 3  /* knp_membrane_kernel  */
 #define KNPEMI_K_UPDATE 4        /* update_pde_kernel    */
-#define KNPEMI_N_KERNELS 5
+#define KNPEMI_K_EMI_MEMBRANE 5  /* emi_membrane_rhs_kernel */
+#define KNPEMI_N_KERNELS 6
 int knpemi_profile(knpemi_handle* h, uint32_t kernel_mask);
 int knpemi_profile_read(knpemi_handle* h, int kernel, int64_t* launches, double* total_ms);
 

@@ -984,6 +984,28 @@ __global__ void update_pde_kernel(KnDev D, const KnConsts* __restrict__ Cp) {
   if (i < D.NQtot) D.phiM[i] = D.VR[(size_t)D.q2i[i] * KN_REC + 7] - D.VR[(size_t)D.q2e[i] * KN_REC + 7];
 }
 
+// Write-back of the KNP solve fused with update_pde_variables (KNPEMI_OPT_FUSE_UPDATE): x holds the solution in the
+// reference's block order [sub-domain][ion][vertex] (pdeSolver.py:117); same arithmetic as update_pde_kernel.
+__global__ void knp_writeback_update_kernel(KnDev D, const KnConsts* __restrict__ Cp, const double* __restrict__ x) {
+  const KnConsts& C = *Cp;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < D.Ntot) {
+    int s = 0;
+    for (int t = 1; t < C.n_sub; ++t) s += i >= C.voff[t];
+    const int v0 = C.voff[s], nv = C.voff[s + 1] - v0;
+    const size_t xb = (size_t)(KN_MAXK - 1) * v0 + (size_t)(i - v0);
+    const double c0 = x[xb], c1 = x[xb + nv];
+    D.csol[i] = c0;
+    D.csol[(size_t)D.Ntot + i] = c1;
+    double el = C.sc[s].rho_term;
+    el += C.elim_coef[0] * c0;
+    el += C.elim_coef[1] * c1;
+    double* rec = D.VR + (size_t)i * KN_REC + 4;
+    rec[0] = c0; rec[1] = c1; rec[2] = el;
+  }
+  if (i < D.NQtot) D.phiM[i] = D.VR[(size_t)D.q2i[i] * KN_REC + 7] - D.VR[(size_t)D.q2e[i] * KN_REC + 7];
+}
+
 // Forward-halo pack / unpack (owner -> ghost copies of dof fields between GPUs).
 __global__ void halo_kernel(KnDev D, int kind, int pack, const int* __restrict__ idx, int n, int n_slots,
                             double* __restrict__ buf) {
@@ -1191,6 +1213,7 @@ int kn_launch_emi_membrane_rhs(knpemi_handle* h, int flags) {
   if (D.M == 0) return KNPEMI_OK;
   const int split = (flags & KNPEMI_NO_SPLITTING) ? 0 : 1;
   dim3 grid((D.M + 255) / 256), block(256);
+  KnProfScope prof(h, KNPEMI_K_EMI_MEMBRANE);
   if (h->NF == 2) hipLaunchKernelGGL((emi_membrane_rhs_kernel<2>), grid, block, 0, h->stream, D, h->d_consts, split);
   else if (h->NF == 3) hipLaunchKernelGGL((emi_membrane_rhs_kernel<3>), grid, block, 0, h->stream, D, h->d_consts, split);
   else hipLaunchKernelGGL((emi_membrane_rhs_kernel<4>), grid, block, 0, h->stream, D, h->d_consts, split);
@@ -1204,6 +1227,15 @@ int kn_launch_update_pde(knpemi_handle* h) {
   KnProfScope prof(h, KNPEMI_K_UPDATE);
   hipLaunchKernelGGL(update_pde_kernel, dim3((n + 255) / 256), dim3(256), 0, h->cur, D, h->d_consts);
   return check_launch("update_pde_kernel");
+}
+
+int kn_launch_knp_writeback_update(knpemi_handle* h, const double* x) {
+  const KnDev& D = h->dev;
+  const int n = std::max(D.Ntot, D.NQtot);
+  if (n == 0) return KNPEMI_OK;
+  KnProfScope prof(h, KNPEMI_K_UPDATE);
+  hipLaunchKernelGGL(knp_writeback_update_kernel, dim3((n + 255) / 256), dim3(256), 0, h->cur, D, h->d_consts, x);
+  return check_launch("knp_writeback_update_kernel");
 }
 
 int kn_launch_halo(knpemi_handle* h, int kind, int pack, const int32_t* idx, int n, double* buf) {

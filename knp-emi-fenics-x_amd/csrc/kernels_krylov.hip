@@ -407,7 +407,8 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     rn = std::sqrt(sc[S_RR]);
     if (!(rn == rn)) { kn_set_error("KNP BiCGStab broke down (NaN residual)"); return KNPEMI_EINVAL; }
   }
-  hipLaunchKernelGGL(knp_order_kernel, grid1(n), dim3(256), 0, h->stream, D.Ntot, KS, h->n_sub, h->d_consts, x, D.csol, 0);
+  if (h->fuse_update) { if ((rc = kn_launch_knp_writeback_update(h, x))) return rc; }
+  else hipLaunchKernelGGL(knp_order_kernel, grid1(n), dim3(256), 0, h->stream, D.Ntot, KS, h->n_sub, h->d_consts, x, D.csol, 0);
   if (iters) *iters = it;
   if (relres) *relres = bnorm > 0 ? rn / bnorm : rn;
   hipError_t e = hipGetLastError();
@@ -417,6 +418,18 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     else if (it > 2 * G.its_ref + 4) G.built = false;
   }
   if (rn > target) { kn_set_error("KNP BiCGStab did not converge (ksp_error_if_not_converged)"); return KNPEMI_ESOLVE; }
+  return KNPEMI_OK;
+}
+
+// x in the reference's block order (pdeSolver.py:117) <-> csol (ion-major over the global vertex numbering)
+int kn_launch_knp_order(knpemi_handle* h, double* x, int to_blocks) {
+  const KnDev& D = h->dev;
+  const int n = (h->K - 1) * D.Ntot;
+  if (n == 0) return KNPEMI_OK;
+  hipLaunchKernelGGL(knp_order_kernel, grid1(n), dim3(256), 0, h->stream, D.Ntot, h->K - 1, h->n_sub, h->d_consts, x, D.csol,
+                     to_blocks);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { kn_set_error(std::string("knp_order_kernel: ") + hipGetErrorString(e)); return KNPEMI_EHIP; }
   return KNPEMI_OK;
 }
 

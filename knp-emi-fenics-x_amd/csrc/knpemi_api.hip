@@ -126,6 +126,8 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   h->device = device;
   KN_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   KN_HIP(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+  KN_HIP(hipStreamCreateWithFlags(&h->aux2, hipStreamNonBlocking));
+  KN_HIP(hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
   h->cur = h->stream;
   KN_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   KN_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
@@ -608,7 +610,10 @@ extern "C" void knpemi_destroy(knpemi_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->aux) (void)hipStreamSynchronize(h->aux);
+  if (h->aux2) (void)hipStreamSynchronize(h->aux2);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
+  if (h->aux2) (void)hipStreamDestroy(h->aux2);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->aux) (void)hipStreamDestroy(h->aux);
@@ -664,6 +669,7 @@ extern "C" int knpemi_set_params(knpemi_handle* h, const knpemi_params* p) {
 extern "C" int knpemi_sync(knpemi_handle* h) {
   if (!h) return fail(KNPEMI_EINVAL, "null handle");
   KN_HIP(hipStreamSynchronize(h->aux));
+  KN_HIP(hipStreamSynchronize(h->aux2));
   KN_HIP(hipStreamSynchronize(h->stream));
   return KNPEMI_OK;
 }
@@ -798,6 +804,7 @@ extern "C" int knpemi_join(knpemi_handle* h) {
   if (!h) return fail(KNPEMI_EINVAL, "null handle");
   KN_HIP(hipSetDevice(h->device));
   KN_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  KN_HIP(hipStreamWaitEvent(h->stream, h->ev_join2, 0));
   return KNPEMI_OK;
 }
 
@@ -961,6 +968,11 @@ extern "C" int knpemi_set_solution(knpemi_handle* h, int which, const double* x,
     if (rc) return rc;
   } else if (which == KNPEMI_B_KNP) {
     const int KS = h->K - 1;
+    if (on_device) {   // one launch, as the write-back of knpemi_solve_knp
+      if (!h->have_params) return fail(KNPEMI_EINVAL, "knpemi_set_solution: knpemi_set_params not called");
+      int rc = h->fuse_update ? kn_launch_knp_writeback_update(h, x) : kn_launch_knp_order(h, const_cast<double*>(x), 0);
+      if (rc) return rc;
+    } else
     for (int s = 0; s < h->n_sub; ++s)
       for (int k = 0; k < KS; ++k) {
         const size_t nv = h->n_vert[s];
@@ -1124,14 +1136,16 @@ extern "C" int knpemi_ode_step(knpemi_handle* h, int sub, int model, double t0, 
   if (!(dt > 0) || !(rtol >= 0) || !(atol >= 0) || (rtol == 0 && atol == 0))
     return fail(KNPEMI_EINVAL, "knpemi_ode_step: bad dt / tolerances");
   KN_HIP(hipSetDevice(h->device));
-  if (flags & KNPEMI_ODE_ON_AUX_STREAM) {
+  if (flags & (KNPEMI_ODE_ON_AUX_STREAM | KNPEMI_ODE_ON_AUX2_STREAM)) {
+    const bool second = (flags & KNPEMI_ODE_ON_AUX2_STREAM) != 0;
+    hipStream_t side = second ? h->aux2 : h->aux;
     KN_HIP(hipEventRecord(h->ev_fork, h->stream));
-    KN_HIP(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
-    h->cur = h->aux;
+    KN_HIP(hipStreamWaitEvent(side, h->ev_fork, 0));
+    h->cur = side;
     int rc = kn_launch_ode_step(h, slot, t0, dt, rtol, atol, flags, ion_param, v_index);
     h->cur = h->stream;
     if (rc) return rc;
-    KN_HIP(hipEventRecord(h->ev_join, h->aux));
+    KN_HIP(hipEventRecord(second ? h->ev_join2 : h->ev_join, side));
     return KNPEMI_OK;
   }
   return kn_launch_ode_step(h, slot, t0, dt, rtol, atol, flags, ion_param, v_index);
@@ -1144,7 +1158,8 @@ extern "C" int knpemi_ode_stats(knpemi_handle* h, int sub, int model, int64_t* n
   KN_HIP(hipSetDevice(h->device));
   KnOdeModel& mo = h->ode[slot];
   std::vector<unsigned long long> part(3 * (size_t)mo.n_stat_blocks);
-  KN_HIP(hipStreamSynchronize(h->aux));   // the sweep may run on the auxiliary stream
+  KN_HIP(hipStreamSynchronize(h->aux));   // the sweep may run on an auxiliary stream
+  KN_HIP(hipStreamSynchronize(h->aux2));
   KN_HIP(hipMemcpyAsync(part.data(), mo.d_stats, part.size() * sizeof(part[0]), hipMemcpyDeviceToHost, h->stream));
   KN_HIP(hipMemsetAsync(mo.d_stats, 0, part.size() * sizeof(part[0]), h->stream));
   KN_HIP(hipStreamSynchronize(h->stream));
@@ -1174,6 +1189,12 @@ extern "C" int knpemi_update_pde(knpemi_handle* h) {
   if (!h->have_params) return fail(KNPEMI_EINVAL, "knpemi_update_pde: knpemi_set_params not called");
   KN_HIP(hipSetDevice(h->device));
   return kn_launch_update_pde(h);
+}
+
+extern "C" int knpemi_set_option(knpemi_handle* h, int option, int value) {
+  if (!h) return fail(KNPEMI_EINVAL, "null handle");
+  if (option == KNPEMI_OPT_FUSE_UPDATE) { h->fuse_update = value ? 1 : 0; return KNPEMI_OK; }
+  return fail(KNPEMI_EINVAL, "knpemi_set_option: unknown option");
 }
 
 extern "C" int knpemi_halo_width(knpemi_handle* h, int kind) {
@@ -1210,6 +1231,7 @@ extern "C" int knpemi_profile_read(knpemi_handle* h, int kernel, int64_t* launch
   KN_HIP(hipSetDevice(h->device));
   KN_HIP(hipStreamSynchronize(h->stream));
   KN_HIP(hipStreamSynchronize(h->aux));
+  KN_HIP(hipStreamSynchronize(h->aux2));
   double sum = 0.0;
   for (size_t i = 0; i + 1 < h->prof_used[kernel]; i += 2) {
     float f = 0.f;

@@ -142,6 +142,8 @@ struct knpemi_handle {
   int device = 0;
   hipStream_t stream = nullptr;          // main stream
   hipStream_t aux = nullptr;             // auxiliary stream (EMI matrix assembly beside the ODE sweep)
+  hipStream_t aux2 = nullptr;            // second auxiliary stream (ODE sweeps of further membrane models)
+  hipEvent_t ev_join2 = nullptr;
   hipStream_t cur = nullptr;             // stream the row-kernel launchers enqueue on (stream or aux)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -170,10 +172,11 @@ struct knpemi_handle {
   struct KnGraph { hipGraphExec_t exec = nullptr; uint64_t key = 0; };
   KnGraph graph_emi, graph_knp;
   int pc_emi = KNPEMI_PC_AMG, pc_knp = KNPEMI_PC_AMG;
+  int fuse_update = 0;                 // KNPEMI_OPT_FUSE_UPDATE
   // per-kernel event profiling (knpemi_profile)
   uint32_t prof_mask = 0;
   std::vector<hipEvent_t> prof_ev[KNPEMI_N_KERNELS];  // begin/end pairs
-  size_t prof_used[KNPEMI_N_KERNELS] = {0, 0, 0, 0, 0};
+  size_t prof_used[KNPEMI_N_KERNELS] = {};
 };
 
 // RAII bracket around one kernel launch; no-op unless the kernel's bit is set in prof_mask.
@@ -219,6 +222,8 @@ int kn_launch_update_pde(knpemi_handle* h);
 int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* iters, double* relres);
 int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* iters, double* relres);
 int kn_extrapolate_guess(knpemi_handle* h, int which);
+int kn_launch_knp_order(knpemi_handle* h, double* x, int to_blocks);
+int kn_launch_knp_writeback_update(knpemi_handle* h, const double* x);
 int kn_launch_halo(knpemi_handle* h, int kind, int pack, const int32_t* idx, int n, double* buf);
 int kn_launch_field_scatter(knpemi_handle* h, const double* src, double* dst, int n, int dst_stride);
 int kn_launch_field_gather(knpemi_handle* h, const double* src, int src_stride, double* dst, int n);

@@ -127,11 +127,23 @@ class SlabHalo:
         dev = torch.device("cuda", dp.device)
         n_slots = int(dp.n_models.sum())
         self.width = {"bulk": 4, "mem": 1 + n_slots * L.MAX_IONS}
-        self._stream_ordered = os.environ.get("KNPEMI_HALO_SYNC") is None
+        # The exchange mode is chosen ONCE, here, and agreed on by all ranks; a communication error during a run
+        # propagates (the rank exits non-zero) instead of switching modes under a half-posted batch.
+        #   "stream-ordered RCCL": pack kernel -> send/recv -> unpack kernel on the library's stream, no host sync
+        #   "host-synchronised RCCL": KNPEMI_HALO_SYNC=1, or torch cannot wrap the library's stream
+        #   "gloo host-staged": single-GPU rehearsals and CPU tests
+        stream_ordered = os.environ.get("KNPEMI_HALO_SYNC") is None
         try:
             self._ext = torch.cuda.ExternalStream(dp.lib.knpemi_stream(dp.h), device=dev)
         except (RuntimeError, TypeError):
-            self._ext, self._stream_ordered = None, False
+            self._ext, stream_ordered = None, False
+        if dist.get_backend() == "gloo":
+            self.mode = "gloo host-staged"
+        else:
+            flag = torch.tensor([1 if stream_ordered else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            self.mode = "stream-ordered RCCL" if int(flag.item()) else "host-synchronised RCCL"
+        self._stream_ordered = self.mode == "stream-ordered RCCL"
         self._dev = {}
         for kind in ("bulk", "mem"):
             # one packed buffer per direction and kind: both neighbours' entries are packed / unpacked by a single
@@ -168,15 +180,9 @@ class SlabHalo:
                 # RCCL: torch's current stream is the library's stream (ExternalStream), so the send/recv kernels
                 # are ordered after the pack kernel and `wait()` orders the unpack kernel after them: no host
                 # synchronisation anywhere in the exchange (tools/check_async_halo.py rehearses this with real RCCL)
-                try:
-                    with self.torch.cuda.stream(self._ext):
-                        for req in dist.batch_isend_irecv(ops):
-                            req.wait()
-                except RuntimeError as exc:      # fall back to the host-synchronised exchange for the rest of the run
-                    import warnings
-                    warnings.warn(f"stream-ordered halo exchange failed ({exc}); using host synchronisation")
-                    self._stream_ordered = False
-                    return self._exchange(kind)
+                with self.torch.cuda.stream(self._ext):
+                    for req in dist.batch_isend_irecv(ops):
+                        req.wait()
             else:
                 dp.sync()                        # packed data is complete before RCCL reads it
                 for req in dist.batch_isend_irecv(ops):
@@ -203,9 +209,10 @@ class SlabHalo:
         self._exchange("mem")
 
 
-def make_slab_layout_and_mesh(kind, r, rank, world):
+def make_slab_layout_and_mesh(kind, r, rank, world, length=None):
+    """length: box length in units of 16 um; default 2 * world (weak scaling: config 2 per rank at r = 1)."""
     cell_type = {"tet": "tetrahedron", "hex": "hexahedron"}[kind]
-    l = 2 * world
+    l = 2 * world if length is None else int(length)
     lay = SlabLayout(r, rank, world, l)
     mesh, ct, ft = make_mesh_3D_slab(r, cell_type, l, (lay.lo, lay.b))
     return lay, (mesh, ct, ft)
@@ -231,12 +238,13 @@ def build_halo(lay, subdomain_list, gather_objects):
     return halo, owned
 
 
-def make_slab_problem(kind, r, rank, world, g_syn=10.0):
-    """The rank-local driver set-up (examples/idealized_geometries/setup_problem.Setup) of the
-    weak-scaling family: global box of length 32*world um at resolution r, x-slab `rank`."""
+def make_slab_problem(kind, r, rank, world, g_syn=10.0, length=None):
+    """The rank-local driver set-up (examples/idealized_geometries/setup_problem.Setup): x-slab `rank` of the box of
+    length 16 * length um at resolution r (default length 2 * world: the weak-scaling family; length = 2 is the
+    reference's own box, cut into `world` slabs: strong scaling)."""
     import torch.distributed as dist
     from setup_problem import Setup
-    lay, mesh_data = make_slab_layout_and_mesh(kind, r, rank, world)
+    lay, mesh_data = make_slab_layout_and_mesh(kind, r, rank, world, length)
     s = Setup(kind, r, g_syn=g_syn, mesh_data=mesh_data, build_forms=True)
 
     def gather(obj):

@@ -23,7 +23,8 @@ from . import _lib as L
 
 class DeviceStepper:
     def __init__(self, forms_emi, forms_knp, c, c_prev, phi, phi_M_prev, solve_emi=None, solve_knp=None,
-                 assemble_knp_twice=False, overlap=True, device_solves=None, extrapolate_guess=True):
+                 assemble_knp_twice=False, overlap=True, device_solves=None, extrapolate_guess=True,
+                 fuse_update=None):
         a = forms_emi[0]
         self.dp = a.dp
         self.a = a
@@ -42,16 +43,23 @@ class DeviceStepper:
             solve_emi = lambda dp: _solve(dp, L.B_EMI, "emi", rtol_emi, 1e-40)
             solve_knp = lambda dp: _solve(dp, L.B_KNP, "knp", rtol_knp, 2e-40)
         self.solve_emi, self.solve_knp = solve_emi, solve_knp
+        # fuse_update: the write-back kernel of the device KNP solve (or of a device-side set_solution) also performs
+        # update_pde_variables, which follows the solve directly in the reference's loop (run_3D.py:356,362): one
+        # launch fewer per step.  Default: on with the device solves, off with caller-supplied callbacks.
+        self.fuse_update = bool(device_solves is not None) if fuse_update is None else bool(fuse_update)
         self.assemble_knp_twice = assemble_knp_twice
         self.overlap = overlap
         # Which of the two overlapped kernels runs on the auxiliary stream: the one that finishes first, so that the
         # kernels after the join follow the longer one on the same stream without a cross-stream signal (~15 us).
         # Decided from their measured durations at the first step (None = not yet known).
         self.ode_on_aux = None
+        self.overlap_threshold_ms = 0.025
         self.k = 0
-        self.models = []   # (MembraneModel, stimulus, locator)
+        self.models = []   # MembraneModel objects, in registration order
+        self._model_setup = []   # (MembraneModel, stimulus, locator, initial time) for reset()
         dp = self.dp
         dp.set_params(a.physical_params, a.ion_list, a.dt)
+        L.check(self.lib.knpemi_set_option(dp.h, L.OPT_FUSE_UPDATE, 1 if self.fuse_update else 0))
         self.dt = float(a.dt)
         self.flags_emi = L.WANT_P | (0 if a.splitting_scheme else L.NO_SPLITTING)
         self.flags_knp = 0 if a.splitting_scheme else L.NO_SPLITTING
@@ -95,10 +103,31 @@ class DeviceStepper:
         st = np.ascontiguousarray(ode_model.states)
         pa = np.ascontiguousarray(ode_model.parameters)
         L.check(self.lib.knpemi_ode_set_tables(dp.h, ode_model._sub, ode_model._model, L.dptr(st), L.dptr(pa)))
-        self.models.append(ode_model)
+        if ode_model not in self.models:
+            self.models.append(ode_model)
+            self._model_setup.append((ode_model, dict(stimulus), stimulus_locator, float(ode_model.time)))
+
+    def reset(self):
+        """Back to the state of the host objects (fields, ODE tables, times): a second run from the same start."""
+        self.dp._uploaded.clear()      # the device copies have moved on although the host versions have not
+        self.upload()
+        for m, stim, loc, t0 in self._model_setup:
+            m.time = t0
+            self.add_membrane_model(m, stim, loc)
+        self.k = 0
+        self.ode_failures()            # clears the counters of the previous run
+
+    def check_ode_failures(self):
+        """`assert success` of odeSolver.py:121 for the device-resident loop: raises KnpemiError(EODE) when LSODA
+        failed on any membrane dof since the last check (the counters live on the device; this synchronises)."""
+        n = self.ode_failures()
+        if n:
+            raise L.KnpemiError(L.EODE, f"LSODA failed on {n} membrane dof(s) (odeSolver.py:121 `assert success`)")
 
     def download(self):
-        """Pull fields and ODE tables back into the host objects (end of a run / output)."""
+        """Pull fields and ODE tables back into the host objects (end of a run / output).  A dof on which LSODA
+        failed keeps a wrong V / I_ch that has fed the PDEs: the download refuses to hand such results out."""
+        self.check_ode_failures()
         dp, a = self.dp, self.a
         n_solved = len(a.ion_list) - 1
         for tag, sd in a.subdomain_list.items():
@@ -123,6 +152,11 @@ class DeviceStepper:
     # -- one time step, everything enqueued on the handle's stream ---------------------------
     def step(self, halo=None):
         dp, lib = self.dp, self.lib
+        if halo is not None and (self.solve_emi is not None or self.solve_knp is not None) \
+                and not getattr(halo, "supports_solves", False):
+            raise NotImplementedError(
+                "this halo does not distribute the linear solves: knpemi_solve_emi/knp on a partitioned problem "
+                "need the halo'd SpMV and the all-reduced dot products (knpemi.fem.partition.DistributedSolves)")
         flags = L.ODE_SET_TRACES | (L.ODE_SET_V if self.k > 0 else 0)
         calibrate = self.overlap and self.ode_on_aux is None and self.models
         if calibrate:
@@ -133,16 +167,30 @@ class DeviceStepper:
             # the EMI matrix (A, P, volume part of b) does not depend on the ODE output: assemble it on the
             # auxiliary stream while the ODE sweep runs on the main one
             L.check(lib.knpemi_assemble_emi(dp.h, self.flags_emi | L.SKIP_MEMBRANE_RHS | L.ON_AUX_STREAM))
+        side_of_sub = {}
         for m in self.models:
-            L.check(lib.knpemi_ode_step(dp.h, m._sub, m._model, float(m.time), self.dt, m.rtol, m.atol,
-                                        flags | (L.ODE_ON_AUX if ode_aux else 0), L.iptr(m._ion_param),
-                                        int(m.V_index)))
-            m.time = m.time + self.dt
+            # The sweeps of different cells (sub-domains) are independent: the first cell's models share the main /
+            # auxiliary stream pair with the EMI assembly, the other cells' run beside them on the second auxiliary
+            # stream.  Several models of ONE cell integrate the same dofs and overwrite phi_M_prev in turn
+            # (odeSolver.py:31-38, benchmark/run_stim_duration.py:163-166): they stay in order on one stream.
+            if m._sub not in side_of_sub:
+                side_of_sub[m._sub] = L.ODE_ON_AUX2 if side_of_sub else (L.ODE_ON_AUX if ode_aux else 0)
+        # side streams first: a side launch is ordered after what the main stream holds at that moment, so it must be
+        # enqueued before this step's main-stream kernels to run beside them
+        for wanted in (L.ODE_ON_AUX2, L.ODE_ON_AUX, 0):
+            for m in self.models:
+                if side_of_sub[m._sub] != wanted:
+                    continue
+                L.check(lib.knpemi_ode_step(dp.h, m._sub, m._model, float(m.time), self.dt, m.rtol, m.atol,
+                                            flags | wanted, L.iptr(m._ion_param), int(m.V_index)))
+                m.time = m.time + self.dt
         if ode_aux:     # the assembly is the longer kernel here: it stays on the main stream
             L.check(lib.knpemi_assemble_emi(dp.h, self.flags_emi | L.SKIP_MEMBRANE_RHS))
         # Partitioned runs: the membrane dofs of the ghost cell layer are integrated redundantly on both ranks
         # (same inputs after the bulk halo, deterministic LSODA => identical bits, tools/check_partition_steps.py),
         # so phi_M / I_ch need no exchange of their own.
+        if len(side_of_sub) > 1 and not self.overlap:
+            L.check(lib.knpemi_join(dp.h))      # the sweeps on the second auxiliary stream
         if self.overlap:
             L.check(lib.knpemi_join(dp.h))
             L.check(lib.knpemi_assemble_emi_membrane_rhs(dp.h, self.flags_emi))
@@ -154,6 +202,10 @@ class DeviceStepper:
                     us[name] = ms.value
                 L.check(lib.knpemi_profile(dp.h, 0))
                 self.ode_on_aux = us["emi_rows_kernel"] > us["ode_step_kernel"]
+                # Running the two side by side costs a cross-stream join and a separate launch for the membrane
+                # Robin term (~25 us together on this stack): not worth it when the shorter kernel is shorter than that
+                if min(us.values()) < self.overlap_threshold_ms:
+                    self.overlap = False
         else:
             L.check(lib.knpemi_assemble_emi(dp.h, self.flags_emi))
         if self.solve_emi is not None:
@@ -165,7 +217,8 @@ class DeviceStepper:
             L.check(lib.knpemi_assemble_knp(dp.h, self.flags_knp))
         if self.solve_knp is not None:
             self.solve_knp(dp)
-        L.check(lib.knpemi_update_pde(dp.h))
+        if not (self.fuse_update and self.solve_knp is not None):
+            L.check(lib.knpemi_update_pde(dp.h))
         if halo is not None:
             halo.exchange_bulk()
         self.k += 1

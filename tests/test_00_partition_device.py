@@ -1,0 +1,49 @@
+"""The x-slab partition on the HIP path (BASELINE.json configs[2] in its stated form, rehearsed on one card): two
+fresh child processes (gloo, both on GPU 0) each step their slab with `DeviceStepper(halo)` -- halo pack / unpack
+kernels, ghost membrane dofs integrated redundantly -- and rank 0 compares every OWNED membrane field, ODE state and
+row of b_emi / b_knp with a single-rank run of the whole box, bit for bit (tools/check_partition_steps.py).
+
+Runs first (file name): the children are started before this process has touched the GPU.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_ranks(args, world=2, timeout=420):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "check_partition_steps.py")] + args,
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return [p.returncode for p in procs], outs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["tet", "hex"])
+@pytest.mark.parametrize("mem_halo", [True, False])
+def test_two_rank_device_steps_equal_single_rank_bit_for_bit(kind, mem_halo):
+    rcs, outs = _run_ranks(["--kind", kind, "--steps", "6"] + ([] if mem_halo else ["--no-mem-halo"]))
+    assert rcs == [0, 0], "\n".join(outs)
+    assert "PARTITION STEPS OK" in outs[0], outs[0]

@@ -985,6 +985,49 @@ def test_device_resident_time_loop_matches_oracle(hip_lib):
     assert all(it[1] <= 1000 for it in st.iterations)
 
 
+def test_fused_update_and_overlap_variants_are_bit_identical(hip_lib):
+    """The stepper's launch-saving variants change no bit: update_pde_variables fused into the write-back kernel of the
+    KNP solve (KNPEMI_OPT_FUSE_UPDATE) vs the separate launch, and the EMI matrix assembled beside the ODE sweep (aux
+    stream, separate Robin-term launch) vs after it (fused Robin term) -- fields, membrane potential, currents and ODE
+    tables after six whole steps with the device solves."""
+    from knpemi.stepper import DeviceStepper
+    out = []
+    for fuse, overlap, thr in ((True, True, 0.025), (False, True, 0.0), (False, False, 0.025)):
+        s = Setup("tet", 0, g_syn=10.0)
+        for t in s.subdomain_list:
+            for k in range(2):
+                s.c[t][k].x.array[:] = s.c_prev[t][k].x._a
+        st = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp), s.c, s.c_prev, s.phi,
+                           s.phi_M_prev, device_solves=(1e-9, 1e-10), fuse_update=fuse, overlap=overlap)
+        st.overlap_threshold_ms = thr
+        ode = s.mem_models[0]['ode']
+        st.add_membrane_model(ode, s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
+        for _ in range(6):
+            st.step()
+        st.download()
+        out.append([s.phi[0].x._a.copy(), s.phi[1].x._a.copy(), s.phi_M_prev[1].x._a.copy(), ode.states.copy(),
+                    ode.parameters.copy()] + [f.x._a.copy() for t in (0, 1) for f in s.c_prev[t]]
+                   + [s.ion_list[-1][f'c_{t}'].x._a.copy() for t in (0, 1)])
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+def test_stepper_reports_lsoda_failures(hip_lib):
+    """`assert success` (odeSolver.py:121) in the device-resident loop: a dof LSODA cannot integrate makes
+    `download()` / `check_ode_failures()` raise instead of handing out fields fed by a wrong V / I_ch."""
+    from knpemi import _lib as L
+    from knpemi.stepper import DeviceStepper
+    s = Setup("2d", 1, g_syn=10.0)
+    ode = s.mem_models[0]['ode']
+    ode.states[7, 3] = np.nan
+    st = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp), s.c, s.c_prev, s.phi, s.phi_M_prev)
+    st.add_membrane_model(ode, s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
+    st.step()
+    with pytest.raises(L.KnpemiError, match="LSODA failed on 1 membrane dof"):
+        st.download()
+
+
 def _load_stim_driver():
     import importlib.util
     import os

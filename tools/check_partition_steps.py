@@ -73,7 +73,8 @@ def main():
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo")
+    dist.init_process_group("gloo", init_method=f"tcp://{os.environ.get('MASTER_ADDR', '127.0.0.1')}:"
+                                                f"{os.environ['MASTER_PORT']}", rank=rank, world_size=world)
     from knpemi.fem.partition import make_slab_problem
     from knpemi.fem import make_mesh_3D
     from setup_problem import Setup
@@ -124,7 +125,8 @@ def main():
         print("membrane dofs compared:", n, "of", len(ref["x"]), "mem halo:", not a.no_mem_halo)
         print("max relative differences:", worst)
         assert n == len(ref["x"])
-        assert max(worst.values()) < 1e-12, worst
+        # owner-computes rows + deterministic kernels: the partitioned run reproduces the single-rank run bit for bit
+        assert max(worst.values()) == 0.0, worst
         print("PARTITION STEPS OK")
     dist.barrier()
     dist.destroy_process_group()
