@@ -321,10 +321,12 @@ def test_ten_time_steps_2d_match_oracle(hip_lib):
     assert v.mean() > -0.0744 + 0.010 and v[x < 15e-6].mean() > v[x > 40e-6].mean()
 
 
-def test_mms_emi_convergence(hip_lib):
+@pytest.mark.parametrize("sizes", [(16, 32, 64), (100, 200, 400)])
+def test_mms_emi_convergence(hip_lib, sizes):
     """BASELINE configs[3]: manufactured solution of tests/run_mms_emi.py on the unit square with
     ICS = [0.25, 0.75]^2; GPU-assembled operator + diffusive RHS, L2 errors must converge at rate ~2
-    (the reference only prints them)."""
+    (the reference only prints them).  (100, 200, 400) are the resolutions of the reference's
+    tests/make_mesh_mms.py:96-98."""
     import contextlib
     import io
     from knpemi import create_functions_emi, create_functions_knp, emi_system, set_initial_conditions
@@ -333,7 +335,7 @@ def test_mms_emi_convergence(hip_lib):
     from knpemi.pdeSolver import create_solver_emi
     from mms_problem import CONC, MMS, MMSMembraneModel
     errs = []
-    for M in (16, 32, 64):
+    for M in sizes:
         mesh, ct, ft = make_mesh_mms(M)
         s1, i2p, iv2p, _, _ = extract_submesh(mesh, ct, 1)
         s0, e2p, ev2p, _, _ = extract_submesh(mesh, ct, 0)
@@ -698,7 +700,7 @@ def test_mms_knp_membrane_convergence(hip_lib, splitting):
     from knpemi.fem import Constant, Function, extract_submesh, make_mesh_mms
     from knpemi.pdeSolver import create_solver_knp
     errs = []
-    for M in (16, 32, 64):
+    for M in sizes:
         mesh, ct, ft = make_mesh_mms(M)
         s0, e2p, ev2p, _, _ = extract_submesh(mesh, ct, 0)
         s1, i2p, iv2p, _, _ = extract_submesh(mesh, ct, 1)
@@ -1179,3 +1181,88 @@ def test_full_size_properties(hip_lib, kind, r, label):
         assert sel.any() and np.all(ode.states[sel] == ode.states[sel][0])
     assert not np.array_equal(ode.states[stim][0], ode.states[~stim][0])
     assert ode.last_stats["n_failed"] == 0
+
+
+@pytest.mark.parametrize("workload", ["config5s"])
+def test_config5_synthetic_full_size(hip_lib, workload):
+    """BASELINE configs[4] stand-in at ~1e6 tetrahedra (bench.py `config5s`: ECS + neuron cells 1,3 with the HH mV/ms
+    model + glial cells 2,4 with the Kir4.1/pump model, pulsed ECS K+ source): properties that need no oracle --
+    structure, symmetry and null space of A_emi, P = A on the ECS rows, A_knp row sums = volume / dt, identical bits on
+    re-assembly, both ODE sweeps giving equal outputs for equal inputs -- and six whole device-resident time steps
+    (device Krylov solves) during which the source raises K+ in its box, the glial membrane there depolarises, no
+    concentration leaves its physical range and LSODA fails nowhere."""
+    import hashlib
+    import bench
+    from knpemi import _lib as L
+    from knpemi.pdeSolver import create_solver_emi, create_solver_knp
+    from knpemi.stepper import DeviceStepper
+    case = bench.Case(workload)
+    p = case.s
+    assert len(p.subdomain_list) == 3 and len(case.models) == 2
+    assert sum(sd["mesh_sub"].num_cells for sd in p.subdomain_list.values()) == 995328
+    emi = create_solver_emi(p.a_emi, p.L_emi, p.phi, p.entity_maps, p.subdomain_list, None, p=p.p_emi, direct=False)
+    knp = create_solver_knp(p.a_knp, p.L_knp, p.c, p.entity_maps, p.subdomain_list, None, p=p.p_knp)
+    A, b = emi.assemble()
+    P = emi.P
+    Ak, bk = knp.assemble()
+    n, n0 = A.shape[0], p.phi[0].x.array.shape[0]
+    scale = np.abs(A.data).max()
+    assert csr_rel_err(A, A.T.tocsr()) < 1e-13
+    assert np.abs(A @ np.ones(n)).max() < 1e-11 * scale
+    M = (P - A).tocsr()
+    assert M[:n0].nnz == 0 or np.abs(M[:n0].data).max() == 0.0
+    # P - A on the cell rows is the mass matrix of the two cellular sub-domains: its entries sum to their volume
+    # (recovered from a difference of much larger numbers, hence only to ~1e-4)
+    vol_cells = 4 * (22e-4 * 0.2e-4 * 0.2e-4)
+    assert abs(M.sum() - vol_cells) < 1e-3 * vol_cells
+    vol = 32e-4 * 0.9e-4 * 0.9e-4      # cm^3: every sub-domain's two ion blocks have row sums = lumped mass / dt
+    rs = Ak @ np.ones(Ak.shape[0])
+    assert abs(rs.sum() - 2 * vol / p.dt) < 1e-9 * (2 * vol / p.dt)
+
+    def digest(*arrays):
+        h = hashlib.sha256()
+        for a in arrays:
+            h.update(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest())
+        return h.hexdigest()
+    d1 = digest(A.data, P.data, b, Ak.data, bk)
+    A2, b2 = emi.assemble()
+    Ak2, bk2 = knp.assemble()
+    assert digest(A2.data, emi.P.data, b2, Ak2.data, bk2) == d1
+    # equal inputs -> equal outputs, bit for bit, for both membrane models (uniform initial fields, no stimulus)
+    from knpemi import update_ode_variables
+    for (m, stim, loc), t in zip(case.models, (1, 2)):
+        st0, pa0, t0 = m.states.copy(), m.parameters.copy(), m.time
+        update_ode_variables(m, p.c_prev, p.phi_M_prev[t], p.ion_list, p.subdomain_list, p.mesh, p.ct, t, 0)
+        m.step_lsoda(p.dt, stim, loc)
+        assert m.last_stats["n_failed"] == 0 and m.last_stats["n_rhs"] > 2 * m.nodes
+        assert np.all(m.states == m.states[0]) and not np.array_equal(m.states[0], st0[0])
+        m.states[:], m.parameters[:], m.time = st0, pa0, t0
+    # whole time steps on the device
+    st = DeviceStepper((p.a_emi, p.p_emi, p.L_emi), (p.a_knp, p.p_knp, p.L_knp), p.c, p.c_prev, p.phi, p.phi_M_prev,
+                       device_solves=case.solver_rtol)
+    for m, stim, loc in case.models:
+        st.add_membrane_model(m, stim, loc)
+    st.set_source(0, case.source)
+    k0 = p.c_prev[0][0].x._a.copy()
+    vm0 = {t: p.phi_M_prev[t].x._a.copy() for t in (1, 2)}
+    for _ in range(6):
+        st.step()
+    st.download()           # raises if LSODA failed anywhere
+    assert all(it[1] < 200 for it in st.iterations)
+    k1 = p.c_prev[0][0].x._a
+    inside = p.region
+    assert inside.sum() > 10 and (k1[inside] - k0[inside]).min() > 1.0          # mM, 0.6 ms of a 97 mM/ms source
+    far = p.subdomain_list[0]["mesh_sub"].x[:, 0] < 4e-4
+    assert np.abs(k1[far] - k0[far]).max() < 0.5
+    for t in p.subdomain_list:
+        for f in p.c_prev[t] + [p.ion_list[-1][f"c_{t}"]]:
+            assert f.x._a.min() > 0.0 and np.all(np.isfinite(f.x._a))
+    # glia near the source depolarises (K+ rises outside it), every membrane potential stays in a physical range
+    xg = p.subdomain_list[2]["mesh_mem"].x
+    near = np.abs(xg[:, 0] - 16e-4) < 2e-4
+    dv = p.phi_M_prev[2].x._a - case.models[1][0].ode.init_state_values()[0]
+    # (the whole glial membrane relaxes by ~0.5 mV from its tabulated initial state; the source adds to that locally)
+    assert near.any() and dv[near].max() > dv[xg[:, 0] < 8e-4].max() + 0.2
+    for t in (1, 2):
+        v = p.phi_M_prev[t].x._a
+        assert -120.0 < v.min() and v.max() < 60.0
