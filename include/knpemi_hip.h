@@ -245,6 +245,25 @@ int knpemi_halo_width(knpemi_handle* h, int kind);
 int knpemi_halo_pack(knpemi_handle* h, int kind, const int32_t* idx_dev, int n, double* buf_dev);
 int knpemi_halo_unpack(knpemi_handle* h, int kind, const int32_t* idx_dev, int n, const double* buf_dev);
 
+/* Distributed solves on a partitioned problem (one handle per rank; the reference runs its KSP solves on the MPI
+ * communicator of the mesh, pdeSolver.py:24-35,74-78,99-110).  The library knows which local vertices this rank owns;
+ * the caller supplies the two communication steps, both ordered on knpemi_stream(h):
+ *   allreduce(ctx, n): sum the first n doubles of `reduce_buf_dev` over all ranks, in place;
+ *   halo(ctx, vec_dev, which): forward halo (owner -> ghost) of a device vector in the unknown order of system `which`
+ *     (KNPEMI_B_EMI: one value per local vertex; KNPEMI_B_KNP: the block order [sub-domain][ion][vertex]).
+ * knpemi_solve_emi / knpemi_solve_knp then run the same Krylov methods on the global system: SpMV over the owned rows
+ * after a halo of its argument, dot products over the owned entries summed with `allreduce`, and each rank's
+ * smoothed-aggregation V-cycle on its own diagonal block as the preconditioner (block Jacobi over the ranks).
+ * `owned` is a host array with one byte per local vertex (global numbering of this handle: sub-mesh vertex + offset
+ * of its sub-domain), 1 = owned.  owned == NULL switches back to the single-rank solves. */
+typedef int (*knpemi_allreduce_fn)(void* ctx, int n);
+typedef int (*knpemi_halo_fn)(void* ctx, void* vec_dev, int which);
+int knpemi_set_distributed(knpemi_handle* h, const uint8_t* owned, void* reduce_buf_dev, knpemi_allreduce_fn allreduce,
+                           knpemi_halo_fn halo, void* ctx);
+/* gather / scatter of entries of a device vector (the pack / unpack of the halo of a solver vector) */
+int knpemi_vec_gather(knpemi_handle* h, const void* vec_dev, const int32_t* idx_dev, int n, void* buf_dev);
+int knpemi_vec_scatter(knpemi_handle* h, void* vec_dev, const int32_t* idx_dev, int n, const void* buf_dev);
+
 /* Per-kernel HIP-event profiling on the handle's stream: every launch of a kernel whose bit is set
  * in `kernel_mask` is bracketed by an event pair; knpemi_profile_read() synchronises, returns the
  * number of bracketed launches and their summed duration, and resets the accumulator. */

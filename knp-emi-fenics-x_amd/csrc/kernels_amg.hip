@@ -294,7 +294,9 @@ int upload(KnAmg& G, const std::vector<T>& src, T** dst, hipStream_t st) {
   const size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
   KN_HIP(hipMalloc(&p, bytes));
   G.allocs.push_back(p);
-  if (!src.empty()) KN_HIP(hipMemcpyAsync(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, st));
+  // blocking copy: the sources are temporaries of the set-up (which is host-bound anyway)
+  (void)st;
+  if (!src.empty()) KN_HIP(hipMemcpy(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
   *dst = static_cast<T*>(p);
   return KNPEMI_OK;
 }
@@ -319,7 +321,7 @@ void kn_amg_free(KnAmg& G) {
 // Build the hierarchy for the n x n device CSR (rowptr, colind, vals).  `singular`: the operator has the
 // constant null space (EMI).
 int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const int* d_colind, const double* d_vals,
-                 bool singular) {
+                 bool singular, const uint8_t* h_owned) {
   kn_amg_free(G);
   hipStream_t st = h->stream;
   HostCsr A;
@@ -332,6 +334,17 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
   KN_HIP(hipMemcpyAsync(A.ci.data(), d_colind, nnz * sizeof(int), hipMemcpyDeviceToHost, st));
   KN_HIP(hipMemcpyAsync(A.v.data(), d_vals, nnz * sizeof(double), hipMemcpyDeviceToHost, st));
   KN_HIP(hipStreamSynchronize(st));
+  if (h_owned) {
+    // partitioned problem: the hierarchy is built for this rank's diagonal block -- couplings between owned and
+    // ghost unknowns are dropped, ghost rows are identity rows (block Jacobi over the ranks; the finest level of the
+    // cycle works on the caller's matrix, whose ghost rows the solver has turned into identity rows too)
+    for (int i = 0; i < n; ++i)
+      for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+        const int c = A.ci[j];
+        if (!h_owned[i]) A.v[j] = c == i ? 1.0 : 0.0;
+        else if (!h_owned[c]) A.v[j] = 0.0;
+      }
+  }
   for (double x : A.v)
     if (!(x == x)) { kn_set_error("AMG set-up: operator contains NaN"); return KNPEMI_EINVAL; }
 

@@ -954,6 +954,15 @@ __global__ void gather_kernel(const double* __restrict__ src, int stride, double
   if (i < n) dst[i] = src[(size_t)i * stride];
 }
 
+// buf[i] = vec[idx[i]] (gather) or vec[idx[i]] = buf[i] (scatter): pack / unpack of the halo of a solver vector
+__global__ void vec_index_kernel(double* __restrict__ vec, const int* __restrict__ idx, int n, double* __restrict__ buf,
+                                 int gather) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (gather) buf[i] = vec[idx[i]];
+  else vec[idx[i]] = buf[i];
+}
+
 // interpolate_to_membrane (utils.py:150-207): for CG-1 on matching meshes the trace is a gather.
 // ue / ui are sub-mesh-local arrays, q2e / q2i hold global vertex ids (offsets v0e = 0, v0i).
 __global__ void trace_kernel(const double* __restrict__ ue, const double* __restrict__ ui,
@@ -1255,6 +1264,12 @@ int kn_launch_field_gather(knpemi_handle* h, const double* src, int src_stride, 
   if (n == 0) return KNPEMI_OK;
   hipLaunchKernelGGL(gather_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, src, src_stride, dst, n);
   return check_launch("gather_kernel");
+}
+
+int kn_launch_vec_index(knpemi_handle* h, double* vec, const int32_t* idx, int n, double* buf, int gather) {
+  if (n == 0) return KNPEMI_OK;
+  hipLaunchKernelGGL(vec_index_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, vec, idx, n, buf, gather);
+  return check_launch("vec_index_kernel");
 }
 
 int kn_launch_trace(knpemi_handle* h, const double* ue, const double* ui, int sub, double* qe, double* qi) {

@@ -23,11 +23,14 @@ template <bool SCALED>
 __global__ __launch_bounds__(256) void spmv_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ colind,
                                                    const double* __restrict__ vals, const double* __restrict__ x,
                                                    const double* __restrict__ dinv, double* __restrict__ y,
-                                                   const double* __restrict__ b = nullptr) {
+                                                   const double* __restrict__ b = nullptr,
+                                                   const uint8_t* __restrict__ owned = nullptr) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int row = t >> 4, l = t & 15;
   double acc = 0.0;
-  if (row < n) {
+  // partitioned problem: only the rows of owned unknowns are assembled completely; ghost rows give 0
+  const bool live = row < n && (!owned || owned[row]);
+  if (live) {
     const int a = rowptr[row], b = rowptr[row + 1];
     for (int j = a + l; j < b; j += 16) {
       const int c = colind[j];
@@ -36,7 +39,23 @@ __global__ __launch_bounds__(256) void spmv_kernel(int n, const int* __restrict_
   }
 #pragma unroll
   for (int m = 8; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
-  if (row < n && l == 0) y[row] = (!SCALED && b) ? b[row] - acc : acc;
+  if (row < n && l == 0) y[row] = live ? ((!SCALED && b) ? b[row] - acc : acc) : 0.0;
+}
+
+// a[i] = 0 on ghost entries (partitioned problems)
+__global__ void mask_kernel(int n, const uint8_t* __restrict__ owned, double* __restrict__ a, int as_ones) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (as_ones) a[i] = owned[i] ? 1.0 : 0.0;
+  else if (!owned[i]) a[i] = 0.0;
+}
+
+// ghost rows of the operator become identity rows: the rank-local V-cycle then leaves ghost entries at zero
+__global__ void ghost_identity_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ colind,
+                                      const uint8_t* __restrict__ owned, double* __restrict__ vals) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n || owned[row]) return;
+  for (int j = rowptr[row]; j < rowptr[row + 1]; ++j) vals[j] = colind[j] == row ? 1.0 : 0.0;
 }
 
 __global__ void diag_inv_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ colind,
@@ -52,6 +71,23 @@ __global__ void diag_inv_kernel(int n, const int* __restrict__ rowptr, const int
 // second-stage scalar algebra of the algorithm step `op`
 enum { OP_STORE3 = 0, OP_CG_INIT, OP_CG_PAP, OP_CG_RHO, OP_BI_RHO, OP_BI_ALPHA, OP_BI_OMEGA, OP_MEAN };
 
+__device__ __forceinline__ void apply_dot_op(double* __restrict__ sc, int op, int nd, double v0, double v1, double v2, int d0,
+                                             int d1, int d2, double scale) {
+  switch (op) {
+    case OP_STORE3: sc[d0] = v0; if (nd > 1) sc[d1] = v1; if (nd > 2) sc[d2] = v2; break;
+    case OP_MEAN: sc[S_MEAN] = v0 * scale; break;
+    case OP_CG_INIT: sc[S_RHO] = v0; sc[S_RR] = v1; if (nd > 2) sc[S_BB] = v2; break;          // r.z, r.r[, b.b]
+    case OP_CG_PAP: sc[S_PAP] = v0; sc[S_ALPHA] = sc[S_RHO] / v0; break;                     // p.Ap
+    case OP_CG_RHO: sc[S_BETA] = v0 / sc[S_RHO]; sc[S_RHO] = v0; sc[S_RR] = v1; break;       // r.z, r.r
+    case OP_BI_RHO:                                                                          // rhat.r
+      sc[S_BETA] = (v0 / sc[S_RHO]) * (sc[S_ALPHA] / sc[S_OMEGA]);
+      sc[S_RHO] = v0;
+      break;
+    case OP_BI_ALPHA: sc[S_ALPHA] = sc[S_RHO] / v0; break;                                   // rhat.v
+    case OP_BI_OMEGA: sc[S_OMEGA] = v1 != 0.0 ? v0 / v1 : 0.0; break;                        // t.s, t.t
+  }
+}
+
 // Up to three dot products and the scalar update that consumes them in ONE launch: every block writes its
 // partial sums, the last block to finish (ticket counter) adds the partials in a fixed order and applies
 // `op` to the device scalars.  The summation order does not depend on which block is last, so the solves stay
@@ -60,7 +96,7 @@ __global__ __launch_bounds__(RED_THREADS) void dots_kernel(int n, int nd, const 
                                                            const double* a1, const double* b1, const double* a2,
                                                            const double* b2, double* partial, unsigned* ticket,
                                                            double* __restrict__ sc, int op, int d0, int d1, int d2,
-                                                           double scale) {
+                                                           double scale, double* __restrict__ red = nullptr) {
   __shared__ double sh[3][RED_THREADS];
   __shared__ bool last;
   double s0 = 0, s1 = 0, s2 = 0;
@@ -101,6 +137,19 @@ __global__ __launch_bounds__(RED_THREADS) void dots_kernel(int n, int nd, const 
   if (threadIdx.x != 0) return;
   *ticket = 0;
   const double v0 = sh[0][0], v1 = nd > 1 ? sh[1][0] : 0.0, v2 = nd > 2 ? sh[2][0] : 0.0;
+  if (red) {   // partitioned problem: the sums of this rank; the scalar algebra follows the all-reduce (dots_apply_kernel)
+    red[0] = v0; red[1] = v1; red[2] = v2;
+    return;
+  }
+  apply_dot_op(sc, op, nd, v0, v1, v2, d0, d1, d2, scale);
+}
+
+__global__ void dots_apply_kernel(double* __restrict__ sc, const double* __restrict__ red, int op, int nd, int d0, int d1,
+                                  int d2, double scale) {
+  apply_dot_op(sc, op, nd, red[0], nd > 1 ? red[1] : 0.0, nd > 2 ? red[2] : 0.0, d0, d1, d2, scale);
+}
+
+#if 0
   switch (op) {
     case OP_STORE3: sc[d0] = v0; if (nd > 1) sc[d1] = v1; if (nd > 2) sc[d2] = v2; break;
     case OP_MEAN: sc[S_MEAN] = v0 * scale; break;
@@ -115,6 +164,7 @@ __global__ __launch_bounds__(RED_THREADS) void dots_kernel(int n, int nd, const 
     case OP_BI_OMEGA: sc[S_OMEGA] = v1 != 0.0 ? v0 / v1 : 0.0; break;                        // t.s, t.t
   }
 }
+#endif
 
 enum { V_RESID = 0, V_SHIFT, V_CG_XR, V_CG_P, V_JACOBI, V_BI_P, V_BI_S, V_COPY };
 
@@ -175,22 +225,41 @@ struct Ctx {
   int n;
   const int* rowptr; const int* colind; const double* vals;
   double* sc; double* partial;
+  // partitioned problem (knpemi_set_distributed): mask of owned unknowns of this system, which system
+  const uint8_t* owned = nullptr;
+  int which = 0;
+  int comm_rc = 0;     // first failure of a communication hook
 };
 
 inline dim3 grid1(int n) { return dim3((n + 255) / 256); }
 
-void spmv(const Ctx& c, const double* x, double* y, const double* dinv, const double* b = nullptr) {
+void spmv(Ctx& c, const double* x, double* y, const double* dinv, const double* b = nullptr) {
   dim3 g(((size_t)c.n * 16 + 255) / 256);
+  if (c.owned) {   // the argument's ghost entries take their owners' values first
+    const KnDist& d = c.h->dist;
+    if (int e = d.halo(d.ctx, const_cast<double*>(x), c.which)) c.comm_rc = c.comm_rc ? c.comm_rc : e;
+  }
   if (dinv) hipLaunchKernelGGL((spmv_kernel<true>), g, dim3(256), 0, c.h->stream, c.n, c.rowptr, c.colind, c.vals, x, dinv, y,
-                               (const double*)nullptr);
-  else hipLaunchKernelGGL((spmv_kernel<false>), g, dim3(256), 0, c.h->stream, c.n, c.rowptr, c.colind, c.vals, x, dinv, y, b);
+                               (const double*)nullptr, c.owned);
+  else hipLaunchKernelGGL((spmv_kernel<false>), g, dim3(256), 0, c.h->stream, c.n, c.rowptr, c.colind, c.vals, x, dinv, y, b,
+                          c.owned);
 }
 
-void dots(const Ctx& c, int nd, const double* a0, const double* b0, const double* a1, const double* b1, const double* a2,
+void dots(Ctx& c, int nd, const double* a0, const double* b0, const double* a1, const double* b1, const double* a2,
           const double* b2, int op, int d0 = 0, int d1 = 0, int d2 = 0, double scale = 1.0) {
   const int nb = std::min(RED_BLOCKS, (c.n + RED_THREADS - 1) / RED_THREADS);
+  double* red = c.owned ? c.h->dist.d_red : nullptr;
   hipLaunchKernelGGL(dots_kernel, dim3(nb), dim3(RED_THREADS), 0, c.h->stream, c.n, nd, a0, b0, a1, b1, a2, b2, c.partial,
-                     reinterpret_cast<unsigned*>(c.partial + 3 * RED_BLOCKS), c.sc, op, d0, d1, d2, scale);
+                     reinterpret_cast<unsigned*>(c.partial + 3 * RED_BLOCKS), c.sc, op, d0, d1, d2, scale, red);
+  if (red) {   // every vector is zero on its ghost entries, so the local sums run over the owned unknowns only
+    const KnDist& d = c.h->dist;
+    if (int e = d.allreduce(d.ctx, nd)) c.comm_rc = c.comm_rc ? c.comm_rc : e;
+    hipLaunchKernelGGL(dots_apply_kernel, dim3(1), dim3(1), 0, c.h->stream, c.sc, red, op, nd, d0, d1, d2, scale);
+  }
+}
+
+void mask(const Ctx& c, double* a, int as_ones = 0) {
+  if (c.owned) hipLaunchKernelGGL(mask_kernel, grid1(c.n), dim3(256), 0, c.h->stream, c.n, c.owned, a, as_ones);
 }
 
 void vec(const Ctx& c, int op, double* a, double* b, const double* cc, const double* d) {
@@ -208,7 +277,8 @@ int read_scalars(const Ctx& c, double* host, int count) {
 // kernel arguments depend on.  KNPEMI_NO_GRAPH=1 launches the kernels directly.
 template <class Body>
 int run_chunk(knpemi_handle* h, knpemi_handle::KnGraph& g, uint64_t key, int chunk, Body&& body) {
-  static const bool no_graph = getenv("KNPEMI_NO_GRAPH") != nullptr;
+  static const bool no_graph_env = getenv("KNPEMI_NO_GRAPH") != nullptr;
+  const bool no_graph = no_graph_env || h->dist.on;   // the communication hooks cannot be captured
   int rc = KNPEMI_OK;
   if (no_graph) {
     for (int k = 0; k < chunk && !rc; ++k) rc = body();
@@ -229,6 +299,11 @@ int run_chunk(knpemi_handle* h, knpemi_handle::KnGraph& g, uint64_t key, int chu
   }
   KN_HIP(hipGraphLaunch(g.exec, h->stream));
   return KNPEMI_OK;
+}
+
+inline bool debug_krylov() {
+  static const bool on = getenv("KNPEMI_DEBUG_KRYLOV") != nullptr;
+  return on;
 }
 
 inline uint64_t graph_key(const knpemi_handle* h, const KnAmg& G, bool amg, int chunk, int n) {
@@ -267,17 +342,39 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   const size_t N = h->kry_n;
   double *x = h->kry, *r = x + N, *z = r + N, *p = z + N, *q = p + N, *b = q + N, *dinv = b + N, *ones = h->kry + 10 * N;
   Ctx c{h, n, D.rowptr, D.colind, D.A_emi, h->kry + 11 * N, h->kry + 11 * N + 64};
+  const KnDist& dist = h->dist;
+  bool has_ghosts = false;
+  double n_mean = (double)n;
+  if (dist.on) {   // partitioned problem: this rank's rows of the global system
+    c.owned = dist.d_owned_emi;
+    c.which = KNPEMI_B_EMI;
+    n_mean = dist.n_owned_global;
+    for (uint8_t o : dist.h_owned_emi) has_ghosts |= !o;
+    hipLaunchKernelGGL(ghost_identity_kernel, grid1(n), dim3(256), 0, h->stream, n, c.rowptr, c.colind, c.owned, D.A_emi);
+  }
+  if (h->kry_ones_masked != (dist.on ? 1 : 0)) {   // `ones` counts the owned unknowns
+    if (dist.on) mask(c, ones, 1);
+    else {
+      std::vector<double> one(n, 1.0);
+      KN_HIP(hipMemcpy(ones, one.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    h->kry_ones_masked = dist.on ? 1 : 0;
+  }
   // x0 = current phi (ksp_initial_guess_nonzero), b = b_emi projected onto zero mean (constant null space)
   if ((rc = kn_launch_field_gather(h, D.VR + 7, KN_REC, x, n))) return rc;
   vec(c, V_COPY, b, nullptr, D.b_emi, nullptr);
-  dots(c, 1, b, ones, nullptr, nullptr, nullptr, nullptr, OP_MEAN, 0, 0, 0, 1.0 / n);
+  mask(c, b);
+  dots(c, 1, b, ones, nullptr, nullptr, nullptr, nullptr, OP_MEAN, 0, 0, 0, 1.0 / n_mean);
   vec(c, V_SHIFT, b, nullptr, nullptr, nullptr);
+  mask(c, b);
   hipLaunchKernelGGL(diag_inv_kernel, grid1(n), dim3(256), 0, h->stream, n, c.rowptr, c.colind, c.vals, dinv);
   KnAmg& G = h->amg_emi;
   const bool amg = h->pc_emi == KNPEMI_PC_AMG;
   if (amg && (!G.built || G.n != n)) {
     G.negative_strength = true;
-    if ((rc = kn_amg_setup(h, G, n, D.rowptr, D.colind, D.A_emi, true))) return rc;
+    // the diagonal block of a rank that has ghosts has lost couplings: it is non-singular
+    if ((rc = kn_amg_setup(h, G, n, D.rowptr, D.colind, D.A_emi, !has_ghosts,
+                           dist.on ? dist.h_owned_emi.data() : nullptr))) return rc;
     G.its_ref = -1;
     ++G.builds;
   }
@@ -317,12 +414,16 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     it += todo;
     if ((rc = read_scalars(c, sc, S_N))) return rc;
     rn = std::sqrt(sc[S_RR]);
+    if (debug_krylov()) fprintf(stderr, "[knpemi] emi cg it %d |r| %.3e target %.3e alpha %.3e beta %.3e\n", it, rn, target, sc[S_ALPHA], sc[S_BETA]);
     if (!(rn == rn)) { kn_set_error("EMI CG broke down (NaN residual)"); return KNPEMI_EINVAL; }
   }
-  // solution orthogonal to constants, then into the phi component of the vertex records
-  dots(c, 1, x, ones, nullptr, nullptr, nullptr, nullptr, OP_MEAN, 0, 0, 0, 1.0 / n);
+  // solution orthogonal to constants, then into the phi component of the vertex records (ghosts included: they
+  // take their owners' values first)
+  dots(c, 1, x, ones, nullptr, nullptr, nullptr, nullptr, OP_MEAN, 0, 0, 0, 1.0 / n_mean);
+  if (dist.on) if (int e = dist.halo(dist.ctx, x, KNPEMI_B_EMI)) c.comm_rc = c.comm_rc ? c.comm_rc : e;
   vec(c, V_SHIFT, x, nullptr, nullptr, nullptr);
   if ((rc = kn_launch_field_scatter(h, x, D.VR + 7, n, KN_REC))) return rc;
+  if (c.comm_rc) { kn_set_error("EMI solve: a communication hook failed"); return KNPEMI_EHIP; }
   if (iters) *iters = it;
   if (relres) *relres = bnorm > 0 ? rn / bnorm : rn;
   hipError_t e = hipGetLastError();
@@ -347,6 +448,13 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   double *x = h->kry, *r = x + N, *rhat = r + N, *p = rhat + N, *v = p + N, *s = v + N, *t = s + N, *dinv = t + N;
   double *phat = h->kry + 8 * N, *shat = h->kry + 9 * N;
   Ctx c{h, n, D.krowptr, D.kcolind, D.A_knp, h->kry + 11 * N, h->kry + 11 * N + 64};
+  const KnDist& dist = h->dist;
+  if (dist.on) {
+    c.owned = dist.d_owned_knp;
+    c.which = KNPEMI_B_KNP;
+    hipLaunchKernelGGL(ghost_identity_kernel, grid1(n), dim3(256), 0, h->stream, n, c.rowptr, c.colind, c.owned, D.A_knp);
+    mask(c, D.b_knp);      // the ghost rows of the right-hand side are not assembled
+  }
   // x0 = previous concentrations in the block order [c[0][0], c[0][1], c[1][0], ...]
   hipLaunchKernelGGL(knp_order_kernel, grid1(n), dim3(256), 0, h->stream, D.Ntot, KS, h->n_sub, h->d_consts, x, D.csol, 1);
   hipLaunchKernelGGL(diag_inv_kernel, grid1(n), dim3(256), 0, h->stream, n, c.rowptr, c.colind, c.vals, dinv);
@@ -354,7 +462,8 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   const bool amg = h->pc_knp == KNPEMI_PC_AMG;
   if (amg && (!G.built || G.n != n)) {
     G.negative_strength = true;
-    if ((rc = kn_amg_setup(h, G, n, D.krowptr, D.kcolind, D.A_knp, false))) return rc;
+    if ((rc = kn_amg_setup(h, G, n, D.krowptr, D.kcolind, D.A_knp, false,
+                           dist.on ? dist.h_owned_knp.data() : nullptr))) return rc;
     G.its_ref = -1;
     ++G.builds;
   }
@@ -407,6 +516,8 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     rn = std::sqrt(sc[S_RR]);
     if (!(rn == rn)) { kn_set_error("KNP BiCGStab broke down (NaN residual)"); return KNPEMI_EINVAL; }
   }
+  if (dist.on) if (int e = dist.halo(dist.ctx, x, KNPEMI_B_KNP)) c.comm_rc = c.comm_rc ? c.comm_rc : e;
+  if (c.comm_rc) { kn_set_error("KNP solve: a communication hook failed"); return KNPEMI_EHIP; }
   if (h->fuse_update) { if ((rc = kn_launch_knp_writeback_update(h, x))) return rc; }
   else hipLaunchKernelGGL(knp_order_kernel, grid1(n), dim3(256), 0, h->stream, D.Ntot, KS, h->n_sub, h->d_consts, x, D.csol, 0);
   if (iters) *iters = it;

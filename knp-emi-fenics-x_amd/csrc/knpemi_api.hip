@@ -1191,6 +1191,56 @@ extern "C" int knpemi_update_pde(knpemi_handle* h) {
   return kn_launch_update_pde(h);
 }
 
+extern "C" int knpemi_set_distributed(knpemi_handle* h, const uint8_t* owned, void* reduce_buf_dev,
+                                      knpemi_allreduce_fn allreduce, knpemi_halo_fn halo, void* ctx) {
+  if (!h) return fail(KNPEMI_EINVAL, "null handle");
+  KnDist& d = h->dist;
+  h->amg_emi.built = false;      // the preconditioner changes with the ownership
+  h->amg_knp.built = false;
+  if (!owned) { d.on = false; return KNPEMI_OK; }
+  if (!reduce_buf_dev || !allreduce || !halo)
+    return fail(KNPEMI_EINVAL, "knpemi_set_distributed: reduction buffer and both communication hooks are required");
+  KN_HIP(hipSetDevice(h->device));
+  const int Ntot = h->dev.Ntot, KS = h->K - 1;
+  d.h_owned_emi.assign(owned, owned + Ntot);
+  d.h_owned_knp.assign((size_t)KS * Ntot, 0);
+  for (int s = 0; s < h->n_sub; ++s) {
+    const int v0 = h->voff[s], nv = h->n_vert[s];
+    for (int k = 0; k < KS; ++k)
+      for (int v = 0; v < nv; ++v) d.h_owned_knp[(size_t)KS * v0 + (size_t)k * nv + v] = owned[v0 + v];
+  }
+  int rc;
+  const uint8_t* p = nullptr;
+  if ((rc = dev_upload(h, d.h_owned_emi, &p))) return rc;
+  d.d_owned_emi = const_cast<uint8_t*>(p);
+  if ((rc = dev_upload(h, d.h_owned_knp, &p))) return rc;
+  d.d_owned_knp = const_cast<uint8_t*>(p);
+  d.d_red = static_cast<double*>(reduce_buf_dev);
+  d.allreduce = allreduce; d.halo = halo; d.ctx = ctx;
+  // number of owned unknowns of the EMI system over all ranks (mean of the constant null space)
+  double cnt = 0.0;
+  for (int i = 0; i < Ntot; ++i) cnt += owned[i] ? 1.0 : 0.0;
+  KN_HIP(hipMemcpyAsync(d.d_red, &cnt, sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (allreduce(ctx, 1)) return fail(KNPEMI_EHIP, "knpemi_set_distributed: allreduce hook failed");
+  KN_HIP(hipMemcpyAsync(&cnt, d.d_red, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  d.n_owned_global = cnt;
+  d.on = true;
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_vec_gather(knpemi_handle* h, const void* vec_dev, const int32_t* idx_dev, int n, void* buf_dev) {
+  if (!h || n < 0 || (n > 0 && (!vec_dev || !idx_dev || !buf_dev))) return fail(KNPEMI_EINVAL, "knpemi_vec_gather: bad argument");
+  KN_HIP(hipSetDevice(h->device));
+  return kn_launch_vec_index(h, static_cast<double*>(const_cast<void*>(vec_dev)), idx_dev, n, static_cast<double*>(buf_dev), 1);
+}
+
+extern "C" int knpemi_vec_scatter(knpemi_handle* h, void* vec_dev, const int32_t* idx_dev, int n, const void* buf_dev) {
+  if (!h || n < 0 || (n > 0 && (!vec_dev || !idx_dev || !buf_dev))) return fail(KNPEMI_EINVAL, "knpemi_vec_scatter: bad argument");
+  KN_HIP(hipSetDevice(h->device));
+  return kn_launch_vec_index(h, static_cast<double*>(vec_dev), idx_dev, n, static_cast<double*>(const_cast<void*>(buf_dev)), 0);
+}
+
 extern "C" int knpemi_set_option(knpemi_handle* h, int option, int value) {
   if (!h) return fail(KNPEMI_EINVAL, "null handle");
   if (option == KNPEMI_OPT_FUSE_UPDATE) { h->fuse_update = value ? 1 : 0; return KNPEMI_OK; }

@@ -134,9 +134,22 @@ struct KnAmg {
 void kn_amg_free(KnAmg& G);
 struct knpemi_handle;
 int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const int* d_colind, const double* d_vals,
-                 bool singular);
+                 bool singular, const uint8_t* h_owned = nullptr);
 int kn_amg_apply(knpemi_handle* h, KnAmg& G, const double* vals, const double* dinv0, const double* r, double* scratch,
                  double* out);
+
+// Distributed solves (knpemi_set_distributed)
+struct KnDist {
+  bool on = false;
+  std::vector<uint8_t> h_owned_emi, h_owned_knp;   // host masks in the unknown order of the two systems
+  uint8_t* d_owned_emi = nullptr;
+  uint8_t* d_owned_knp = nullptr;
+  double* d_red = nullptr;                         // caller's reduction buffer (>= 8 doubles)
+  knpemi_allreduce_fn allreduce = nullptr;
+  knpemi_halo_fn halo = nullptr;
+  void* ctx = nullptr;
+  double n_owned_global = 0.0;                     // owned EMI unknowns summed over the ranks
+};
 
 struct knpemi_handle {
   int device = 0;
@@ -165,6 +178,7 @@ struct knpemi_handle {
   std::vector<int> h_rowptr, h_colind, h_rowptrL, h_colindL;
   double* d_stage = nullptr; size_t stage_len = 0;   // staging buffer for strided field I/O
   double* kry = nullptr; size_t kry_n = 0;           // Krylov workspace (kernels_krylov.hip)
+  int kry_ones_masked = 0;                           // the workspace's `ones` vector currently holds the ownership mask
   double* guess_old[2] = {nullptr, nullptr};         // previous solutions (EMI, KNP) for knpemi_extrapolate_guess
   bool guess_have[2] = {false, false};
   KnAmg amg_emi, amg_knp;
@@ -173,6 +187,7 @@ struct knpemi_handle {
   KnGraph graph_emi, graph_knp;
   int pc_emi = KNPEMI_PC_AMG, pc_knp = KNPEMI_PC_AMG;
   int fuse_update = 0;                 // KNPEMI_OPT_FUSE_UPDATE
+  KnDist dist;
   // per-kernel event profiling (knpemi_profile)
   uint32_t prof_mask = 0;
   std::vector<hipEvent_t> prof_ev[KNPEMI_N_KERNELS];  // begin/end pairs
@@ -228,3 +243,4 @@ int kn_launch_halo(knpemi_handle* h, int kind, int pack, const int32_t* idx, int
 int kn_launch_field_scatter(knpemi_handle* h, const double* src, double* dst, int n, int dst_stride);
 int kn_launch_field_gather(knpemi_handle* h, const double* src, int src_stride, double* dst, int n);
 int kn_launch_trace(knpemi_handle* h, const double* ue, const double* ui, int sub, double* qe, double* qi);
+int kn_launch_vec_index(knpemi_handle* h, double* vec, const int32_t* idx, int n, double* buf, int gather);

@@ -56,6 +56,10 @@ class Params(C.Structure):
     ]
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+
+
 class KnpemiError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libknpemi_hip error {code}: {msg}")
@@ -107,6 +111,9 @@ SIGNATURES = {
     "knpemi_halo_width": (C.c_int, [C.c_void_p, C.c_int]),
     "knpemi_halo_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "knpemi_halo_unpack": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "knpemi_set_distributed": (C.c_int, [C.c_void_p, c_u8_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "knpemi_vec_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "knpemi_vec_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "knpemi_profile": (C.c_int, [C.c_void_p, C.c_uint32]),
     "knpemi_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), c_dbl_p]),
     "knpemi_timer_start": (C.c_int, [C.c_void_p]),

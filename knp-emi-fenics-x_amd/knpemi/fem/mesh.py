@@ -341,6 +341,17 @@ def extract_submesh(mesh, tags, values):
     return sub, emap, vmap, None, None
 
 
+def match_facets(parent, submesh, sub_vertex_to_parent):
+    """Parent facet index of every facet of `submesh` (same vertices), -1 where the parent has no such facet."""
+    pv = sub_vertex_to_parent.sub_to_parent
+    key_sub = _row_keys(np.sort(pv[submesh.facets], axis=1), parent.num_vertices)
+    key_parent = _row_keys(np.sort(parent.facets, axis=1), parent.num_vertices)
+    order = np.argsort(key_parent)
+    pos = np.clip(np.searchsorted(key_parent[order], key_sub), 0, max(order.shape[0] - 1, 0))
+    hit = key_parent[order][pos] == key_sub
+    return np.where(hit, order[pos], -1).astype(np.int64)
+
+
 def transfer_meshtags_to_submesh(ft, submesh, sub_vertex_to_parent, sub_cell_to_parent):
     """`scifem.transfer_meshtags_to_submesh` for facet tags (`emiWeakForm.py:349-351`)."""
     parent = ft.mesh

@@ -18,6 +18,7 @@ import os
 
 import numpy as np
 
+from .distributed import Halo
 from .idealized import make_mesh_3D_slab
 
 
@@ -48,18 +49,16 @@ class SlabLayout:
         return self.plane_of_local_vertex(v), v // (self.nxl + 1)
 
 
-class SlabHalo:
-    """Forward (owner -> ghost) halo of one rank.  `plans[kind][side]` hold, for kind in
-    {'bulk', 'mem'} and side in {'lo', 'hi'}: `send` / `recv` index arrays (global device
-    numbering of the DeviceProblem: vertex ids across sub-meshes, Q-dof ids)."""
+class SlabHalo(Halo):
+    """Halo of the structured x-slab partition (the slab meshes are generated directly, without the global mesh):
+    `plans[kind][side]`, side in {'lo', 'hi'}, keyed by (vertex plane, y-z index).  Exchange, device plumbing and the
+    hooks of the distributed solves are those of `knpemi.fem.distributed.Halo`."""
 
     def __init__(self, layout, sub_keys, sub_offsets, q_keys, q_offsets):
+        super().__init__()
         self.layout = layout
         self.sub_keys, self.sub_offsets = sub_keys, sub_offsets
         self.q_keys, self.q_offsets = q_keys, q_offsets
-        self.plans = None
-        self.dp = None
-        self._dev = None
 
     # -- set-up handshake: tell each neighbour which of its owned plane entries we hold as ghosts ----
     def _needs(self):
@@ -101,112 +100,6 @@ class SlabHalo:
                                          recv=np.concatenate(recv).astype(np.int32))
         self.plans = plans
         return plans
-
-    # -- host exchange (CPU tests, Vector.scatter_forward): `fields` = [n_global_ids, width] array --
-    def forward_host_array(self, kind, arr, dist):
-        import torch
-        ops, bufs = [], []
-        for side, pl in self.plans[kind].items():
-            sb = torch.from_numpy(np.ascontiguousarray(arr[pl["send"]]))
-            rb = torch.empty((len(pl["recv"]),) + arr.shape[1:], dtype=torch.float64)
-            ops += [dist.P2POp(dist.isend, sb, pl["nb"]), dist.P2POp(dist.irecv, rb, pl["nb"])]
-            bufs.append((pl, rb, sb))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        for pl, rb, _ in bufs:
-            arr[pl["recv"]] = rb.numpy()
-
-    # -- device exchange (bench / production) ------------------------------------------------------------
-    def attach(self, dp):
-        import torch
-        from .. import _lib as L
-        self.dp, self.L, self.torch = dp, L, torch
-        import torch.distributed as dist
-        self.dist = dist
-        dev = torch.device("cuda", dp.device)
-        n_slots = int(dp.n_models.sum())
-        self.width = {"bulk": 4, "mem": 1 + n_slots * L.MAX_IONS}
-        # The exchange mode is chosen ONCE, here, and agreed on by all ranks; a communication error during a run
-        # propagates (the rank exits non-zero) instead of switching modes under a half-posted batch.
-        #   "stream-ordered RCCL": pack kernel -> send/recv -> unpack kernel on the library's stream, no host sync
-        #   "host-synchronised RCCL": KNPEMI_HALO_SYNC=1, or torch cannot wrap the library's stream
-        #   "gloo host-staged": single-GPU rehearsals and CPU tests
-        stream_ordered = os.environ.get("KNPEMI_HALO_SYNC") is None
-        try:
-            self._ext = torch.cuda.ExternalStream(dp.lib.knpemi_stream(dp.h), device=dev)
-        except (RuntimeError, TypeError):
-            self._ext, stream_ordered = None, False
-        if dist.get_backend() == "gloo":
-            self.mode = "gloo host-staged"
-        else:
-            flag = torch.tensor([1 if stream_ordered else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            self.mode = "stream-ordered RCCL" if int(flag.item()) else "host-synchronised RCCL"
-        self._stream_ordered = self.mode == "stream-ordered RCCL"
-        self._dev = {}
-        for kind in ("bulk", "mem"):
-            # one packed buffer per direction and kind: both neighbours' entries are packed / unpacked by a single
-            # kernel launch, the point-to-point operations work on slices of it
-            w = self.width[kind]
-            sides = list(self.plans[kind].values())
-            if not sides:
-                continue
-            send_idx = np.concatenate([pl["send"] for pl in sides]).astype(np.int32)
-            recv_idx = np.concatenate([pl["recv"] for pl in sides]).astype(np.int32)
-            d = dict(send_idx=torch.from_numpy(send_idx).to(dev), recv_idx=torch.from_numpy(recv_idx).to(dev),
-                     send_buf=torch.empty(len(send_idx) * w, dtype=torch.float64, device=dev),
-                     recv_buf=torch.empty(len(recv_idx) * w, dtype=torch.float64, device=dev), parts=[])
-            so = ro = 0
-            for pl in sides:
-                ns, nr = len(pl["send"]) * w, len(pl["recv"]) * w
-                d["parts"].append((pl["nb"], slice(so, so + ns), slice(ro, ro + nr)))
-                so, ro = so + ns, ro + nr
-            self._dev[kind] = d
-
-    def _exchange(self, kind):
-        L, dp, dist = self.L, self.dp, self.dist
-        d = self._dev.get(kind)
-        if d is None:
-            return
-        k = 0 if kind == "bulk" else 1
-        L.check(dp.lib.knpemi_halo_pack(dp.h, k, d["send_idx"].data_ptr(), d["send_idx"].numel(),
-                                        d["send_buf"].data_ptr()))
-        if dist.get_backend() != "gloo":
-            ops = []
-            for nb, ss, rs in d["parts"]:
-                ops += [dist.P2POp(dist.isend, d["send_buf"][ss], nb), dist.P2POp(dist.irecv, d["recv_buf"][rs], nb)]
-            if self._stream_ordered:
-                # RCCL: torch's current stream is the library's stream (ExternalStream), so the send/recv kernels
-                # are ordered after the pack kernel and `wait()` orders the unpack kernel after them: no host
-                # synchronisation anywhere in the exchange (tools/check_async_halo.py rehearses this with real RCCL)
-                with self.torch.cuda.stream(self._ext):
-                    for req in dist.batch_isend_irecv(ops):
-                        req.wait()
-            else:
-                dp.sync()                        # packed data is complete before RCCL reads it
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
-                self.torch.cuda.current_stream().synchronize()
-        else:                           # single-GPU rehearsal: stage through host memory
-            dp.sync()
-            sb = d["send_buf"].cpu()
-            rb = self.torch.empty(d["recv_buf"].shape, dtype=self.torch.float64)
-            ops = []
-            for nb, ss, rs in d["parts"]:
-                ops += [dist.P2POp(dist.isend, sb[ss], nb), dist.P2POp(dist.irecv, rb[rs], nb)]
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-            d["recv_buf"].copy_(rb)
-            self.torch.cuda.current_stream().synchronize()
-        L.check(dp.lib.knpemi_halo_unpack(dp.h, k, d["recv_idx"].data_ptr(), d["recv_idx"].numel(),
-                                          d["recv_buf"].data_ptr()))
-
-    def exchange_bulk(self):
-        self._exchange("bulk")
-
-    def exchange_membrane(self):
-        self._exchange("mem")
 
 
 def make_slab_layout_and_mesh(kind, r, rank, world, length=None):

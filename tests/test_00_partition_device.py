@@ -47,3 +47,25 @@ def test_two_rank_device_steps_equal_single_rank_bit_for_bit(kind, mem_halo):
     rcs, outs = _run_ranks(["--kind", kind, "--steps", "6"] + ([] if mem_halo else ["--no-mem-halo"]))
     assert rcs == [0, 0], "\n".join(outs)
     assert "PARTITION STEPS OK" in outs[0], outs[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,method,world", [("tet", "rcb", 2), ("tet", "rcb", 3), ("hex", "slab", 2)])
+def test_general_partition_device_steps_equal_single_rank_bit_for_bit(kind, method, world):
+    """The same check with the general cell partitioner (recursive coordinate bisection / layer slabs on the global
+    mesh, id-keyed halo: knpemi.fem.distributed), also on three ranks."""
+    rcs, outs = _run_ranks(["--kind", kind, "--steps", "4", "--method", method], world=world)
+    assert rcs == [0] * world, "\n".join(outs)
+    assert "PARTITION STEPS OK" in outs[0], outs[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,method", [("tet", "rcb"), ("tet", "slabgen"), ("hex", "slab")])
+def test_two_rank_time_steps_with_distributed_solves(kind, method):
+    """Whole time steps on a partitioned problem: knpemi_solve_emi / knpemi_solve_knp as distributed solves (halo'd
+    SpMV, all-reduced dot products, each rank's AMG V-cycle on its diagonal block) give the fields, membrane
+    potentials, currents and ODE states of the single-rank run to solver tolerance (pdeSolver.py:24-35,74-78,99-110
+    run the reference's KSP solves on the mesh communicator)."""
+    rcs, outs = _run_ranks(["--kind", kind, "--steps", "4", "--method", method, "--solves"])
+    assert rcs == [0, 0], "\n".join(outs)
+    assert "PARTITION STEPS OK" in outs[0], outs[0]

@@ -28,9 +28,10 @@ def init_fields(s, L_x):
         s.phi[tag].x.array[:] = (-0.0744 if tag > 0 else 0.0) + 1e-3 * w
 
 
-def run(s, K, halo, mem_halo):
+def run(s, K, halo, mem_halo, solves=None):
     from knpemi.stepper import DeviceStepper
-    st = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp), s.c, s.c_prev, s.phi, s.phi_M_prev)
+    st = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp), s.c, s.c_prev, s.phi, s.phi_M_prev,
+                       device_solves=solves)
     for mm in s.mem_models:
         st.add_membrane_model(mm['ode'], s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
     if halo is not None:
@@ -39,11 +40,16 @@ def run(s, K, halo, mem_halo):
         halo.exchange_membrane()
         if not mem_halo:
             halo.exchange_membrane = lambda: None
+        if solves is not None:
+            halo.enable_solves()
     for _ in range(K):
         st.step(halo)
     st.download()
+    if halo is not None and getattr(halo, "_hook_error", None) is not None:
+        raise halo._hook_error
     ode = s.mem_models[0]['ode']
     out = dict(x=ode.dof_locations.copy(), phiM=s.phi_M_prev[1].x._a.copy(), states=ode.states.copy())
+    out["iterations"] = list(getattr(st, "iterations", []))
     for n, f in s.mem_models[0]['I_ch_k'].items():
         out["I_" + n] = f.x._a.copy()
     # right-hand sides of the last step (they see the ghost membrane dofs through the facets of ghost cells)
@@ -70,6 +76,12 @@ def main():
     ap.add_argument("--no-mem-halo", action="store_true")
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--kind", default="tet")
+    ap.add_argument("--method", default="slabgen", choices=["slabgen", "slab", "rcb"],
+                    help="slabgen: slab meshes generated directly (knpemi.fem.partition); slab / rcb: the general cell "
+                         "partitioner of knpemi.fem.distributed on the global mesh")
+    ap.add_argument("--solves", action="store_true",
+                    help="whole time steps: distributed CG / BiCGStab (halo'd SpMV, all-reduced dots, per-rank AMG) "
+                         "against the single-rank solves, to solver tolerance instead of bit for bit")
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
@@ -78,18 +90,29 @@ def main():
     from knpemi.fem.partition import make_slab_problem
     from knpemi.fem import make_mesh_3D
     from setup_problem import Setup
+    solves = (1e-8, 1e-10) if a.solves else None
     with contextlib.redirect_stdout(io.StringIO()):
-        s = make_slab_problem(a.kind, 0, rank, world, g_syn=10.0)
+        if a.method == "slabgen":
+            s = make_slab_problem(a.kind, 0, rank, world, g_syn=10.0)
+        else:
+            from knpemi.fem.distributed import make_partitioned_problem
+            s = make_partitioned_problem(a.kind, 0, rank, world, g_syn=10.0, method=a.method)
     L_x = s.global_length
     init_fields(s, L_x)
-    loc = run(s, a.steps, s.halo, not a.no_mem_halo)
-    lay = s.layout
-    hx = L_x / lay.nx
-    plane = np.rint(loc["x"][:, 0] / hx).astype(int)
-    own = (plane >= lay.own_lo) & (plane <= lay.own_hi)
+    loc = run(s, a.steps, s.halo, not a.no_mem_halo, solves)
+    its_local = loc.pop("iterations")
     rows = loc.pop("rows")
-    rplane = np.rint(rows["x"][:, 0] / hx).astype(int)
-    rown = (rplane >= lay.own_lo) & (rplane <= lay.own_hi)
+    hx = L_x / (2 * world * 16)
+    if a.method == "slabgen":
+        lay = s.layout
+        plane = np.rint(loc["x"][:, 0] / hx).astype(int)
+        own = (plane >= lay.own_lo) & (plane <= lay.own_hi)
+        rplane = np.rint(rows["x"][:, 0] / hx).astype(int)
+        rown = (rplane >= lay.own_lo) & (rplane <= lay.own_hi)
+    else:
+        halo = s.halo
+        own = np.concatenate([ow == rank for _, (gid, ow, _) in sorted(halo.keys["mem"].items())])
+        rown = np.concatenate([ow == rank for _, (gid, ow, _) in sorted(halo.keys["bulk"].items())])
     gathered = [None] * world
     dist.all_gather_object(gathered, ({k: v[own] for k, v in loc.items()}, {k: v[rown] for k, v in rows.items()}))
     if rank == 0:
@@ -97,7 +120,8 @@ def main():
             ctype = {"tet": "tetrahedron", "hex": "hexahedron"}[a.kind]
             g = Setup(a.kind, 0, g_syn=10.0, mesh_data=make_mesh_3D(0, ctype, l=2 * world))
         init_fields(g, L_x)
-        ref = run(g, a.steps, None, True)
+        ref = run(g, a.steps, None, True, solves)
+        its_ref = ref.pop("iterations")
         ref_rows = ref.pop("rows")
         key = lambda x: tuple(np.rint(x / (hx / 64)).astype(np.int64))
         lookup = {key(x): i for i, x in enumerate(ref["x"])}
@@ -125,8 +149,17 @@ def main():
         print("membrane dofs compared:", n, "of", len(ref["x"]), "mem halo:", not a.no_mem_halo)
         print("max relative differences:", worst)
         assert n == len(ref["x"])
-        # owner-computes rows + deterministic kernels: the partitioned run reproduces the single-rank run bit for bit
-        assert max(worst.values()) == 0.0, worst
+        if a.solves:
+            # distributed Krylov (block-Jacobi AMG over the ranks) vs the single-rank solve, both to rtol 1e-8 / 1e-10
+            # (one-level block Jacobi has no global coarse space: its attainable accuracy on the 35:1 cables ends
+            # near 1e-9 relative, far below the reference's rtol 1e-5 / 1e-7)
+            print("iterations per solve, partitioned:", [it[1] for it in its_local], "single rank:",
+                  [it[1] for it in its_ref])
+            worst.pop("b_emi", None)          # right-hand sides of the LAST step see the solutions through phi_M only
+            assert max(worst.values()) < 1e-5, worst
+        else:
+            # owner-computes rows + deterministic kernels: the partitioned run reproduces the single-rank run bit for bit
+            assert max(worst.values()) == 0.0, worst
         print("PARTITION STEPS OK")
     dist.barrier()
     dist.destroy_process_group()
