@@ -12,7 +12,8 @@ work a real run gives it (`ode_rhs_evals_per_dof_per_step`).
 
 At N > 1 the mesh is partitioned into x-slabs (weak: N times longer box; --scaling strong: the fixed config-3 box),
 every step exchanges the ghost-dof halo of the bulk fields (stream-ordered RCCL point-to-point; ghost membrane dofs
-are integrated redundantly) and the fields are held at their initial state (no recorded trajectory).
+are integrated redundantly), and the recorded trajectory comes from the distributed Krylov solves
+(knpemi_set_distributed: halo'd SpMV, all-reduced dot products, per-GPU AMG).
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -214,7 +215,7 @@ def device_solvers(case, its, maxit=1000):
     return solver(L.B_EMI, "emi", rtol_emi, 1e-40), solver(L.B_KNP, "knp", rtol_knp, 2e-40)
 
 
-def record_trajectory(case, stepper, n_steps, torch):
+def record_trajectory(case, stepper, n_steps, torch, halo=None):
     """Untimed: n_steps whole time steps with the device Krylov solves; returns the solutions (phi, c in the unknown
     order of the two systems) of every step as device tensors [n_steps, n]."""
     import numpy as np
@@ -238,14 +239,14 @@ def record_trajectory(case, stepper, n_steps, torch):
         k[0] += 1
     stepper.solve_emi, stepper.solve_knp = emi, knp
     for _ in range(n_steps):
-        stepper.step()
+        stepper.step(halo)
     dp.sync()
     stepper.solve_emi = stepper.solve_knp = None
     dev = torch.device("cuda", dp.device)
     return torch.from_numpy(phi_t).to(dev), torch.from_numpy(c_t).to(dev), its
 
 
-def with_solves(case, stepper, n_steps, torch):
+def with_solves(case, stepper, n_steps, torch, halo=None):
     """Whole time steps of run_3D.py:345-368 on the device, Krylov solves included: the
     same stepper with `knpemi_solve_emi` (CG + AMG) and `knpemi_solve_knp` (BiCGStab + AMG) between the assemblies,
     continuing from the end of the timed trajectory.  Not part of `value`."""
@@ -254,13 +255,13 @@ def with_solves(case, stepper, n_steps, torch):
     its = {"emi": [], "knp": []}
     stepper.solve_emi, stepper.solve_knp = device_solvers(case, its)
     for _ in range(2):
-        stepper.step()
+        stepper.step(halo)
     torch.cuda.synchronize()
     its["emi"].clear()
     its["knp"].clear()
     t0 = time.perf_counter()
     for _ in range(n_steps):
-        stepper.step()
+        stepper.step(halo)
     dp.sync()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n_steps * 1e3
@@ -323,7 +324,7 @@ def main():
         args.workload = "config3"       # the fixed mesh of BASELINE.json configs[2]
     case = Case(args.workload, rank, world, args.scaling)
     s = case.s
-    frozen = args.frozen_state or world > 1
+    frozen = args.frozen_state
     if frozen and case.family == "idealized":
         # synthetic stationary state: c = c_prev (the update keeps the fields), rest potential + a smooth perturbation
         s.perturb(seed=12345 + rank)
@@ -339,7 +340,7 @@ def main():
 
     stepper = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp),
                             s.c, s.c_prev, s.phi, s.phi_M_prev, assemble_knp_twice=args.knp_twice,
-                            overlap=not args.no_overlap, fuse_update=not (args.frozen_state or world > 1))
+                            overlap=not args.no_overlap, fuse_update=not args.frozen_state)
     dp = stepper.dp
     for m, stim, loc in case.models:
         stepper.add_membrane_model(m, stim, loc)
@@ -350,6 +351,8 @@ def main():
         halo.attach(dp)
         halo.exchange_bulk()        # ghosts start from their owners' values
         halo.exchange_membrane()    # once: afterwards the ghost membrane dofs are integrated redundantly
+        if not frozen:
+            halo.enable_solves()    # knpemi_solve_emi / knp solve the global systems
 
     def sync():
         if dist is not None:
@@ -360,8 +363,11 @@ def main():
     n_traj = args.warmup + PROFILE_STEPS + args.steps
     traj_its = None
     if not frozen:
-        phi_t, c_t, traj_its = record_trajectory(case, stepper, n_traj, torch)
+        phi_t, c_t, traj_its = record_trajectory(case, stepper, n_traj, torch, halo)
         stepper.reset()
+        if halo is not None:
+            halo.exchange_bulk()
+            halo.exchange_membrane()
         if case.source is not None:
             stepper.set_source(0, case.source)
         cursor = [0]
@@ -490,9 +496,13 @@ def main():
             out["config"]["halo"] = halo.mode
         if traj_its is not None:
             out["config"]["trajectory_iterations_avg"] = {k: sum(v) / max(1, len(v)) for k, v in traj_its.items()}
-        if args.solve_steps > 0 and world == 1:
-            stepper.solve_emi = stepper.solve_knp = None
-            out["with_solves"] = with_solves(case, stepper, args.solve_steps, torch)
+    ws = None
+    if args.solve_steps > 0 and not frozen:      # collective at N > 1: every rank takes part
+        stepper.solve_emi = stepper.solve_knp = None
+        ws = with_solves(case, stepper, args.solve_steps, torch, halo)
+    if rank == 0:
+        if ws is not None:
+            out["with_solves"] = ws
         if args.cpu_steps > 0 and world == 1 and case.family == "idealized":
             avail = len(os.sched_getaffinity(0))
             # bounded sample: --cpu-steps refers to the config-2 size and shrinks with the problem size
