@@ -182,6 +182,16 @@ int knpemi_solver_info(knpemi_handle* h, int which, int* levels, double* op_comp
 /* Membrane ODEs: MembraneModel (src/knpemi/odeSolver.py:6-188).  `states`/`params` are the
  * row-major [n_q][n_states|n_params] tables `MembraneModel.states/.parameters`. */
 int knpemi_ode_bind(knpemi_handle* h, int sub, int model, int model_id, int n_states, int n_params);
+/* A membrane model that brings its own right-hand side (the reference accepts any module with a numba cfunc
+ * `rhs_numba(t, states, values, parameters)`, odeSolver.py:96, e.g. examples/benchmark/mm_glial.py:127-215).
+ * `rhs_source` is HIP source that defines
+ *     __device__ void rhs(double t, const double* states, double* values, double* parameters);
+ * with the cfunc's semantics (parameters is the in/out row of the dof: what the last call stores in I_ch_* is handed
+ * to the PDEs).  It is compiled for gfx950 with hipRTC under the sweep kernel of the shipped models; one lane per
+ * state component for 1, 2, 4 or 8 states, one thread per dof otherwise.  knpemi_ode_compile_source only compiles
+ * (no device needed) and returns the compiler's messages. */
+int knpemi_ode_bind_source(knpemi_handle* h, int sub, int model, int n_states, int n_params, const char* rhs_source);
+int knpemi_ode_compile_source(int n_states, int n_params, const char* rhs_source, char* log, size_t log_len);
 int knpemi_ode_set_tables(knpemi_handle* h, int sub, int model, const double* states,
                           const double* params);
 int knpemi_ode_get_tables(knpemi_handle* h, int sub, int model, double* states, double* params);

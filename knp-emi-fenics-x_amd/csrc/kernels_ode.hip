@@ -18,112 +18,13 @@
 
 #include "knpemi_internal.h"
 #include "membrane_models.h"
+#include "ode_kernel.h"
 
 namespace {
 
-struct OdeArgs {
-  int nq, q0, n_stim, flags, v_index, model_slot, NQtot;
-  int ion_param[3 * KN_MAXK];
-  int stim_idx[8];
-  double stim_val[8];
-  double t0, dt, rtol, atol;
-  double* states;
-  double* params;
-  const uint8_t* mask;
-  unsigned long long* stats;
-  unsigned long long* stamps;   // diagnostic build: [workgroup][24] phase cycle sums and counts
-};
-
-constexpr int ODE_BLOCK = 64;
-
-// LANES = M::NS: lane c of every group of NS adjacent lanes integrates component c of one membrane dof
-// (lsoda_core.h); LANES = 1: one thread per dof (one-state models).
-// WAVES = 2 caps the register budget at 256 per lane so that two waves share a SIMD.  It pays once there are more
-// waves than SIMDs (large membranes); small sweeps run one wave per SIMD with the full register file.
-template <class M, int LANES, int WAVES = 1, bool STAMPS = false>
-__global__ __launch_bounds__(ODE_BLOCK, WAVES) void ode_step_kernel(KnDev D, OdeArgs a, const LsodaCoef* __restrict__ cf) {
-  using Integrator = Lsoda<M::NS, M, LANES, STAMPS, ODE_BLOCK>;
-  constexpr int NI = Integrator::NI;
-  // factorised iteration matrix + pivots of the BDF method, one column per lane (touched by stiff dofs only)
-  __shared__ double work[Integrator::WORK * ODE_BLOCK];
-  // LSODA's coefficient tables (4 kB) are consulted with a per-lane order index whenever an order changes: keep the
-  // workgroup's copy in LDS.  Everything else the non-stiff integrator touches lives in registers.
-  __shared__ LsodaCoef scf;
-  {
-    const double* src = reinterpret_cast<const double*>(cf);
-    double* dst = reinterpret_cast<double*>(&scf);
-    for (int i = threadIdx.x; i < (int)(sizeof(LsodaCoef) / sizeof(double)); i += ODE_BLOCK) dst[i] = src[i];
-    __syncthreads();
-  }
-  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
-  // the lanes past the last dof repeat the last dof and drop their results: every lane of the wave stays active,
-  // so the wave-level sums below see all 64 lanes
-  const bool live = gt / LANES < a.nq;
-  const int q = live ? gt / LANES : a.nq - 1, comp = gt % LANES;
-  const int qg = a.q0 + q;
-  const StridedRow<0> p{a.params + q, (size_t)a.nq};   // this dof's parameter row in the transposed table
-  double y[NI];
-#pragma unroll
-  for (int j = 0; j < NI; ++j) y[j] = a.states[(size_t)(comp + j) * a.nq + q];
-  // 1. concentration traces (record components 4..6 hold c_0, c_1, c_eliminated) -> parameter columns.
-  //    With several lanes per dof every lane writes the same values and later reads only its own stores.
-  if (a.flags & KNPEMI_ODE_SET_TRACES) {
-    const double* re = D.VR + (size_t)D.q2e[qg] * KN_REC + 4;
-    const double* ri = D.VR + (size_t)D.q2i[qg] * KN_REC + 4;
-    for (int k = 0; k < KN_MAXK; ++k) {
-      p[a.ion_param[3 * k]] = re[k];
-      p[a.ion_param[3 * k + 1]] = ri[k];
-    }
-  }
-  if (a.flags & KNPEMI_ODE_SET_V) {
-    const double v = D.phiM[qg];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) y[j] = (comp + j == a.v_index) ? v : y[j];
-  }
-  // 2. stimulus + LSODA (the parameter row is read once by prepare(); only the currents change)
-  if (a.n_stim > 0 && (!a.mask || a.mask[q]))
-    for (int i = 0; i < a.n_stim; ++i) p[a.stim_idx[i]] = a.stim_val[i];
-  Integrator s;
-  if constexpr (STAMPS) s.st_last = __builtin_amdgcn_s_memtime();
-  s.f.prepare(p);
-  const int rc = s.integrate(&scf, work + threadIdx.x, y, a.t0, a.t0 + a.dt, a.rtol, a.atol, 10000, comp);
-  // 3. write back: state row, phi_M_prev <- V; the lane that owns V stores the currents (the reference's
-  //    RHS side effect) into the parameter row and the I_ch_k fields
-  const bool owner = live && (LANES == 1 || comp == M::CURRENT_LANE);
-  if (live) {
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      a.states[(size_t)(comp + j) * a.nq + q] = y[j];
-      if (comp + j == a.v_index) D.phiM[qg] = y[j];
-    }
-  }
-  if (owner) {
-    s.f.finish(p);
-    for (int k = 0; k < KN_MAXK; ++k)
-      D.Ich[((size_t)a.model_slot * KN_MAXK + k) * a.NQtot + qg] = p[a.ion_param[3 * k + 2]];
-  }
-  // counters: summed over the wave, then added to this workgroup's own slot -- no atomics (thousands of atomic adds
-  // to one word serialise at ~90 per microsecond: the tail of the sweep); knpemi_ode_stats() adds the slots up
-  unsigned n_rhs = owner ? (unsigned)s.nfe : 0u, n_st = owner ? (unsigned)s.nst : 0u, n_bad = (owner && rc != 0) ? 1u : 0u;
-#pragma unroll
-  for (int msk = 32; msk >= 1; msk >>= 1) {
-    n_rhs += __shfl_xor(n_rhs, msk);
-    n_st += __shfl_xor(n_st, msk);
-    n_bad += __shfl_xor(n_bad, msk);
-  }
-  if constexpr (STAMPS) {
-    if (threadIdx.x == 0 && a.stamps)
-      for (int i = 0; i < 12; ++i) {
-        a.stamps[24 * (size_t)blockIdx.x + i] = s.st_acc[i];
-        a.stamps[24 * (size_t)blockIdx.x + 12 + i] = s.st_cnt[i];
-      }
-  }
-  if (threadIdx.x == 0) {
-    unsigned long long* st = a.stats + 3 * (size_t)blockIdx.x;
-    st[0] += n_rhs;
-    st[1] += n_st;
-    st[2] += n_bad;
-  }
+OdeDev ode_dev(const knpemi_handle* h) {
+  const KnDev& D = h->dev;
+  return OdeDev{D.VR, D.q2e, D.q2i, D.phiM, D.Ich};
 }
 
 template <class M, int LANES>
@@ -131,9 +32,9 @@ void launch_model(knpemi_handle* h, const OdeArgs& a, const LsodaCoef* cf, int f
   dim3 grid(((size_t)a.nq * LANES + ODE_BLOCK - 1) / ODE_BLOCK), block(ODE_BLOCK);
   // more waves than 1.5 x the chip's 1024 SIMDs: trade registers for a second resident wave per SIMD
   const bool dense = force_waves ? force_waves == 2 : (size_t)grid.x > 1536;
-  if (a.stamps) hipLaunchKernelGGL((ode_step_kernel<M, LANES, 1, true>), grid, block, 0, h->cur, h->dev, a, cf);
-  else if (dense) hipLaunchKernelGGL((ode_step_kernel<M, LANES, 2>), grid, block, 0, h->cur, h->dev, a, cf);
-  else hipLaunchKernelGGL((ode_step_kernel<M, LANES, 1>), grid, block, 0, h->cur, h->dev, a, cf);
+  if (a.stamps) hipLaunchKernelGGL((ode_step_kernel<M, LANES, 1, true>), grid, block, 0, h->cur, ode_dev(h), a, cf);
+  else if (dense) hipLaunchKernelGGL((ode_step_kernel<M, LANES, 2>), grid, block, 0, h->cur, ode_dev(h), a, cf);
+  else hipLaunchKernelGGL((ode_step_kernel<M, LANES, 1>), grid, block, 0, h->cur, ode_dev(h), a, cf);
 }
 
 }  // namespace
@@ -183,6 +84,11 @@ int kn_launch_ode_step(knpemi_handle* h, int slot, double t0, double dt, double 
   // many CUs as possible instead of stacking four of them on one.
   static const int force_waves = [] { const char* e = getenv("KNPEMI_ODE_WAVES"); return e ? atoi(e) : 0; }();
   KnProfScope prof(h, KNPEMI_K_ODE);
+  if (m.rtc_function) {   // plug-in compiled at bind time (kernels_rtc.hip)
+    const OdeDev dv = ode_dev(h);
+    a.stamps = nullptr;
+    return kn_rtc_launch(h, m, &dv, sizeof(dv), &a, sizeof(a), cf);
+  }
   switch (m.model_id) {
     case KNPEMI_MODEL_HH_SI: launch_model<ModelHHSI, 4>(h, a, cf, force_waves); break;
     case KNPEMI_MODEL_HH_MV: launch_model<ModelHHMV, 4>(h, a, cf, force_waves); break;

@@ -622,6 +622,7 @@ extern "C" void knpemi_destroy(knpemi_handle* h) {
   if (h->graph_emi.exec) (void)hipGraphExecDestroy(h->graph_emi.exec);
   if (h->graph_knp.exec) (void)hipGraphExecDestroy(h->graph_knp.exec);
   for (void* p : h->allocs) (void)hipFree(p);
+  for (void* m : h->rtc_modules) (void)hipModuleUnload(static_cast<hipModule_t>(m));
   for (auto& v : h->prof_ev) for (hipEvent_t e : v) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1042,6 +1043,27 @@ extern "C" int knpemi_ode_bind(knpemi_handle* h, int sub, int model, int model_i
   if ((rc = dev_zeros(h, (size_t)n_states * m.nq, &m.d_states))) return rc;
   if ((rc = dev_zeros(h, (size_t)n_params * m.nq, &m.d_params))) return rc;
   m.n_stat_blocks = (int)(((size_t)m.nq * n_states + 63) / 64) + 1;   // one slot per workgroup of the sweep
+  if ((rc = dev_zeros(h, 3 * (size_t)m.n_stat_blocks, &m.d_stats))) return rc;
+  m.bound = 1;
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_ode_bind_source(knpemi_handle* h, int sub, int model, int n_states, int n_params,
+                                      const char* rhs_source) {
+  int slot = ode_slot(h, sub, model, 0);
+  if (slot < 0) return KNPEMI_EINVAL;
+  if (!rhs_source || n_states < 1 || n_states > 16 || n_params < 1 || n_params > 128)
+    return fail(KNPEMI_EINVAL, "knpemi_ode_bind_source: bad argument (1..16 states, 1..128 parameters)");
+  KN_HIP(hipSetDevice(h->device));
+  KnOdeModel& m = h->ode[slot];
+  if (m.bound) return fail(KNPEMI_EINVAL, "knpemi_ode_bind_source: model already bound");
+  int rc = kn_rtc_bind(h, m, n_states, n_params, rhs_source);
+  if (rc) return rc;
+  m.sub = sub; m.model_id = -1; m.n_states = n_states; m.n_params = n_params;
+  m.nq = h->n_q[sub];
+  if ((rc = dev_zeros(h, (size_t)n_states * m.nq, &m.d_states))) return rc;
+  if ((rc = dev_zeros(h, (size_t)n_params * m.nq, &m.d_params))) return rc;
+  m.n_stat_blocks = (int)(((size_t)m.nq * n_states + 63) / 64) + 1;
   if ((rc = dev_zeros(h, 3 * (size_t)m.n_stat_blocks, &m.d_stats))) return rc;
   m.bound = 1;
   return KNPEMI_OK;

@@ -107,6 +107,10 @@ struct KnOdeModel {
   unsigned long long* d_stats = nullptr; // [n_stat_blocks][3]: rhs evals, steps, failures per workgroup of the sweep
   int n_stat_blocks = 0;
   unsigned long long* d_stamps = nullptr;   // diagnostic phase stamps (KNPEMI_ODE_STAMPS)
+  // model compiled at bind time from the plug-in's HIP source (kernels_rtc.hip); NULL for the shipped models
+  void* rtc_module = nullptr;
+  void* rtc_function = nullptr;
+  int rtc_lanes = 1;
 };
 
 // Algebraic multigrid hierarchy (kernels_amg.hip)
@@ -173,6 +177,7 @@ struct knpemi_handle {
   int lds_doubles_emi = 0, lds_doubles_knp = 0; // per-block LDS segment sizes (doubles)
   int lds_uniq_max = 0;                         // most distinct vertices touched by one row block
   std::vector<void*> allocs;  // everything hipMalloc'ed
+  std::vector<void*> rtc_modules;   // hipModule_t of run-time compiled membrane models
   std::vector<KnOdeModel> ode; // [moff[n_sub]]
   // host copies of patterns for export
   std::vector<int> h_rowptr, h_colind, h_rowptrL, h_colindL;
@@ -234,6 +239,9 @@ int kn_launch_membrane_mass(knpemi_handle* h, int n_entries, const int* d_entry_
 int kn_launch_ode_step(knpemi_handle* h, int slot, double t0, double dt, double rtol, double atol,
                        int flags, const int32_t* ion_param, int v_index);
 int kn_launch_update_pde(knpemi_handle* h);
+int kn_rtc_bind(knpemi_handle* h, KnOdeModel& m, int n_states, int n_params, const char* rhs_source);
+int kn_rtc_launch(knpemi_handle* h, const KnOdeModel& m, const void* dev_view, size_t dev_bytes, const void* args,
+                  size_t args_bytes, const void* coef);
 int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* iters, double* relres);
 int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* iters, double* relres);
 int kn_extrapolate_guess(knpemi_handle* h, int which);

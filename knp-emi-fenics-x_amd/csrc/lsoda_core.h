@@ -31,9 +31,12 @@
 // code on the CPU -- it is not a CPU fallback of the product).
 #pragma once
 
+#if !defined(__HIPCC_RTC__)   // (hipRTC provides the device math functions and size_t itself)
 #include <math.h>
+#include <stddef.h>
+#endif
 
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
 #define KN_HD __host__ __device__ __forceinline__
 #define KN_HDN __host__ __device__ __forceinline__
 #else
@@ -61,6 +64,7 @@ struct LsodaCoef {
   double sm1[13];
 };
 
+#if !defined(__HIPCC_RTC__)
 // Host-side construction of the coefficient tables (exact restatement of CFODE).
 inline void lsoda_fill_coef(LsodaCoef* c) {
   for (int m = 0; m < 2; ++m)
@@ -125,6 +129,7 @@ inline void lsoda_fill_coef(LsodaCoef* c) {
   static const double sm1[13] = {0.0, 0.5, 0.575, 0.55, 0.45, 0.35, 0.25, 0.2, 0.15, 0.1, 0.075, 0.05, 0.025};
   for (int i = 0; i < 13; ++i) c->sm1[i] = sm1[i];
 }
+#endif
 
 // LANES: number of GPU lanes that share one ODE system.  LANES = 1: one thread integrates all N
 // components (host build, and N = 1 models).  LANES = N (device only): lane c of a group of N adjacent

@@ -11,7 +11,7 @@
 // like the originals (mm_hh.py:220-225).
 #pragma once
 
-#include "lsoda_core.h"
+#include "ode_kernel.h"   // lsoda_core.h, StridedRow
 
 // Each model is a functor.  `prepare(p)` reads the parameter row once (any indexable row: a plain
 // array on the host, a strided view of the transposed device table in the kernel) and caches what the
@@ -27,12 +27,6 @@ KN_HD double kn_fmod_period(double t, double period) {
   return fmod(t, period);
 }
 
-template <int S>
-struct StridedRow {   // p[j] of dof q in a [column][dof] table: base + j * S
-  double* b;
-  size_t stride;
-  KN_HD double& operator[](int j) const { return b[(size_t)j * stride]; }
-};
 struct ModelHHSI {
   static constexpr int NS = 4, NP = 22;
   double E_Na, E_K, i_pump, gNa, gK, glNa, glK, Cm, stim;

@@ -97,6 +97,8 @@ SIGNATURES = {
     "knpemi_set_solution": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "knpemi_get_solution": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p]),
     "knpemi_ode_bind": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "knpemi_ode_bind_source": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]),
+    "knpemi_ode_compile_source": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]),
     "knpemi_ode_set_tables": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dbl_p, c_dbl_p]),
     "knpemi_ode_get_tables": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dbl_p, c_dbl_p]),
     "knpemi_ode_set_stimulus": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_u8_p, C.c_int, c_int_p, c_dbl_p]),

@@ -9,10 +9,13 @@ membrane dof running LSODA.
 
 Membrane-model plug-ins keep the reference's module protocol
 (`init_state_values`, `init_parameter_values`, `state_indices`,
-`parameter_indices`, `__name__`), but instead of a numba `cfunc`
-(`rhs_numba.address`, `odeSolver.py:96`) they name one of the RHS functions
-compiled into the library through a `MODEL_ID` attribute ("hh_si", "hh_mv",
-"glial"); arbitrary Python RHS code cannot run on the device.
+`parameter_indices`, `__name__`).  Where the reference takes the address of a
+numba `cfunc` (`rhs_numba.address`, `odeSolver.py:96`) -- a host function a GPU
+cannot call -- a plug-in here either names one of the right-hand sides compiled
+into the library (`MODEL_ID` = "hh_si", "hh_mv" or "glial") or brings its own
+as HIP source in `RHS_HIP`: a `__device__ void rhs(double t, const double*
+states, double* values, double* parameters)` with the cfunc's semantics, compiled
+for gfx950 with hipRTC when the model is bound (csrc/kernels_rtc.hip).
 """
 from __future__ import annotations
 
@@ -58,12 +61,19 @@ class MembraneModel:
         if self._dp is dp:
             return
         model_id = getattr(self.ode, "MODEL_ID", None)
-        if model_id not in _MODEL_IDS:
+        source = getattr(self.ode, "RHS_HIP", None)
+        if model_id in _MODEL_IDS:
+            L.check(dp.lib.knpemi_ode_bind(dp.h, sub, model, _MODEL_IDS[model_id],
+                                           self.states.shape[1], self.parameters.shape[1]))
+        elif source is not None:
+            # the plug-in's own right-hand side, compiled for gfx950 now (a few seconds, cached per process)
+            L.check(dp.lib.knpemi_ode_bind_source(dp.h, sub, model, self.states.shape[1], self.parameters.shape[1],
+                                                  source.encode()))
+        else:
             raise NotImplementedError(
-                f"membrane model module '{self.prefix}' has no MODEL_ID naming a device RHS "
-                f"(one of {sorted(_MODEL_IDS)}); user-defined Python RHS functions cannot run on the GPU")
-        L.check(dp.lib.knpemi_ode_bind(dp.h, sub, model, _MODEL_IDS[model_id],
-                                       self.states.shape[1], self.parameters.shape[1]))
+                f"membrane model module '{self.prefix}' has neither a MODEL_ID naming a shipped device RHS "
+                f"(one of {sorted(_MODEL_IDS)}) nor its own RHS_HIP source; a numba / Python RHS is host code and "
+                f"cannot run on the GPU (see examples/benchmark/mm_glial.py for a plug-in with RHS_HIP)")
         self._dp, self._sub, self._model = dp, sub, model
         idx = []
         for name in ion_names:
