@@ -47,7 +47,7 @@ extern "C" {
 #define KNPEMI_MODEL_HH_MV 1
 #define KNPEMI_MODEL_GLIAL 2
 
-#define KNPEMI_MAX_IONS 3
+#define KNPEMI_MAX_IONS 4   /* ionic species K = 2..4, the last one eliminated (knpWeakForm.py:53,92,131) */
 #define KNPEMI_MAX_SUB 8
 #define KNPEMI_MAX_MODELS 4   /* membrane models per cellular sub-domain */
 
@@ -94,7 +94,7 @@ typedef struct {
   int32_t gdim;                      /* 2 or 3 */
   int32_t cell_kind;                 /* KNPEMI_TRIANGLE | TETRAHEDRON | HEXAHEDRON */
   int32_t n_sub;                     /* sub-domains, ECS first */
-  int32_t n_ions;                    /* K; the last ion is eliminated (run_3D.py:255-256) */
+  int32_t n_ions;                    /* K = 2..4; the last ion is eliminated (run_3D.py:255-256) */
   const int32_t* n_vert;             /* [n_sub] vertices (owned + ghost) of each sub-mesh */
   const int32_t* n_cell;             /* [n_sub] */
   const double* const* x;            /* [n_sub] -> n_vert*gdim, row-major */
@@ -247,10 +247,10 @@ int knpemi_trace(knpemi_handle* h, int sub, const double* u_e, const double* u_i
 /* Multi-GPU forward halo (owner -> ghost) of dof fields; replaces
  * Function.x.scatter_forward() (utils.py:100,199,204,254,293).  idx_dev / buf_dev are DEVICE pointers
  * (the caller moves buf between GPUs, e.g. torch.distributed send/recv over RCCL).
- * kind 0 (bulk): idx = global vertex ids (sub-mesh vertex + offset of its sub-domain), 4 doubles per
- *   entry: c_prev[0], c_prev[1], c_eliminated, phi;
+ * kind 0 (bulk): idx = global vertex ids (sub-mesh vertex + offset of its sub-domain), 5 doubles per
+ *   entry: the K concentrations (solved ones as c_prev, the eliminated one last) and phi;
  * kind 1 (membrane): idx = global Q-dof ids, 1 + 3*n_model_slots doubles per entry: phi_M_prev and
- *   the I_ch_k of every membrane model. */
+ *   the I_ch_k (KNPEMI_MAX_IONS slots per model) of every membrane model. */
 int knpemi_halo_width(knpemi_handle* h, int kind);
 int knpemi_halo_pack(knpemi_handle* h, int kind, const int32_t* idx_dev, int n, double* buf_dev);
 int knpemi_halo_unpack(knpemi_handle* h, int kind, const int32_t* idx_dev, int n, const double* buf_dev);

@@ -24,14 +24,14 @@ __device__ __forceinline__ int logical_block(int bid, int nb) {
 }
 
 struct Rec {
-  double x, y, z, c0, c1, c2, phi;
+  double x, y, z, c[KN_MAXK], phi;   // c[k]: ion k (record slot KN_CSLOT(k))
 };
 
 __device__ __forceinline__ Rec load_rec(const double* __restrict__ VR, int v) {
   const double4* p = reinterpret_cast<const double4*>(VR) + 2 * (size_t)v;
   const double4 a = p[0], b = p[1];
   Rec r;
-  r.x = a.x; r.y = a.y; r.z = a.z; r.c0 = b.x; r.c1 = b.y; r.c2 = b.z; r.phi = b.w;
+  r.x = a.x; r.y = a.y; r.z = a.z; r.c[0] = b.x; r.c[1] = b.y; r.c[2] = b.z; r.c[3] = a.w; r.phi = b.w;
   return r;
 }
 
@@ -105,7 +105,7 @@ __device__ __forceinline__ double emi_membrane_entry_rhs(const KnDev& D, const K
     double gq = D.phiM[q];
     if (!(splitting & 1)) {
       double it = 0.0;
-      for (int k = 0; k < KN_MAXK; ++k) it += D.Ich[((size_t)ms * KN_MAXK + k) * D.NQtot + q];
+      for (int k = 0; k < C.K; ++k) it += D.Ich[((size_t)ms * KN_MAXK + k) * D.NQtot + q];
       gq -= it / C.C_phi;
     }
     gs += D.me_mass[(size_t)e * NF + bb] * gq;
@@ -164,14 +164,27 @@ __global__ void membrane_mass_kernel(KnDev D, int n_entries, int v_cells, const 
 // =============================================================================================
 #define KN_PREFETCH 8   // pair entries per lane fetched ahead into registers
 
-struct Rec6 {
-  double x, y, z, a, b, c;   // EMI: c_prev0, c_prev1, c_elim;  KNP: f0, f1 (= c_prev/dt + f_source), phi
+// staged record of a KNP row block: coordinates, f_k = c_prev_k / dt (+ f_source_k) of the KS solved ions, phi
+template <int KS>
+struct RecK {
+  double x, y, z, f[KS], c;   // c = phi
 };
 
-__device__ __forceinline__ Rec6 lds_rec(const double* recs, int i) {
-  const double2* p = reinterpret_cast<const double2*>(recs + (size_t)i * 6);
-  const double2 u = p[0], v = p[1], w = p[2];
-  return Rec6{u.x, u.y, v.x, v.y, w.x, w.y};
+template <int KS>
+__device__ __forceinline__ RecK<KS> lds_rec(const double* recs, int i) {
+  RecK<KS> r;
+  if constexpr (KS == 2) {   // 48-byte records: three 16-byte LDS reads
+    const double2* p = reinterpret_cast<const double2*>(recs + (size_t)i * 6);
+    const double2 u = p[0], v = p[1], w = p[2];
+    r.x = u.x; r.y = u.y; r.z = v.x; r.f[0] = v.y; r.f[1] = w.x; r.c = w.y;
+  } else {
+    const double* p = recs + (size_t)i * (4 + KS);
+    r.x = p[0]; r.y = p[1]; r.z = p[2];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) r.f[k] = p[3 + k];
+    r.c = p[3 + KS];
+  }
+  return r;
 }
 
 template <int GDIM, class R>
@@ -241,7 +254,39 @@ __device__ __forceinline__ Rec5 lds_rec5(const double* recs, int i) {
   return Rec5{p[0], p[1], p[2], p[3], p[4]};
 }
 
-template <bool KNP>
+// one staged record from the 64-byte vertex record u (x y | z c3 | c0 c1 | c2 phi).  KS = 0: EMI (5 doubles),
+// KS >= 1: KNP with KS solved ions (4 + KS doubles).  fs / nvs: ECS source term (NULL when unused), v the vertex.
+template <int KS>
+__device__ __forceinline__ void write_staged(double* recs, int i, const double2 (&u)[4], double inv_dt, const double* fs0,
+                                             int nvs, int v, const KnSubConst* scp) {
+  if constexpr (KS == 0) {
+    double* d5 = recs + (size_t)i * 5;
+    const double c0 = u[2].x, c1 = u[2].y, c2 = u[3].x, c3 = u[1].y;   // ions beyond K have kap = sig = 0 (and c = 0)
+    d5[0] = u[0].x; d5[1] = u[0].y; d5[2] = u[1].x;
+    d5[3] = scp->kap[0] * c0 + scp->kap[1] * c1 + scp->kap[2] * c2 + scp->kap[3] * c3;
+    d5[4] = scp->sig[0] * c0 + scp->sig[1] * c1 + scp->sig[2] * c2 + scp->sig[3] * c3;
+  } else {
+    const double cp[3] = {u[2].x, u[2].y, u[3].x};     // the solved ions live in slots 4..6
+    double f[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      f[k] = cp[k] * inv_dt;                            // (1/dt) c_prev (+ f_source on the ECS)
+      if (fs0) f[k] += fs0[(size_t)k * nvs + v];
+    }
+    if constexpr (KS == 2) {
+      double2* dst = reinterpret_cast<double2*>(recs + (size_t)i * 6);
+      dst[0] = u[0]; dst[1] = double2{u[1].x, f[0]}; dst[2] = double2{f[1], u[3].y};
+    } else {
+      double* d = recs + (size_t)i * (4 + KS);
+      d[0] = u[0].x; d[1] = u[0].y; d[2] = u[1].x;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) d[3 + k] = f[k];
+      d[3 + KS] = u[3].y;
+    }
+  }
+}
+
+template <int KS>
 __device__ __forceinline__ void stage_records(const KnDev& D, const BlkInfo& B, double* recs, uint16_t* eloc, int tid,
                                               double inv_dt, const double* fs0, int nvs,
                                               const KnSubConst* scp = nullptr) {
@@ -257,39 +302,16 @@ __device__ __forceinline__ void stage_records(const KnDev& D, const BlkInfo& B, 
   for (int k = 0; k < KN_STAGE; ++k)
     if (vv[k] >= 0) {
       const double2* src = reinterpret_cast<const double2*>(D.VR + (size_t)vv[k] * KN_REC);
-      u[k][0] = src[0]; u[k][1] = src[1]; u[k][2] = src[2]; u[k][3] = src[3];   // x y | z _ | c0 c1 | c2 phi
+      u[k][0] = src[0]; u[k][1] = src[1]; u[k][2] = src[2]; u[k][3] = src[3];   // x y | z c3 | c0 c1 | c2 phi
     }
 #pragma unroll
   for (int k = 0; k < KN_STAGE; ++k)
-    if (vv[k] >= 0) {
-      double2* dst = reinterpret_cast<double2*>(recs + (size_t)(tid + k * KN_BLOCK) * 6);
-      if constexpr (KNP) {
-        double f0 = u[k][2].x * inv_dt, f1 = u[k][2].y * inv_dt;   // (1/dt) c_prev (+ f_source on the ECS)
-        if (fs0) { f0 += fs0[vv[k]]; f1 += fs0[nvs + vv[k]]; }
-        dst[0] = u[k][0]; dst[1] = double2{u[k][1].x, f0}; dst[2] = double2{f1, u[k][3].y};
-      } else {
-        double* d5 = recs + (size_t)(tid + k * KN_BLOCK) * 5;
-        const double c0 = u[k][2].x, c1 = u[k][2].y, c2 = u[k][3].x;
-        d5[0] = u[k][0].x; d5[1] = u[k][0].y; d5[2] = u[k][1].x;
-        d5[3] = scp->kap[0] * c0 + scp->kap[1] * c1 + scp->kap[2] * c2;
-        d5[4] = scp->sig[0] * c0 + scp->sig[1] * c1 + scp->sig[2] * c2;
-      }
-    }
+    if (vv[k] >= 0) write_staged<KS>(recs, tid + k * KN_BLOCK, u[k], inv_dt, fs0, nvs, vv[k], scp);
   for (int i = tid + KN_STAGE * KN_BLOCK; i < B.nuniq; i += KN_BLOCK) {   // oversized blocks only
     const int v = D.blk_uverts[B.uoff + i];
     const double2* src = reinterpret_cast<const double2*>(D.VR + (size_t)v * KN_REC);
-    const double2 u0 = src[0], u1 = src[1], u2 = src[2], u3 = src[3];
-    double2* dst = reinterpret_cast<double2*>(recs + (size_t)i * 6);
-    if constexpr (KNP) {
-      double f0 = u2.x * inv_dt, f1 = u2.y * inv_dt;
-      if (fs0) { f0 += fs0[v]; f1 += fs0[nvs + v]; }
-      dst[0] = u0; dst[1] = double2{u1.x, f0}; dst[2] = double2{f1, u3.y};
-    } else {
-      double* d5 = recs + (size_t)i * 5;
-      d5[0] = u0.x; d5[1] = u0.y; d5[2] = u1.x;
-      d5[3] = scp->kap[0] * u2.x + scp->kap[1] * u2.y + scp->kap[2] * u3.x;
-      d5[4] = scp->sig[0] * u2.x + scp->sig[1] * u2.y + scp->sig[2] * u3.x;
-    }
+    const double2 uu[4] = {src[0], src[1], src[2], src[3]};
+    write_staged<KS>(recs, i, uu, inv_dt, fs0, nvs, v, scp);
   }
 }
 
@@ -320,7 +342,7 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
   // phase A: zero accumulators, stage the records of the block's Laplacian entries
   for (int i = tid; i < seglen; i += KN_BLOCK) accA[i] = 0.0;
   const KnSubConst& sc = C.sc[s];
-  stage_records<false>(D, B, recs, eloc, tid, 0.0, nullptr, 0, &sc);
+  stage_records<0>(D, B, recs, eloc, tid, 0.0, nullptr, 0, &sc);
   __syncthreads();
 
   const bool cell_side = s > 0;
@@ -373,15 +395,14 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
   }
 }
 
-template <int GDIM, int LPR>
+template <int GDIM, int LPR, int KS>
 __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n, int rec_n) {
   constexpr int NV = GDIM + 1;
   const KnConsts& C = *Cp;
   extern __shared__ __align__(16) double lds[];
-  double* acc0 = lds;
-  double* acc1 = lds + acc_n;
-  double* recs = lds + 2 * (size_t)acc_n;
-  uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + 6 * (size_t)rec_n);
+  double* acc = lds;                                   // KS accumulator arrays of acc_n doubles, one per solved ion
+  double* recs = lds + (size_t)KS * acc_n;
+  uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + (size_t)(4 + KS) * rec_n + (((4 + KS) * rec_n) & 1));
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
   const BlkInfo B = load_blk(D, b, tid >> 6);
@@ -398,24 +419,31 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
   for (int p = 0; p < KN_PREFETCH; ++p)
     slr[p] = (valid && p < np) ? D.pair_sl[base + (int64_t)p * KN_SLICE] : 0xFFFFFFFFu;
   const int4 ri = D.row_info[g];
-  for (int i = tid; i < nnzLb; i += KN_BLOCK) { acc0[i] = 0.0; acc1[i] = 0.0; }
-  stage_records<true>(D, B, recs, eloc, tid, C.inv_dt, fs0, nvs);
+  for (int i = tid; i < nnzLb; i += KN_BLOCK) {
+#pragma unroll
+    for (int k = 0; k < KS; ++k) acc[(size_t)k * acc_n + i] = 0.0;
+  }
+  stage_records<KS>(D, B, recs, eloc, tid, C.inv_dt, fs0, nvs);
   __syncthreads();
 
   const KnSubConst& sc = C.sc[s];
-  double b0 = 0.0, b1 = 0.0;
+  double bk[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) bk[k] = 0.0;
   if (valid) {
     const int rL = ri.z;
     int diag = -1;
-    double d0 = 0.0, d1 = 0.0;   // diagonal entries of the two ion blocks, added once after the loop
-    Rec6 r[NV];
+    double dk[KS];   // diagonal entries of the ion blocks, added once after the loop
+#pragma unroll
+    for (int k = 0; k < KS; ++k) dk[k] = 0.0;
+    RecK<KS> r[NV];
     auto do_pair = [&](uint32_t sl) {
       int slot[NV];
 #pragma unroll
       for (int j = 0; j < NV; ++j) slot[j] = (sl >> (8 * j)) & 255;
-      if (diag < 0) { diag = slot[0]; r[0] = lds_rec(recs, eloc[rL + diag]); }
+      if (diag < 0) { diag = slot[0]; r[0] = lds_rec<KS>(recs, eloc[rL + diag]); }
 #pragma unroll
-      for (int j = 1; j < NV; ++j) r[j] = lds_rec(recs, eloc[rL + slot[j]]);
+      for (int j = 1; j < NV; ++j) r[j] = lds_rec<KS>(recs, eloc[rL + slot[j]]);
       double d[NV];
       const double vol = simplex_row0<GDIM>(r, d);
       double gp = 0;
@@ -423,16 +451,18 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
       for (int j = 0; j < NV; ++j) gp += r[j].c * d[j];
       const double m = vol * (1.0 / ((GDIM + 1) * (GDIM + 2)));
       const double drift = gp * vol * (1.0 / (GDIM + 1));
-      d0 += 2.0 * m * C.inv_dt + sc.D[0] * vol * d[0] + sc.zpsiD[0] * drift;
-      d1 += 2.0 * m * C.inv_dt + sc.D[1] * vol * d[0] + sc.zpsiD[1] * drift;
-      b0 += 2.0 * m * r[0].a;
-      b1 += 2.0 * m * r[0].b;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        dk[k] += 2.0 * m * C.inv_dt + sc.D[k] * vol * d[0] + sc.zpsiD[k] * drift;
+        bk[k] += 2.0 * m * r[0].f[k];
+      }
 #pragma unroll
       for (int j = 1; j < NV; ++j) {
-        unsafeAtomicAdd(&acc0[rL + slot[j]], m * C.inv_dt + sc.D[0] * vol * d[j] + sc.zpsiD[0] * drift);
-        unsafeAtomicAdd(&acc1[rL + slot[j]], m * C.inv_dt + sc.D[1] * vol * d[j] + sc.zpsiD[1] * drift);
-        b0 += m * r[j].a;
-        b1 += m * r[j].b;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          unsafeAtomicAdd(&acc[(size_t)k * acc_n + rL + slot[j]], m * C.inv_dt + sc.D[k] * vol * d[j] + sc.zpsiD[k] * drift);
+          bk[k] += m * r[j].f[k];
+        }
       }
     };
 #pragma unroll
@@ -443,31 +473,35 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
       if (sl != 0xFFFFFFFFu) do_pair(sl);
     }
     if (diag >= 0) {
-      unsafeAtomicAdd(&acc0[rL + diag], d0);
-      unsafeAtomicAdd(&acc1[rL + diag], d1);
+#pragma unroll
+      for (int k = 0; k < KS; ++k) unsafeAtomicAdd(&acc[(size_t)k * acc_n + rL + diag], dk[k]);
     }
     // membrane Robin/coupling contributions, written per (row, facet) entry by knp_membrane_kernel
     if (sub == 0) {
       const int ne = (unsigned)ri.y >> 16;
       for (int e = ri.w; e < ri.w + ne; ++e) {
-        const double2 gc = *reinterpret_cast<const double2*>(D.gam_e + 2 * (size_t)e);
-        b0 += gc.x;
-        b1 += gc.y;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) bk[k] += D.gam_e[(size_t)KS * e + k];
       }
     }
   }
 #pragma unroll
-  for (int m = 1; m < LPR; m <<= 1) { b0 += __shfl_xor(b0, m); b1 += __shfl_xor(b1, m); }
+  for (int m = 1; m < LPR; m <<= 1) {
+#pragma unroll
+    for (int k = 0; k < KS; ++k) bk[k] += __shfl_xor(bk[k], m);
+  }
   if (valid && sub == 0) {
-    const size_t bb = (size_t)(KN_MAXK - 1) * v0 + (size_t)(g - v0);
-    D.b_knp[bb] = b0;
-    D.b_knp[bb + nvs] = b1;
+    const size_t bb = (size_t)KS * v0 + (size_t)(g - v0);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) D.b_knp[bb + (size_t)k * nvs] = bk[k];
   }
   __syncthreads();
   const int64_t subnnz0 = D.rowptrL[v0], subnnz = D.rowptrL[v0 + nvs] - subnnz0;
-  double* out0 = D.A_knp + (size_t)(KN_MAXK - 1) * subnnz0 + (segL0 - subnnz0);
-  double* out1 = out0 + subnnz;
-  for (int i = tid; i < nnzLb; i += KN_BLOCK) { out0[i] = acc0[i]; out1[i] = acc1[i]; }
+  double* out0 = D.A_knp + (size_t)KS * subnnz0 + (segL0 - subnnz0);
+  for (int i = tid; i < nnzLb; i += KN_BLOCK) {
+#pragma unroll
+    for (int k = 0; k < KS; ++k) out0[(size_t)k * subnnz + i] = acc[(size_t)k * acc_n + i];
+  }
 }
 
 // =============================================================================================
@@ -662,8 +696,8 @@ __device__ __forceinline__ void hex_emi_row(const Rec5 (&r)[8], int li, double (
 }
 
 // Row l of the KNP element matrices: M = mass, S = stiffness, Cc = drift (grad phi . grad N_l) N_j
-template <bool AFFINE>
-__device__ __forceinline__ void hex_knp_row(const Rec6 (&r)[8], int li, double (&M)[8], double (&S)[8], double (&Cc)[8]) {
+template <bool AFFINE, class R8>
+__device__ __forceinline__ void hex_knp_row(const R8 (&r)[8], int li, double (&M)[8], double (&S)[8], double (&Cc)[8]) {
   double phi[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { phi[j] = r[j].c; M[j] = 0.0; S[j] = 0.0; Cc[j] = 0.0; }
@@ -716,7 +750,7 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
   const int4 ri = D.row_info[g];
   for (int i = tid; i < seglen; i += KN_BLOCK) accA[i] = 0.0;
   const KnSubConst& sc = C.sc[s];
-  stage_records<false>(D, B, recs, eloc, tid, 0.0, nullptr, 0, &sc);
+  stage_records<0>(D, B, recs, eloc, tid, 0.0, nullptr, 0, &sc);
   __syncthreads();
 
   const bool cell_side = s > 0;
@@ -755,14 +789,13 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
   }
 }
 
-template <int LPR, bool AFFINE>
+template <int LPR, bool AFFINE, int KS>
 __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n, int rec_n) {
   const KnConsts& C = *Cp;
   extern __shared__ __align__(16) double lds[];
-  double* acc0 = lds;
-  double* acc1 = lds + acc_n;
-  double* recs = lds + 2 * (size_t)acc_n;
-  uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + 6 * (size_t)rec_n);
+  double* acc = lds;
+  double* recs = lds + (size_t)KS * acc_n;
+  uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + (size_t)(4 + KS) * rec_n + (((4 + KS) * rec_n) & 1));
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
   const BlkInfo B = load_blk(D, b, tid >> 6);
@@ -781,12 +814,17 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDe
     sl0 = *reinterpret_cast<const uint2*>(D.pair_slots + 2 * base);
   }
   const int4 ri = D.row_info[g];
-  for (int i = tid; i < nnzLb; i += KN_BLOCK) { acc0[i] = 0.0; acc1[i] = 0.0; }
-  stage_records<true>(D, B, recs, eloc, tid, C.inv_dt, fs0, nvs);
+  for (int i = tid; i < nnzLb; i += KN_BLOCK) {
+#pragma unroll
+    for (int k = 0; k < KS; ++k) acc[(size_t)k * acc_n + i] = 0.0;
+  }
+  stage_records<KS>(D, B, recs, eloc, tid, C.inv_dt, fs0, nvs);
   __syncthreads();
 
   const KnSubConst& sc = C.sc[s];
-  double b0 = 0.0, b1 = 0.0;
+  double bk[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) bk[k] = 0.0;
   if (valid) {
     const int rL = ri.z;
     auto do_pair = [&](int pc, uint2 sl) {
@@ -794,17 +832,18 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDe
       int slot[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) { slot[j] = (sl.x >> (8 * j)) & 255; slot[4 + j] = (sl.y >> (8 * j)) & 255; }
-      Rec6 r[8];
+      RecK<KS> r[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) r[j] = lds_rec(recs, eloc[rL + slot[j]]);
+      for (int j = 0; j < 8; ++j) r[j] = lds_rec<KS>(recs, eloc[rL + slot[j]]);
       double M[8], S[8], Cc[8];
       hex_knp_row<AFFINE>(r, li, M, S, Cc);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        unsafeAtomicAdd(&acc0[rL + slot[j]], M[j] * C.inv_dt + sc.D[0] * S[j] + sc.zpsiD[0] * Cc[j]);
-        unsafeAtomicAdd(&acc1[rL + slot[j]], M[j] * C.inv_dt + sc.D[1] * S[j] + sc.zpsiD[1] * Cc[j]);
-        b0 += M[j] * r[j].a;
-        b1 += M[j] * r[j].b;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          unsafeAtomicAdd(&acc[(size_t)k * acc_n + rL + slot[j]], M[j] * C.inv_dt + sc.D[k] * S[j] + sc.zpsiD[k] * Cc[j]);
+          bk[k] += M[j] * r[j].f[k];
+        }
       }
     };
     if (pc0 >= 0) do_pair(pc0, sl0);
@@ -816,24 +855,28 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDe
     if (sub == 0) {
       const int ne = (unsigned)ri.y >> 16;
       for (int e = ri.w; e < ri.w + ne; ++e) {
-        const double2 gc = *reinterpret_cast<const double2*>(D.gam_e + 2 * (size_t)e);
-        b0 += gc.x;
-        b1 += gc.y;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) bk[k] += D.gam_e[(size_t)KS * e + k];
       }
     }
   }
 #pragma unroll
-  for (int m = 1; m < LPR; m <<= 1) { b0 += __shfl_xor(b0, m); b1 += __shfl_xor(b1, m); }
+  for (int m = 1; m < LPR; m <<= 1) {
+#pragma unroll
+    for (int k = 0; k < KS; ++k) bk[k] += __shfl_xor(bk[k], m);
+  }
   if (valid && sub == 0) {
-    const size_t bb = (size_t)(KN_MAXK - 1) * v0 + (size_t)(g - v0);
-    D.b_knp[bb] = b0;
-    D.b_knp[bb + nvs] = b1;
+    const size_t bb = (size_t)KS * v0 + (size_t)(g - v0);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) D.b_knp[bb + (size_t)k * nvs] = bk[k];
   }
   __syncthreads();
   const int64_t subnnz0 = D.rowptrL[v0], subnnz = D.rowptrL[v0 + nvs] - subnnz0;
-  double* out0 = D.A_knp + (size_t)(KN_MAXK - 1) * subnnz0 + (segL0 - subnnz0);
-  double* out1 = out0 + subnnz;
-  for (int i = tid; i < nnzLb; i += KN_BLOCK) { out0[i] = acc0[i]; out1[i] = acc1[i]; }
+  double* out0 = D.A_knp + (size_t)KS * subnnz0 + (segL0 - subnnz0);
+  for (int i = tid; i < nnzLb; i += KN_BLOCK) {
+#pragma unroll
+    for (int k = 0; k < KS; ++k) out0[(size_t)k * subnnz + i] = acc[(size_t)k * acc_n + i];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -856,17 +899,19 @@ __global__ __launch_bounds__(256) void knp_membrane_kernel(KnDev D, const KnCons
   const double* qdN = qt + nq * (1 + NF);
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 2 * D.nftot) return;
+  const int K = C.K, KS = K - 1;
   const int fg = t >> 1;
   const bool cell_side = t & 1;
   const int ms = D.fmodel[fg];
   const int* pos = D.gam_pos + (size_t)t * NF;   // entry of (facet, side, local vertex) in the membrane row lists
   if (ms < 0) {
 #pragma unroll
-    for (int a = 0; a < NF; ++a) *reinterpret_cast<double2*>(D.gam_e + 2 * (size_t)pos[a]) = double2{0.0, 0.0};
+    for (int a = 0; a < NF; ++a)
+      for (int k = 0; k < KS; ++k) D.gam_e[(size_t)KS * pos[a] + k] = 0.0;
     return;
   }
   Rec pe[NF], pi[NF];
-  double pm[NF], I0[NF], I1[NF], It[NF];
+  double pm[NF], Ik[NF][KN_MAXK], It[NF];
   int si = 0;  // sub-domain of the cell side of this facet
 #pragma unroll
   for (int bb = 0; bb < NF; ++bb) {
@@ -876,27 +921,36 @@ __global__ __launch_bounds__(256) void knp_membrane_kernel(KnDev D, const KnCons
     const int q = D.fq[(size_t)fg * NF + bb];
     pm[bb] = D.phiM[q];
     const double* ich = D.Ich + (size_t)ms * KN_MAXK * D.NQtot + q;
-    I0[bb] = ich[0];
-    I1[bb] = ich[D.NQtot];
-    It[bb] = I0[bb] + I1[bb] + ich[2 * (size_t)D.NQtot];
+    double it = 0.0;
+#pragma unroll
+    for (int k = 0; k < KN_MAXK; ++k) {
+      Ik[bb][k] = k < K ? ich[(size_t)k * D.NQtot] : 0.0;
+      it += Ik[bb][k];
+    }
+    It[bb] = it;
     if (bb == 0) for (int tt = 1; tt < C.n_sub; ++tt) si += vi >= C.voff[tt];
   }
   const KnSubConst& so = C.sc[cell_side ? si : 0];   // own-side constants
   double meas = 0.0;
   if constexpr (NF != 4) meas = facet_measure<NF>(pe);
-  double acc0[NF], acc1[NF];
+  double acc[NF][KN_MAXK - 1];
 #pragma unroll
-  for (int a = 0; a < NF; ++a) { acc0[a] = 0.0; acc1[a] = 0.0; }
+  for (int a = 0; a < NF; ++a)
+#pragma unroll
+    for (int k = 0; k < KN_MAXK - 1; ++k) acc[a][k] = 0.0;
   const double sgn = cell_side ? 1.0 : -1.0;
   for (int q = 0; q < nq; ++q) {
-    double c0 = 0, c1 = 0, c2 = 0, ph_e = 0, ph_i = 0, pmq = 0, i0 = 0, i1 = 0, it = 0;
+    double cq[KN_MAXK], iq[KN_MAXK], ph_e = 0, ph_i = 0, pmq = 0, it = 0;
+#pragma unroll
+    for (int k = 0; k < KN_MAXK; ++k) { cq[k] = 0.0; iq[k] = 0.0; }
 #pragma unroll
     for (int bb = 0; bb < NF; ++bb) {
       const double N = qN[q * NF + bb];
       const Rec& o = cell_side ? pi[bb] : pe[bb];
-      c0 += N * o.c0; c1 += N * o.c1; c2 += N * o.c2;
+#pragma unroll
+      for (int k = 0; k < KN_MAXK; ++k) { cq[k] += N * o.c[k]; iq[k] += N * Ik[bb][k]; }
       ph_e += N * pe[bb].phi; ph_i += N * pi[bb].phi;
-      pmq += N * pm[bb]; i0 += N * I0[bb]; i1 += N * I1[bb]; it += N * It[bb];
+      pmq += N * pm[bb]; it += N * It[bb];
     }
     double wq;
     if constexpr (NF == 4) {
@@ -913,32 +967,28 @@ __global__ __launch_bounds__(256) void knp_membrane_kernel(KnDev D, const KnCons
     } else {
       wq = qw[q] * meas * (NF == 2 ? 1.0 : 2.0);  // reference measure 1 (interval), 1/2 (triangle)
     }
-    const double asum = so.az2D[0] * c0 + so.az2D[1] * c1 + so.az2D[2] * c2;
-    const double jump = ph_i - ph_e;
-    double f0, f1;
-    {
-      const double al = so.az2D[0] * c0 / asum;
-      const double Cc = al * C.C_M / (C.F * C.z[0] * C.dt);
-      double gr = pmq - C.dt / (C.C_M * al) * i0;
-      if (splitting) gr += (C.dt / C.C_M) * it;
-      f0 = wq * sgn * (Cc * gr - Cc * jump);
-    }
-    {
-      const double al = so.az2D[1] * c1 / asum;
-      const double Cc = al * C.C_M / (C.F * C.z[1] * C.dt);
-      double gr = pmq - C.dt / (C.C_M * al) * i1;
-      if (splitting) gr += (C.dt / C.C_M) * it;
-      f1 = wq * sgn * (Cc * gr - Cc * jump);
-    }
+    double asum = 0.0;      // sum over ALL K ions (knpWeakForm.py:97); az2D = 0 beyond K
 #pragma unroll
-    for (int a = 0; a < NF; ++a) {
-      const double Na = qN[q * NF + a];
-      acc0[a] += Na * f0;
-      acc1[a] += Na * f1;
+    for (int k = 0; k < KN_MAXK; ++k) asum += so.az2D[k] * cq[k];
+    const double jump = ph_i - ph_e;
+#pragma unroll
+    for (int k = 0; k < KN_MAXK - 1; ++k) {
+      if (k < KS) {
+        const double al = so.az2D[k] * cq[k] / asum;
+        const double Cc = al * C.C_M / (C.F * C.z[k] * C.dt);
+        double gr = pmq - C.dt / (C.C_M * al) * iq[k];
+        if (splitting) gr += (C.dt / C.C_M) * it;
+        const double fk = wq * sgn * (Cc * gr - Cc * jump);
+#pragma unroll
+        for (int a = 0; a < NF; ++a) acc[a][k] += qN[q * NF + a] * fk;
+      }
     }
   }
 #pragma unroll
-  for (int a = 0; a < NF; ++a) *reinterpret_cast<double2*>(D.gam_e + 2 * (size_t)pos[a]) = double2{acc0[a], acc1[a]};
+  for (int a = 0; a < NF; ++a)
+#pragma unroll
+    for (int k = 0; k < KN_MAXK - 1; ++k)
+      if (k < KS) D.gam_e[(size_t)KS * pos[a] + k] = acc[a][k];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -983,12 +1033,15 @@ __global__ void update_pde_kernel(KnDev D, const KnConsts* __restrict__ Cp) {
   if (i < D.Ntot) {
     int s = 0;
     for (int t = 1; t < C.n_sub; ++t) s += i >= C.voff[t];
-    const double c0 = D.csol[i], c1 = D.csol[(size_t)D.Ntot + i];
+    const int KS = C.K - 1;
+    double* rec = D.VR + (size_t)i * KN_REC;  // the phi component is left untouched
     double el = C.sc[s].rho_term;
-    el += C.elim_coef[0] * c0;
-    el += C.elim_coef[1] * c1;
-    double* rec = D.VR + (size_t)i * KN_REC + 4;  // the phi component is left untouched
-    rec[0] = c0; rec[1] = c1; rec[2] = el;
+    for (int k = 0; k < KS; ++k) {
+      const double ck = D.csol[(size_t)k * D.Ntot + i];
+      el += C.elim_coef[k] * ck;
+      rec[KN_CSLOT(k)] = ck;
+    }
+    rec[KN_CSLOT(KS)] = el;
   }
   if (i < D.NQtot) D.phiM[i] = D.VR[(size_t)D.q2i[i] * KN_REC + 7] - D.VR[(size_t)D.q2e[i] * KN_REC + 7];
 }
@@ -1002,15 +1055,17 @@ __global__ void knp_writeback_update_kernel(KnDev D, const KnConsts* __restrict_
     int s = 0;
     for (int t = 1; t < C.n_sub; ++t) s += i >= C.voff[t];
     const int v0 = C.voff[s], nv = C.voff[s + 1] - v0;
-    const size_t xb = (size_t)(KN_MAXK - 1) * v0 + (size_t)(i - v0);
-    const double c0 = x[xb], c1 = x[xb + nv];
-    D.csol[i] = c0;
-    D.csol[(size_t)D.Ntot + i] = c1;
+    const int KS = C.K - 1;
+    const size_t xb = (size_t)KS * v0 + (size_t)(i - v0);
+    double* rec = D.VR + (size_t)i * KN_REC;
     double el = C.sc[s].rho_term;
-    el += C.elim_coef[0] * c0;
-    el += C.elim_coef[1] * c1;
-    double* rec = D.VR + (size_t)i * KN_REC + 4;
-    rec[0] = c0; rec[1] = c1; rec[2] = el;
+    for (int k = 0; k < KS; ++k) {
+      const double ck = x[xb + (size_t)k * nv];
+      D.csol[(size_t)k * D.Ntot + i] = ck;
+      el += C.elim_coef[k] * ck;
+      rec[KN_CSLOT(k)] = ck;
+    }
+    rec[KN_CSLOT(KS)] = el;
   }
   if (i < D.NQtot) D.phiM[i] = D.VR[(size_t)D.q2i[i] * KN_REC + 7] - D.VR[(size_t)D.q2e[i] * KN_REC + 7];
 }
@@ -1021,11 +1076,11 @@ __global__ void halo_kernel(KnDev D, int kind, int pack, const int* __restrict__
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int g = idx[i];
-  if (kind == 0) {
-    double* rec = D.VR + (size_t)g * KN_REC + 4;
-    double* b = buf + (size_t)i * 4;
+  if (kind == 0) {   // record slots 3..7: every concentration (K <= 4) and phi
+    double* rec = D.VR + (size_t)g * KN_REC + 3;
+    double* b = buf + (size_t)i * 5;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 5; ++c) {
       if (pack) b[c] = rec[c];
       else rec[c] = b[c];
     }
@@ -1111,21 +1166,23 @@ template <int GDIM>
 static int launch_knp_v2(knpemi_handle* h) {
   const KnDev& D = h->dev;
   const int acc_n = (h->lds_doubles_knp + 1) & ~1, rec_n = h->lds_uniq_max;
-  const size_t lds = ((size_t)2 * acc_n + 6 * (size_t)rec_n) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
+  const int KS = h->K - 1;
+  const size_t lds = ((size_t)KS * acc_n + (4 + KS) * (size_t)rec_n + 1) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
   if (lds > 160 * 1024) { kn_set_error("KNP row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   dim3 grid(D.nblocks), block(KN_BLOCK);
   int rc = 0;
-#define KN_CASE(L)                                                                                  \
-  case L:                                                                                           \
-    if ((rc = set_lds_limit(knp_rows_v2<GDIM, L>, lds))) return rc;                                 \
-    {                                                                                               \
-      KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                       \
-      hipLaunchKernelGGL((knp_rows_v2<GDIM, L>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n); \
-    }                                                                                               \
-    break;
-  switch (h->lpr) { KN_CASE(1) KN_CASE(2) KN_CASE(4) KN_CASE(8) default: kn_set_error("bad lanes-per-row"); return KNPEMI_EINVAL; }
+#define KN_CASE(L, S)                                                                               \
+  if (h->lpr == L && KS == S) {                                                                     \
+    if ((rc = set_lds_limit(knp_rows_v2<GDIM, L, S>, lds))) return rc;                              \
+    KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                         \
+    hipLaunchKernelGGL((knp_rows_v2<GDIM, L, S>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n); \
+    return check_launch("knp_rows_v2");                                                             \
+  }
+  // lanes per row: 2 (triangles) or 4 by default, KNPEMI_LPR for experiments; K - 1 = 1..3 solved ions
+  KN_CASE(2, 2) KN_CASE(4, 2) KN_CASE(1, 2) KN_CASE(8, 2) KN_CASE(2, 1) KN_CASE(4, 1) KN_CASE(2, 3) KN_CASE(4, 3)
 #undef KN_CASE
-  return check_launch("knp_rows_v2");
+  kn_set_error("knp_rows: unsupported lanes-per-row / ion-count combination");
+  return KNPEMI_EINVAL;
 }
 
 static int launch_emi_hex_v2(knpemi_handle* h, int want_p, int split) {
@@ -1155,24 +1212,23 @@ static int launch_emi_hex_v2(knpemi_handle* h, int want_p, int split) {
 static int launch_knp_hex_v2(knpemi_handle* h) {
   const KnDev& D = h->dev;
   const int acc_n = (h->lds_doubles_knp + 1) & ~1, rec_n = h->lds_uniq_max;
-  const size_t lds = ((size_t)2 * acc_n + 6 * (size_t)rec_n) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
+  const int KS = h->K - 1;
+  const size_t lds = ((size_t)KS * acc_n + (4 + KS) * (size_t)rec_n + 1) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
   if (lds > 160 * 1024) { kn_set_error("KNP row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   dim3 grid(D.nblocks), block(KN_BLOCK);
   int rc = 0;
-#define KN_CASE2(L, AFF)                                                                            \
-    if ((rc = set_lds_limit(knp_rows_hex_v2<L, AFF>, lds))) return rc;                              \
-    {                                                                                               \
-      KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                       \
-      hipLaunchKernelGGL((knp_rows_hex_v2<L, AFF>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n); \
-    }
-#define KN_CASE(L)                                                                                  \
-  case L:                                                                                           \
-    if (h->hex_affine) { KN_CASE2(L, true) } else { KN_CASE2(L, false) }                            \
-    break;
-  switch (h->lpr) { KN_CASE(1) KN_CASE(2) KN_CASE(4) KN_CASE(8) default: kn_set_error("bad lanes-per-row"); return KNPEMI_EINVAL; }
+#define KN_CASE(L, AFF, S)                                                                          \
+  if (h->lpr == L && h->hex_affine == AFF && KS == S) {                                             \
+    if ((rc = set_lds_limit(knp_rows_hex_v2<L, AFF, S>, lds))) return rc;                           \
+    KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                         \
+    hipLaunchKernelGGL((knp_rows_hex_v2<L, AFF, S>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n); \
+    return check_launch("knp_rows_hex_v2");                                                         \
+  }
+  KN_CASE(4, true, 2) KN_CASE(4, false, 2) KN_CASE(2, true, 2) KN_CASE(2, false, 2) KN_CASE(8, true, 2) KN_CASE(8, false, 2)
+  KN_CASE(1, true, 2) KN_CASE(1, false, 2) KN_CASE(4, true, 1) KN_CASE(4, false, 1) KN_CASE(4, true, 3) KN_CASE(4, false, 3)
 #undef KN_CASE
-#undef KN_CASE2
-  return check_launch("knp_rows_hex_v2");
+  kn_set_error("knp_rows (hexahedra): unsupported lanes-per-row / ion-count combination");
+  return KNPEMI_EINVAL;
 }
 
 int kn_launch_emi_rows(knpemi_handle* h, int flags) {

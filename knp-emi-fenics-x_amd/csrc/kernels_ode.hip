@@ -62,8 +62,8 @@ int kn_launch_ode_step(knpemi_handle* h, int slot, double t0, double dt, double 
   if (rc) return rc;
   OdeArgs a;
   a.nq = m.nq; a.q0 = h->qoff[m.sub]; a.n_stim = m.n_stim; a.flags = flags; a.v_index = v_index;
-  a.model_slot = slot; a.NQtot = h->dev.NQtot;
-  for (int i = 0; i < 3 * KN_MAXK; ++i) a.ion_param[i] = ion_param[i];
+  a.model_slot = slot; a.NQtot = h->dev.NQtot; a.n_ions = h->K;
+  for (int i = 0; i < 3 * KN_MAXK; ++i) a.ion_param[i] = i < 3 * h->K ? ion_param[i] : 0;
   for (int i = 0; i < 8; ++i) { a.stim_idx[i] = m.stim_idx[i]; a.stim_val[i] = m.stim_val[i]; }
   a.t0 = t0; a.dt = dt; a.rtol = rtol; a.atol = atol;
   a.states = m.d_states; a.params = m.d_params; a.mask = m.d_mask; a.stats = m.d_stats;

@@ -105,9 +105,9 @@ int kn_gamma_quadrature(int NF, std::vector<double>* out) {
 extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_handle** out) {
   if (!d || !out) return fail(KNPEMI_EINVAL, "knpemi_create: null argument");
   *out = nullptr;
-  if (d->n_ions != KN_MAXK)
-    return fail(KNPEMI_EINVAL, "knpemi_create: exactly 3 ionic species (2 solved + 1 eliminated) "
-                               "are supported, as in every reference driver (run_3D.py:256)");
+  if (d->n_ions < 2 || d->n_ions > KN_MAXK)
+    return fail(KNPEMI_EINVAL, "knpemi_create: 2 to 4 ionic species (the last one eliminated) are supported; the "
+                               "reference drivers use 3 (run_3D.py:256)");
   if (d->n_sub < 1 || d->n_sub > KN_MAXSUB) return fail(KNPEMI_EINVAL, "knpemi_create: bad n_sub");
   int NV, NF;
   if (d->cell_kind == KNPEMI_TRIANGLE && d->gdim == 2) { NV = 3; NF = 2; }
@@ -558,8 +558,8 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   if ((rc = dev_zeros(h, (size_t)(K - 1) * D.nnzL, &D.A_knp))) return rc;
   if ((rc = dev_zeros(h, (size_t)(K - 1) * Ntot, &D.b_knp))) return rc;
   if ((rc = dev_zeros(h, (size_t)NQtot, &D.phiM))) return rc;
-  if ((rc = dev_zeros(h, std::max<size_t>(1, mentry.size()) * 2, &D.gam_e))) return rc;
-  if ((rc = dev_zeros(h, (size_t)std::max(1, h->moff[S]) * K * std::max(1, NQtot), &D.Ich))) return rc;
+  if ((rc = dev_zeros(h, std::max<size_t>(1, mentry.size()) * (size_t)(K - 1), &D.gam_e))) return rc;
+  if ((rc = dev_zeros(h, (size_t)std::max(1, h->moff[S]) * KN_MAXK * std::max(1, NQtot), &D.Ich))) return rc;
   {
     std::vector<int> krp((size_t)(K - 1) * Ntot + 1, 0), kci((size_t)(K - 1) * colindL.size());
     int64_t row = 0, pos = 0;
@@ -692,8 +692,8 @@ int locate(knpemi_handle* h, int field, int sub, int idx, FieldLoc* loc) {
     case KNPEMI_F_PHI: *loc = {D.VR + v0 * KN_REC + 7, KN_REC, nv}; return 0;
     case KNPEMI_F_C_PREV:
       if (idx < 0 || idx >= K - 1) return fail(KNPEMI_EINVAL, "field: bad ion index");
-      *loc = {D.VR + v0 * KN_REC + 4 + idx, KN_REC, nv}; return 0;
-    case KNPEMI_F_C_ELIM: *loc = {D.VR + v0 * KN_REC + 4 + (K - 1), KN_REC, nv}; return 0;
+      *loc = {D.VR + v0 * KN_REC + KN_CSLOT(idx), KN_REC, nv}; return 0;
+    case KNPEMI_F_C_ELIM: *loc = {D.VR + v0 * KN_REC + KN_CSLOT(K - 1), KN_REC, nv}; return 0;
     case KNPEMI_F_C:
       if (idx < 0 || idx >= K - 1) return fail(KNPEMI_EINVAL, "field: bad ion index");
       *loc = {D.csol + (size_t)idx * D.Ntot + v0, 1, nv}; return 0;
@@ -704,7 +704,7 @@ int locate(knpemi_handle* h, int field, int sub, int idx, FieldLoc* loc) {
       int m = idx / KN_MAXK, k = idx % KN_MAXK;
       if (sub == 0 || m < 0 || m >= h->n_models[sub] || k >= K)
         return fail(KNPEMI_EINVAL, "field: bad I_ch index");
-      *loc = {D.Ich + ((size_t)(h->moff[sub] + m) * K + k) * std::max(1, D.NQtot) + q0, 1, nq};
+      *loc = {D.Ich + ((size_t)(h->moff[sub] + m) * KN_MAXK + k) * std::max(1, D.NQtot) + q0, 1, nq};
       return 0;
     }
     case KNPEMI_F_SOURCE:
@@ -1271,7 +1271,7 @@ extern "C" int knpemi_set_option(knpemi_handle* h, int option, int value) {
 
 extern "C" int knpemi_halo_width(knpemi_handle* h, int kind) {
   if (!h) return KNPEMI_EINVAL;
-  return kind == 0 ? 4 : 1 + KN_MAXK * h->moff[h->n_sub];
+  return kind == 0 ? 5 : 1 + KN_MAXK * h->moff[h->n_sub];
 }
 
 extern "C" int knpemi_halo_pack(knpemi_handle* h, int kind, const int32_t* idx_dev, int n, double* buf_dev) {

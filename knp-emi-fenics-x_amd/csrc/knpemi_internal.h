@@ -13,7 +13,9 @@
 
 #define KN_MAXK KNPEMI_MAX_IONS
 #define KN_MAXSUB KNPEMI_MAX_SUB
-#define KN_REC 8          // doubles per vertex record: x y z _ | c0 c1 c_elim phi
+#define KN_REC 8          // doubles per vertex record: x y z c3 | c0 c1 c2 phi  (ion k lives in slot KN_CSLOT(k);
+                          // K = 3: c2 is the eliminated ion and slot 3 is unused, as in every reference driver)
+#define KN_CSLOT(k) ((k) < 3 ? 4 + (k) : 3)
 #define KN_BLOCK 256          // threads per row-kernel workgroup (rows per block = KN_BLOCK / lanes-per-row)
 #define KN_SLICE 64       // rows per sliced-ELL slice == wavefront width on gfx950
 

@@ -6,8 +6,9 @@
 
 #include "lsoda_core.h"
 
-#define KN_ODE_MAXK 3     // == KNPEMI_MAX_IONS
-#define KN_ODE_REC 8      // == KN_REC: doubles per vertex record, concentrations at 4..6
+#define KN_ODE_MAXK 4     // == KNPEMI_MAX_IONS
+#define KN_ODE_REC 8      // == KN_REC: doubles per vertex record, ion k in slot KN_ODE_CSLOT(k)
+#define KN_ODE_CSLOT(k) ((k) < 3 ? 4 + (k) : 3)
 
 // the slice of the device problem the sweep touches
 struct OdeDev {
@@ -19,7 +20,7 @@ struct OdeDev {
 };
 
 struct OdeArgs {
-  int nq, q0, n_stim, flags, v_index, model_slot, NQtot;
+  int nq, q0, n_stim, flags, v_index, model_slot, NQtot, n_ions;
   int ion_param[3 * KN_ODE_MAXK];
   int stim_idx[8];
   double stim_val[8];
@@ -76,11 +77,11 @@ __device__ __forceinline__ void ode_step_body(const OdeDev& D, const OdeArgs& a,
   // 1. concentration traces (record components 4..6 hold c_0, c_1, c_eliminated) -> parameter columns.
   //    With several lanes per dof every lane writes the same values and later reads only its own stores.
   if (a.flags & KN_ODE_SET_TRACES) {
-    const double* re = D.VR + (size_t)D.q2e[qg] * KN_ODE_REC + 4;
-    const double* ri = D.VR + (size_t)D.q2i[qg] * KN_ODE_REC + 4;
-    for (int k = 0; k < KN_ODE_MAXK; ++k) {
-      p[a.ion_param[3 * k]] = re[k];
-      p[a.ion_param[3 * k + 1]] = ri[k];
+    const double* re = D.VR + (size_t)D.q2e[qg] * KN_ODE_REC;
+    const double* ri = D.VR + (size_t)D.q2i[qg] * KN_ODE_REC;
+    for (int k = 0; k < a.n_ions; ++k) {
+      p[a.ion_param[3 * k]] = re[KN_ODE_CSLOT(k)];
+      p[a.ion_param[3 * k + 1]] = ri[KN_ODE_CSLOT(k)];
     }
   }
   if (a.flags & KN_ODE_SET_V) {
@@ -107,7 +108,7 @@ __device__ __forceinline__ void ode_step_body(const OdeDev& D, const OdeArgs& a,
   }
   if (owner) {
     s.f.finish(p);
-    for (int k = 0; k < KN_ODE_MAXK; ++k)
+    for (int k = 0; k < a.n_ions; ++k)
       D.Ich[((size_t)a.model_slot * KN_ODE_MAXK + k) * a.NQtot + qg] = p[a.ion_param[3 * k + 2]];
   }
   // counters: summed over the wave, then added to this workgroup's own slot -- no atomics (thousands of atomic adds

@@ -17,7 +17,7 @@ OK, EINVAL, EHIP, ENOMEM, EODE, ESOLVE = 0, -1, -2, -3, -4, -5
 PC_JACOBI, PC_AMG = 0, 1
 TRIANGLE, TETRAHEDRON, HEXAHEDRON = 0, 1, 2
 MODEL_HH_SI, MODEL_HH_MV, MODEL_GLIAL = 0, 1, 2
-MAX_IONS, MAX_SUB, MAX_MODELS = 3, 8, 4
+MAX_IONS, MAX_SUB, MAX_MODELS = 4, 8, 4
 F_PHI, F_C, F_C_PREV, F_C_ELIM, F_PHI_M, F_I_CH, F_SOURCE = range(7)
 A_EMI, P_EMI, A_KNP = 0, 1, 2
 B_EMI, B_KNP = 0, 1

@@ -134,7 +134,7 @@ class Halo:
         dev = torch.device("cuda", dp.device)
         self._device = dev
         n_slots = int(dp.n_models.sum())
-        self.width = {"bulk": 4, "mem": 1 + n_slots * L.MAX_IONS}
+        self.width = {"bulk": int(dp.lib.knpemi_halo_width(dp.h, 0)), "mem": int(dp.lib.knpemi_halo_width(dp.h, 1))}
         # The exchange mode is chosen ONCE, here, and agreed on by all ranks; a communication error during a run
         # propagates (the rank exits non-zero) instead of switching modes under a half-posted batch.
         #   "stream-ordered RCCL": pack kernel -> send/recv -> unpack kernel on the library's stream, no host sync
@@ -239,7 +239,7 @@ class Halo:
         """knpemi_solve_emi / knpemi_solve_knp on this handle become solves of the GLOBAL systems
         (knpemi_set_distributed): halo'd SpMV, all-reduced dot products, per-rank AMG (block Jacobi)."""
         L, dp, torch = self.L, self.dp, self.torch
-        KS = L.MAX_IONS - 1
+        KS = dp.K - 1
         voff, nvs = dp.voff, dp.n_vert
 
         def knp_index(g):          # (vertex id) -> its KS entries in the block order [sub][ion][vertex]

@@ -30,7 +30,7 @@ def test_constants_match_header():
                  "TRIANGLE", "TETRAHEDRON", "HEXAHEDRON", "MODEL_HH_SI", "MODEL_HH_MV", "MODEL_GLIAL",
                  "EINVAL", "EHIP", "EODE", "MAX_IONS", "MAX_SUB", "K_ODE", "K_EMI_ROWS", "K_UPDATE"):
         assert int(consts[name]) == getattr(L, name), name
-    assert C.sizeof(L.Params) == 8 * (4 + 3 + 8 * 3 + 1 + 8)
+    assert C.sizeof(L.Params) == 8 * (4 + L.MAX_IONS + 8 * L.MAX_IONS + 1 + 8)
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
@@ -55,9 +55,9 @@ def test_null_and_bad_arguments(hip_lib):
     assert hip_lib.knpemi_update_pde(None) == L.EINVAL
     hip_lib.knpemi_destroy(None)   # harmless
     n1 = np.array([3], np.int32)
-    desc = L.ProblemDesc(gdim=2, cell_kind=L.TRIANGLE, n_sub=1, n_ions=2, n_vert=L.iptr(n1), n_cell=L.iptr(n1))
+    desc = L.ProblemDesc(gdim=2, cell_kind=L.TRIANGLE, n_sub=1, n_ions=5, n_vert=L.iptr(n1), n_cell=L.iptr(n1))
     h = C.c_void_p()
     assert hip_lib.knpemi_create(C.byref(desc), 0, C.byref(h)) == L.EINVAL
-    assert b"3 ionic species" in hip_lib.knpemi_last_error()
+    assert b"2 to 4 ionic species" in hip_lib.knpemi_last_error()
     desc.n_ions, desc.gdim = 3, 3
     assert hip_lib.knpemi_create(C.byref(desc), 0, C.byref(h)) == L.EINVAL

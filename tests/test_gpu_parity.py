@@ -700,7 +700,7 @@ def test_mms_knp_membrane_convergence(hip_lib, splitting):
     from knpemi.fem import Constant, Function, extract_submesh, make_mesh_mms
     from knpemi.pdeSolver import create_solver_knp
     errs = []
-    for M in sizes:
+    for M in (16, 32, 64):
         mesh, ct, ft = make_mesh_mms(M)
         s0, e2p, ev2p, _, _ = extract_submesh(mesh, ct, 0)
         s1, i2p, iv2p, _, _ = extract_submesh(mesh, ct, 1)
@@ -1266,3 +1266,85 @@ def test_config5_synthetic_full_size(hip_lib, workload):
     for t in (1, 2):
         v = p.phi_M_prev[t].x._a
         assert -120.0 < v.min() and v.max() < 60.0
+
+
+@pytest.mark.parametrize("kind,r", [("2d", 1), ("tet", 0), ("hex", 0)])
+@pytest.mark.parametrize("n_ions", [2, 4])
+def test_ion_counts_other_than_three_match_oracle(hip_lib, kind, r, n_ions):
+    """The forms loop over an arbitrary `ion_list` (knpWeakForm.py:92,131, emiWeakForm.py:97); every reference driver
+    uses three species.  K = 2 (one solved + one eliminated) and K = 4 (three solved, one of them divalent): operators,
+    right-hand sides in both splitting modes, and the end-of-step update (eliminated ion from electroneutrality)
+    against the oracle, which is generic in K."""
+    import contextlib
+    import io
+    from helpers import C_M, FARADAY, PSI, make_mesh
+    from knpemi import (create_functions_emi, create_functions_knp, emi_system, knp_system, set_initial_conditions,
+                        update_pde_variables)
+    from knpemi.fem import Constant, Function, extract_submesh
+    from knpemi.pdeSolver import create_solver_emi, create_solver_knp
+    import adapters
+    spec = {2: [("K", 1.0, 3.3, 124.2, 1.96e-9), ("Na", 1.0, 100.7, 12.8, 1.33e-9)],
+            4: [("K", 1.0, 3.3, 124.2, 1.96e-9), ("Cl", -1.0, 104.0, 137.0, 2.03e-9), ("Ca", 2.0, 1.2, 1e-1, 0.71e-9),
+                ("Na", 1.0, 100.7, 12.8, 1.33e-9)]}[n_ions]
+    mesh, ct, ft = make_mesh(kind, r)
+    dt = 1e-4
+
+    class Dummy:        # the forms only read the facet tag of a membrane model (emiWeakForm.py:162)
+        tag = 1
+    for splitting in (True, False):
+        subs = {}
+        for t in (0, 1):
+            sm, e2p, v2p, _, _ = extract_submesh(mesh, ct, t)
+            subs[t] = dict(tag=t, name=f"sub{t}", mesh_sub=sm, sub_to_parent=e2p, sub_vertex_to_parent=v2p)
+        g, g2p, _, _, _ = extract_submesh(mesh, ft, [1])
+        subs[1].update(mesh_mem=g, mem_to_parent=g2p, membrane_tags=[1])
+        rho = {'z': -1, 0: Constant(subs[0]['mesh_sub'], 0.05), 1: Constant(subs[1]['mesh_sub'], 0.2)}
+        pp = {'dt': Constant(mesh, dt), 'F': Constant(mesh, FARADAY), 'psi': Constant(mesh, PSI),
+              'C_phi': Constant(mesh, C_M / dt), 'C_M': Constant(mesh, C_M), 'rho': rho}
+        ions = [dict(name=n, z=z, D={0: Constant(None, D), 1: Constant(None, 1.1 * D)},
+                     c_init={0: Constant(None, ce), 1: Constant(None, ci)}) for n, z, ce, ci, D in spec]
+        with contextlib.redirect_stdout(io.StringIO()):
+            phi, phi_M_prev = create_functions_emi(subs, degree=1)
+            c, c_prev = create_functions_knp(subs, ions, degree=1)
+            set_initial_conditions(ions, subs, c_prev)
+        Q = phi_M_prev[1].function_space
+        subs[1]['mem_models'] = [{'ode': Dummy(), 'I_ch_k': {ion['name']: Function(Q, name=f"I_{ion['name']}") for ion in ions}}]
+        rng = np.random.default_rng(11)
+        for t in (0, 1):
+            ions[-1][f'c_{t}'].x.array[:] = spec[-1][2 + t]
+            for f in c_prev[t] + [ions[-1][f'c_{t}']]:
+                f.x.array[:] *= 1.0 + 1e-2 * rng.uniform(-1, 1, f.x.array.shape[0])
+            phi[t].x.array[:] = 1e-3 * rng.uniform(-1, 1, phi[t].x.array.shape[0])
+            for f in c[t]:
+                f.x.array[:] = rng.uniform(1.0, 100.0, f.x.array.shape[0])
+        phi_M_prev[1].x.array[:] = -0.07 + 1e-3 * rng.uniform(-1, 1, phi_M_prev[1].x.array.shape[0])
+        for f in subs[1]['mem_models'][0]['I_ch_k'].values():
+            f.x.array[:] = 1e-2 * rng.uniform(-1, 1, f.x.array.shape[0])
+        a_emi, p_emi, L_emi = emi_system(mesh, ct, ft, pp, ions, subs, phi, phi_M_prev, c_prev, dt,
+                                         splitting_scheme=splitting)
+        a_knp, p_knp, L_knp = knp_system(mesh, ct, ft, pp, ions, subs, phi, phi_M_prev, c, c_prev, dt,
+                                         splitting_scheme=splitting)
+        s = type("S", (), {})()
+        s.__dict__.update(mesh=mesh, ct=ct, ft=ft, subdomain_list=subs, ion_list=ions, physical_parameters=pp, dt=dt,
+                          phi=phi, phi_M_prev=phi_M_prev, c=c, c_prev=c_prev)
+        o, P, params, oions = adapters.oracle_problem(s, {0: [], 1: [1]})
+        c_all, ophi, phiM, mm = adapters.oracle_fields(s)
+        emi = create_solver_emi(a_emi, L_emi, phi, [], subs, None, p=p_emi, direct=False)
+        knp = create_solver_knp(a_knp, L_knp, c, [], subs, None, p=p_knp)
+        A, b = emi.assemble()
+        Ak, bk = knp.assemble()
+        Ao, Po, bo = o.assemble_emi(P, params, oions, c_all, phiM, mm, splitting_scheme=splitting)
+        Ako, bko = o.assemble_knp(P, params, oions, c_all, ophi, phiM, mm, dt, splitting_scheme=splitting)
+        errs = dict(A_emi=csr_rel_err(A, Ao), P_emi=csr_rel_err(emi.P, Po), b_emi=rel_err(b, bo),
+                    A_knp=csr_rel_err(Ak, Ako), b_knp=rel_err(bk, bko))
+        assert Ak.shape[0] == (n_ions - 1) * A.shape[0]
+        assert max(errs.values()) < 1e-10, (n_ions, splitting, errs)
+        # end-of-step update: c_prev <- c, eliminated ion from electroneutrality with the background charge
+        cnew = {t: [f.x._a.copy() for f in c[t]] for t in (0, 1)}
+        update_pde_variables(c, c_prev, phi, phi_M_prev, pp, ions, subs, mesh, ct)
+        zs = [i['z'] for i in ions]
+        for t in (0, 1):
+            for k in range(n_ions - 1):
+                assert np.array_equal(c_prev[t][k].x._a, cnew[t][k])
+            el = -(1.0 / zs[-1]) * (-1 * float(rho[t]) + sum(z * ck for z, ck in zip(zs[:-1], cnew[t])))
+            assert rel_err(ions[-1][f'c_{t}'].x._a, el) < 1e-14
