@@ -235,8 +235,16 @@ int knpemi_update_pde(knpemi_handle* h);
  * KNPEMI_OPT_FUSE_UPDATE (0/1): update_pde_variables follows problem_knp.solve() directly in the reference's loop
  *   (run_3D.py:356,362); with this option the write-back kernel of knpemi_solve_knp -- and of
  *   knpemi_set_solution(KNPEMI_B_KNP, device pointer) -- also performs that update (same arithmetic, one launch
- *   fewer per step), and the caller does not call knpemi_update_pde. */
+ *   fewer per step), and the caller does not call knpemi_update_pde.
+ * KNPEMI_OPT_FUSE_MEMBRANE (0/1, default 0): 1 evaluates the membrane-facet integrals of b_knp
+ *   (knpWeakForm.py:178-214) inside the KNP row kernel -- each row block integrates the (facet, local vertex) entries
+ *   of its rows before it sums them, same arithmetic and order as the stand-alone facet kernel, bit-identical b_knp --
+ *   instead of in a launch of their own that hands them over through HBM.  Measured on MI355X it does not pay: the
+ *   degree-6 facet quadrature lands on the few row blocks that own membrane rows, so the row kernel's tail grows by as
+ *   much as (24,794 dofs: 17.0 + 16.3 us apart, 34.2 us fused) or more than (219,542 dofs: 59.3 + 18.7 us apart,
+ *   107 us fused) the stand-alone kernel costs spread over all CUs.  Kept as an option for small, launch-bound cases. */
 #define KNPEMI_OPT_FUSE_UPDATE 1
+#define KNPEMI_OPT_FUSE_MEMBRANE 2
 int knpemi_set_option(knpemi_handle* h, int option, int value);
 
 /* Nodal trace of an (ECS, cell) pair of bulk functions onto Q_sub: interpolate_to_membrane

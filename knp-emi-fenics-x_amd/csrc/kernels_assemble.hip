@@ -164,6 +164,11 @@ __global__ void membrane_mass_kernel(KnDev D, int n_entries, int v_cells, const 
 // =============================================================================================
 #define KN_PREFETCH 8   // pair entries per lane fetched ahead into registers
 
+// (defined with the membrane-facet code further down)
+template <int NF, int KS>
+__device__ __forceinline__ void membrane_entries_to_lds(const KnDev& D, const KnConsts& C, int e0, int ne, bool cell_side,
+                                                        int splitting, int tid, double* gam);
+
 // staged record of a KNP row block: coordinates, f_k = c_prev_k / dt (+ f_source_k) of the KS solved ions, phi
 template <int KS>
 struct RecK {
@@ -225,7 +230,7 @@ __device__ __forceinline__ double simplex_row0(const R (&r)[GDIM + 1], double (&
 // Block descriptor (uniform) and the staging of the block's Laplacian-entry records: all index loads
 // are issued together, then all record loads, so a wave waits for memory twice instead of 2 x trips.
 struct BlkInfo {
-  int row0, nrows, sub, seg0, seglen, segL0, nnzLb, uoff, nuniq, slbase, np;
+  int row0, nrows, sub, seg0, seglen, segL0, nnzLb, uoff, nuniq, slbase, np, me0, mne;
 };
 
 __device__ __forceinline__ BlkInfo load_blk(const KnDev& D, int b, int wave) {
@@ -237,6 +242,7 @@ __device__ __forceinline__ BlkInfo load_blk(const KnDev& D, int b, int wave) {
   B.slbase = wave == 0 ? i2.x : (wave == 1 ? i2.y : (wave == 2 ? i2.z : i2.w));
   B.np = ((unsigned)i3.x >> (8 * wave)) & 255;
   B.nuniq = i3.y;
+  B.me0 = i3.z; B.mne = i3.w;      // membrane entries of the block's rows: [me0, me0 + mne)
   return B;
 }
 
@@ -396,13 +402,15 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
 }
 
 template <int GDIM, int LPR, int KS>
-__global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n, int rec_n) {
+__global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n, int rec_n,
+                                                        int gam_n, int splitting) {
   constexpr int NV = GDIM + 1;
   const KnConsts& C = *Cp;
   extern __shared__ __align__(16) double lds[];
   double* acc = lds;                                   // KS accumulator arrays of acc_n doubles, one per solved ion
   double* recs = lds + (size_t)KS * acc_n;
-  uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + (size_t)(4 + KS) * rec_n + (((4 + KS) * rec_n) & 1));
+  double* gam = recs + (size_t)(4 + KS) * rec_n + (((4 + KS) * rec_n) & 1);   // gam_n > 0: fused membrane integrals
+  uint16_t* eloc = reinterpret_cast<uint16_t*>(gam + (size_t)KS * gam_n);
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
   const BlkInfo B = load_blk(D, b, tid >> 6);
@@ -424,6 +432,7 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
     for (int k = 0; k < KS; ++k) acc[(size_t)k * acc_n + i] = 0.0;
   }
   stage_records<KS>(D, B, recs, eloc, tid, C.inv_dt, fs0, nvs);
+  if (gam_n > 0) membrane_entries_to_lds<GDIM, KS>(D, C, B.me0, B.mne, s > 0, splitting, tid, gam);
   __syncthreads();
 
   const KnSubConst& sc = C.sc[s];
@@ -481,7 +490,7 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
       const int ne = (unsigned)ri.y >> 16;
       for (int e = ri.w; e < ri.w + ne; ++e) {
 #pragma unroll
-        for (int k = 0; k < KS; ++k) bk[k] += D.gam_e[(size_t)KS * e + k];
+        for (int k = 0; k < KS; ++k) bk[k] += gam_n > 0 ? gam[(size_t)(e - B.me0) * KS + k] : D.gam_e[(size_t)KS * e + k];
       }
     }
   }
@@ -790,12 +799,14 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
 }
 
 template <int LPR, bool AFFINE, int KS>
-__global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n, int rec_n) {
+__global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n, int rec_n,
+                                                                            int gam_n, int splitting) {
   const KnConsts& C = *Cp;
   extern __shared__ __align__(16) double lds[];
   double* acc = lds;
   double* recs = lds + (size_t)KS * acc_n;
-  uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + (size_t)(4 + KS) * rec_n + (((4 + KS) * rec_n) & 1));
+  double* gam = recs + (size_t)(4 + KS) * rec_n + (((4 + KS) * rec_n) & 1);
+  uint16_t* eloc = reinterpret_cast<uint16_t*>(gam + (size_t)KS * gam_n);
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
   const BlkInfo B = load_blk(D, b, tid >> 6);
@@ -819,6 +830,7 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDe
     for (int k = 0; k < KS; ++k) acc[(size_t)k * acc_n + i] = 0.0;
   }
   stage_records<KS>(D, B, recs, eloc, tid, C.inv_dt, fs0, nvs);
+  if (gam_n > 0) membrane_entries_to_lds<4, KS>(D, C, B.me0, B.mne, s > 0, splitting, tid, gam);
   __syncthreads();
 
   const KnSubConst& sc = C.sc[s];
@@ -856,7 +868,7 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDe
       const int ne = (unsigned)ri.y >> 16;
       for (int e = ri.w; e < ri.w + ne; ++e) {
 #pragma unroll
-        for (int k = 0; k < KS; ++k) bk[k] += D.gam_e[(size_t)KS * e + k];
+        for (int k = 0; k < KS; ++k) bk[k] += gam_n > 0 ? gam[(size_t)(e - B.me0) * KS + k] : D.gam_e[(size_t)KS * e + k];
       }
     }
   }
@@ -886,6 +898,97 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDe
 // NF x 2 (ions) partial integrals to `gam_contrib`; the row kernel adds them into b_knp in a fixed
 // order, so nothing is accumulated atomically.
 // ---------------------------------------------------------------------------------------------
+// everything one side of a membrane facet contributes to the integrand: loaded once per (facet, side)
+template <int NF>
+struct FacetData {
+  Rec pe[NF], pi[NF];
+  double pm[NF], Ik[NF][KN_MAXK], It[NF];
+  double meas, sgn;
+  const KnSubConst* so;    // own-side constants
+  bool cell_side;
+};
+
+template <int NF>
+__device__ __forceinline__ void load_facet(const KnDev& D, const KnConsts& C, int fg, bool cell_side, int ms,
+                                           FacetData<NF>& f) {
+  const int K = C.K;
+  int si = 0;  // sub-domain of the cell side of this facet
+#pragma unroll
+  for (int bb = 0; bb < NF; ++bb) {
+    const int vi = D.fi[(size_t)fg * NF + bb];
+    f.pe[bb] = load_rec(D.VR, D.fe[(size_t)fg * NF + bb]);
+    f.pi[bb] = load_rec(D.VR, vi);
+    const int q = D.fq[(size_t)fg * NF + bb];
+    f.pm[bb] = D.phiM[q];
+    const double* ich = D.Ich + (size_t)ms * KN_MAXK * D.NQtot + q;
+    double it = 0.0;
+#pragma unroll
+    for (int k = 0; k < KN_MAXK; ++k) {
+      f.Ik[bb][k] = k < K ? ich[(size_t)k * D.NQtot] : 0.0;
+      it += f.Ik[bb][k];
+    }
+    f.It[bb] = it;
+    if (bb == 0) for (int tt = 1; tt < C.n_sub; ++tt) si += vi >= C.voff[tt];
+  }
+  f.so = &C.sc[cell_side ? si : 0];
+  f.meas = 0.0;
+  if constexpr (NF != 4) f.meas = facet_measure<NF>(f.pe);
+  f.sgn = cell_side ? 1.0 : -1.0;
+  f.cell_side = cell_side;
+}
+
+// weight x integrand of the K - 1 solved ions at quadrature point q (knpWeakForm.py:178-214):
+//   fk[k] = w_q * sgn * (C_k g_k - C_k [phi]),  C_k = alpha_k C_M / (F z_k dt),  alpha_k = D_k z_k^2 c_k / sum_j D_j z_j^2 c_j
+template <int NF>
+__device__ __forceinline__ void facet_point(const FacetData<NF>& f, const KnConsts& C, int q, const double* qw,
+                                            const double* qN, const double* qdN, int splitting, double (&fk)[KN_MAXK - 1]) {
+  const int KS = C.K - 1;
+  double cq[KN_MAXK], iq[KN_MAXK], ph_e = 0, ph_i = 0, pmq = 0, it = 0;
+#pragma unroll
+  for (int k = 0; k < KN_MAXK; ++k) { cq[k] = 0.0; iq[k] = 0.0; }
+#pragma unroll
+  for (int bb = 0; bb < NF; ++bb) {
+    const double N = qN[q * NF + bb];
+    const Rec& o = f.cell_side ? f.pi[bb] : f.pe[bb];
+#pragma unroll
+    for (int k = 0; k < KN_MAXK; ++k) { cq[k] += N * o.c[k]; iq[k] += N * f.Ik[bb][k]; }
+    ph_e += N * f.pe[bb].phi; ph_i += N * f.pi[bb].phi;
+    pmq += N * f.pm[bb]; it += N * f.It[bb];
+  }
+  double wq;
+  if constexpr (NF == 4) {
+    // surface Jacobian of the bilinear facet at this point
+    double ux = 0, uy = 0, uz = 0, vx = 0, vy = 0, vz = 0;
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      const double da = qdN[(q * 4 + bb) * 2], db = qdN[(q * 4 + bb) * 2 + 1];
+      ux += da * f.pe[bb].x; uy += da * f.pe[bb].y; uz += da * f.pe[bb].z;
+      vx += db * f.pe[bb].x; vy += db * f.pe[bb].y; vz += db * f.pe[bb].z;
+    }
+    const double nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+    wq = qw[q] * sqrt(nx * nx + ny * ny + nz * nz);
+  } else {
+    wq = qw[q] * f.meas * (NF == 2 ? 1.0 : 2.0);  // reference measure 1 (interval), 1/2 (triangle)
+  }
+  double asum = 0.0;      // sum over ALL K ions (knpWeakForm.py:97); az2D = 0 beyond K
+#pragma unroll
+  for (int k = 0; k < KN_MAXK; ++k) asum += f.so->az2D[k] * cq[k];
+  const double jump = ph_i - ph_e;
+#pragma unroll
+  for (int k = 0; k < KN_MAXK - 1; ++k) {
+    fk[k] = 0.0;
+    if (k < KS) {
+      const double al = f.so->az2D[k] * cq[k] / asum;
+      const double Cc = al * C.C_M / (C.F * C.z[k] * C.dt);
+      double gr = pmq - C.dt / (C.C_M * al) * iq[k];
+      if (splitting) gr += (C.dt / C.C_M) * it;
+      fk[k] = wq * f.sgn * (Cc * gr - Cc * jump);
+    }
+  }
+}
+
+// Stand-alone form (diagnostics, KNPEMI_OPT_FUSE_MEMBRANE = 0): one thread per (facet, side) tests the integrand
+// against all NF facet functions and writes NF x (K - 1) partial integrals to gam_e.
 template <int NF>
 __global__ __launch_bounds__(256) void knp_membrane_kernel(KnDev D, const KnConsts* __restrict__ Cp, int splitting) {
   const KnConsts& C = *Cp;
@@ -899,7 +1002,7 @@ __global__ __launch_bounds__(256) void knp_membrane_kernel(KnDev D, const KnCons
   const double* qdN = qt + nq * (1 + NF);
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 2 * D.nftot) return;
-  const int K = C.K, KS = K - 1;
+  const int KS = C.K - 1;
   const int fg = t >> 1;
   const bool cell_side = t & 1;
   const int ms = D.fmodel[fg];
@@ -910,85 +1013,61 @@ __global__ __launch_bounds__(256) void knp_membrane_kernel(KnDev D, const KnCons
       for (int k = 0; k < KS; ++k) D.gam_e[(size_t)KS * pos[a] + k] = 0.0;
     return;
   }
-  Rec pe[NF], pi[NF];
-  double pm[NF], Ik[NF][KN_MAXK], It[NF];
-  int si = 0;  // sub-domain of the cell side of this facet
-#pragma unroll
-  for (int bb = 0; bb < NF; ++bb) {
-    const int vi = D.fi[(size_t)fg * NF + bb];
-    pe[bb] = load_rec(D.VR, D.fe[(size_t)fg * NF + bb]);
-    pi[bb] = load_rec(D.VR, vi);
-    const int q = D.fq[(size_t)fg * NF + bb];
-    pm[bb] = D.phiM[q];
-    const double* ich = D.Ich + (size_t)ms * KN_MAXK * D.NQtot + q;
-    double it = 0.0;
-#pragma unroll
-    for (int k = 0; k < KN_MAXK; ++k) {
-      Ik[bb][k] = k < K ? ich[(size_t)k * D.NQtot] : 0.0;
-      it += Ik[bb][k];
-    }
-    It[bb] = it;
-    if (bb == 0) for (int tt = 1; tt < C.n_sub; ++tt) si += vi >= C.voff[tt];
-  }
-  const KnSubConst& so = C.sc[cell_side ? si : 0];   // own-side constants
-  double meas = 0.0;
-  if constexpr (NF != 4) meas = facet_measure<NF>(pe);
+  FacetData<NF> f;
+  load_facet<NF>(D, C, fg, cell_side, ms, f);
   double acc[NF][KN_MAXK - 1];
 #pragma unroll
   for (int a = 0; a < NF; ++a)
 #pragma unroll
     for (int k = 0; k < KN_MAXK - 1; ++k) acc[a][k] = 0.0;
-  const double sgn = cell_side ? 1.0 : -1.0;
   for (int q = 0; q < nq; ++q) {
-    double cq[KN_MAXK], iq[KN_MAXK], ph_e = 0, ph_i = 0, pmq = 0, it = 0;
+    double fk[KN_MAXK - 1];
+    facet_point<NF>(f, C, q, qw, qN, qdN, splitting, fk);
 #pragma unroll
-    for (int k = 0; k < KN_MAXK; ++k) { cq[k] = 0.0; iq[k] = 0.0; }
+    for (int a = 0; a < NF; ++a)
 #pragma unroll
-    for (int bb = 0; bb < NF; ++bb) {
-      const double N = qN[q * NF + bb];
-      const Rec& o = cell_side ? pi[bb] : pe[bb];
-#pragma unroll
-      for (int k = 0; k < KN_MAXK; ++k) { cq[k] += N * o.c[k]; iq[k] += N * Ik[bb][k]; }
-      ph_e += N * pe[bb].phi; ph_i += N * pi[bb].phi;
-      pmq += N * pm[bb]; it += N * It[bb];
-    }
-    double wq;
-    if constexpr (NF == 4) {
-      // surface Jacobian of the bilinear facet at this point
-      double ux = 0, uy = 0, uz = 0, vx = 0, vy = 0, vz = 0;
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb) {
-        const double da = qdN[(q * 4 + bb) * 2], db = qdN[(q * 4 + bb) * 2 + 1];
-        ux += da * pe[bb].x; uy += da * pe[bb].y; uz += da * pe[bb].z;
-        vx += db * pe[bb].x; vy += db * pe[bb].y; vz += db * pe[bb].z;
-      }
-      const double nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
-      wq = qw[q] * sqrt(nx * nx + ny * ny + nz * nz);
-    } else {
-      wq = qw[q] * meas * (NF == 2 ? 1.0 : 2.0);  // reference measure 1 (interval), 1/2 (triangle)
-    }
-    double asum = 0.0;      // sum over ALL K ions (knpWeakForm.py:97); az2D = 0 beyond K
-#pragma unroll
-    for (int k = 0; k < KN_MAXK; ++k) asum += so.az2D[k] * cq[k];
-    const double jump = ph_i - ph_e;
-#pragma unroll
-    for (int k = 0; k < KN_MAXK - 1; ++k) {
-      if (k < KS) {
-        const double al = so.az2D[k] * cq[k] / asum;
-        const double Cc = al * C.C_M / (C.F * C.z[k] * C.dt);
-        double gr = pmq - C.dt / (C.C_M * al) * iq[k];
-        if (splitting) gr += (C.dt / C.C_M) * it;
-        const double fk = wq * sgn * (Cc * gr - Cc * jump);
-#pragma unroll
-        for (int a = 0; a < NF; ++a) acc[a][k] += qN[q * NF + a] * fk;
-      }
-    }
+      for (int k = 0; k < KN_MAXK - 1; ++k) acc[a][k] += qN[q * NF + a] * fk[k];
   }
 #pragma unroll
   for (int a = 0; a < NF; ++a)
 #pragma unroll
     for (int k = 0; k < KN_MAXK - 1; ++k)
       if (k < KS) D.gam_e[(size_t)KS * pos[a] + k] = acc[a][k];
+}
+
+// Fused form: the KNP row kernels call this before their barrier.  The membrane entries (row, facet, local vertex a)
+// of a row block are contiguous [e0, e0 + ne); each thread integrates the entries i = tid, tid + 256, ... against the
+// ONE facet function of its entry -- the same sums, in the same order, as the stand-alone kernel forms for that
+// function -- and leaves the K - 1 integrals in LDS for the row's lane.  No separate launch, nothing through HBM.
+template <int NF, int KS>
+__device__ __forceinline__ void membrane_entries_to_lds(const KnDev& D, const KnConsts& C, int e0, int ne, bool cell_side,
+                                                        int splitting, int tid, double* gam) {
+  const int nq = D.nq_gamma;
+  const double* qw = D.qtab;
+  const double* qN = D.qtab + nq;
+  const double* qdN = D.qtab + nq * (1 + NF);
+  for (int i = tid; i < ne; i += KN_BLOCK) {
+    const int e = e0 + i;
+    const int ms = D.me_model[e];
+    double acc[KN_MAXK - 1];
+#pragma unroll
+    for (int k = 0; k < KN_MAXK - 1; ++k) acc[k] = 0.0;
+    if (ms >= 0) {
+      const int ent = D.mentry[e];
+      const int fg = ent >> 3, a = ent & 7;
+      FacetData<NF> f;
+      load_facet<NF>(D, C, fg, cell_side, ms, f);
+      for (int q = 0; q < nq; ++q) {
+        double fk[KN_MAXK - 1];
+        facet_point<NF>(f, C, q, qw, qN, qdN, splitting, fk);
+        const double Na = qN[q * NF + a];
+#pragma unroll
+        for (int k = 0; k < KN_MAXK - 1; ++k) acc[k] += Na * fk[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k) gam[(size_t)i * KS + k] = acc[k];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1163,11 +1242,13 @@ static int launch_emi_v2(knpemi_handle* h, int want_p, int split) {
 }
 
 template <int GDIM>
-static int launch_knp_v2(knpemi_handle* h) {
+static int launch_knp_v2(knpemi_handle* h, int split) {
   const KnDev& D = h->dev;
   const int acc_n = (h->lds_doubles_knp + 1) & ~1, rec_n = h->lds_uniq_max;
   const int KS = h->K - 1;
-  const size_t lds = ((size_t)KS * acc_n + (4 + KS) * (size_t)rec_n + 1) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
+  const int gam_n = h->fuse_membrane ? std::max(1, h->lds_gam_max) : 0;
+  const size_t lds = ((size_t)KS * acc_n + (4 + KS) * (size_t)rec_n + 1 + (size_t)KS * gam_n) * sizeof(double)
+                     + 2 * (size_t)h->lds_doubles_knp + 16;
   if (lds > 160 * 1024) { kn_set_error("KNP row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   dim3 grid(D.nblocks), block(KN_BLOCK);
   int rc = 0;
@@ -1175,7 +1256,7 @@ static int launch_knp_v2(knpemi_handle* h) {
   if (h->lpr == L && KS == S) {                                                                     \
     if ((rc = set_lds_limit(knp_rows_v2<GDIM, L, S>, lds))) return rc;                              \
     KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                         \
-    hipLaunchKernelGGL((knp_rows_v2<GDIM, L, S>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n); \
+    hipLaunchKernelGGL((knp_rows_v2<GDIM, L, S>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n, gam_n, split); \
     return check_launch("knp_rows_v2");                                                             \
   }
   // lanes per row: 2 (triangles) or 4 by default, KNPEMI_LPR for experiments; K - 1 = 1..3 solved ions
@@ -1209,11 +1290,13 @@ static int launch_emi_hex_v2(knpemi_handle* h, int want_p, int split) {
   return check_launch("emi_rows_hex_v2");
 }
 
-static int launch_knp_hex_v2(knpemi_handle* h) {
+static int launch_knp_hex_v2(knpemi_handle* h, int split) {
   const KnDev& D = h->dev;
   const int acc_n = (h->lds_doubles_knp + 1) & ~1, rec_n = h->lds_uniq_max;
   const int KS = h->K - 1;
-  const size_t lds = ((size_t)KS * acc_n + (4 + KS) * (size_t)rec_n + 1) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
+  const int gam_n = h->fuse_membrane ? std::max(1, h->lds_gam_max) : 0;
+  const size_t lds = ((size_t)KS * acc_n + (4 + KS) * (size_t)rec_n + 1 + (size_t)KS * gam_n) * sizeof(double)
+                     + 2 * (size_t)h->lds_doubles_knp + 16;
   if (lds > 160 * 1024) { kn_set_error("KNP row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   dim3 grid(D.nblocks), block(KN_BLOCK);
   int rc = 0;
@@ -1221,7 +1304,7 @@ static int launch_knp_hex_v2(knpemi_handle* h) {
   if (h->lpr == L && h->hex_affine == AFF && KS == S) {                                             \
     if ((rc = set_lds_limit(knp_rows_hex_v2<L, AFF, S>, lds))) return rc;                           \
     KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                         \
-    hipLaunchKernelGGL((knp_rows_hex_v2<L, AFF, S>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n); \
+    hipLaunchKernelGGL((knp_rows_hex_v2<L, AFF, S>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n, gam_n, split); \
     return check_launch("knp_rows_hex_v2");                                                         \
   }
   KN_CASE(4, true, 2) KN_CASE(4, false, 2) KN_CASE(2, true, 2) KN_CASE(2, false, 2) KN_CASE(8, true, 2) KN_CASE(8, false, 2)
@@ -1241,11 +1324,11 @@ int kn_launch_emi_rows(knpemi_handle* h, int flags) {
 }
 
 int kn_launch_knp_rows(knpemi_handle* h, int flags) {
-  (void)flags;
   const KnDev& D = h->dev;
   if (D.nblocks == 0) return KNPEMI_OK;
-  if (h->NV == 8) return launch_knp_hex_v2(h);
-  return h->gdim == 2 ? launch_knp_v2<2>(h) : launch_knp_v2<3>(h);
+  const int split = (flags & KNPEMI_NO_SPLITTING) ? 0 : 1;
+  if (h->NV == 8) return launch_knp_hex_v2(h, split);
+  return h->gdim == 2 ? launch_knp_v2<2>(h, split) : launch_knp_v2<3>(h, split);
 }
 
 int kn_launch_membrane_mass(knpemi_handle* h, int n_entries, const int* d_entry_row, double* d_out) {

@@ -454,6 +454,17 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
       steps |= (uint32_t)np << (8 * w);
     }
     bi[12] = (int)steps;
+    {   // membrane entries of the block's rows (entries are sorted by row, so they form one range)
+      int me0 = 0, mne = 0;
+      for (int g = g0; g < g1; ++g) {
+        const int m = gam_idx[g];
+        if (m < 0) continue;
+        if (mne == 0) me0 = mptr[m];
+        mne = mptr[m + 1] - me0;
+      }
+      bi[14] = me0; bi[15] = mne;
+      h->lds_gam_max = std::max(h->lds_gam_max, mne);
+    }
     // distinct vertices touched by the block's rows (sorted: consecutive ids = contiguous records)
     {
       std::vector<int> u(colindL.begin() + rowptrL[g0], colindL.begin() + rowptrL[g1]);
@@ -820,8 +831,10 @@ extern "C" int knpemi_assemble_knp(knpemi_handle* h, int flags) {
   if (!h) return fail(KNPEMI_EINVAL, "null handle");
   if (!h->have_params) return fail(KNPEMI_EINVAL, "knpemi_assemble_knp: knpemi_set_params not called");
   KN_HIP(hipSetDevice(h->device));
-  int rc = kn_launch_knp_membrane(h, flags);   // partial integrals first, the row kernel adds them
-  if (rc) return rc;
+  if (!h->fuse_membrane) {   // stand-alone facet kernel: partial integrals through gam_e, the row kernel adds them
+    int rc = kn_launch_knp_membrane(h, flags);
+    if (rc) return rc;
+  }
   return kn_launch_knp_rows(h, flags);
 }
 
@@ -1266,6 +1279,7 @@ extern "C" int knpemi_vec_scatter(knpemi_handle* h, void* vec_dev, const int32_t
 extern "C" int knpemi_set_option(knpemi_handle* h, int option, int value) {
   if (!h) return fail(KNPEMI_EINVAL, "null handle");
   if (option == KNPEMI_OPT_FUSE_UPDATE) { h->fuse_update = value ? 1 : 0; return KNPEMI_OK; }
+  if (option == KNPEMI_OPT_FUSE_MEMBRANE) { h->fuse_membrane = value ? 1 : 0; return KNPEMI_OK; }
   return fail(KNPEMI_EINVAL, "knpemi_set_option: unknown option");
 }
 

@@ -194,6 +194,8 @@ struct knpemi_handle {
   KnGraph graph_emi, graph_knp;
   int pc_emi = KNPEMI_PC_AMG, pc_knp = KNPEMI_PC_AMG;
   int fuse_update = 0;                 // KNPEMI_OPT_FUSE_UPDATE
+  int fuse_membrane = 0;               // KNPEMI_OPT_FUSE_MEMBRANE
+  int lds_gam_max = 0;                 // most membrane entries of one row block
   KnDist dist;
   // per-kernel event profiling (knpemi_profile)
   uint32_t prof_mask = 0;

@@ -24,7 +24,7 @@ from . import _lib as L
 class DeviceStepper:
     def __init__(self, forms_emi, forms_knp, c, c_prev, phi, phi_M_prev, solve_emi=None, solve_knp=None,
                  assemble_knp_twice=False, overlap=True, device_solves=None, extrapolate_guess=True,
-                 fuse_update=None):
+                 fuse_update=None, fuse_membrane=False):
         a = forms_emi[0]
         self.dp = a.dp
         self.a = a
@@ -60,6 +60,9 @@ class DeviceStepper:
         dp = self.dp
         dp.set_params(a.physical_params, a.ion_list, a.dt)
         L.check(self.lib.knpemi_set_option(dp.h, L.OPT_FUSE_UPDATE, 1 if self.fuse_update else 0))
+        # membrane-facet integrals of b_knp inside the KNP row kernel (default) or as a launch of their own
+        self.fuse_membrane = bool(fuse_membrane)
+        L.check(self.lib.knpemi_set_option(dp.h, L.OPT_FUSE_MEMBRANE, 1 if self.fuse_membrane else 0))
         self.dt = float(a.dt)
         self.flags_emi = L.WANT_P | (0 if a.splitting_scheme else L.NO_SPLITTING)
         self.flags_knp = 0 if a.splitting_scheme else L.NO_SPLITTING

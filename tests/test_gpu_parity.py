@@ -990,17 +990,19 @@ def test_device_resident_time_loop_matches_oracle(hip_lib):
 def test_fused_update_and_overlap_variants_are_bit_identical(hip_lib):
     """The stepper's launch-saving variants change no bit: update_pde_variables fused into the write-back kernel of the
     KNP solve (KNPEMI_OPT_FUSE_UPDATE) vs the separate launch, and the EMI matrix assembled beside the ODE sweep (aux
-    stream, separate Robin-term launch) vs after it (fused Robin term) -- fields, membrane potential, currents and ODE
+    stream, separate Robin-term launch) vs after it (fused Robin term), and the membrane-facet integrals of b_knp inside
+    the KNP row kernel (KNPEMI_OPT_FUSE_MEMBRANE) vs the stand-alone facet kernel -- fields, membrane potential, currents and ODE
     tables after six whole steps with the device solves."""
     from knpemi.stepper import DeviceStepper
     out = []
-    for fuse, overlap, thr in ((True, True, 0.025), (False, True, 0.0), (False, False, 0.025)):
+    for fuse, overlap, thr, fuse_mem in ((True, True, 0.025, True), (False, True, 0.0, True), (False, False, 0.025, False)):
         s = Setup("tet", 0, g_syn=10.0)
         for t in s.subdomain_list:
             for k in range(2):
                 s.c[t][k].x.array[:] = s.c_prev[t][k].x._a
         st = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp), s.c, s.c_prev, s.phi,
-                           s.phi_M_prev, device_solves=(1e-9, 1e-10), fuse_update=fuse, overlap=overlap)
+                           s.phi_M_prev, device_solves=(1e-9, 1e-10), fuse_update=fuse, overlap=overlap,
+                           fuse_membrane=fuse_mem)
         st.overlap_threshold_ms = thr
         ode = s.mem_models[0]['ode']
         st.add_membrane_model(ode, s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
