@@ -301,6 +301,81 @@ int knpemi_timer_stop_ms(knpemi_handle* h, double* ms);
 /* HIP stream (hipStream_t) the handle enqueues on, for external event timing / ordering. */
 void* knpemi_stream(knpemi_handle* h);
 
+/* ---- DG(P1) + symmetric interior penalty variant -------------------------------------
+ * The reference's README (README.md:5-7) describes a "DG fem method" and its 2D mesh script keeps the "interior
+ * facets are tagged 0" convention of that method (examples/idealized_geometries/make_mesh_2D.py:88-90), but the
+ * code under src/knpemi is continuous Galerkin on sub-meshes: there is NO reference interface these entry points
+ * replace.  They provide the same step on ONE mesh with broken P1 functions: the volume terms of
+ * emiWeakForm.py:138-241 / knpWeakForm.py:123-166 cell by cell, interior-penalty and upwind terms on the interior
+ * facets of every sub-domain, and the reference's membrane terms (emiWeakForm.py:160-165,228-239,
+ * knpWeakForm.py:168-214) on the tagged facets, with phi_M and I_ch living at the vertices of each membrane facet.
+ * Simplices only (triangles, tetrahedra).  Dof (cell c, local vertex j) = c * nv + j; membrane node (facet f,
+ * vertex a) = f * nf + a; CSR rows hold one nv-wide block per cell (the cell itself and its facet neighbours, in
+ * increasing cell order).  The K - 1 concentration systems share the pattern of the potential system. */
+typedef struct knpemi_dg knpemi_dg;
+
+typedef struct {
+  int32_t cell_kind;            /* KNPEMI_TRIANGLE | KNPEMI_TETRAHEDRON */
+  int32_t n_sub;                /* sub-domains, ECS = 0 */
+  int32_t n_ions;               /* K = 2..4, the last one eliminated */
+  int64_t n_cells, n_vertices, n_mem_facets;
+  const double* x;              /* [n_vertices][gdim] */
+  const int32_t* cells;         /* [n_cells][nv] vertex ids */
+  const int32_t* cell_sub;      /* [n_cells] sub-domain index of every cell */
+  const int32_t* mem_facets;    /* [n_mem_facets][nf] vertex ids of the membrane facets: every one separates an ECS
+                                   cell from a cell of a sub-domain > 0; every other facet between two cells must
+                                   lie inside one sub-domain */
+} knpemi_dg_desc;
+
+typedef struct {
+  double dt, F, psi, C_M;
+  double gamma;                                         /* interior penalty parameter (10 is a safe default) */
+  double z[KNPEMI_MAX_IONS];
+  double D[KNPEMI_MAX_SUB][KNPEMI_MAX_IONS];
+  double rho_z;
+  double rho[KNPEMI_MAX_SUB];
+} knpemi_dg_params;
+
+#define KNPEMI_DG_C 0         /* previous-step concentration of ion idx < K (the eliminated ion last)  [n_dofs] */
+#define KNPEMI_DG_PHI 1       /* potential                                                            [n_dofs] */
+#define KNPEMI_DG_PHI_M 2     /* phi_M_prev at the membrane nodes                                     [n_mem_nodes] */
+#define KNPEMI_DG_I_CH 3      /* channel current of ion idx < K at the membrane nodes                 [n_mem_nodes] */
+#define KNPEMI_DG_SOURCE 4    /* source term of solved ion idx < K - 1 (used in ECS cells only)       [n_dofs] */
+
+int knpemi_dg_create(const knpemi_dg_desc* desc, int device, knpemi_dg** out);
+void knpemi_dg_destroy(knpemi_dg* h);
+int knpemi_dg_set_params(knpemi_dg* h, const knpemi_dg_params* p);
+int knpemi_dg_dims(knpemi_dg* h, int64_t* n_dofs, int64_t* nnz, int64_t* n_mem_nodes);
+int knpemi_dg_get_pattern(knpemi_dg* h, int32_t* rowptr, int32_t* colind);
+/* dofs of the ECS cell / of the intracellular cell that sit at every membrane node */
+int knpemi_dg_get_membrane_dofs(knpemi_dg* h, int32_t* dof_e, int32_t* dof_i);
+int knpemi_dg_set_field(knpemi_dg* h, int field, int idx, const double* host, size_t n);
+int knpemi_dg_get_field(knpemi_dg* h, int field, int idx, double* host, size_t n);
+/* flags: KNPEMI_NO_SPLITTING.  assemble_emi fills A_emi, b_emi from the concentrations, phi_M (and I_ch without the
+ * splitting scheme); assemble_knp fills the K - 1 matrices and right-hand sides from the concentrations, the potential,
+ * phi_M and I_ch.  One kernel launch each. */
+int knpemi_dg_assemble_emi(knpemi_dg* h, int flags);
+int knpemi_dg_assemble_knp(knpemi_dg* h, int flags);
+/* which: 0 = potential system, 1 + k = concentration system of solved ion k */
+int knpemi_dg_get_values(knpemi_dg* h, int which, double* vals);
+int knpemi_dg_get_rhs(knpemi_dg* h, int which, double* b);
+int knpemi_dg_device_system(knpemi_dg* h, int which, const int32_t** rowptr, const int32_t** colind, const double** vals,
+                            const double** b);
+/* End of step (utils.py:238-295): c_prev <- c_new ([K-1][n_dofs], host or device pointer), eliminated ion from
+ * electroneutrality dof by dof, phi_M <- phi_i - phi_e at the membrane nodes. */
+int knpemi_dg_update(knpemi_dg* h, const double* c_new, int on_device);
+/* Membrane ODE sweep over the membrane nodes with one of the built-in models (KNPEMI_MODEL_*): same kernel, tables and
+ * flags as knpemi_ode_step; states / params are [n_mem_nodes][n_states | n_params] row-major on the host. */
+int knpemi_dg_ode_bind(knpemi_dg* h, int model_id, int n_states, int n_params, const double* states, const double* params,
+                       const int32_t* ion_param, int v_index);
+int knpemi_dg_ode_step(knpemi_dg* h, double t0, double dt, double rtol, double atol, int flags);
+int knpemi_dg_ode_get_tables(knpemi_dg* h, double* states, double* params);
+int knpemi_dg_ode_stats(knpemi_dg* h, int64_t* n_rhs, int64_t* n_steps, int64_t* n_failed);
+int knpemi_dg_sync(knpemi_dg* h);
+/* average duration (ms) of `reps` back-to-back launches of one assembly kernel (0 = potential, 1 = concentrations),
+ * measured with HIP events on the stream the kernel is launched on */
+int knpemi_dg_time_kernel(knpemi_dg* h, int which, int flags, int reps, double* avg_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,1118 @@
+// DG(P1) + symmetric interior penalty variant of the per-step assembly on gfx950.
+//
+// No reference file is restated here: /root/reference is continuous Galerkin on sub-meshes; only its README
+// (README.md:5-7) and the "interior facets tagged 0" convention of make_mesh_2D.py:88-90 point at the DG method.  The
+// discrete problem is the one oracle/knpemi_dg_oracle.py spells out (volume terms of emiWeakForm.py:138-241 and
+// knpWeakForm.py:123-166 cell by cell, SIP + upwind terms on interior facets, the reference's membrane terms on tagged
+// facets) and these kernels are held to that restatement at 1e-10.
+//
+// Layout in HBM
+//   rec      [n_dof][8]   one 64-byte record per broken dof (cell c, local vertex j) = c * nv + j:
+//                         x y z c3 | c0 c1 c2 phi -- the vertex record of the CG path (KN_REC, KN_CSLOT), so the membrane
+//                         ODE sweep (ode_kernel.h) reads its concentration traces from it unchanged
+//   nbr      [n_cell][nv] cell across local facet f (-1: outer boundary)
+//   finfo    [n_cell][nv] packed: kind (0 boundary, 1 interior, 2 membrane seen from the ECS cell, 3 from the other
+//                         side) | the neighbour's local vertex opposite the facet | for every local vertex a of this
+//                         cell the neighbour's local index of the same vertex | its node index on the membrane facet
+//   A_*      CSR values: every row holds one nv-wide block per cell (itself and its facet neighbours, sorted by cell),
+//            so the rows of one cell are contiguous and the rows of consecutive cells follow each other
+//
+// One lane per row.  All lanes of a cell compute the cell geometry redundantly (a few dozen flops) rather than share it:
+// the kernels write 20 (tetrahedra) or 12 (triangles) doubles per row and ion and read about a quarter of that, so
+// they are bound by the HBM write stream.  To make that stream coalesced the workgroup builds the image of its rows in
+// LDS exactly as it sits in the CSR value array and then copies it out linearly (each wave instruction stores 1 KiB
+// of consecutive addresses), instead of 64 lanes storing to 64 different rows.
+//
+// The lane rotates the cell's local numbering so that its own row vertex is local vertex 0 and reads a neighbour's dofs
+// in the order of the vertices they share, the neighbour's far vertex taking the place of the vertex opposite the
+// facet: every index into a register array is then a compile-time constant and only memory addresses are computed.
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstring>
+
+#include "knpemi_internal.h"
+#include "ode_kernel.h"
+
+namespace {
+
+constexpr int DG_BLOCK = 128;
+
+struct DgConsts {
+  int n_sub, K;
+  double F, psi, C_M, dt, inv_dt, C_phi, gamma;
+  double z[KN_MAXK];
+  double elim[KN_MAXK];              // -(z_k / z_K)
+  double D[KN_MAXSUB][KN_MAXK];
+  double kap[KN_MAXSUB][KN_MAXK];    // F psi z_k^2 D_k
+  double sig[KN_MAXSUB][KN_MAXK];    // F z_k D_k
+  double az2D[KN_MAXSUB][KN_MAXK];   // D_k z_k^2
+  double rho_term[KN_MAXSUB];        // -(1 / z_K) rho_z rho^s
+};
+
+struct DgDev {
+  int n_cell, n_dof, nq;             // nq: membrane nodes
+  int nquad;                         // points of the degree-6 membrane rule
+  long long nnz;
+  double* rec;
+  const int* nbr;
+  const unsigned* finfo;
+  const int* mfid;                   // [n_cell][nv] membrane facet of local facet f (-1)
+  const unsigned char* cell_sub;
+  const int* rowptr;
+  double* A_emi;
+  double* b_emi;
+  double* A_knp;                     // [K-1][nnz]
+  double* b_knp;                     // [K-1][n_dof]
+  double* phiM;                      // [nq]
+  double* Ich;                       // [KN_MAXK][nq]
+  const double* fsrc;                // [K-1][n_dof] or NULL
+  const double* qtab;                // weights, then shape values [nquad][nf]
+  const int* q2e;
+  const int* q2i;
+};
+
+struct DofRec {
+  double x[3], c[KN_MAXK], phi;
+};
+
+__device__ __forceinline__ DofRec load_rec(const double* rec, int dof) {
+  const double2* p = reinterpret_cast<const double2*>(rec + (size_t)dof * KN_REC);
+  const double2 a = p[0], b = p[1], c = p[2], d = p[3];
+  DofRec r;
+  r.x[0] = a.x; r.x[1] = a.y; r.x[2] = b.x;
+  r.c[3] = b.y; r.c[0] = c.x; r.c[1] = c.y; r.c[2] = d.x; r.phi = d.y;
+  return r;
+}
+
+template <int NV>
+struct Geo {
+  double g[NV][NV - 1];   // gradients of the barycentric coordinates
+  double vol;
+};
+
+template <int GD>
+__device__ __forceinline__ double dot(const double (&a)[GD], const double (&b)[GD]) {
+  double s = a[0] * b[0];
+#pragma unroll
+  for (int d = 1; d < GD; ++d) s += a[d] * b[d];
+  return s;
+}
+
+template <int NV>
+__device__ __forceinline__ void geometry(const double (&X)[NV][NV - 1], Geo<NV>& G) {
+  if constexpr (NV == 3) {
+    const double e1x = X[1][0] - X[0][0], e1y = X[1][1] - X[0][1];
+    const double e2x = X[2][0] - X[0][0], e2y = X[2][1] - X[0][1];
+    const double det = e1x * e2y - e1y * e2x, inv = 1.0 / det;
+    G.g[1][0] = e2y * inv; G.g[1][1] = -e2x * inv;
+    G.g[2][0] = -e1y * inv; G.g[2][1] = e1x * inv;
+    G.g[0][0] = -(G.g[1][0] + G.g[2][0]); G.g[0][1] = -(G.g[1][1] + G.g[2][1]);
+    G.vol = 0.5 * fabs(det);
+  } else {
+    double e[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) e[a][d] = X[a + 1][d] - X[0][d];
+    double cr[3][3];   // cr[a] = e[a+1] x e[a+2]
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int b = (a + 1) % 3, c = (a + 2) % 3;
+      cr[a][0] = e[b][1] * e[c][2] - e[b][2] * e[c][1];
+      cr[a][1] = e[b][2] * e[c][0] - e[b][0] * e[c][2];
+      cr[a][2] = e[b][0] * e[c][1] - e[b][1] * e[c][0];
+    }
+    const double det = e[0][0] * cr[0][0] + e[0][1] * cr[0][1] + e[0][2] * cr[0][2], inv = 1.0 / det;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      G.g[1][d] = cr[0][d] * inv; G.g[2][d] = cr[1][d] * inv; G.g[3][d] = cr[2][d] * inv;
+      G.g[0][d] = -(G.g[1][d] + G.g[2][d] + G.g[3][d]);
+    }
+    G.vol = fabs(det) * (1.0 / 6.0);
+  }
+}
+
+// Workgroups are dealt to the 8 XCDs round robin; give every XCD a contiguous run of cells so that the neighbour
+// records a workgroup reads are mostly the ones its XCD's L2 already holds.  Bijection on [0, 8 * chunk).
+__device__ __forceinline__ int dg_block_index(int b, int chunk) { return (b & 7) * chunk + (b >> 3); }
+
+// position of every block of the row: the cell itself and the neighbours in increasing cell order
+template <int NV>
+__device__ __forceinline__ void block_slots(int T, const int (&nb)[NV], int& slot_self, int (&slot)[NV]) {
+  slot_self = 0;
+#pragma unroll
+  for (int f = 0; f < NV; ++f) {
+    slot_self += nb[f] >= 0 && nb[f] < T;
+    int s = T < nb[f];
+#pragma unroll
+    for (int g = 0; g < NV; ++g) s += nb[g] >= 0 && nb[g] < nb[f];
+    slot[f] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// potential system: A_emi, b_emi
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(DG_BLOCK) void dg_emi_kernel(DgDev D, const DgConsts* __restrict__ Cp, int chunk, int splitting) {
+  constexpr int GD = NV - 1, NF = NV - 1;
+  constexpr int RPB = (DG_BLOCK / NV) * NV;
+  extern __shared__ double img[];
+  const DgConsts& C = *Cp;
+  const int row0 = dg_block_index(blockIdx.x, chunk) * RPB;
+  if (row0 >= D.n_dof) return;
+  const int nrows = min(RPB, D.n_dof - row0);
+  const int tid = threadIdx.x;
+  const int base = D.rowptr[row0];
+  const int span = D.rowptr[row0 + nrows] - base;
+  if (tid < nrows) {
+    const int row = row0 + tid, T = row / NV, i = row - T * NV;
+    int p[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) p[j] = i + j >= NV ? i + j - NV : i + j;
+    const int s = D.cell_sub[T];
+    double X[NV][GD], kap[NV], sg[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const DofRec r = load_rec(D.rec, T * NV + p[j]);
+#pragma unroll
+      for (int d = 0; d < GD; ++d) X[j][d] = r.x[d];
+      double k = 0.0, g = 0.0;
+#pragma unroll
+      for (int q = 0; q < KN_MAXK; ++q) { k += C.kap[s][q] * r.c[q]; g += C.sig[s][q] * r.c[q]; }
+      kap[j] = k; sg[j] = g;
+    }
+    Geo<NV> G;
+    geometry<NV>(X, G);
+    double J[GD];   // sum_k F z_k D_k grad c_k
+#pragma unroll
+    for (int d = 0; d < GD; ++d) {
+      double a = 0.0;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) a += sg[j] * G.g[j][d];
+      J[d] = a;
+    }
+    double kbar = 0.0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) kbar += kap[j];
+    kbar *= 1.0 / NV;
+    double self[NV], nbv[NV][NV];   // nbv[f][b]: column of the neighbour's dof at my vertex b; b == f: its far vertex
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      self[j] = G.vol * kbar * dot<GD>(G.g[0], G.g[j]);
+#pragma unroll
+      for (int b = 0; b < NV; ++b) nbv[j][b] = 0.0;
+    }
+    double rhs = -G.vol * dot<GD>(G.g[0], J);
+    int nb[NV];
+    unsigned fi[NV];
+#pragma unroll
+    for (int f = 0; f < NV; ++f) {
+      nb[f] = D.nbr[T * NV + p[f]];
+      fi[f] = D.finfo[T * NV + p[f]];
+    }
+#pragma unroll
+    for (int f = 0; f < NV; ++f) {
+      if (nb[f] < 0) continue;
+      const bool on0 = f != 0;   // the row's basis function does not vanish on this facet
+      const int kind = fi[f] & 3;
+      const double gf = sqrt(dot<GD>(G.g[f], G.g[f]));
+      double n[GD];
+#pragma unroll
+      for (int d = 0; d < GD; ++d) n[d] = -G.g[f][d] / gf;
+      const double area = GD * G.vol * gf;
+      const double c2 = area * (1.0 / (GD * (GD + 1)));
+      if (kind == 1) {
+        const int N = nb[f];
+        double XN[NV][GD], kN[NV], sN[NV];
+#pragma unroll
+        for (int b = 0; b < NV; ++b) {
+          const int jn = b == f ? (fi[f] >> 2) & 3 : (fi[f] >> (4 + 2 * p[b])) & 3;
+          const DofRec r = load_rec(D.rec, N * NV + jn);
+#pragma unroll
+          for (int d = 0; d < GD; ++d) XN[b][d] = b == f ? r.x[d] : X[b][d];
+          double k = 0.0, g = 0.0;
+#pragma unroll
+          for (int q = 0; q < KN_MAXK; ++q) { k += C.kap[s][q] * r.c[q]; g += C.sig[s][q] * r.c[q]; }
+          kN[b] = k; sN[b] = g;
+        }
+        Geo<NV> GN;
+        geometry<NV>(XN, GN);
+        const double inv_h = 0.5 * (gf + sqrt(dot<GD>(GN.g[f], GN.g[f])));
+        double JNn = 0.0, gNn[NV];
+#pragma unroll
+        for (int b = 0; b < NV; ++b) { gNn[b] = dot<GD>(GN.g[b], n); JNn += sN[b] * gNn[b]; }
+        double ST = 0.0, SN = 0.0, St = 0.0, kt[NV];
+#pragma unroll
+        for (int b = 0; b < NV; ++b) {
+          kt[b] = 0.5 * (kap[b] + kN[b]);
+          if (b != f) { ST += kap[b]; SN += kN[b]; St += kt[b]; }
+        }
+        const double c3 = area * (GD == 2 ? 1.0 / 24.0 : 1.0 / 60.0);
+        const double gin = dot<GD>(G.g[0], n);
+        const double pen = C.gamma * inv_h;
+        const double K1T0 = c2 * (ST + kap[0]), K1N0 = c2 * (SN + kN[0]);   // int kappa lambda_0 over the facet (on0 only)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          if (on0) {   // consistency: -1/2 (grad lambda_j . n) int kappa lambda_0, both sides, every j
+            self[j] -= 0.5 * dot<GD>(G.g[j], n) * K1T0;
+            nbv[f][j] -= 0.5 * gNn[j] * K1N0;
+          }
+          if (j != f) {   // symmetry and penalty: columns of the dofs on the facet
+            const double K1Tj = c2 * (ST + kap[j]);
+            self[j] -= 0.5 * gin * K1Tj;
+            nbv[f][j] += 0.5 * gin * K1Tj;
+            if (on0) {
+              const double P3 = j == 0 ? c3 * (2.0 * St + 4.0 * kt[0]) : c3 * (St + kt[0] + kt[j]);
+              self[j] += pen * P3;
+              nbv[f][j] -= pen * P3;
+            }
+          }
+        }
+        if (on0) rhs += 0.5 * (dot<GD>(J, n) + JNn) * (area * (1.0 / GD));
+      } else if (on0) {   // membrane: C_phi [u][v] and C_phi g [v]  (emiWeakForm.py:160-165, 228-239)
+        const int mf = D.mfid[T * NV + p[f]];
+        double gsum = 0.0;
+#pragma unroll
+        for (int a = 0; a < NV; ++a) {
+          if (a == f) continue;
+          const double m2 = C.C_phi * c2 * (a == 0 ? 2.0 : 1.0);
+          self[a] += m2;
+          nbv[f][a] -= m2;
+          const int q = mf * NF + ((fi[f] >> (12 + 2 * p[a])) & 3);
+          double g = D.phiM[q];
+          if (!splitting) {
+            double it = 0.0;
+            for (int k = 0; k < C.K; ++k) it += D.Ich[(size_t)k * D.nq + q];
+            g -= it / C.C_phi;
+          }
+          gsum += g * m2;
+        }
+        rhs += kind == 3 ? gsum : -gsum;
+      }
+    }
+    // the row, as it sits in the CSR value array
+    int slot_self, slot[NV];
+    block_slots<NV>(T, nb, slot_self, slot);
+    double* out = img + (D.rowptr[row] - base);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) out[slot_self * NV + p[j]] = self[j];
+#pragma unroll
+    for (int f = 0; f < NV; ++f) {
+      if (nb[f] < 0) continue;
+#pragma unroll
+      for (int b = 0; b < NV; ++b) {
+        const int jn = b == f ? (fi[f] >> 2) & 3 : (fi[f] >> (4 + 2 * p[b])) & 3;
+        out[slot[f] * NV + jn] = nbv[f][b];
+      }
+    }
+    D.b_emi[row] = rhs;
+  }
+  __syncthreads();
+  double* dst = D.A_emi + base;
+  for (int e = tid; e < span; e += DG_BLOCK) dst[e] = img[e];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// concentration systems: A_knp[k], b_knp[k], k < K - 1
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NV, int KS>
+__global__ __launch_bounds__(DG_BLOCK) void dg_knp_kernel(DgDev D, const DgConsts* __restrict__ Cp, int chunk, int splitting) {
+  constexpr int GD = NV - 1, NF = NV - 1;
+  constexpr int RPB = (DG_BLOCK / NV) * NV;
+  constexpr int CAP = RPB * NV * (NV + 1);   // doubles per image
+  extern __shared__ double img[];
+  const DgConsts& C = *Cp;
+  const int row0 = dg_block_index(blockIdx.x, chunk) * RPB;
+  if (row0 >= D.n_dof) return;
+  const int nrows = min(RPB, D.n_dof - row0);
+  const int tid = threadIdx.x;
+  const int base = D.rowptr[row0];
+  const int span = D.rowptr[row0 + nrows] - base;
+  if (tid < nrows) {
+    const int row = row0 + tid, T = row / NV, i = row - T * NV;
+    int p[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) p[j] = i + j >= NV ? i + j - NV : i + j;
+    const int s = D.cell_sub[T];
+    double X[NV][GD], ph[NV], cc[NV][KN_MAXK];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const DofRec r = load_rec(D.rec, T * NV + p[j]);
+#pragma unroll
+      for (int d = 0; d < GD; ++d) X[j][d] = r.x[d];
+#pragma unroll
+      for (int q = 0; q < KN_MAXK; ++q) cc[j][q] = r.c[q];
+      ph[j] = r.phi;
+    }
+    Geo<NV> G;
+    geometry<NV>(X, G);
+    double gphi[GD];
+#pragma unroll
+    for (int d = 0; d < GD; ++d) {
+      double a = 0.0;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) a += ph[j] * G.g[j][d];
+      gphi[d] = a;
+    }
+    const double drift = dot<GD>(G.g[0], gphi) * G.vol * (1.0 / (GD + 1));
+    const double m0 = G.vol * (1.0 / ((GD + 1) * (GD + 2)));
+    // unit-diffusivity SIP entries (same for every ion: D_k is constant inside a sub-domain)
+    double P[NV], Pn[NV][NV], bf[NV], c2f[NV];
+    double rhs[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      double a = 0.0;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        double v = cc[j][k] * C.inv_dt;
+        if (s == 0 && D.fsrc) v += D.fsrc[(size_t)k * D.n_dof + T * NV + p[j]];
+        a += (j == 0 ? 2.0 : 1.0) * m0 * v;
+      }
+      rhs[k] = a;
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      P[j] = G.vol * dot<GD>(G.g[0], G.g[j]);
+      bf[j] = 0.0; c2f[j] = 0.0;
+#pragma unroll
+      for (int b = 0; b < NV; ++b) Pn[j][b] = 0.0;
+    }
+    int nb[NV];
+    unsigned fi[NV];
+#pragma unroll
+    for (int f = 0; f < NV; ++f) {
+      nb[f] = D.nbr[T * NV + p[f]];
+      fi[f] = D.finfo[T * NV + p[f]];
+    }
+#pragma unroll
+    for (int f = 0; f < NV; ++f) {
+      if (nb[f] < 0) continue;
+      const bool on0 = f != 0;
+      const int kind = fi[f] & 3;
+      const int N = nb[f];
+      const double gf = sqrt(dot<GD>(G.g[f], G.g[f]));
+      double n[GD];
+#pragma unroll
+      for (int d = 0; d < GD; ++d) n[d] = -G.g[f][d] / gf;
+      const double area = GD * G.vol * gf;
+      const double c2 = area * (1.0 / (GD * (GD + 1)));
+      if (kind == 1) {
+        double XN[NV][GD], phN[NV];
+#pragma unroll
+        for (int b = 0; b < NV; ++b) {
+          const int jn = b == f ? (fi[f] >> 2) & 3 : (fi[f] >> (4 + 2 * p[b])) & 3;
+          const double* r = D.rec + (size_t)(N * NV + jn) * KN_REC;
+          phN[b] = r[7];
+#pragma unroll
+          for (int d = 0; d < GD; ++d) XN[b][d] = b == f ? r[d] : X[b][d];
+        }
+        Geo<NV> GN;
+        geometry<NV>(XN, GN);
+        const double inv_h = 0.5 * (gf + sqrt(dot<GD>(GN.g[f], GN.g[f])));
+        double gphiNn = 0.0, gNn[NV];
+#pragma unroll
+        for (int b = 0; b < NV; ++b) { gNn[b] = dot<GD>(GN.g[b], n); gphiNn += phN[b] * gNn[b]; }
+        const double m1 = area * (1.0 / GD);
+        const double gin = dot<GD>(G.g[0], n);
+        const double pen = C.gamma * inv_h;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          if (on0) {
+            P[j] -= 0.5 * dot<GD>(G.g[j], n) * m1;
+            Pn[f][j] -= 0.5 * gNn[j] * m1;
+          }
+          if (j != f) {
+            P[j] -= 0.5 * gin * m1;
+            Pn[f][j] += 0.5 * gin * m1;
+            if (on0) {
+              const double m2 = pen * c2 * (j == 0 ? 2.0 : 1.0);
+              P[j] += m2;
+              Pn[f][j] -= m2;
+            }
+          }
+        }
+        bf[f] = -0.5 * (dot<GD>(gphi, n) + gphiNn);   // beta_k = z_k psi D_k bf: drift speed out of this cell
+        c2f[f] = on0 ? c2 : 0.0;
+      } else if (on0) {
+        // membrane flux (knpWeakForm.py:168-214), degree-6 rule; with alpha_k = D_k z_k^2 c_k / sum_j D_j z_j^2 c_j of this
+        // side the integrand  -/+ (C_k g_k - C_k [phi])  is
+        //   sgn * [ alpha_k C_M / (F z_k dt) ([phi] - phi_M - (dt / C_M) I_ch) + I_ch_k / (F z_k) ],  sgn = +1 on the ECS side
+        const int mf = D.mfid[T * NV + p[f]];
+        double jm[NV], pm[NV], It[NV], Ik[NV][KN_MAXK];
+#pragma unroll
+        for (int a = 0; a < NV; ++a) {
+          if (a == f) continue;
+          const int jn = (fi[f] >> (4 + 2 * p[a])) & 3;
+          const double phn = D.rec[(size_t)(N * NV + jn) * KN_REC + 7];
+          jm[a] = kind == 2 ? phn - ph[a] : ph[a] - phn;
+          const int q = mf * NF + ((fi[f] >> (12 + 2 * p[a])) & 3);
+          pm[a] = D.phiM[q];
+          double it = 0.0;
+#pragma unroll
+          for (int k = 0; k < KN_MAXK; ++k) {
+            Ik[a][k] = k < C.K ? D.Ich[(size_t)k * D.nq + q] : 0.0;
+            it += Ik[a][k];
+          }
+          It[a] = it;
+        }
+        const double sgn = kind == 2 ? 1.0 : -1.0;
+        const double* qw = D.qtab;
+        const double* qN = D.qtab + D.nquad;
+        for (int q = 0; q < D.nquad; ++q) {
+          double cq[KN_MAXK], iq[KN_MAXK], jq = 0.0, pq = 0.0, itq = 0.0, lam0 = 0.0;
+#pragma unroll
+          for (int k = 0; k < KN_MAXK; ++k) { cq[k] = 0.0; iq[k] = 0.0; }
+#pragma unroll
+          for (int a = 0; a < NV; ++a) {
+            if (a == f) continue;
+            const double Nq = qN[q * NF + (a < f ? a : a - 1)];
+            if (a == 0) lam0 = Nq;
+#pragma unroll
+            for (int k = 0; k < KN_MAXK; ++k) { cq[k] += Nq * cc[a][k]; iq[k] += Nq * Ik[a][k]; }
+            jq += Nq * jm[a]; pq += Nq * pm[a]; itq += Nq * It[a];
+          }
+          double asum = 0.0;
+#pragma unroll
+          for (int k = 0; k < KN_MAXK; ++k) asum += C.az2D[s][k] * cq[k];
+          const double w = sgn * qw[q] * area * (NF == 2 ? 1.0 : 2.0) * lam0;
+          double drive = jq - pq;
+          if (splitting) drive -= (C.dt / C.C_M) * itq;
+#pragma unroll
+          for (int k = 0; k < KS; ++k) {
+            const double al = C.az2D[s][k] * cq[k] / asum;
+            const double fz = 1.0 / (C.F * C.z[k]);
+            rhs[k] += w * (al * C.C_M * fz * C.inv_dt * drive + iq[k] * fz);
+          }
+        }
+      }
+    }
+    int slot_self, slot[NV];
+    block_slots<NV>(T, nb, slot_self, slot);
+    const int off = D.rowptr[row] - base;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const double Dk = C.D[s][k], zpD = C.z[k] * C.psi * Dk;
+      double* out = img + k * CAP + off;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        double v = (j == 0 ? 2.0 : 1.0) * m0 * C.inv_dt + Dk * P[j] + zpD * drift;
+#pragma unroll
+        for (int f = 0; f < NV; ++f) {   // upwinding: the drift leaves through facet f -> this cell's own value
+          const double beta = zpD * bf[f];
+          if (j != f && beta > 0.0) v += beta * c2f[f] * (j == 0 ? 2.0 : 1.0);
+        }
+        out[slot_self * NV + p[j]] = v;
+      }
+#pragma unroll
+      for (int f = 0; f < NV; ++f) {
+        if (nb[f] < 0) continue;
+        const double beta = zpD * bf[f];
+#pragma unroll
+        for (int b = 0; b < NV; ++b) {
+          const int jn = b == f ? (fi[f] >> 2) & 3 : (fi[f] >> (4 + 2 * p[b])) & 3;
+          double v = Dk * Pn[f][b];
+          if (b != f && !(beta > 0.0)) v += beta * c2f[f] * (b == 0 ? 2.0 : 1.0);   // ... enters: the neighbour's value
+          out[slot[f] * NV + jn] = v;
+        }
+      }
+      D.b_knp[(size_t)k * D.n_dof + row] = rhs[k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    double* dst = D.A_knp + (size_t)k * D.nnz + base;
+    const double* src = img + k * CAP;
+    for (int e = tid; e < span; e += DG_BLOCK) dst[e] = src[e];
+  }
+}
+
+// end of step (utils.py:238-295): c_prev <- c, eliminated ion from electroneutrality, phi_M <- phi_i - phi_e
+__global__ void dg_update_kernel(DgDev D, const DgConsts* __restrict__ Cp, const double* __restrict__ cnew, int nv) {
+  const DgConsts& C = *Cp;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < D.n_dof) {
+    const int s = D.cell_sub[t / nv];
+    double* r = D.rec + (size_t)t * KN_REC;
+    double acc = C.rho_term[s];
+    for (int k = 0; k < C.K - 1; ++k) {
+      const double v = cnew[(size_t)k * D.n_dof + t];
+      r[KN_CSLOT(k)] = v;
+      acc += C.elim[k] * v;
+    }
+    r[KN_CSLOT(C.K - 1)] = acc;
+  }
+  if (t < D.nq) D.phiM[t] = D.rec[(size_t)D.q2i[t] * KN_REC + 7] - D.rec[(size_t)D.q2e[t] * KN_REC + 7];
+}
+
+__global__ void dg_slot_kernel(double* rec, int slot, double* buf, int n, int to_records) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  if (to_records) rec[(size_t)t * KN_REC + slot] = buf[t];
+  else buf[t] = rec[(size_t)t * KN_REC + slot];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+struct knpemi_dg {
+  int device = 0, NV = 0, K = 0, n_sub = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  DgDev dev{};
+  DgConsts consts{};
+  DgConsts* d_consts = nullptr;
+  int have_params = 0;
+  std::vector<void*> allocs;
+  std::vector<int> h_rowptr, h_colind, h_q2e, h_q2i;
+  double* d_stage = nullptr;
+  size_t stage_len = 0;
+  double* d_fsrc = nullptr;
+  const int* d_colind = nullptr;
+  // membrane ODE sweep
+  int ode_model = -1, ode_ns = 0, ode_np = 0, ode_v = 0, ode_blocks = 0;
+  int ode_ion_param[3 * KN_MAXK] = {0};
+  double* d_states = nullptr;
+  double* d_params = nullptr;
+  unsigned long long* d_stats = nullptr;
+  void* d_coef = nullptr;
+};
+
+namespace {
+
+int dg_fail(int code, const std::string& msg) {
+  kn_set_error(msg);
+  return code;
+}
+
+template <class T>
+int dg_alloc(knpemi_dg* h, size_t n, T** out) {
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+  KN_HIP(hipMalloc(&p, bytes));
+  h->allocs.push_back(p);
+  // zero on the handle's own (non-blocking) stream: a null-stream hipMemset is not ordered with it
+  KN_HIP(hipMemsetAsync(p, 0, bytes, h->stream));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  *out = static_cast<T*>(p);
+  return 0;
+}
+
+template <class T>
+int dg_upload(knpemi_dg* h, const std::vector<T>& v, const T** out) {
+  T* p = nullptr;
+  int rc = dg_alloc(h, v.size(), &p);
+  if (rc) return rc;
+  if (!v.empty()) KN_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = p;
+  return 0;
+}
+
+int dg_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return dg_fail(KNPEMI_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+  return KNPEMI_OK;
+}
+
+int launch_emi(knpemi_dg* h, int flags) {
+  const int NV = h->NV, rpb = (DG_BLOCK / NV) * NV;
+  const int nblocks = (h->dev.n_dof + rpb - 1) / rpb, chunk = (nblocks + 7) / 8;
+  const size_t lds = (size_t)rpb * NV * (NV + 1) * sizeof(double);
+  const int split = !(flags & KNPEMI_NO_SPLITTING);
+  if (NV == 3) hipLaunchKernelGGL(dg_emi_kernel<3>, dim3(8 * chunk), dim3(DG_BLOCK), lds, h->stream, h->dev, h->d_consts, chunk, split);
+  else hipLaunchKernelGGL(dg_emi_kernel<4>, dim3(8 * chunk), dim3(DG_BLOCK), lds, h->stream, h->dev, h->d_consts, chunk, split);
+  return dg_check_launch("dg_emi_kernel");
+}
+
+template <int NV>
+int launch_knp_nv(knpemi_dg* h, int chunk, int split) {
+  constexpr int rpb = (DG_BLOCK / NV) * NV;
+  const size_t lds1 = (size_t)rpb * NV * (NV + 1) * sizeof(double);
+  const dim3 grid(8 * chunk), block(DG_BLOCK);
+  switch (h->K - 1) {
+    case 1: hipLaunchKernelGGL((dg_knp_kernel<NV, 1>), grid, block, lds1, h->stream, h->dev, h->d_consts, chunk, split); break;
+    case 2: hipLaunchKernelGGL((dg_knp_kernel<NV, 2>), grid, block, 2 * lds1, h->stream, h->dev, h->d_consts, chunk, split); break;
+    default: hipLaunchKernelGGL((dg_knp_kernel<NV, 3>), grid, block, 3 * lds1, h->stream, h->dev, h->d_consts, chunk, split); break;
+  }
+  return dg_check_launch("dg_knp_kernel");
+}
+
+int launch_knp(knpemi_dg* h, int flags) {
+  const int NV = h->NV, rpb = (DG_BLOCK / NV) * NV;
+  const int nblocks = (h->dev.n_dof + rpb - 1) / rpb, chunk = (nblocks + 7) / 8;
+  const int split = !(flags & KNPEMI_NO_SPLITTING);
+  return NV == 3 ? launch_knp_nv<3>(h, chunk, split) : launch_knp_nv<4>(h, chunk, split);
+}
+
+}  // namespace
+
+extern "C" void knpemi_dg_destroy(knpemi_dg* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->d_coef) (void)hipFree(h->d_coef);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" int knpemi_dg_create(const knpemi_dg_desc* d, int device, knpemi_dg** out) {
+  if (!d || !out) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: null argument");
+  *out = nullptr;
+  int NV;
+  if (d->cell_kind == KNPEMI_TRIANGLE) NV = 3;
+  else if (d->cell_kind == KNPEMI_TETRAHEDRON) NV = 4;
+  else return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: the DG variant is built for simplices (triangles, tetrahedra)");
+  const int GD = NV - 1, NF = NV - 1;
+  if (d->n_ions < 2 || d->n_ions > KN_MAXK) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: 2 to 4 ionic species are supported");
+  if (d->n_sub < 1 || d->n_sub > KN_MAXSUB) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: bad n_sub");
+  if (d->n_cells < 1 || d->n_cells * NV >= (int64_t)1 << 31) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: bad n_cells");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return dg_fail(KNPEMI_EHIP, "knpemi_dg_create: no HIP device visible (the hot path has no CPU fallback)");
+  if (device < 0 || device >= ndev) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: bad device index");
+  KN_HIP(hipSetDevice(device));
+  auto* h = new knpemi_dg();
+  std::unique_ptr<knpemi_dg, void (*)(knpemi_dg*)> guard(h, knpemi_dg_destroy);
+  h->device = device; h->NV = NV; h->K = d->n_ions; h->n_sub = d->n_sub;
+  KN_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  KN_HIP(hipEventCreate(&h->ev0));
+  KN_HIP(hipEventCreate(&h->ev1));
+
+  const int nc = (int)d->n_cells, nmf = (int)d->n_mem_facets, n = nc * NV;
+  for (int c = 0; c < nc; ++c)
+    if (d->cell_sub[c] < 0 || d->cell_sub[c] >= d->n_sub) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: cell_sub out of range");
+  // facet -> (cell, local facet) by sorting the facets' sorted vertex tuples; membrane facets ride along with id < 0
+  struct Ent { std::array<int, 3> key; int id; };
+  std::vector<Ent> ents;
+  ents.reserve((size_t)n + nmf);
+  auto make_key = [&](const int32_t* v, int skip, int cnt) {
+    std::array<int, 3> k = {-1, -1, -1};
+    int m = 0;
+    for (int a = 0; a < cnt; ++a) if (a != skip) k[m++] = v[a];
+    std::sort(k.begin(), k.begin() + m);
+    return k;
+  };
+  for (int c = 0; c < nc; ++c)
+    for (int f = 0; f < NV; ++f) {
+      for (int a = 0; a < NV; ++a)
+        if (d->cells[(size_t)c * NV + a] < 0 || d->cells[(size_t)c * NV + a] >= d->n_vertices)
+          return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: vertex id out of range");
+      ents.push_back({make_key(d->cells + (size_t)c * NV, f, NV), c * NV + f});
+    }
+  for (int m = 0; m < nmf; ++m) ents.push_back({make_key(d->mem_facets + (size_t)m * NF, -1, NF), -1 - m});
+  std::sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key != b.key ? a.key < b.key : a.id < b.id; });
+
+  std::vector<int> nbr((size_t)n, -1), mfid((size_t)n, -1);
+  std::vector<unsigned> finfo((size_t)n, 0u);
+  std::vector<unsigned char> csub((size_t)nc);
+  for (int c = 0; c < nc; ++c) csub[c] = (unsigned char)d->cell_sub[c];
+  h->h_q2e.assign((size_t)nmf * NF, -1);
+  h->h_q2i.assign((size_t)nmf * NF, -1);
+  auto local_of = [&](int c, int v) {
+    for (int a = 0; a < NV; ++a) if (d->cells[(size_t)c * NV + a] == v) return a;
+    return -1;
+  };
+  for (size_t e = 0; e < ents.size();) {
+    size_t e1 = e;
+    while (e1 < ents.size() && ents[e1].key == ents[e].key) ++e1;
+    int mem = -1, cf[2], ncf = 0;
+    for (size_t t = e; t < e1; ++t) {
+      if (ents[t].id < 0) {
+        if (mem >= 0) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: membrane facet listed twice");
+        mem = -1 - ents[t].id;
+      } else {
+        if (ncf == 2) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: a facet is shared by more than two cells");
+        cf[ncf++] = ents[t].id;
+      }
+    }
+    e = e1;
+    if (ncf < 2) {
+      if (mem >= 0) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: membrane facet is not shared by two cells");
+      continue;
+    }
+    const int c0 = cf[0] / NV, f0 = cf[0] % NV, c1 = cf[1] / NV, f1 = cf[1] % NV;
+    const int s0 = d->cell_sub[c0], s1 = d->cell_sub[c1];
+    int kind0 = 1, kind1 = 1;
+    if (mem >= 0) {
+      if (!((s0 == 0) != (s1 == 0)))
+        return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: a membrane facet must separate an ECS cell from a cell of a sub-domain > 0");
+      kind0 = s0 == 0 ? 2 : 3;
+      kind1 = s1 == 0 ? 2 : 3;
+    } else if (s0 != s1) {
+      return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: facet between two sub-domains is not in mem_facets");
+    }
+    for (int side = 0; side < 2; ++side) {
+      const int c = side ? c1 : c0, f = side ? f1 : f0, o = side ? c0 : c1, fo = side ? f0 : f1;
+      unsigned w = (unsigned)(side ? kind1 : kind0) | (unsigned)fo << 2;
+      for (int a = 0; a < NV; ++a) {
+        if (a == f) continue;
+        const int v = d->cells[(size_t)c * NV + a];
+        w |= (unsigned)local_of(o, v) << (4 + 2 * a);
+        if (mem >= 0) {
+          int node = -1;
+          for (int t = 0; t < NF; ++t) if (d->mem_facets[(size_t)mem * NF + t] == v) node = t;
+          w |= (unsigned)node << (12 + 2 * a);
+          (d->cell_sub[c] == 0 ? h->h_q2e : h->h_q2i)[(size_t)mem * NF + node] = c * NV + a;
+        }
+      }
+      nbr[(size_t)c * NV + f] = o;
+      finfo[(size_t)c * NV + f] = w;
+      mfid[(size_t)c * NV + f] = mem;
+    }
+  }
+  // CSR pattern: per row one nv-wide block per cell of {self} + neighbours, increasing cell order
+  h->h_rowptr.assign((size_t)n + 1, 0);
+  int64_t nnz = 0;
+  for (int c = 0; c < nc; ++c) {
+    int cnt = 1;
+    for (int f = 0; f < NV; ++f) cnt += nbr[(size_t)c * NV + f] >= 0;
+    for (int i = 0; i < NV; ++i) { nnz += (int64_t)cnt * NV; h->h_rowptr[(size_t)c * NV + i + 1] = (int)nnz; }
+    if (nnz >= ((int64_t)1 << 31) - 64) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: more than 2^31 matrix entries");
+  }
+  h->h_colind.resize((size_t)nnz);
+  for (int c = 0; c < nc; ++c) {
+    int blk[5], cnt = 0;
+    blk[cnt++] = c;
+    for (int f = 0; f < NV; ++f) if (nbr[(size_t)c * NV + f] >= 0) blk[cnt++] = nbr[(size_t)c * NV + f];
+    std::sort(blk, blk + cnt);
+    for (int i = 0; i < NV; ++i) {
+      int* ci = h->h_colind.data() + h->h_rowptr[(size_t)c * NV + i];
+      for (int b = 0; b < cnt; ++b) for (int j = 0; j < NV; ++j) *ci++ = blk[b] * NV + j;
+    }
+  }
+  std::vector<double> rec((size_t)n * KN_REC, 0.0);
+  for (int c = 0; c < nc; ++c)
+    for (int j = 0; j < NV; ++j)
+      for (int dd = 0; dd < GD; ++dd) rec[((size_t)c * NV + j) * KN_REC + dd] = d->x[(size_t)d->cells[(size_t)c * NV + j] * GD + dd];
+
+  DgDev& D = h->dev;
+  D.n_cell = nc; D.n_dof = n; D.nq = nmf * NF; D.nnz = nnz;
+  int rc;
+  const double* crec = nullptr;
+  if ((rc = dg_upload(h, rec, &crec))) return rc;
+  D.rec = const_cast<double*>(crec);
+  if ((rc = dg_upload(h, nbr, &D.nbr))) return rc;
+  if ((rc = dg_upload(h, finfo, &D.finfo))) return rc;
+  if ((rc = dg_upload(h, mfid, &D.mfid))) return rc;
+  if ((rc = dg_upload(h, csub, &D.cell_sub))) return rc;
+  if ((rc = dg_upload(h, h->h_rowptr, &D.rowptr))) return rc;
+  if ((rc = dg_upload(h, h->h_q2e, &D.q2e))) return rc;
+  if ((rc = dg_upload(h, h->h_q2i, &D.q2i))) return rc;
+  if ((rc = dg_alloc(h, (size_t)nnz, &D.A_emi))) return rc;
+  if ((rc = dg_alloc(h, (size_t)n, &D.b_emi))) return rc;
+  if ((rc = dg_alloc(h, (size_t)(h->K - 1) * nnz, &D.A_knp))) return rc;
+  if ((rc = dg_alloc(h, (size_t)(h->K - 1) * n, &D.b_knp))) return rc;
+  if ((rc = dg_alloc(h, (size_t)D.nq, &D.phiM))) return rc;
+  if ((rc = dg_alloc(h, (size_t)KN_MAXK * std::max(D.nq, 1), &D.Ich))) return rc;
+  D.fsrc = nullptr;
+  {
+    std::vector<double> qt;
+    D.nquad = kn_gamma_quadrature(NF, &qt);
+    if ((rc = dg_upload(h, qt, &D.qtab))) return rc;
+  }
+  h->stage_len = (size_t)std::max(n, 1) * (size_t)std::max(1, h->K - 1);
+  if ((rc = dg_alloc(h, h->stage_len, &h->d_stage))) return rc;
+  if ((rc = dg_alloc(h, 1, &h->d_consts))) return rc;
+  for (size_t t = 0; t < h->h_q2e.size(); ++t)
+    if (h->h_q2e[t] < 0 || h->h_q2i[t] < 0) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: membrane facet without two cells");
+  guard.release();
+  *out = h;
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_dg_set_params(knpemi_dg* h, const knpemi_dg_params* p) {
+  if (!h || !p) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_set_params: null argument");
+  if (!(p->dt > 0) || !(p->gamma > 0)) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_set_params: dt and gamma must be positive");
+  KN_HIP(hipSetDevice(h->device));
+  DgConsts& C = h->consts;
+  std::memset(&C, 0, sizeof(C));
+  C.n_sub = h->n_sub; C.K = h->K;
+  C.F = p->F; C.psi = p->psi; C.C_M = p->C_M; C.dt = p->dt; C.inv_dt = 1.0 / p->dt; C.C_phi = p->C_M / p->dt; C.gamma = p->gamma;
+  const double zK = p->z[h->K - 1];
+  if (zK == 0.0) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_set_params: the eliminated ion needs a non-zero valence");
+  for (int k = 0; k < h->K; ++k) {
+    C.z[k] = p->z[k];
+    C.elim[k] = -(p->z[k] / zK);
+    if (k < h->K - 1 && p->z[k] == 0.0) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_set_params: zero valence");
+  }
+  for (int s = 0; s < h->n_sub; ++s) {
+    for (int k = 0; k < h->K; ++k) {
+      const double Dk = p->D[s][k], z = p->z[k];
+      C.D[s][k] = Dk;
+      C.kap[s][k] = p->F * z * z * Dk * p->psi;
+      C.sig[s][k] = p->F * z * Dk;
+      C.az2D[s][k] = Dk * z * z;
+    }
+    C.rho_term[s] = -(1.0 / zK) * p->rho_z * p->rho[s];
+  }
+  KN_HIP(hipMemcpyAsync(h->d_consts, &C, sizeof(C), hipMemcpyHostToDevice, h->stream));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  h->have_params = 1;
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_dg_dims(knpemi_dg* h, int64_t* n_dofs, int64_t* nnz, int64_t* n_mem_nodes) {
+  if (!h) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_dims: null handle");
+  if (n_dofs) *n_dofs = h->dev.n_dof;
+  if (nnz) *nnz = h->dev.nnz;
+  if (n_mem_nodes) *n_mem_nodes = h->dev.nq;
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_dg_get_pattern(knpemi_dg* h, int32_t* rowptr, int32_t* colind) {
+  if (!h || !rowptr || !colind) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_get_pattern: null argument");
+  std::memcpy(rowptr, h->h_rowptr.data(), h->h_rowptr.size() * sizeof(int));
+  std::memcpy(colind, h->h_colind.data(), h->h_colind.size() * sizeof(int));
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_dg_get_membrane_dofs(knpemi_dg* h, int32_t* dof_e, int32_t* dof_i) {
+  if (!h || !dof_e || !dof_i) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_get_membrane_dofs: null argument");
+  std::memcpy(dof_e, h->h_q2e.data(), h->h_q2e.size() * sizeof(int));
+  std::memcpy(dof_i, h->h_q2i.data(), h->h_q2i.size() * sizeof(int));
+  return KNPEMI_OK;
+}
+
+namespace {
+// (device pointer, length, record slot or -1) of a field
+int dg_field(knpemi_dg* h, int field, int idx, double** ptr, size_t* len, int* slot) {
+  const DgDev& D = h->dev;
+  *slot = -1;
+  switch (field) {
+    case KNPEMI_DG_C:
+      if (idx < 0 || idx >= h->K) return dg_fail(KNPEMI_EINVAL, "knpemi_dg field: ion index out of range");
+      *slot = KN_CSLOT(idx); *ptr = D.rec; *len = D.n_dof; return 0;
+    case KNPEMI_DG_PHI: *slot = 7; *ptr = D.rec; *len = D.n_dof; return 0;
+    case KNPEMI_DG_PHI_M: *ptr = D.phiM; *len = D.nq; return 0;
+    case KNPEMI_DG_I_CH:
+      if (idx < 0 || idx >= h->K) return dg_fail(KNPEMI_EINVAL, "knpemi_dg field: ion index out of range");
+      *ptr = D.Ich + (size_t)idx * D.nq; *len = D.nq; return 0;
+    case KNPEMI_DG_SOURCE:
+      if (idx < 0 || idx >= h->K - 1) return dg_fail(KNPEMI_EINVAL, "knpemi_dg field: ion index out of range");
+      if (!h->d_fsrc) {
+        int rc = dg_alloc(h, (size_t)(h->K - 1) * D.n_dof, &h->d_fsrc);
+        if (rc) return rc;
+        h->dev.fsrc = h->d_fsrc;
+      }
+      *ptr = h->d_fsrc + (size_t)idx * D.n_dof; *len = D.n_dof; return 0;
+  }
+  return dg_fail(KNPEMI_EINVAL, "knpemi_dg field: unknown field");
+}
+}  // namespace
+
+extern "C" int knpemi_dg_set_field(knpemi_dg* h, int field, int idx, const double* host, size_t n) {
+  if (!h || !host) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_set_field: null argument");
+  KN_HIP(hipSetDevice(h->device));
+  double* ptr; size_t len; int slot;
+  int rc = dg_field(h, field, idx, &ptr, &len, &slot);
+  if (rc) return rc;
+  if (n != len) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_set_field: length mismatch");
+  if (len == 0) return KNPEMI_OK;
+  if (slot < 0) {
+    KN_HIP(hipMemcpyAsync(ptr, host, len * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  } else {
+    KN_HIP(hipMemcpyAsync(h->d_stage, host, len * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(dg_slot_kernel, dim3((len + 255) / 256), dim3(256), 0, h->stream, ptr, slot, h->d_stage, (int)len, 1);
+    if ((rc = dg_check_launch("dg_slot_kernel"))) return rc;
+  }
+  KN_HIP(hipStreamSynchronize(h->stream));
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_dg_get_field(knpemi_dg* h, int field, int idx, double* host, size_t n) {
+  if (!h || !host) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_get_field: null argument");
+  KN_HIP(hipSetDevice(h->device));
+  double* ptr; size_t len; int slot;
+  int rc = dg_field(h, field, idx, &ptr, &len, &slot);
+  if (rc) return rc;
+  if (n != len) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_get_field: length mismatch");
+  if (len == 0) return KNPEMI_OK;
+  if (slot < 0) {
+    KN_HIP(hipMemcpyAsync(host, ptr, len * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  } else {
+    hipLaunchKernelGGL(dg_slot_kernel, dim3((len + 255) / 256), dim3(256), 0, h->stream, ptr, slot, h->d_stage, (int)len, 0);
+    if ((rc = dg_check_launch("dg_slot_kernel"))) return rc;
+    KN_HIP(hipMemcpyAsync(host, h->d_stage, len * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  KN_HIP(hipStreamSynchronize(h->stream));
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_dg_assemble_emi(knpemi_dg* h, int flags) {
+  if (!h) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_assemble_emi: null handle");
+  if (!h->have_params) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_assemble_emi: knpemi_dg_set_params has not been called");
+  KN_HIP(hipSetDevice(h->device));
+  return launch_emi(h, flags);
+}
+
+extern "C" int knpemi_dg_assemble_knp(knpemi_dg* h, int flags) {
+  if (!h) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_assemble_knp: null handle");
+  if (!h->have_params) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_assemble_knp: knpemi_dg_set_params has not been called");
+  KN_HIP(hipSetDevice(h->device));
+  return launch_knp(h, flags);
+}
+
+extern "C" int knpemi_dg_get_values(knpemi_dg* h, int which, double* vals) {
+  if (!h || !vals || which < 0 || which > h->K - 1) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_get_values: bad argument");
+  KN_HIP(hipSetDevice(h->device));
+  const double* src = which == 0 ? h->dev.A_emi : h->dev.A_knp + (size_t)(which - 1) * h->dev.nnz;
+  KN_HIP(hipMemcpyAsync(vals, src, (size_t)h->dev.nnz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_dg_get_rhs(knpemi_dg* h, int which, double* b) {
+  if (!h || !b || which < 0 || which > h->K - 1) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_get_rhs: bad argument");
+  KN_HIP(hipSetDevice(h->device));
+  const double* src = which == 0 ? h->dev.b_emi : h->dev.b_knp + (size_t)(which - 1) * h->dev.n_dof;
+  KN_HIP(hipMemcpyAsync(b, src, (size_t)h->dev.n_dof * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_dg_device_system(knpemi_dg* h, int which, const int32_t** rowptr, const int32_t** colind,
+                                       const double** vals, const double** b) {
+  if (!h || which < 0 || which > h->K - 1) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_device_system: bad argument");
+  if (colind) {   // uploaded on first request: the assembly kernels never read the column indices
+    if (!h->d_colind) {
+      KN_HIP(hipSetDevice(h->device));
+      int rc = dg_upload(h, h->h_colind, &h->d_colind);
+      if (rc) return rc;
+    }
+    *colind = h->d_colind;
+  }
+  if (rowptr) *rowptr = h->dev.rowptr;
+  if (vals) *vals = which == 0 ? h->dev.A_emi : h->dev.A_knp + (size_t)(which - 1) * h->dev.nnz;
+  if (b) *b = which == 0 ? h->dev.b_emi : h->dev.b_knp + (size_t)(which - 1) * h->dev.n_dof;
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_dg_update(knpemi_dg* h, const double* c_new, int on_device) {
+  if (!h || !c_new) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_update: null argument");
+  if (!h->have_params) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_update: knpemi_dg_set_params has not been called");
+  KN_HIP(hipSetDevice(h->device));
+  const size_t len = (size_t)(h->K - 1) * h->dev.n_dof;
+  const double* src = c_new;
+  if (!on_device) {
+    KN_HIP(hipMemcpyAsync(h->d_stage, c_new, len * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    src = h->d_stage;
+  }
+  const int nt = std::max(h->dev.n_dof, h->dev.nq);
+  hipLaunchKernelGGL(dg_update_kernel, dim3((nt + 255) / 256), dim3(256), 0, h->stream, h->dev, h->d_consts, src, h->NV);
+  int rc = dg_check_launch("dg_update_kernel");
+  if (rc) return rc;
+  if (!on_device) KN_HIP(hipStreamSynchronize(h->stream));
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_dg_sync(knpemi_dg* h) {
+  if (!h) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_sync: null handle");
+  KN_HIP(hipSetDevice(h->device));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_dg_time_kernel(knpemi_dg* h, int which, int flags, int reps, double* avg_ms) {
+  if (!h || !avg_ms || reps < 1 || which < 0 || which > 1) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_time_kernel: bad argument");
+  if (!h->have_params) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_time_kernel: knpemi_dg_set_params has not been called");
+  KN_HIP(hipSetDevice(h->device));
+  int rc = which == 0 ? launch_emi(h, flags) : launch_knp(h, flags);   // warm-up
+  if (rc) return rc;
+  KN_HIP(hipEventRecord(h->ev0, h->stream));
+  for (int r = 0; r < reps; ++r)
+    if ((rc = which == 0 ? launch_emi(h, flags) : launch_knp(h, flags))) return rc;
+  KN_HIP(hipEventRecord(h->ev1, h->stream));
+  KN_HIP(hipEventSynchronize(h->ev1));
+  float ms = 0.f;
+  KN_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *avg_ms = (double)ms / reps;
+  return KNPEMI_OK;
+}
+
+// ---- membrane ODE sweep over the membrane nodes ------------------------------------------------------------------
+extern "C" int knpemi_dg_ode_bind(knpemi_dg* h, int model_id, int n_states, int n_params, const double* states,
+                                  const double* params, const int32_t* ion_param, int v_index) {
+  if (!h || !states || !params || !ion_param) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_ode_bind: null argument");
+  static const int ns_of[3] = {4, 4, 1}, np_of[3] = {22, 22, 23};
+  if (model_id < 0 || model_id > 2) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_ode_bind: unknown model id");
+  if (n_states != ns_of[model_id] || n_params != np_of[model_id])
+    return dg_fail(KNPEMI_EINVAL, "knpemi_dg_ode_bind: state/parameter count does not match the model");
+  if (h->ode_model >= 0) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_ode_bind: model already bound");
+  if (v_index < 0 || v_index >= n_states) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_ode_bind: bad v_index");
+  for (int i = 0; i < 3 * h->K; ++i)
+    if (ion_param[i] < 0 || ion_param[i] >= n_params) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_ode_bind: parameter index out of range");
+  KN_HIP(hipSetDevice(h->device));
+  const int nq = h->dev.nq;
+  int rc;
+  if ((rc = dg_alloc(h, (size_t)n_states * nq, &h->d_states))) return rc;
+  if ((rc = dg_alloc(h, (size_t)n_params * nq, &h->d_params))) return rc;
+  h->ode_blocks = (int)(((size_t)nq * n_states + 63) / 64) + 1;
+  if ((rc = dg_alloc(h, 3 * (size_t)h->ode_blocks, &h->d_stats))) return rc;
+  std::vector<double> t((size_t)std::max(n_states, n_params) * std::max(nq, 1));
+  for (int pass = 0; pass < 2; ++pass) {
+    const int cols = pass ? n_params : n_states;
+    const double* src = pass ? params : states;
+    for (int r = 0; r < nq; ++r) for (int c = 0; c < cols; ++c) t[(size_t)c * nq + r] = src[(size_t)r * cols + c];
+    if (nq) KN_HIP(hipMemcpy(pass ? h->d_params : h->d_states, t.data(), (size_t)cols * nq * sizeof(double), hipMemcpyHostToDevice));
+  }
+  if ((rc = kn_lsoda_coef_upload(&h->d_coef))) return rc;
+  for (int i = 0; i < 3 * KN_MAXK; ++i) h->ode_ion_param[i] = i < 3 * h->K ? ion_param[i] : 0;
+  h->ode_model = model_id; h->ode_ns = n_states; h->ode_np = n_params; h->ode_v = v_index;
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_dg_ode_step(knpemi_dg* h, double t0, double dt, double rtol, double atol, int flags) {
+  if (!h || h->ode_model < 0) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_ode_step: no membrane model bound");
+  if (h->dev.nq == 0) return KNPEMI_OK;
+  KN_HIP(hipSetDevice(h->device));
+  const DgDev& D = h->dev;
+  OdeDev dv{D.rec, D.q2e, D.q2i, D.phiM, D.Ich};
+  OdeArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.nq = D.nq; a.q0 = 0; a.n_stim = 0; a.flags = flags & (KNPEMI_ODE_SET_V | KNPEMI_ODE_SET_TRACES); a.v_index = h->ode_v;
+  a.model_slot = 0; a.NQtot = D.nq; a.n_ions = h->K;
+  for (int i = 0; i < 3 * KN_MAXK; ++i) a.ion_param[i] = h->ode_ion_param[i];
+  a.t0 = t0; a.dt = dt; a.rtol = rtol; a.atol = atol;
+  a.states = h->d_states; a.params = h->d_params; a.mask = nullptr; a.stats = h->d_stats; a.stamps = nullptr;
+  return kn_launch_ode_raw(h->stream, h->ode_model, dv, a, h->d_coef);
+}
+
+extern "C" int knpemi_dg_ode_get_tables(knpemi_dg* h, double* states, double* params) {
+  if (!h || h->ode_model < 0) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_ode_get_tables: no membrane model bound");
+  KN_HIP(hipSetDevice(h->device));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  const int nq = h->dev.nq;
+  std::vector<double> t((size_t)std::max(h->ode_ns, h->ode_np) * std::max(nq, 1));
+  for (int pass = 0; pass < 2; ++pass) {
+    double* dst = pass ? params : states;
+    if (!dst || !nq) continue;
+    const int cols = pass ? h->ode_np : h->ode_ns;
+    KN_HIP(hipMemcpy(t.data(), pass ? h->d_params : h->d_states, (size_t)cols * nq * sizeof(double), hipMemcpyDeviceToHost));
+    for (int r = 0; r < nq; ++r) for (int c = 0; c < cols; ++c) dst[(size_t)r * cols + c] = t[(size_t)c * nq + r];
+  }
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_dg_ode_stats(knpemi_dg* h, int64_t* n_rhs, int64_t* n_steps, int64_t* n_failed) {
+  if (!h || h->ode_model < 0) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_ode_stats: no membrane model bound");
+  KN_HIP(hipSetDevice(h->device));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  std::vector<unsigned long long> part(3 * (size_t)h->ode_blocks);
+  KN_HIP(hipMemcpyAsync(part.data(), h->d_stats, part.size() * sizeof(part[0]), hipMemcpyDeviceToHost, h->stream));
+  KN_HIP(hipMemsetAsync(h->d_stats, 0, part.size() * sizeof(part[0]), h->stream));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  unsigned long long st[3] = {0, 0, 0};
+  for (size_t i = 0; i < part.size(); ++i) st[i % 3] += part[i];
+  if (n_rhs) *n_rhs = (int64_t)st[0];
+  if (n_steps) *n_steps = (int64_t)st[1];
+  if (n_failed) *n_failed = (int64_t)st[2];
+  if (st[2]) return dg_fail(KNPEMI_EODE, "LSODA failed on at least one membrane node (odeSolver.py:121 `assert success`)");
+  return KNPEMI_OK;
+}

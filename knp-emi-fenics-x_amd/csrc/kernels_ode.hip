@@ -28,13 +28,27 @@ OdeDev ode_dev(const knpemi_handle* h) {
 }
 
 template <class M, int LANES>
-void launch_model(knpemi_handle* h, const OdeArgs& a, const LsodaCoef* cf, int force_waves) {
+void launch_model(hipStream_t st, const OdeDev& dv, const OdeArgs& a, const LsodaCoef* cf, int force_waves) {
   dim3 grid(((size_t)a.nq * LANES + ODE_BLOCK - 1) / ODE_BLOCK), block(ODE_BLOCK);
   // more waves than 1.5 x the chip's 1024 SIMDs: trade registers for a second resident wave per SIMD
   const bool dense = force_waves ? force_waves == 2 : (size_t)grid.x > 1536;
-  if (a.stamps) hipLaunchKernelGGL((ode_step_kernel<M, LANES, 1, true>), grid, block, 0, h->cur, ode_dev(h), a, cf);
-  else if (dense) hipLaunchKernelGGL((ode_step_kernel<M, LANES, 2>), grid, block, 0, h->cur, ode_dev(h), a, cf);
-  else hipLaunchKernelGGL((ode_step_kernel<M, LANES, 1>), grid, block, 0, h->cur, ode_dev(h), a, cf);
+  if (a.stamps) hipLaunchKernelGGL((ode_step_kernel<M, LANES, 1, true>), grid, block, 0, st, dv, a, cf);
+  else if (dense) hipLaunchKernelGGL((ode_step_kernel<M, LANES, 2>), grid, block, 0, st, dv, a, cf);
+  else hipLaunchKernelGGL((ode_step_kernel<M, LANES, 1>), grid, block, 0, st, dv, a, cf);
+}
+
+int launch_builtin(hipStream_t st, int model_id, const OdeDev& dv, const OdeArgs& a, const LsodaCoef* cf, int force_waves) {
+  switch (model_id) {
+    case KNPEMI_MODEL_HH_SI: launch_model<ModelHHSI, 4>(st, dv, a, cf, force_waves); break;
+    case KNPEMI_MODEL_HH_MV: launch_model<ModelHHMV, 4>(st, dv, a, cf, force_waves); break;
+    default: launch_model<ModelGlial, 1>(st, dv, a, cf, force_waves); break;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    kn_set_error(std::string("ode_step_kernel: ") + hipGetErrorString(e));
+    return KNPEMI_EHIP;
+  }
+  return KNPEMI_OK;
 }
 
 }  // namespace
@@ -89,15 +103,20 @@ int kn_launch_ode_step(knpemi_handle* h, int slot, double t0, double dt, double 
     a.stamps = nullptr;
     return kn_rtc_launch(h, m, &dv, sizeof(dv), &a, sizeof(a), cf);
   }
-  switch (m.model_id) {
-    case KNPEMI_MODEL_HH_SI: launch_model<ModelHHSI, 4>(h, a, cf, force_waves); break;
-    case KNPEMI_MODEL_HH_MV: launch_model<ModelHHMV, 4>(h, a, cf, force_waves); break;
-    default: launch_model<ModelGlial, 1>(h, a, cf, force_waves); break;
-  }
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) {
-    kn_set_error(std::string("ode_step_kernel: ") + hipGetErrorString(e));
-    return KNPEMI_EHIP;
-  }
+  return launch_builtin(h->cur, m.model_id, ode_dev(h), a, cf, force_waves);
+}
+
+// The same sweep over a caller-described table (the DG variant, kernels_dg.hip: membrane nodes of the broken space).
+int kn_launch_ode_raw(hipStream_t st, int model_id, const OdeDev& dv, const OdeArgs& a, const void* coef) {
+  return launch_builtin(st, model_id, dv, a, static_cast<const LsodaCoef*>(coef), 0);
+}
+
+int kn_lsoda_coef_upload(void** out) {
+  LsodaCoef c;
+  lsoda_fill_coef(&c);
+  void* d = nullptr;
+  KN_HIP(hipMalloc(&d, sizeof(LsodaCoef)));
+  KN_HIP(hipMemcpy(d, &c, sizeof(LsodaCoef), hipMemcpyHostToDevice));
+  *out = d;
   return KNPEMI_OK;
 }

@@ -53,6 +53,8 @@ int fail(int code, const std::string& msg) {
   return code;
 }
 
+}  // namespace
+
 // Degree-6 rules on the membrane facet (UFL estimates degree 6 for the
 // rational KNP coupling integrand; Basix would pick Gauss-Jacobi with 4 points per direction on
 // intervals/quadrilaterals and the 12-point Xiao-Gimbutas rule on triangles).  Layout: nq weights
@@ -99,8 +101,6 @@ int kn_gamma_quadrature(int NF, std::vector<double>* out) {
   }
   return 16;
 }
-
-}  // namespace
 
 extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_handle** out) {
   if (!d || !out) return fail(KNPEMI_EINVAL, "knpemi_create: null argument");

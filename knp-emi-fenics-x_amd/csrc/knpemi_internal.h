@@ -234,6 +234,12 @@ void kn_set_error(const std::string& msg);
     }                                                                                    \
   } while (0)
 
+struct OdeDev;
+struct OdeArgs;
+int kn_launch_ode_raw(hipStream_t st, int model_id, const OdeDev& dv, const OdeArgs& a, const void* coef);   // kernels_ode.hip
+int kn_lsoda_coef_upload(void** out);
+int kn_gamma_quadrature(int NF, std::vector<double>* out);   // degree-6 membrane-facet rule (knpemi_api.hip)
+
 // kernel launchers (kernels_*.hip) ------------------------------------------------------------
 int kn_launch_emi_rows(knpemi_handle* h, int flags);
 int kn_launch_knp_rows(knpemi_handle* h, int flags);

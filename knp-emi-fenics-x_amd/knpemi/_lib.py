@@ -56,6 +56,26 @@ class Params(C.Structure):
     ]
 
 
+class DGDesc(C.Structure):
+    _fields_ = [
+        ("cell_kind", C.c_int32), ("n_sub", C.c_int32), ("n_ions", C.c_int32),
+        ("n_cells", C.c_int64), ("n_vertices", C.c_int64), ("n_mem_facets", C.c_int64),
+        ("x", c_dbl_p), ("cells", c_int_p), ("cell_sub", c_int_p), ("mem_facets", c_int_p),
+    ]
+
+
+class DGParams(C.Structure):
+    _fields_ = [
+        ("dt", C.c_double), ("F", C.c_double), ("psi", C.c_double), ("C_M", C.c_double), ("gamma", C.c_double),
+        ("z", C.c_double * MAX_IONS),
+        ("D", (C.c_double * MAX_IONS) * MAX_SUB),
+        ("rho_z", C.c_double),
+        ("rho", C.c_double * MAX_SUB),
+    ]
+
+
+DG_C, DG_PHI, DG_PHI_M, DG_I_CH, DG_SOURCE = range(5)
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
 
@@ -121,6 +141,28 @@ SIGNATURES = {
     "knpemi_timer_start": (C.c_int, [C.c_void_p]),
     "knpemi_timer_stop_ms": (C.c_int, [C.c_void_p, c_dbl_p]),
     "knpemi_stream": (C.c_void_p, [C.c_void_p]),
+    # DG(P1) + interior penalty variant
+    "knpemi_dg_create": (C.c_int, [C.POINTER(DGDesc), C.c_int, C.POINTER(C.c_void_p)]),
+    "knpemi_dg_destroy": (None, [C.c_void_p]),
+    "knpemi_dg_set_params": (C.c_int, [C.c_void_p, C.POINTER(DGParams)]),
+    "knpemi_dg_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "knpemi_dg_get_pattern": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),
+    "knpemi_dg_get_membrane_dofs": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),
+    "knpemi_dg_set_field": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dbl_p, C.c_size_t]),
+    "knpemi_dg_get_field": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_dbl_p, C.c_size_t]),
+    "knpemi_dg_assemble_emi": (C.c_int, [C.c_void_p, C.c_int]),
+    "knpemi_dg_assemble_knp": (C.c_int, [C.c_void_p, C.c_int]),
+    "knpemi_dg_get_values": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p]),
+    "knpemi_dg_get_rhs": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p]),
+    "knpemi_dg_device_system": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "knpemi_dg_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "knpemi_dg_ode_bind": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_dbl_p, c_dbl_p, c_int_p, C.c_int]),
+    "knpemi_dg_ode_step": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]),
+    "knpemi_dg_ode_get_tables": (C.c_int, [C.c_void_p, c_dbl_p, c_dbl_p]),
+    "knpemi_dg_ode_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "knpemi_dg_sync": (C.c_int, [C.c_void_p]),
+    "knpemi_dg_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_dbl_p]),
 }
 
 

@@ -1,0 +1,209 @@
+"""Host side of the DG(P1) + symmetric-interior-penalty variant (include/knpemi_hip.h,
+`knpemi_dg_*`).
+
+The reference has no such class -- its code is continuous Galerkin on sub-meshes; only `README.md:5-7` and the marker
+convention of `examples/idealized_geometries/make_mesh_2D.py:88-90` ("interior facets tagged 0") refer to the DG method
+of the legacy solver.  `DGProblem` therefore takes what those mesh scripts produce (one mesh, a cell marker, a facet
+marker) and the `ion_list` / `physical_params` dictionaries of the drivers (`run_2D.py:204-251`), and exposes the
+assembled systems as scipy CSR matrices the way `knpemi.device.DeviceProblem` does for the CG path.
+
+Broken dof (cell c, local vertex j) = c * nv + j; fields are arrays of shape (n_cells, nv).  Membrane node
+(facet f, vertex a) = f * nf + a; membrane fields are (n_mem_facets, nf).  All arithmetic happens in the HIP kernels
+(csrc/kernels_dg.hip); without the extension or a GPU the constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib as L
+
+_KIND = {"triangle": L.TRIANGLE, "tetrahedron": L.TETRAHEDRON}
+
+
+class DGProblem:
+    def __init__(self, mesh, ct, ft, subdomain_tags, membrane_tags, n_ions=3, device=0):
+        """`ct`, `ft`: cell and facet MeshTags of `mesh` (or dense arrays); `subdomain_tags`: cell tags in sub-domain
+        order, ECS first (`run_2D.py:145-169`); `membrane_tags`: facet tags that mark membranes."""
+        if mesh.cell_type not in _KIND:
+            raise ValueError("the DG variant is built for triangles and tetrahedra")
+        self.lib = L.load()
+        self.mesh = mesh
+        self.nv = mesh.cells.shape[1]
+        self.nf = self.nv - 1
+        self.K = int(n_ions)
+        cell_tags = np.asarray(ct.dense() if hasattr(ct, "dense") else ct)
+        tag_to_sub = {int(t): i for i, t in enumerate(subdomain_tags)}
+        try:
+            self.cell_sub = np.array([tag_to_sub[int(t)] for t in cell_tags], np.int32)
+        except KeyError as e:
+            raise ValueError(f"cell tag {e} is not in subdomain_tags") from None
+        self.n_sub = len(subdomain_tags)
+        if hasattr(ft, "indices"):
+            sel = np.isin(ft.values, list(membrane_tags))
+            fidx = np.sort(ft.indices[sel])
+            order = np.argsort(ft.indices[sel], kind="stable")
+            self.mem_tags = np.asarray(ft.values[sel])[order]
+        else:
+            dense = np.asarray(ft)
+            fidx = np.flatnonzero(np.isin(dense, list(membrane_tags)))
+            self.mem_tags = dense[fidx]
+        self.mem_facets = np.ascontiguousarray(mesh.facets[fidx], np.int32).reshape(-1, self.nf)
+        self.n_cells = mesh.num_cells
+        self.n = self.n_cells * self.nv
+        self.nmf = self.mem_facets.shape[0]
+        x = np.ascontiguousarray(mesh.x, np.float64)
+        cells = np.ascontiguousarray(mesh.cells, np.int32)
+        desc = L.DGDesc(_KIND[mesh.cell_type], self.n_sub, self.K, self.n_cells, mesh.num_vertices, self.nmf,
+                        L.dptr(x), L.iptr(cells), L.iptr(self.cell_sub), L.iptr(self.mem_facets))
+        h = C.c_void_p()
+        L.check(self.lib.knpemi_dg_create(C.byref(desc), int(device), C.byref(h)))
+        self.h = h
+        n, nnz, nq = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(self.lib.knpemi_dg_dims(self.h, C.byref(n), C.byref(nnz), C.byref(nq)))
+        assert n.value == self.n and nq.value == self.nmf * self.nf
+        self.nnz = nnz.value
+        self.indptr = np.zeros(self.n + 1, np.int32)
+        self.indices = np.zeros(self.nnz, np.int32)
+        L.check(self.lib.knpemi_dg_get_pattern(self.h, L.iptr(self.indptr), L.iptr(self.indices)))
+        self.X = x[cells]                                   # (n_cells, nv, d) coordinates of the broken dofs
+        self.XM = x[self.mem_facets]                        # (nmf, nf, d)
+        self.gamma = 10.0
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            try:
+                self.lib.knpemi_dg_destroy(h)
+            except Exception:
+                pass
+
+    # -- parameters and fields ---------------------------------------------------------------------------------
+    def set_params(self, physical_params, ion_list, gamma=None, rho=None):
+        """`physical_params`: dt, F, psi, C_M (floats or knpemi.fem.Constant); `ion_list`: dicts with 'z' and 'D'
+        (sequence or {sub-domain index: value}); `rho`: (rho_z, per-sub-domain densities) or None."""
+        val = lambda v: float(getattr(v, "value", v))
+        p = L.DGParams()
+        p.dt, p.F, p.psi, p.C_M = (val(physical_params[k]) for k in ("dt", "F", "psi", "C_M"))
+        if gamma is not None:
+            self.gamma = float(gamma)
+        p.gamma = self.gamma
+        if len(ion_list) != self.K:
+            raise ValueError("ion_list does not match n_ions")
+        for k, ion in enumerate(ion_list):
+            p.z[k] = val(ion["z"])
+            for s in range(self.n_sub):
+                p.D[s][k] = val(ion["D"][s])
+        if rho is not None:
+            p.rho_z = val(rho[0])
+            for s in range(self.n_sub):
+                p.rho[s] = val(rho[1][s])
+        L.check(self.lib.knpemi_dg_set_params(self.h, C.byref(p)))
+
+    def _set(self, field, idx, a, n):
+        a = np.ascontiguousarray(a, np.float64).reshape(-1)
+        if a.size != n:
+            raise ValueError("field has the wrong size")
+        L.check(self.lib.knpemi_dg_set_field(self.h, field, idx, L.dptr(a), n))
+
+    def _get(self, field, idx, n, shape):
+        a = np.zeros(n)
+        L.check(self.lib.knpemi_dg_get_field(self.h, field, idx, L.dptr(a), n))
+        return a.reshape(shape)
+
+    def set_concentration(self, k, c):
+        self._set(L.DG_C, k, c, self.n)
+
+    def get_concentration(self, k):
+        return self._get(L.DG_C, k, self.n, (self.n_cells, self.nv))
+
+    def set_potential(self, phi):
+        self._set(L.DG_PHI, 0, phi, self.n)
+
+    def get_potential(self):
+        return self._get(L.DG_PHI, 0, self.n, (self.n_cells, self.nv))
+
+    def set_membrane_potential(self, phi_M):
+        self._set(L.DG_PHI_M, 0, phi_M, self.nmf * self.nf)
+
+    def get_membrane_potential(self):
+        return self._get(L.DG_PHI_M, 0, self.nmf * self.nf, (self.nmf, self.nf))
+
+    def set_channel_current(self, k, I):
+        self._set(L.DG_I_CH, k, I, self.nmf * self.nf)
+
+    def get_channel_current(self, k):
+        return self._get(L.DG_I_CH, k, self.nmf * self.nf, (self.nmf, self.nf))
+
+    def set_source(self, k, f):
+        self._set(L.DG_SOURCE, k, f, self.n)
+
+    def membrane_dofs(self):
+        e = np.zeros(self.nmf * self.nf, np.int32)
+        i = np.zeros(self.nmf * self.nf, np.int32)
+        L.check(self.lib.knpemi_dg_get_membrane_dofs(self.h, L.iptr(e), L.iptr(i)))
+        return e.reshape(self.nmf, self.nf), i.reshape(self.nmf, self.nf)
+
+    # -- the hot path ------------------------------------------------------------------------------------------
+    def assemble_emi(self, splitting_scheme=True):
+        L.check(self.lib.knpemi_dg_assemble_emi(self.h, 0 if splitting_scheme else L.NO_SPLITTING))
+
+    def assemble_knp(self, splitting_scheme=True):
+        L.check(self.lib.knpemi_dg_assemble_knp(self.h, 0 if splitting_scheme else L.NO_SPLITTING))
+
+    def matrix(self, which):
+        """which = 0: potential system; 1 + k: concentration system of solved ion k."""
+        v = np.zeros(self.nnz)
+        L.check(self.lib.knpemi_dg_get_values(self.h, which, L.dptr(v)))
+        return sp.csr_matrix((v, self.indices, self.indptr), shape=(self.n, self.n))
+
+    def rhs(self, which):
+        b = np.zeros(self.n)
+        L.check(self.lib.knpemi_dg_get_rhs(self.h, which, L.dptr(b)))
+        return b
+
+    def update(self, c_new):
+        """End of step: c_prev <- c_new (K-1, n), eliminated ion, phi_M <- phi_i - phi_e."""
+        a = np.ascontiguousarray(c_new, np.float64).reshape(-1)
+        if a.size != (self.K - 1) * self.n:
+            raise ValueError("c_new has the wrong size")
+        L.check(self.lib.knpemi_dg_update(self.h, a.ctypes.data_as(C.c_void_p), 0))
+
+    # -- membrane ODEs -----------------------------------------------------------------------------------------
+    def ode_bind(self, model_id, states_row, params_row, ion_param, v_index):
+        """One state / parameter row per membrane node, all initialised to the given rows (MembraneModel.__init__,
+        odeSolver.py:40-55); ion_param[3 k + (0, 1, 2)] = parameter columns of ion k's ECS trace, intracellular trace
+        and channel current."""
+        nq = self.nmf * self.nf
+        st = np.tile(np.asarray(states_row, np.float64), (nq, 1))
+        pr = np.tile(np.asarray(params_row, np.float64), (nq, 1))
+        ip = np.ascontiguousarray(ion_param, np.int32)
+        self._ode_shape = (st.shape[1], pr.shape[1])
+        L.check(self.lib.knpemi_dg_ode_bind(self.h, model_id, st.shape[1], pr.shape[1], L.dptr(st), L.dptr(pr),
+                                            L.iptr(ip), int(v_index)))
+
+    def ode_step(self, t0, dt, rtol=1e-8, atol=1e-10, set_v=True, set_traces=True):
+        flags = (L.ODE_SET_V if set_v else 0) | (L.ODE_SET_TRACES if set_traces else 0)
+        L.check(self.lib.knpemi_dg_ode_step(self.h, t0, dt, rtol, atol, flags))
+
+    def ode_tables(self):
+        nq = self.nmf * self.nf
+        st = np.zeros((nq, self._ode_shape[0]))
+        pr = np.zeros((nq, self._ode_shape[1]))
+        L.check(self.lib.knpemi_dg_ode_get_tables(self.h, L.dptr(st), L.dptr(pr)))
+        return st, pr
+
+    def ode_stats(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(self.lib.knpemi_dg_ode_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def sync(self):
+        L.check(self.lib.knpemi_dg_sync(self.h))
+
+    def time_kernel(self, which, reps=20, splitting_scheme=True):
+        ms = C.c_double()
+        L.check(self.lib.knpemi_dg_time_kernel(self.h, which, 0 if splitting_scheme else L.NO_SPLITTING, reps, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,227 @@
+"""GPU tests of the DG(P1)+SIP variant: the HIP kernels (csrc/kernels_dg.hip) through the C ABI against
+the CPU restatement (oracle/knpemi_dg_oracle.py) at 1e-10, the manufactured problems of tests/dg_cases.py through the
+device assembly, the end-of-step update and the membrane ODE sweep over the membrane nodes."""
+import numpy as np
+import pytest
+
+import dg_cases as C
+from helpers import csr_rel_err, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+def _problem(dim, M, membrane, n_ions=3, gamma=10.0):
+    from knpemi.dg import DGProblem
+    from knpemi.fem import create_box, create_unit_square
+    from knpemi.fem.idealized import _tag
+    import knpemi_dg_oracle as dg
+    mesh = create_unit_square(None, M, M) if dim == 2 else create_box(None, [np.zeros(3), np.ones(3)], (M, M, M),
+                                                                       "tetrahedron")
+    if membrane:
+        ct, ft = _tag(mesh, [([0.25] * dim, [0.75] * dim)], [1], full_facet_tags=False)
+    else:
+        ct, ft = _tag(mesh, [], [], full_facet_tags=False)
+    dp = DGProblem(mesh, ct, ft, [0, 1], [1], n_ions=n_ions)
+    dp.gamma = gamma
+    o = dg.DGOracle(mesh.x, mesh.cells, mesh.cell_type, dp.cell_sub, dp.mem_facets, dp.mem_tags)
+    return dp, o
+
+
+def _random_state(dp, K, seed):
+    rng = np.random.default_rng(seed)
+    shape, mshape = (dp.n_cells, dp.nv), (dp.nmf, dp.nf)
+    smooth = lambda a, b: a + b * np.cos(3.0 * dp.X[:, :, 0] + 1.0) * np.sin(2.0 * dp.X[:, :, 1] + 0.5)
+    c_all = [smooth(2.0 + k, 0.4) + 0.05 * rng.random(shape) for k in range(K)]
+    phi = smooth(0.1, 0.3) + 0.02 * rng.random(shape)
+    phi_M = 0.2 + 0.1 * rng.random(mshape)
+    I_ch = [0.3 * rng.standard_normal(mshape) for _ in range(K)]
+    src = {k: rng.standard_normal(shape) for k in range(K - 1)}
+    return c_all, phi, phi_M, I_ch, src
+
+
+def _push(dp, params, ions, c_all, phi, phi_M, I_ch, src=None, rho=None):
+    dp.set_params(params, ions, rho=rho)
+    for k, c in enumerate(c_all):
+        dp.set_concentration(k, c)
+    dp.set_potential(phi)
+    dp.set_membrane_potential(phi_M)
+    for k, I in enumerate(I_ch):
+        dp.set_channel_current(k, I)
+    if src is not None:
+        for k, f in src.items():
+            dp.set_source(k, f)
+
+
+@pytest.mark.parametrize("splitting", [True, False])
+@pytest.mark.parametrize("dim,M,K", [(2, 8, 3), (2, 12, 2), (2, 8, 4), (3, 4, 3), (3, 8, 3), (3, 4, 4)])
+def test_dg_assembly_matches_oracle(hip_lib, dim, M, K, splitting):
+    """A_emi, b_emi and the K-1 concentration systems, membrane terms and source included, different diffusivities on
+    the two sides, non-default penalty: 1e-10 of the largest entry."""
+    dp, o = _problem(dim, M, True, n_ions=K, gamma=7.5)
+    zs = [1.0, -1.0, 2.0, -1.0][:K]
+    ions = [dict(name=f"i{k}", z=zs[k], D=[1.0 + 0.3 * k, 0.6 + 0.2 * k]) for k in range(K)]
+    params = dict(dt=0.05, F=1.3, psi=0.8, C_M=0.7)
+    c_all, phi, phi_M, I_ch, src = _random_state(dp, K, 1)
+    _push(dp, params, ions, c_all, phi, phi_M, I_ch, src)
+    dp.assemble_emi(splitting)
+    dp.assemble_knp(splitting)
+    A, b = o.assemble_emi(params, ions, c_all, phi_M, I_ch, splitting_scheme=splitting, gamma=7.5)
+    assert csr_rel_err(dp.matrix(0), A) < TOL and rel_err(dp.rhs(0), b) < TOL
+    As, bs = o.assemble_knp(params, ions, c_all, phi, phi_M, I_ch, splitting_scheme=splitting, gamma=7.5, f_source=src)
+    for k in range(K - 1):
+        assert csr_rel_err(dp.matrix(1 + k), As[k]) < TOL, k
+        assert rel_err(dp.rhs(1 + k), bs[k]) < TOL, k
+    # the pattern is the one the header promises: one nv-wide block per cell and facet neighbour, sorted
+    assert np.all(np.diff(dp.indptr) % dp.nv == 0)
+    for r in (0, dp.n // 2, dp.n - 1):
+        cols = dp.indices[dp.indptr[r]:dp.indptr[r + 1]]
+        assert np.all(np.diff(cols) > 0) and r in cols
+
+
+def test_dg_assembly_without_membrane_and_bit_reproducible(hip_lib):
+    dp, o = _problem(3, 6, False)
+    ions = C.ions_unit()
+    params = dict(dt=0.1, F=1.0, psi=1.0, C_M=1.0)
+    c_all, phi, phi_M, I_ch, _ = _random_state(dp, 3, 2)
+    _push(dp, params, ions, c_all, phi, phi_M, I_ch)
+    dp.assemble_emi()
+    dp.assemble_knp()
+    A0, A1 = dp.matrix(0), dp.matrix(1)
+    A, b = o.assemble_emi(params, ions, c_all, phi_M, I_ch)
+    assert csr_rel_err(A0, A) < TOL
+    assert abs(A0 - A0.T).max() < 1e-12 * abs(A0).max()
+    dp.assemble_emi()
+    dp.assemble_knp()
+    assert np.array_equal(dp.matrix(0).data, A0.data) and np.array_equal(dp.matrix(1).data, A1.data)
+
+
+def test_dg_update_matches_oracle(hip_lib):
+    dp, o = _problem(2, 8, True)
+    ions = C.ions_unit()
+    params = dict(dt=0.1, F=1.0, psi=1.0, C_M=1.0)
+    c_all, phi, phi_M, I_ch, _ = _random_state(dp, 3, 3)
+    rho = (-1.0, [0.0, 0.4])
+    _push(dp, params, ions, c_all, phi, phi_M, I_ch, rho=rho)
+    rng = np.random.default_rng(5)
+    c_new = [rng.random((dp.n_cells, dp.nv)) + 1.0 for _ in range(2)]
+    dp.update(np.array(c_new))
+    want, pm = o.update(ions, [rho[0] * r for r in rho[1]], c_new, phi)
+    for k in range(3):
+        assert rel_err(dp.get_concentration(k), want[k]) < 1e-14
+    assert rel_err(dp.get_membrane_potential(), pm) < 1e-14
+    e, i = dp.membrane_dofs()
+    assert np.all(dp.cell_sub[e // dp.nv] == 0) and np.all(dp.cell_sub[i // dp.nv] == 1)
+    assert np.array_equal(dp.X.reshape(-1, 2)[e.ravel()], dp.XM.reshape(-1, 2))
+
+
+class DeviceBackend:
+    """tests/dg_cases.py backend on the HIP kernels."""
+
+    def __init__(self, dim, M, membrane, gamma=10.0):
+        self.dp, self.o = _problem(dim, M, membrane, gamma=gamma)
+        self.X, self.XM, self.cell_sub, self.vol = self.dp.X, self.dp.XM, self.dp.cell_sub, self.o.vol
+
+    def emi(self, params, ions, c_all, phi_M, I_ch, splitting):
+        dp = self.dp
+        _push(dp, params, ions, c_all, np.zeros((dp.n_cells, dp.nv)), np.zeros((dp.nmf, dp.nf)) + phi_M,
+              [np.zeros((dp.nmf, dp.nf)) + I for I in I_ch])
+        dp.assemble_emi(splitting)
+        return dp.matrix(0), dp.rhs(0)
+
+    def knp(self, params, ions, c_all, phi, phi_M, I_ch, splitting, f_source):
+        dp = self.dp
+        _push(dp, params, ions, c_all, phi, np.zeros((dp.nmf, dp.nf)) + phi_M,
+              [np.zeros((dp.nmf, dp.nf)) + I for I in I_ch], f_source)
+        dp.assemble_knp(splitting)
+        return [dp.matrix(1 + k) for k in range(len(ions) - 1)], np.array([dp.rhs(1 + k) for k in range(len(ions) - 1)])
+
+
+@pytest.mark.parametrize("dim,sizes", [(2, (16, 32, 64)), (3, (8, 12))])
+def test_dg_mms_rates_through_the_device_assembly(hip_lib, dim, sizes):
+    """Second order in L2 for the potential (Boltzmann problem with a membrane jump) and the concentrations (membrane
+    flux problem) with the matrices the HIP kernels produce."""
+    e_emi, e_knp = [], []
+    for M in sizes:
+        be = DeviceBackend(dim, M, True)
+        e_emi.append(C.emi_membrane(be, True)[0])
+        e_knp.append(C.knp_membrane(be, True)[0])
+    h = np.log2(sizes[-1] / sizes[-2])
+    r_emi = np.log2(e_emi[-2] / e_emi[-1]) / h
+    r_knp = np.log2(np.array(e_knp[-2]) / np.array(e_knp[-1])) / h
+    print("DG MMS on the device: EMI", e_emi, r_emi, "KNP", e_knp, r_knp)
+    assert r_emi > 1.7 and np.all(r_knp > 1.6), (e_emi, e_knp)
+
+
+def test_dg_volume_mms_with_source_on_device(hip_lib):
+    errs = [C.knp_volume(DeviceBackend(2, M, False))[0] for M in (8, 16, 32)]
+    rates = np.log2(np.array(errs[:-1]) / np.array(errs[1:]))
+    assert np.all(rates[-1] > 1.8), (errs, rates)
+
+
+def test_dg_membrane_ode_sweep_matches_scipy_lsoda(hip_lib):
+    """Hodgkin-Huxley sweep over the membrane nodes of the broken space: traces of the concentrations taken from the
+    two cells of every membrane facet, V <- phi_M, LSODA, phi_M <- V, I_ch_k <- parameter columns -- against ODEPACK
+    (scipy) on the same tables, tolerances of the CG-path test (tests/test_gpu_parity.py)."""
+    import knpemi_oracle as ko
+    from knpemi import _lib as L
+    from setup_problem import C_M, PSI
+    dp, o = _problem(2, 8, True)
+    m = ko.MODELS["hh_si"]
+    ix = m["pidx"]
+    names = ["Na", "K", "Cl"]
+    ions = [dict(name=n, z=z, D=[1e-9, 1e-9]) for n, z in zip(names, (1.0, 1.0, -1.0))]
+    dp.set_params(dict(dt=1e-4, F=96485.0, psi=PSI, C_M=C_M), ions)
+    ins = (dp.cell_sub > 0)[:, None]
+    vary = 1.0 + 0.05 * np.cos(6.0 * dp.X[:, :, 0])
+    conc = [np.where(ins, 12.0, 100.0) * vary, np.where(ins, 125.0, 4.0) * vary, np.where(ins, 137.0, 104.0) * vary]
+    for k in range(3):
+        dp.set_concentration(k, conc[k])
+    prow = np.array(m["params"], float)
+    prow[ix["Cm"]] = C_M
+    prow[ix["z_Na"]], prow[ix["z_K"]], prow[ix["z_Cl"]], prow[ix["psi"]] = 1.0, 1.0, -1.0, PSI
+    ion_param = [ix[f"{n}{s}"] for n in names for s in ("_e", "_i")]
+    ion_param = sum(([ix[f"{n}_e"], ix[f"{n}_i"], ix[f"I_ch_{n}"]] for n in names), [])
+    dp.ode_bind(L.MODEL_HH_SI, m["states"], prow, ion_param, m["V"])
+    nq = dp.nmf * dp.nf
+    st_o, p_o = np.tile(np.array(m["states"]), (nq, 1)), np.tile(prow, (nq, 1))
+    t = 0.0
+    for step in range(3):
+        if step:
+            pm = dp.get_membrane_potential() + 1e-3 * np.cos(5.0 * dp.XM[:, :, 1])
+            dp.set_membrane_potential(pm)
+            st_o[:, m["V"]] = pm.ravel()
+        dp.ode_step(t, 1e-4, set_v=step > 0)
+        for k, n in enumerate(names):
+            te, ti = o.traces(conc[k])
+            p_o[:, ix[f"{n}_e"]], p_o[:, ix[f"{n}_i"]] = te.ravel(), ti.ravel()
+        ko.ode_sweep("hh_si", st_o, p_o, t, 1e-4)
+        t += 1e-4
+        st, pr = dp.ode_tables()
+        assert rel_err(st, st_o) < 1e-6
+        ich = [ix["I_ch_Na"], ix["I_ch_K"], ix["I_ch_Cl"]]
+        assert np.abs(pr[:, ich] - p_o[:, ich]).max() / max(np.abs(p_o[:, ich]).max(), 1e-3) < 1e-5
+        assert rel_err(dp.get_membrane_potential().ravel(), st[:, m["V"]]) == 0.0
+        for k, n in enumerate(names):
+            assert np.array_equal(dp.get_channel_current(k).ravel(), pr[:, ix[f"I_ch_{n}"]])
+    n_rhs, n_steps, n_failed = dp.ode_stats()
+    assert n_failed == 0 and n_rhs > 0
+
+
+def test_dg_error_paths(hip_lib):
+    from knpemi.dg import DGProblem
+    from knpemi.fem import create_box, create_unit_square
+    from knpemi.fem.idealized import _tag
+    from knpemi._lib import KnpemiError
+    mesh = create_unit_square(None, 8, 8)
+    ct, ft = _tag(mesh, [([0.25] * 2, [0.75] * 2)], [1], full_facet_tags=False)
+    with pytest.raises(KnpemiError, match="not in mem_facets"):
+        DGProblem(mesh, ct, ft, [0, 1], [7])                # the interface is not declared a membrane
+    with pytest.raises(ValueError, match="triangles and tetrahedra"):
+        DGProblem(create_box(None, [np.zeros(3), np.ones(3)], (2, 2, 2), "hexahedron"), ct, ft, [0, 1], [1])
+    dp = DGProblem(mesh, ct, ft, [0, 1], [1])
+    with pytest.raises(KnpemiError, match="set_params"):
+        dp.assemble_emi()
+    with pytest.raises(ValueError):
+        dp.set_potential(np.zeros(3))
