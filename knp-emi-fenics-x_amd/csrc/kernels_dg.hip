@@ -36,7 +36,15 @@
 
 namespace {
 
-constexpr int DG_BLOCK = 128;
+#ifndef KN_DG_BLOCK
+#define KN_DG_BLOCK 64
+#endif
+#ifndef KN_DG_ROUND
+#define KN_DG_ROUND KN_DG_BLOCK
+#endif
+constexpr int DG_BLOCK = KN_DG_BLOCK;   // threads (= rows) per workgroup
+constexpr int DG_RPITCH = 10;           // doubles per staged record in LDS
+constexpr int DG_ROUND = KN_DG_ROUND;   // rows whose image is in LDS at a time
 
 struct DgConsts {
   int n_sub, K;
@@ -85,11 +93,43 @@ __device__ __forceinline__ DofRec load_rec(const double* rec, int dof) {
   return r;
 }
 
+// The workgroup's own records are staged in LDS by one coalesced pass (lane t loads record row0 + t) and read from there
+// by the NV lanes of each cell; 10-double pitch keeps the 16-byte reads of a wave on distinct banks.
+
+__device__ __forceinline__ void stage_rec(double* lrec, const double* rec, int dof, int t) {
+  const double2* p = reinterpret_cast<const double2*>(rec + (size_t)dof * KN_REC);
+  double2* q = reinterpret_cast<double2*>(lrec + t * DG_RPITCH);
+  const double2 a = p[0], b = p[1], c = p[2], d = p[3];
+  q[0] = a; q[1] = b; q[2] = c; q[3] = d;
+}
+
+__device__ __forceinline__ DofRec lds_rec(const double* lrec, int t) {
+  const double2* p = reinterpret_cast<const double2*>(lrec + t * DG_RPITCH);
+  const double2 a = p[0], b = p[1], c = p[2], d = p[3];
+  DofRec r;
+  r.x[0] = a.x; r.x[1] = a.y; r.x[2] = b.x;
+  r.c[3] = b.y; r.c[0] = c.x; r.c[1] = c.y; r.c[2] = d.x; r.phi = d.y;
+  return r;
+}
+
 template <int NV>
 struct Geo {
   double g[NV][NV - 1];   // gradients of the barycentric coordinates
   double vol;
 };
+
+// 1 / a and 1 / sqrt(a) from the hardware estimates plus two Newton steps (relative error ~1e-16): a fraction of the
+// instruction count of the IEEE division / square-root sequences, and the results are only compared at 1e-10.
+__device__ __forceinline__ double fast_rcp(double a) {
+  double r = __builtin_amdgcn_rcp(a);
+  r = fma(fma(-a, r, 1.0), r, r);
+  return fma(fma(-a, r, 1.0), r, r);
+}
+__device__ __forceinline__ double fast_rsqrt(double a) {
+  double y = __builtin_amdgcn_rsq(a);
+  y = y * fma(-0.5 * a * y, y, 1.5);
+  return y * fma(-0.5 * a * y, y, 1.5);
+}
 
 template <int GD>
 __device__ __forceinline__ double dot(const double (&a)[GD], const double (&b)[GD]) {
@@ -104,7 +144,7 @@ __device__ __forceinline__ void geometry(const double (&X)[NV][NV - 1], Geo<NV>&
   if constexpr (NV == 3) {
     const double e1x = X[1][0] - X[0][0], e1y = X[1][1] - X[0][1];
     const double e2x = X[2][0] - X[0][0], e2y = X[2][1] - X[0][1];
-    const double det = e1x * e2y - e1y * e2x, inv = 1.0 / det;
+    const double det = e1x * e2y - e1y * e2x, inv = fast_rcp(det);
     G.g[1][0] = e2y * inv; G.g[1][1] = -e2x * inv;
     G.g[2][0] = -e1y * inv; G.g[2][1] = e1x * inv;
     G.g[0][0] = -(G.g[1][0] + G.g[2][0]); G.g[0][1] = -(G.g[1][1] + G.g[2][1]);
@@ -123,7 +163,7 @@ __device__ __forceinline__ void geometry(const double (&X)[NV][NV - 1], Geo<NV>&
       cr[a][1] = e[b][2] * e[c][0] - e[b][0] * e[c][2];
       cr[a][2] = e[b][0] * e[c][1] - e[b][1] * e[c][0];
     }
-    const double det = e[0][0] * cr[0][0] + e[0][1] * cr[0][1] + e[0][2] * cr[0][2], inv = 1.0 / det;
+    const double det = e[0][0] * cr[0][0] + e[0][1] * cr[0][1] + e[0][2] * cr[0][2], inv = fast_rcp(det);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       G.g[1][d] = cr[0][d] * inv; G.g[2][d] = cr[1][d] * inv; G.g[3][d] = cr[2][d] * inv;
@@ -152,30 +192,94 @@ __device__ __forceinline__ void block_slots(int T, const int (&nb)[NV], int& slo
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// potential system: A_emi, b_emi
+// Both kernels work in two phases.  Phase 1: lane (cell, i) prepares facet i of its cell -- the facet opposite its
+// own vertex -- i.e. the neighbour's geometry and traces, and leaves what the rows need of it in LDS (FS doubles per
+// facet, indexed by the cell's ORIGINAL local numbering).  Phase 2: every lane builds its row from the four facet
+// summaries of its cell.  Each neighbour geometry is thus computed once per cell instead of once per row.
 // ---------------------------------------------------------------------------------------------------------------------
+// The LDS row image holds the block's rows in CSR order, so that it can be copied out linearly.  Rows are 20 (12)
+// doubles apart: lanes 8 rows apart would hit the same banks (8 x 40 dwords = 5 x 64), an 8-way conflict on every one of
+// the 20 stores of a row.  Two doubles of padding after every 8 interior rows' worth of entries (DG_PADQ) shift those
+// lanes onto different banks and keep the 16-byte alignment of the copy-out.
+template <int NV> constexpr int dg_padq() { return 8 * NV * (NV + 1); }
+template <int NV> constexpr int dg_img_doubles() { return DG_ROUND * NV * (NV + 1) + 2 * (DG_ROUND / 8 + 1); }
+// LDS scratch behind the facet summaries: first the staged records of the whole workgroup, later NIMG row images
+template <int NV, int NIMG> constexpr int dg_scratch_doubles() {
+  constexpr int a = NIMG * dg_img_doubles<NV>(), b = (DG_BLOCK / NV) * NV * DG_RPITCH;
+  return a > b ? a : b;
+}
+
+template <int NV>
+struct ImgRow {
+  double* base;    // image address of the row's first entry
+  int to_pad;      // entries of this row before the next padding point
+  __device__ __forceinline__ ImgRow(double* img, int off) {
+    const int q = off / dg_padq<NV>();
+    base = img + off + 2 * q;
+    to_pad = (q + 1) * dg_padq<NV>() - off;
+  }
+  __device__ __forceinline__ void put(int k, double v) const { base[k + (k >= to_pad ? 2 : 0)] = v; }
+};
+
+// LDS row image -> CSR value array.  Rows of tetrahedra are multiples of 4 doubles long, so the block's span starts
+// 32-byte aligned: two doubles per lane and store (1 KiB of consecutive addresses per wave instruction).
+template <int NV>
+__device__ __forceinline__ void copy_out(double* __restrict__ dst, const double* img, int span, int tid) {
+  constexpr int PQ = dg_padq<NV>();
+  if constexpr (NV == 4) {
+    double2* d2 = reinterpret_cast<double2*>(dst);
+    for (int e = tid; e < span / 2; e += DG_BLOCK)
+      d2[e] = *reinterpret_cast<const double2*>(img + 2 * e + 2 * ((2 * e) / PQ));
+  } else {
+    for (int e = tid; e < span; e += DG_BLOCK) dst[e] = img[e + 2 * (e / PQ)];
+  }
+}
+
+template <int NV> constexpr int dg_fs_emi() { return (6 + 2 * NV) | 1; }   // n[3] area inv_h JNn | gNn[nv] | kN[nv]
+template <int NV> constexpr int dg_fs_knp() { return (6 + NV) | 1; }       // n[3] area inv_h gphiNn | gNn[nv]
+
 template <int NV>
 __global__ __launch_bounds__(DG_BLOCK) void dg_emi_kernel(DgDev D, const DgConsts* __restrict__ Cp, int chunk, int splitting) {
   constexpr int GD = NV - 1, NF = NV - 1;
   constexpr int RPB = (DG_BLOCK / NV) * NV;
-  extern __shared__ double img[];
+  constexpr int FS = dg_fs_emi<NV>();
+  extern __shared__ double lds[];
+  double* fs = lds;
+  double* img = lds + RPB * FS;
   const DgConsts& C = *Cp;
   const int row0 = dg_block_index(blockIdx.x, chunk) * RPB;
   if (row0 >= D.n_dof) return;
   const int nrows = min(RPB, D.n_dof - row0);
   const int tid = threadIdx.x;
+  const bool valid = tid < nrows;
   const int base = D.rowptr[row0];
-  const int span = D.rowptr[row0 + nrows] - base;
-  if (tid < nrows) {
-    const int row = row0 + tid, T = row / NV, i = row - T * NV;
-    int p[NV];
+  const int row = row0 + tid, T = row / NV, i = row - T * NV;
+  int p[NV], nb[NV];
+  unsigned fi[NV];
+  double X[NV][GD], kap[NV], J[GD];
+  Geo<NV> G;
+  int s = 0;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) p[j] = i + j >= NV ? i + j - NV : i + j;
-    const int s = D.cell_sub[T];
-    double X[NV][GD], kap[NV], sg[NV];
+  for (int j = 0; j < NV; ++j) p[j] = i + j >= NV ? i + j - NV : i + j;
+  // everything that does not depend on other loads is requested now, before the first barrier: one round trip to
+  // memory instead of three (the waves spend most of their life waiting for loads, not computing)
+  int rowoff = 0;
+  if (valid) {
+    stage_rec(img, D.rec, row, tid);
+    s = D.cell_sub[T];
+    rowoff = D.rowptr[row] - base;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const DofRec r = load_rec(D.rec, T * NV + p[j]);
+      nb[j] = D.nbr[T * NV + p[j]];
+      fi[j] = D.finfo[T * NV + p[j]];
+    }
+  }
+  __syncthreads();
+  if (valid) {
+    double sg[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const DofRec r = lds_rec(img, tid - i + p[j]);
 #pragma unroll
       for (int d = 0; d < GD; ++d) X[j][d] = r.x[d];
       double k = 0.0, g = 0.0;
@@ -183,21 +287,60 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_emi_kernel(DgDev D, const DgConst
       for (int q = 0; q < KN_MAXK; ++q) { k += C.kap[s][q] * r.c[q]; g += C.sig[s][q] * r.c[q]; }
       kap[j] = k; sg[j] = g;
     }
-    Geo<NV> G;
     geometry<NV>(X, G);
-    double J[GD];   // sum_k F z_k D_k grad c_k
 #pragma unroll
-    for (int d = 0; d < GD; ++d) {
+    for (int d = 0; d < GD; ++d) {   // sum_k F z_k D_k grad c_k
       double a = 0.0;
 #pragma unroll
       for (int j = 0; j < NV; ++j) a += sg[j] * G.g[j][d];
       J[d] = a;
     }
+    // phase 1: the facet opposite my vertex
+    double* my = fs + tid * FS;
+    const double g2 = dot<GD>(G.g[0], G.g[0]), rgf = fast_rsqrt(g2), gf = g2 * rgf;
+    double n[GD];
+#pragma unroll
+    for (int d = 0; d < GD; ++d) { n[d] = -G.g[0][d] * rgf; my[d] = n[d]; }
+    my[3] = GD * G.vol * gf;
+    if (nb[0] >= 0 && (fi[0] & 3) == 1) {
+      const int N = nb[0];
+      // The neighbour's gradients are needed along n only, and those follow from this cell's own gradients and the
+      // neighbour's far vertex x_far: with h_N = (x_far - x_1) . n its height over the facet,
+      //   grad lambda^N_far . n = 1 / h_N,     grad lambda^N_b . n = grad lambda_b . n - lambda_b(x_far) / h_N  (b on the facet).
+      double kN[NV], sN[NV], dfar[GD];
+#pragma unroll
+      for (int b = 0; b < NV; ++b) {
+        const int jn = b == 0 ? (fi[0] >> 2) & 3 : (fi[0] >> (4 + 2 * p[b])) & 3;
+        const DofRec r = load_rec(D.rec, N * NV + jn);
+        if (b == 0) {
+#pragma unroll
+          for (int d = 0; d < GD; ++d) dfar[d] = r.x[d] - X[1][d];
+        }
+        double k = 0.0, g = 0.0;
+#pragma unroll
+        for (int q = 0; q < KN_MAXK; ++q) { k += C.kap[s][q] * r.c[q]; g += C.sig[s][q] * r.c[q]; }
+        kN[b] = k; sN[b] = g;
+      }
+      const double rh = fast_rcp(dot<GD>(dfar, n));
+      my[4] = 0.5 * (gf + rh);
+      double JNn = 0.0;
+#pragma unroll
+      for (int b = 0; b < NV; ++b) {
+        const double gn = b == 0 ? rh : dot<GD>(G.g[b], n) - ((b == 1 ? 1.0 : 0.0) + dot<GD>(G.g[b], dfar)) * rh;
+        JNn += sN[b] * gn;
+        my[6 + p[b]] = gn;
+        my[6 + NV + p[b]] = kN[b];
+      }
+      my[5] = JNn;
+    }
+  }
+  __syncthreads();
+  double self[NV], nbv[NV][NV];   // nbv[f][b]: column of the neighbour's dof at my vertex b; b == f: its far vertex
+  if (valid) {
     double kbar = 0.0;
 #pragma unroll
     for (int j = 0; j < NV; ++j) kbar += kap[j];
     kbar *= 1.0 / NV;
-    double self[NV], nbv[NV][NV];   // nbv[f][b]: column of the neighbour's dof at my vertex b; b == f: its far vertex
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       self[j] = G.vol * kbar * dot<GD>(G.g[0], G.g[j]);
@@ -205,44 +348,22 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_emi_kernel(DgDev D, const DgConst
       for (int b = 0; b < NV; ++b) nbv[j][b] = 0.0;
     }
     double rhs = -G.vol * dot<GD>(G.g[0], J);
-    int nb[NV];
-    unsigned fi[NV];
-#pragma unroll
-    for (int f = 0; f < NV; ++f) {
-      nb[f] = D.nbr[T * NV + p[f]];
-      fi[f] = D.finfo[T * NV + p[f]];
-    }
 #pragma unroll
     for (int f = 0; f < NV; ++f) {
       if (nb[f] < 0) continue;
       const bool on0 = f != 0;   // the row's basis function does not vanish on this facet
       const int kind = fi[f] & 3;
-      const double gf = sqrt(dot<GD>(G.g[f], G.g[f]));
+      const double* fd = fs + (tid - i + p[f]) * FS;
       double n[GD];
 #pragma unroll
-      for (int d = 0; d < GD; ++d) n[d] = -G.g[f][d] / gf;
-      const double area = GD * G.vol * gf;
+      for (int d = 0; d < GD; ++d) n[d] = fd[d];
+      const double area = fd[3];
       const double c2 = area * (1.0 / (GD * (GD + 1)));
       if (kind == 1) {
-        const int N = nb[f];
-        double XN[NV][GD], kN[NV], sN[NV];
+        const double inv_h = fd[4], JNn = fd[5];
+        double gNn[NV], kN[NV];
 #pragma unroll
-        for (int b = 0; b < NV; ++b) {
-          const int jn = b == f ? (fi[f] >> 2) & 3 : (fi[f] >> (4 + 2 * p[b])) & 3;
-          const DofRec r = load_rec(D.rec, N * NV + jn);
-#pragma unroll
-          for (int d = 0; d < GD; ++d) XN[b][d] = b == f ? r.x[d] : X[b][d];
-          double k = 0.0, g = 0.0;
-#pragma unroll
-          for (int q = 0; q < KN_MAXK; ++q) { k += C.kap[s][q] * r.c[q]; g += C.sig[s][q] * r.c[q]; }
-          kN[b] = k; sN[b] = g;
-        }
-        Geo<NV> GN;
-        geometry<NV>(XN, GN);
-        const double inv_h = 0.5 * (gf + sqrt(dot<GD>(GN.g[f], GN.g[f])));
-        double JNn = 0.0, gNn[NV];
-#pragma unroll
-        for (int b = 0; b < NV; ++b) { gNn[b] = dot<GD>(GN.g[b], n); JNn += sN[b] * gNn[b]; }
+        for (int b = 0; b < NV; ++b) { gNn[b] = fd[6 + p[b]]; kN[b] = fd[6 + NV + p[b]]; }
         double ST = 0.0, SN = 0.0, St = 0.0, kt[NV];
 #pragma unroll
         for (int b = 0; b < NV; ++b) {
@@ -292,63 +413,88 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_emi_kernel(DgDev D, const DgConst
         rhs += kind == 3 ? gsum : -gsum;
       }
     }
-    // the row, as it sits in the CSR value array
-    int slot_self, slot[NV];
-    block_slots<NV>(T, nb, slot_self, slot);
-    double* out = img + (D.rowptr[row] - base);
-#pragma unroll
-    for (int j = 0; j < NV; ++j) out[slot_self * NV + p[j]] = self[j];
-#pragma unroll
-    for (int f = 0; f < NV; ++f) {
-      if (nb[f] < 0) continue;
-#pragma unroll
-      for (int b = 0; b < NV; ++b) {
-        const int jn = b == f ? (fi[f] >> 2) & 3 : (fi[f] >> (4 + 2 * p[b])) & 3;
-        out[slot[f] * NV + jn] = nbv[f][b];
-      }
-    }
     D.b_emi[row] = rhs;
   }
-  __syncthreads();
-  double* dst = D.A_emi + base;
-  for (int e = tid; e < span; e += DG_BLOCK) dst[e] = img[e];
+  // The rows go out through an LDS image of DG_ROUND rows at a time, laid out as they sit in the CSR value array: the
+  // wave that owns them fills it, the whole workgroup copies it out linearly.  (One image for all rows of the
+  // workgroup would cost 2.5 x the LDS and a third of the resident waves.)
+  int slot_self = 0, slot[NV];
+  if (valid) block_slots<NV>(T, nb, slot_self, slot);
+  for (int r0 = 0; r0 < nrows; r0 += DG_ROUND) {
+    const int r1 = min(r0 + DG_ROUND, nrows);
+    const int wbase = D.rowptr[row0 + r0] - base, wspan = D.rowptr[row0 + r1] - base - wbase;
+    if (tid >= r0 && tid < r1) {
+      const ImgRow<NV> out(img, rowoff - wbase);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) out.put(slot_self * NV + p[j], self[j]);
+#pragma unroll
+      for (int f = 0; f < NV; ++f) {
+        if (nb[f] < 0) continue;
+#pragma unroll
+        for (int b = 0; b < NV; ++b) {
+          const int jn = b == f ? (fi[f] >> 2) & 3 : (fi[f] >> (4 + 2 * p[b])) & 3;
+          out.put(slot[f] * NV + jn, nbv[f][b]);
+        }
+      }
+    }
+    __syncthreads();
+    copy_out<NV>(D.A_emi + base + wbase, img, wspan, tid);
+    if (r1 < nrows) __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// concentration systems: A_knp[k], b_knp[k], k < K - 1
+// concentration systems: A_knp[k], b_knp[k], k < K - 1.  The unit-diffusivity SIP entries are the same for every ion
+// (D_k is constant inside a sub-domain); the K - 1 matrices go through one LDS row image, one after the other.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NV, int KS>
 __global__ __launch_bounds__(DG_BLOCK) void dg_knp_kernel(DgDev D, const DgConsts* __restrict__ Cp, int chunk, int splitting) {
   constexpr int GD = NV - 1, NF = NV - 1;
   constexpr int RPB = (DG_BLOCK / NV) * NV;
-  constexpr int CAP = RPB * NV * (NV + 1);   // doubles per image
-  extern __shared__ double img[];
+  constexpr int FS = dg_fs_knp<NV>();
+  extern __shared__ double lds[];
+  double* fs = lds;
+  double* img = lds + RPB * FS;
   const DgConsts& C = *Cp;
   const int row0 = dg_block_index(blockIdx.x, chunk) * RPB;
   if (row0 >= D.n_dof) return;
   const int nrows = min(RPB, D.n_dof - row0);
   const int tid = threadIdx.x;
+  const bool valid = tid < nrows;
   const int base = D.rowptr[row0];
-  const int span = D.rowptr[row0 + nrows] - base;
-  if (tid < nrows) {
-    const int row = row0 + tid, T = row / NV, i = row - T * NV;
-    int p[NV];
+  const int row = row0 + tid, T = row / NV, i = row - T * NV;
+  int p[NV], nb[NV];
+  unsigned fi[NV];
+  double X[NV][GD], ph[NV], cc[NV][KN_MAXK], gphi[GD];
+  Geo<NV> G;
+  int s = 0;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) p[j] = i + j >= NV ? i + j - NV : i + j;
-    const int s = D.cell_sub[T];
-    double X[NV][GD], ph[NV], cc[NV][KN_MAXK];
+  for (int j = 0; j < NV; ++j) p[j] = i + j >= NV ? i + j - NV : i + j;
+  // everything that does not depend on other loads is requested now, before the first barrier: one round trip to
+  // memory instead of three (the waves spend most of their life waiting for loads, not computing)
+  int rowoff = 0;
+  if (valid) {
+    stage_rec(img, D.rec, row, tid);
+    s = D.cell_sub[T];
+    rowoff = D.rowptr[row] - base;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const DofRec r = load_rec(D.rec, T * NV + p[j]);
+      nb[j] = D.nbr[T * NV + p[j]];
+      fi[j] = D.finfo[T * NV + p[j]];
+    }
+  }
+  __syncthreads();
+  if (valid) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const DofRec r = lds_rec(img, tid - i + p[j]);
 #pragma unroll
       for (int d = 0; d < GD; ++d) X[j][d] = r.x[d];
 #pragma unroll
       for (int q = 0; q < KN_MAXK; ++q) cc[j][q] = r.c[q];
       ph[j] = r.phi;
     }
-    Geo<NV> G;
     geometry<NV>(X, G);
-    double gphi[GD];
 #pragma unroll
     for (int d = 0; d < GD; ++d) {
       double a = 0.0;
@@ -356,11 +502,44 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_knp_kernel(DgDev D, const DgConst
       for (int j = 0; j < NV; ++j) a += ph[j] * G.g[j][d];
       gphi[d] = a;
     }
-    const double drift = dot<GD>(G.g[0], gphi) * G.vol * (1.0 / (GD + 1));
-    const double m0 = G.vol * (1.0 / ((GD + 1) * (GD + 2)));
-    // unit-diffusivity SIP entries (same for every ion: D_k is constant inside a sub-domain)
-    double P[NV], Pn[NV][NV], bf[NV], c2f[NV];
-    double rhs[KS];
+    double* my = fs + tid * FS;
+    const double g2 = dot<GD>(G.g[0], G.g[0]), rgf = fast_rsqrt(g2), gf = g2 * rgf;
+    double n[GD];
+#pragma unroll
+    for (int d = 0; d < GD; ++d) { n[d] = -G.g[0][d] * rgf; my[d] = n[d]; }
+    my[3] = GD * G.vol * gf;
+    if (nb[0] >= 0 && (fi[0] & 3) == 1) {
+      const int N = nb[0];
+      double phN[NV], dfar[GD];   // normal components of the neighbour's gradients: see dg_emi_kernel
+#pragma unroll
+      for (int b = 0; b < NV; ++b) {
+        const int jn = b == 0 ? (fi[0] >> 2) & 3 : (fi[0] >> (4 + 2 * p[b])) & 3;
+        const double* r = D.rec + (size_t)(N * NV + jn) * KN_REC;
+        phN[b] = r[7];
+        if (b == 0) {
+#pragma unroll
+          for (int d = 0; d < GD; ++d) dfar[d] = r[d] - X[1][d];
+        }
+      }
+      const double rh = fast_rcp(dot<GD>(dfar, n));
+      my[4] = 0.5 * (gf + rh);
+      double gphiNn = 0.0;
+#pragma unroll
+      for (int b = 0; b < NV; ++b) {
+        const double gn = b == 0 ? rh : dot<GD>(G.g[b], n) - ((b == 1 ? 1.0 : 0.0) + dot<GD>(G.g[b], dfar)) * rh;
+        gphiNn += phN[b] * gn;
+        my[6 + p[b]] = gn;
+      }
+      my[5] = gphiNn;
+    }
+  }
+  __syncthreads();
+  double P[NV], Pn[NV][NV], bf[NV], c2f[NV], rhs[KS];
+  double drift = 0.0, m0 = 0.0;
+  int slot_self = 0, slot[NV], off = 0;
+  if (valid) {
+    drift = dot<GD>(G.g[0], gphi) * G.vol * (1.0 / (GD + 1));
+    m0 = G.vol * (1.0 / ((GD + 1) * (GD + 2)));
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
       double a = 0.0;
@@ -379,41 +558,19 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_knp_kernel(DgDev D, const DgConst
 #pragma unroll
       for (int b = 0; b < NV; ++b) Pn[j][b] = 0.0;
     }
-    int nb[NV];
-    unsigned fi[NV];
-#pragma unroll
-    for (int f = 0; f < NV; ++f) {
-      nb[f] = D.nbr[T * NV + p[f]];
-      fi[f] = D.finfo[T * NV + p[f]];
-    }
 #pragma unroll
     for (int f = 0; f < NV; ++f) {
       if (nb[f] < 0) continue;
       const bool on0 = f != 0;
       const int kind = fi[f] & 3;
-      const int N = nb[f];
-      const double gf = sqrt(dot<GD>(G.g[f], G.g[f]));
+      const double* fd = fs + (tid - i + p[f]) * FS;
       double n[GD];
 #pragma unroll
-      for (int d = 0; d < GD; ++d) n[d] = -G.g[f][d] / gf;
-      const double area = GD * G.vol * gf;
+      for (int d = 0; d < GD; ++d) n[d] = fd[d];
+      const double area = fd[3];
       const double c2 = area * (1.0 / (GD * (GD + 1)));
       if (kind == 1) {
-        double XN[NV][GD], phN[NV];
-#pragma unroll
-        for (int b = 0; b < NV; ++b) {
-          const int jn = b == f ? (fi[f] >> 2) & 3 : (fi[f] >> (4 + 2 * p[b])) & 3;
-          const double* r = D.rec + (size_t)(N * NV + jn) * KN_REC;
-          phN[b] = r[7];
-#pragma unroll
-          for (int d = 0; d < GD; ++d) XN[b][d] = b == f ? r[d] : X[b][d];
-        }
-        Geo<NV> GN;
-        geometry<NV>(XN, GN);
-        const double inv_h = 0.5 * (gf + sqrt(dot<GD>(GN.g[f], GN.g[f])));
-        double gphiNn = 0.0, gNn[NV];
-#pragma unroll
-        for (int b = 0; b < NV; ++b) { gNn[b] = dot<GD>(GN.g[b], n); gphiNn += phN[b] * gNn[b]; }
+        const double inv_h = fd[4], gphiNn = fd[5];
         const double m1 = area * (1.0 / GD);
         const double gin = dot<GD>(G.g[0], n);
         const double pen = C.gamma * inv_h;
@@ -421,7 +578,7 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_knp_kernel(DgDev D, const DgConst
         for (int j = 0; j < NV; ++j) {
           if (on0) {
             P[j] -= 0.5 * dot<GD>(G.g[j], n) * m1;
-            Pn[f][j] -= 0.5 * gNn[j] * m1;
+            Pn[f][j] -= 0.5 * fd[6 + p[j]] * m1;
           }
           if (j != f) {
             P[j] -= 0.5 * gin * m1;
@@ -439,6 +596,7 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_knp_kernel(DgDev D, const DgConst
         // membrane flux (knpWeakForm.py:168-214), degree-6 rule; with alpha_k = D_k z_k^2 c_k / sum_j D_j z_j^2 c_j of this
         // side the integrand  -/+ (C_k g_k - C_k [phi])  is
         //   sgn * [ alpha_k C_M / (F z_k dt) ([phi] - phi_M - (dt / C_M) I_ch) + I_ch_k / (F z_k) ],  sgn = +1 on the ECS side
+        const int N = nb[f];
         const int mf = D.mfid[T * NV + p[f]];
         double jm[NV], pm[NV], It[NV], Ik[NV][KN_MAXK];
 #pragma unroll
@@ -488,44 +646,47 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_knp_kernel(DgDev D, const DgConst
         }
       }
     }
-    int slot_self, slot[NV];
     block_slots<NV>(T, nb, slot_self, slot);
-    const int off = D.rowptr[row] - base;
+    off = rowoff;
 #pragma unroll
-    for (int k = 0; k < KS; ++k) {
-      const double Dk = C.D[s][k], zpD = C.z[k] * C.psi * Dk;
-      double* out = img + k * CAP + off;
-#pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        double v = (j == 0 ? 2.0 : 1.0) * m0 * C.inv_dt + Dk * P[j] + zpD * drift;
-#pragma unroll
-        for (int f = 0; f < NV; ++f) {   // upwinding: the drift leaves through facet f -> this cell's own value
-          const double beta = zpD * bf[f];
-          if (j != f && beta > 0.0) v += beta * c2f[f] * (j == 0 ? 2.0 : 1.0);
-        }
-        out[slot_self * NV + p[j]] = v;
-      }
-#pragma unroll
-      for (int f = 0; f < NV; ++f) {
-        if (nb[f] < 0) continue;
-        const double beta = zpD * bf[f];
-#pragma unroll
-        for (int b = 0; b < NV; ++b) {
-          const int jn = b == f ? (fi[f] >> 2) & 3 : (fi[f] >> (4 + 2 * p[b])) & 3;
-          double v = Dk * Pn[f][b];
-          if (b != f && !(beta > 0.0)) v += beta * c2f[f] * (b == 0 ? 2.0 : 1.0);   // ... enters: the neighbour's value
-          out[slot[f] * NV + jn] = v;
-        }
-      }
-      D.b_knp[(size_t)k * D.n_dof + row] = rhs[k];
-    }
+    for (int k = 0; k < KS; ++k) D.b_knp[(size_t)k * D.n_dof + row] = rhs[k];
   }
-  __syncthreads();
+  // the K - 1 matrices go through the one LDS image in turn (DG_ROUND rows at a time, as in dg_emi_kernel)
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
-    double* dst = D.A_knp + (size_t)k * D.nnz + base;
-    const double* src = img + k * CAP;
-    for (int e = tid; e < span; e += DG_BLOCK) dst[e] = src[e];
+    const double Dk = C.D[s][k], zpD = C.z[k] * C.psi * Dk;
+    for (int r0 = 0; r0 < nrows; r0 += DG_ROUND) {
+      const int r1 = min(r0 + DG_ROUND, nrows);
+      const int wbase = D.rowptr[row0 + r0] - base, wspan = D.rowptr[row0 + r1] - base - wbase;
+      if (k > 0 || r0 > 0) __syncthreads();   // the previous image has been copied out
+      if (tid >= r0 && tid < r1) {
+        const ImgRow<NV> out(img, off - wbase);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          double v = (j == 0 ? 2.0 : 1.0) * m0 * C.inv_dt + Dk * P[j] + zpD * drift;
+#pragma unroll
+          for (int f = 0; f < NV; ++f) {   // upwinding: the drift leaves through facet f -> this cell's own value
+            const double beta = zpD * bf[f];
+            if (j != f && beta > 0.0) v += beta * c2f[f] * (j == 0 ? 2.0 : 1.0);
+          }
+          out.put(slot_self * NV + p[j], v);
+        }
+#pragma unroll
+        for (int f = 0; f < NV; ++f) {
+          if (nb[f] < 0) continue;
+          const double beta = zpD * bf[f];
+#pragma unroll
+          for (int b = 0; b < NV; ++b) {
+            const int jn = b == f ? (fi[f] >> 2) & 3 : (fi[f] >> (4 + 2 * p[b])) & 3;
+            double v = Dk * Pn[f][b];
+            if (b != f && !(beta > 0.0)) v += beta * c2f[f] * (b == 0 ? 2.0 : 1.0);   // ... enters: the neighbour's value
+            out.put(slot[f] * NV + jn, v);
+          }
+        }
+      }
+      __syncthreads();
+      copy_out<NV>(D.A_knp + (size_t)k * D.nnz + base + wbase, img, wspan, tid);
+    }
   }
 }
 
@@ -621,7 +782,8 @@ int dg_check_launch(const char* what) {
 int launch_emi(knpemi_dg* h, int flags) {
   const int NV = h->NV, rpb = (DG_BLOCK / NV) * NV;
   const int nblocks = (h->dev.n_dof + rpb - 1) / rpb, chunk = (nblocks + 7) / 8;
-  const size_t lds = (size_t)rpb * NV * (NV + 1) * sizeof(double);
+  const size_t lds = ((size_t)rpb * (NV == 3 ? dg_fs_emi<3>() : dg_fs_emi<4>()) +
+                      (NV == 3 ? dg_scratch_doubles<3, 1>() : dg_scratch_doubles<4, 1>())) * sizeof(double);
   const int split = !(flags & KNPEMI_NO_SPLITTING);
   if (NV == 3) hipLaunchKernelGGL(dg_emi_kernel<3>, dim3(8 * chunk), dim3(DG_BLOCK), lds, h->stream, h->dev, h->d_consts, chunk, split);
   else hipLaunchKernelGGL(dg_emi_kernel<4>, dim3(8 * chunk), dim3(DG_BLOCK), lds, h->stream, h->dev, h->d_consts, chunk, split);
@@ -631,12 +793,12 @@ int launch_emi(knpemi_dg* h, int flags) {
 template <int NV>
 int launch_knp_nv(knpemi_dg* h, int chunk, int split) {
   constexpr int rpb = (DG_BLOCK / NV) * NV;
-  const size_t lds1 = (size_t)rpb * NV * (NV + 1) * sizeof(double);
+  const size_t fsb = (size_t)rpb * dg_fs_knp<NV>();
   const dim3 grid(8 * chunk), block(DG_BLOCK);
   switch (h->K - 1) {
-    case 1: hipLaunchKernelGGL((dg_knp_kernel<NV, 1>), grid, block, lds1, h->stream, h->dev, h->d_consts, chunk, split); break;
-    case 2: hipLaunchKernelGGL((dg_knp_kernel<NV, 2>), grid, block, 2 * lds1, h->stream, h->dev, h->d_consts, chunk, split); break;
-    default: hipLaunchKernelGGL((dg_knp_kernel<NV, 3>), grid, block, 3 * lds1, h->stream, h->dev, h->d_consts, chunk, split); break;
+    case 1: hipLaunchKernelGGL((dg_knp_kernel<NV, 1>), grid, block, (fsb + dg_scratch_doubles<NV, 1>()) * sizeof(double), h->stream, h->dev, h->d_consts, chunk, split); break;
+    case 2: hipLaunchKernelGGL((dg_knp_kernel<NV, 2>), grid, block, (fsb + dg_scratch_doubles<NV, 1>()) * sizeof(double), h->stream, h->dev, h->d_consts, chunk, split); break;
+    default: hipLaunchKernelGGL((dg_knp_kernel<NV, 3>), grid, block, (fsb + dg_scratch_doubles<NV, 1>()) * sizeof(double), h->stream, h->dev, h->d_consts, chunk, split); break;
   }
   return dg_check_launch("dg_knp_kernel");
 }

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libknpemi_hip.so")
+LIB_PATH = os.environ.get("KNPEMI_HIP_LIB") or os.path.join(_HERE, "libknpemi_hip.so")   # override: build experiments
 
 OK, EINVAL, EHIP, ENOMEM, EODE, ESOLVE = 0, -1, -2, -3, -4, -5
 PC_JACOBI, PC_AMG = 0, 1

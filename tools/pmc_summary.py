@@ -9,7 +9,7 @@ for f in sorted(glob.glob(f"{root}/p*/*/*_counter_collection.csv")):
         acc[(m.group(1) if m else r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in acc.items():
         out[k][c] = sum(v) / len(v)
-keep = {k: v for k, v in out.items() if "rows" in k or "ode" in k}
+keep = {k: v for k, v in out.items() if "rows" in k or "ode" in k or "dg_" in k}
 json.dump(keep, open(f"{root}/summary.json", "w"), indent=1, sort_keys=True)
 for k, v in keep.items():
     print(k)
