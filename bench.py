@@ -274,6 +274,102 @@ def with_solves(case, stepper, n_steps, torch, halo=None):
                     **info["knp"]}}
 
 
+def run_dg(args, torch, steps=None, warmup=None, cpu=True):
+    """The DG(P1) + interior-penalty variant (csrc/kernels_dg.hip) on the workload's mesh: one step =
+    membrane ODE sweep over the facet nodes + potential-system assembly + concentration-systems assembly + end-of-step
+    update, device-resident.  Its linear solves are not on the device, so the fields stay at the initial state."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import dg_time
+    from knpemi import _lib as L
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    family, kind, r = WORKLOADS[args.workload]
+    if family != "idealized" or kind != "tet":
+        raise SystemExit("--variant dg runs on the idealized tetrahedral workloads (config2, config3, r3)")
+    with contextlib.redirect_stdout(io.StringIO()):
+        dp = dg_time.build(r)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import knpemi_oracle as ko
+    m = ko.MODELS["hh_si"]
+    ix = m["pidx"]
+    prow = np.array(m["params"], float)
+    prow[ix["Cm"]] = 0.02
+    prow[ix["z_Na"]], prow[ix["z_K"]], prow[ix["z_Cl"]], prow[ix["psi"]] = 1.0, 1.0, -1.0, 96485.0 / (8.314 * 300.0)
+    names = ("Na", "K", "Cl")
+    dp.ode_bind(L.MODEL_HH_SI, m["states"], prow, sum(([ix[f"{n}_e"], ix[f"{n}_i"], ix[f"I_ch_{n}"]] for n in names), []), m["V"])
+    c_new = torch.tensor(np.stack([dp.get_concentration(k).ravel() for k in range(2)]), device="cuda")
+    torch.cuda.synchronize()
+    dt = 1e-4
+
+    def step(k):
+        dp.ode_step(k * dt, dt, set_v=k > 0)
+        dp.assemble_emi()
+        dp.assemble_knp()
+        dp.update_device(c_new.data_ptr())
+
+    for k in range(warmup):
+        step(k)
+    dp.sync()
+    dp.ode_stats()
+    dp.profile(True)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(warmup + k)
+    dp.sync()
+    elapsed = time.perf_counter() - t0
+    dp.profile(False)
+    (_, emi_us), (_, knp_us) = dp.profile_read(0), dp.profile_read(1)
+    n_rhs, _, n_failed = dp.ode_stats()
+    if n_failed:
+        raise SystemExit("LSODA failed on the device")
+    dofs = dp.n * dp.K
+    ms = elapsed / steps * 1e3
+
+    def roof(which, name, us):
+        by = dg_time.algorithmic_bytes(dp, which)
+        return {"bound": "hbm", "kernel": name, "achieved": by / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": by,
+                "avg_launch_us": us}
+    out = {
+        "metric": "assembled dofs/s (DG volume + interior-facet SIP + membrane-facet assembly + membrane ODE sweep) per "
+                  "timestep; 3D idealized mesh, fp64",
+        "value": dofs / (elapsed / steps), "unit": "dofs/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: make_mesh_3D geometry r={r}, {dp.n_cells} tetrahedra, broken P1: {dp.n} dofs "
+                               f"per field, {dp.nnz} CSR entries per system, {dp.nmf * dp.nf} membrane facet nodes (HH), 3 ions",
+                   "variant": "DG(P1) + symmetric interior penalty (gamma = 10), upwinded drift", "dofs_per_step": dofs,
+                   "state": "fields held at the initial state (the DG systems are not solved on the device)"},
+        "roofline": roof(1, "dg_knp_kernel", knp_us),
+        "roofline_potential_kernel": roof(0, "dg_emi_kernel", emi_us),
+        "kernels_us_per_step": {"dg_emi_kernel": emi_us, "dg_knp_kernel": knp_us},
+        "ode": {"rhs_evals_per_dof_per_step": n_rhs / max(1, dp.nmf * dp.nf) / steps},
+    }
+    if cpu:
+        import knpemi_dg_oracle as dgo
+        from knpemi.fem.idealized import make_mesh_3D
+        mesh, ct, ft = make_mesh_3D(0, "tetrahedron")
+        sel = ft.values == 1
+        o = dgo.DGOracle(mesh.x, mesh.cells, mesh.cell_type, ct.dense(), mesh.facets[ft.indices[sel]], ft.values[sel])
+        shape, ms_ = (o.nc, o.nv), (o.nmf, o.nf)
+        ions = [dict(z=1.0, D=[1.33e-9] * 2), dict(z=1.0, D=[1.96e-9] * 2), dict(z=-1.0, D=[2.03e-9] * 2)]
+        pr = dict(dt=dt, F=96485.0, psi=96485.0 / (8.314 * 300.0), C_M=0.02)
+        c_all = [np.full(shape, v) for v in (100.0, 4.0, 104.0)]
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 10.0:
+            o.assemble_emi(pr, ions, c_all, np.zeros(ms_), [np.zeros(ms_)] * 3)
+            o.assemble_knp(pr, ions, c_all, np.zeros(shape), np.zeros(ms_), [np.zeros(ms_)] * 3)
+            reps += 1
+        tc = (time.perf_counter() - t0) / reps
+        out["cpu_baseline"] = {"value": o.n * 3 / tc, "unit": "dofs/s", "cores": 1, "kind": "port",
+                               "sample": f"{reps} assemblies (potential + 2 concentration systems, no ODE sweep) of the numpy "
+                                         f"restatement oracle/knpemi_dg_oracle.py on the r=0 mesh ({o.nc} tetrahedra, "
+                                         f"{o.n} dofs per field), {tc * 1e3:.0f} ms each; there is no reference DG code"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -294,6 +390,11 @@ def main():
                          "round-1 measurement: phi_M is reset every step and the cell never fires)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the EMI matrix assembly after the ODE sweep instead of beside it (aux stream)")
+    ap.add_argument("--variant", default="cg", choices=["cg", "dg"],
+                    help="cg: the reference's formulation (CG on sub-meshes, the parity path); dg: the DG(P1) + interior "
+                         "penalty variant of SURVEY.md section 8 f4 on the same mesh (assembly + ODE sweep + update, fields "
+                         "held at the initial state: its linear solves are not on the device)")
+    ap.add_argument("--no-dg", action="store_true", help="skip the short DG-variant measurement appended to the cg line")
     ap.add_argument("--knp-twice", action="store_true",
                     help="assemble A_knp twice per step as the reference does (p = a, knpWeakForm.py:319)")
     args = ap.parse_args()
@@ -320,6 +421,11 @@ def main():
     from knpemi import _lib as L
     from knpemi.stepper import DeviceStepper
 
+    if args.variant == "dg":
+        if world > 1:
+            raise SystemExit("the DG variant is single-GPU (no ghost-cell exchange yet): run it with --gpus 1")
+        print(json.dumps(run_dg(args, torch)))
+        return
     if world > 1 and args.scaling == "strong" and args.workload == "config2":
         args.workload = "config3"       # the fixed mesh of BASELINE.json configs[2]
     case = Case(args.workload, rank, world, args.scaling)
@@ -530,6 +636,11 @@ def main():
                 "value": dofs_total / t_one, "unit": "dofs/s", "cores": 1, "kind": "port",
                 "sample": f"{n1} " + what.format(a=a_one * 1e3, o=o_one * 1e3, n=nrows)
                           + "; one thread, as the reference's serial run"}
+        if world == 1 and not args.no_dg and case.family == "idealized" and case.kind == "tet":
+            del stepper, s, case          # free the CG problem first
+            dg = run_dg(args, torch, steps=10, warmup=2, cpu=False)
+            out["dg_variant"] = {k: dg[k] for k in ("value", "unit", "ms_per_step", "config", "roofline",
+                                                     "roofline_potential_kernel", "kernels_us_per_step")}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

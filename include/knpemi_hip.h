@@ -375,6 +375,13 @@ int knpemi_dg_sync(knpemi_dg* h);
 /* average duration (ms) of `reps` back-to-back launches of one assembly kernel (0 = potential, 1 = concentrations),
  * measured with HIP events on the stream the kernel is launched on */
 int knpemi_dg_time_kernel(knpemi_dg* h, int which, int flags, int reps, double* avg_ms);
+/* per-launch HIP event brackets of the assembly kernels inside a running time loop (as knpemi_profile):
+ * profile_read synchronises, returns the number of bracketed launches of kernel `which` and their summed duration,
+ * and resets the accumulator */
+int knpemi_dg_profile(knpemi_dg* h, int on);
+int knpemi_dg_profile_read(knpemi_dg* h, int which, int64_t* launches, double* total_ms);
+/* HIP stream the handle enqueues on */
+void* knpemi_dg_stream(knpemi_dg* h);
 
 #ifdef __cplusplus
 }

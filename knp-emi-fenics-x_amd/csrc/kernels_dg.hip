@@ -734,6 +734,10 @@ struct knpemi_dg {
   size_t stage_len = 0;
   double* d_fsrc = nullptr;
   const int* d_colind = nullptr;
+  // per-launch event brackets of the two assembly kernels (knpemi_dg_profile)
+  int prof_on = 0;
+  std::vector<hipEvent_t> prof_ev[2];
+  size_t prof_used[2] = {0, 0};
   // membrane ODE sweep
   int ode_model = -1, ode_ns = 0, ode_np = 0, ode_v = 0, ode_blocks = 0;
   int ode_ion_param[3 * KN_MAXK] = {0};
@@ -779,7 +783,27 @@ int dg_check_launch(const char* what) {
   return KNPEMI_OK;
 }
 
+struct DgProf {   // brackets one launch with an event pair on the handle's stream
+  knpemi_dg* h; int k; bool on;
+  DgProf(knpemi_dg* h_, int k_) : h(h_), k(k_), on(h_->prof_on != 0) {
+    if (!on) return;
+    auto& v = h->prof_ev[k];
+    if (h->prof_used[k] + 2 > v.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+      v.push_back(a); v.push_back(b);
+    }
+    (void)hipEventRecord(v[h->prof_used[k]], h->stream);
+  }
+  ~DgProf() {
+    if (!on) return;
+    (void)hipEventRecord(h->prof_ev[k][h->prof_used[k] + 1], h->stream);
+    h->prof_used[k] += 2;
+  }
+};
+
 int launch_emi(knpemi_dg* h, int flags) {
+  DgProf prof(h, 0);
   const int NV = h->NV, rpb = (DG_BLOCK / NV) * NV;
   const int nblocks = (h->dev.n_dof + rpb - 1) / rpb, chunk = (nblocks + 7) / 8;
   const size_t lds = ((size_t)rpb * (NV == 3 ? dg_fs_emi<3>() : dg_fs_emi<4>()) +
@@ -804,6 +828,7 @@ int launch_knp_nv(knpemi_dg* h, int chunk, int split) {
 }
 
 int launch_knp(knpemi_dg* h, int flags) {
+  DgProf prof(h, 1);
   const int NV = h->NV, rpb = (DG_BLOCK / NV) * NV;
   const int nblocks = (h->dev.n_dof + rpb - 1) / rpb, chunk = (nblocks + 7) / 8;
   const int split = !(flags & KNPEMI_NO_SPLITTING);
@@ -818,6 +843,7 @@ extern "C" void knpemi_dg_destroy(knpemi_dg* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->d_coef) (void)hipFree(h->d_coef);
+  for (auto& v : h->prof_ev) for (hipEvent_t e : v) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1195,6 +1221,30 @@ extern "C" int knpemi_dg_time_kernel(knpemi_dg* h, int which, int flags, int rep
   float ms = 0.f;
   KN_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   *avg_ms = (double)ms / reps;
+  return KNPEMI_OK;
+}
+
+extern "C" void* knpemi_dg_stream(knpemi_dg* h) { return h ? (void*)h->stream : nullptr; }
+
+extern "C" int knpemi_dg_profile(knpemi_dg* h, int on) {
+  if (!h) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_profile: null handle");
+  h->prof_on = on ? 1 : 0;
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_dg_profile_read(knpemi_dg* h, int which, int64_t* launches, double* total_ms) {
+  if (!h || which < 0 || which > 1) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_profile_read: bad argument");
+  KN_HIP(hipSetDevice(h->device));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  double tot = 0.0;
+  for (size_t i = 0; i + 1 < h->prof_used[which]; i += 2) {
+    float ms = 0.f;
+    KN_HIP(hipEventElapsedTime(&ms, h->prof_ev[which][i], h->prof_ev[which][i + 1]));
+    tot += ms;
+  }
+  if (launches) *launches = (int64_t)(h->prof_used[which] / 2);
+  if (total_ms) *total_ms = tot;
+  h->prof_used[which] = 0;
   return KNPEMI_OK;
 }
 

@@ -163,6 +163,9 @@ SIGNATURES = {
     "knpemi_dg_ode_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "knpemi_dg_sync": (C.c_int, [C.c_void_p]),
     "knpemi_dg_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_dbl_p]),
+    "knpemi_dg_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "knpemi_dg_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), c_dbl_p]),
+    "knpemi_dg_stream": (C.c_void_p, [C.c_void_p]),
 }
 
 

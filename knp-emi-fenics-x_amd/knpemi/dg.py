@@ -200,6 +200,19 @@ class DGProblem:
         L.check(self.lib.knpemi_dg_ode_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def update_device(self, c_new_ptr):
+        """As `update`, with c_new (K-1, n) already in device memory (pointer as int)."""
+        L.check(self.lib.knpemi_dg_update(self.h, C.c_void_p(c_new_ptr), 1))
+
+    def profile(self, on):
+        L.check(self.lib.knpemi_dg_profile(self.h, 1 if on else 0))
+
+    def profile_read(self, which):
+        """(launches, average microseconds) of the bracketed launches of kernel `which` since the last read."""
+        n, ms = C.c_int64(), C.c_double()
+        L.check(self.lib.knpemi_dg_profile_read(self.h, which, C.byref(n), C.byref(ms)))
+        return n.value, (ms.value / n.value * 1e3 if n.value else 0.0)
+
     def sync(self):
         L.check(self.lib.knpemi_dg_sync(self.h))
 
