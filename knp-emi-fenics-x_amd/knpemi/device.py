@@ -191,12 +191,21 @@ class DeviceProblem:
         """Upload `fn.x` if it changed since the last upload of this field."""
         vec = fn.x
         key = (field, sub, idx)
-        stamp = (id(vec), vec.version)
+        stamp = self._stamp(vec)
         if self._uploaded.get(key) == stamp:
             return
         a = vec._a
         L.check(self.lib.knpemi_set_field(self.h, field, sub, idx, L.dptr(a), a.shape[0]))
         self._uploaded[key] = stamp
+
+    @staticmethod
+    def _stamp(vec):
+        """What "unchanged since the last upload" means: same vector object, no `.array` access since (`version`),
+        and the same content fingerprint -- a caller may keep a view (`a = f.x.array; ...; a[:] = v`, common in DOLFINx
+        driver code) and write through it without touching `.array` again; summing the array (one pass over host
+        memory, far cheaper than the upload it may save) catches that."""
+        a = vec._a
+        return (id(vec), vec.version, float(a.sum()), float(a[:: max(1, a.shape[0] // 64)].dot(a[:: max(1, a.shape[0] // 64)])))
 
     def push_array(self, field, sub, idx, a):
         a = np.ascontiguousarray(a, np.float64)
@@ -209,7 +218,7 @@ class DeviceProblem:
         a = vec._a
         L.check(self.lib.knpemi_get_field(self.h, field, sub, idx, L.dptr(a), a.shape[0]))
         vec.version += 1
-        self._uploaded[(field, sub, idx)] = (id(vec), vec.version)
+        self._uploaded[(field, sub, idx)] = self._stamp(vec)
 
     def pull_array(self, field, sub, idx, n):
         a = np.empty(n, np.float64)

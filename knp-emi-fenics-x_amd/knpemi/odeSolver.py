@@ -151,7 +151,9 @@ class MembraneModel:
         if stimulus is None:
             stimulus = {}
         dp, lib = self._dp, self._dp.lib
-        key = id(stimulus_locator)
+        # keyed on the locator object itself (the cache holds a reference, so a fresh lambda can never reuse the id
+        # of a dead one and pick up its mask)
+        key = stimulus_locator
         if key not in self._mask_cache:
             if stimulus_locator is None:
                 mask = np.ones(self.nodes, np.uint8)

@@ -105,6 +105,31 @@ def test_update_pde_matches_oracle(hip_lib):
     assert rel_err(s.phi_M_prev[1].x._a, phiM[1]) < 1e-15
 
 
+def test_write_through_a_retained_array_view_is_uploaded(hip_lib):
+    """DOLFINx driver code keeps views (`a = f.x.array`) and writes through them later; the upload skipping of the
+    drop-in layer must notice (content fingerprint), not hand the kernels a stale device copy.  A second locator
+    object for the stimulus mask must get its own mask even if it reuses the id of a dead lambda."""
+    from knpemi import _lib as L
+    s = Setup("2d", 1)
+    dp = s.a_emi.dp
+    f = s.c_prev[0][0]
+    view = f.x.array
+    dp.push(L.F_C_PREV, 0, 0, f)
+    view[:] = 7.25                       # no `.array` access after the upload
+    dp.push(L.F_C_PREV, 0, 0, f)
+    assert np.all(dp.pull_array(L.F_C_PREV, 0, 0, view.shape[0]) == 7.25)
+    dp.push(L.F_C_PREV, 0, 0, f)         # unchanged: skipped (same stamp)
+    assert dp._uploaded[(L.F_C_PREV, 0, 0)] == dp._stamp(f.x)
+    ode = s.mem_models[0]['ode']
+    from knpemi.utils import update_ode_variables
+    update_ode_variables(ode, s.c_prev, s.phi_M_prev[1], s.ion_list, s.subdomain_list, s.mesh, s.ct, 1, 0)
+    ode.step_lsoda(s.dt, s.stim_params['stimulus'], lambda x: x[0] < 20e-6)
+    m1 = next(iter(ode._mask_cache.values())).copy()
+    ode.step_lsoda(s.dt, s.stim_params['stimulus'], lambda x: x[0] > 40e-6)
+    m2 = next(iter(ode._mask_cache.values()))
+    assert m1.sum() > 0 and m2.sum() > 0 and not np.array_equal(m1, m2)
+
+
 def test_trace_matches_oracle(hip_lib):
     from knpemi import interpolate_to_membrane
     s = Setup("2d", 1)
