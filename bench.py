@@ -328,8 +328,14 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True):
 
     def roof(which, name, us):
         by = dg_time.algorithmic_bytes(dp, which)
+        traffic = None      # PMC counters of this build, collected in their own profiler passes (tools/collect_traffic.sh)
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))[args.workload][name]
+            traffic = (2.0 * tr["FETCH_SIZE_KiB"] + tr["WRITE_SIZE_KiB"]) * 1024.0
+        except (OSError, KeyError, ValueError):
+            pass
         return {"bound": "hbm", "kernel": name, "achieved": by / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": by,
+                "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": by,
                 "avg_launch_us": us}
     out = {
         "metric": "assembled dofs/s (DG volume + interior-facet SIP + membrane-facet assembly + membrane ODE sweep) per "
