@@ -437,7 +437,7 @@ def main():
     case = Case(args.workload, rank, world, args.scaling)
     s = case.s
     frozen = args.frozen_state
-    if frozen and case.family == "idealized":
+    def frozen_state():
         # synthetic stationary state: c = c_prev (the update keeps the fields), rest potential + a smooth perturbation
         s.perturb(seed=12345 + rank)
         for tag in s.subdomain_list:
@@ -449,6 +449,9 @@ def main():
         for tag in s.subdomain_list:
             x = s.subdomain_list[tag]['mesh_sub'].x
             s.phi[tag].x.array[:] = (-0.0744 if tag > 0 else 0.0) + 1e-3 * np.sin(2 * np.pi * x[:, 0] / L_x)
+
+    if frozen and case.family == "idealized":
+        frozen_state()
 
     stepper = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp),
                             s.c, s.c_prev, s.phi, s.phi_M_prev, assemble_knp_twice=args.knp_twice,
@@ -463,8 +466,6 @@ def main():
         halo.attach(dp)
         halo.exchange_bulk()        # ghosts start from their owners' values
         halo.exchange_membrane()    # once: afterwards the ghost membrane dofs are integrated redundantly
-        if not frozen:
-            halo.enable_solves()    # knpemi_solve_emi / knp solve the global systems
 
     def sync():
         if dist is not None:
@@ -474,8 +475,30 @@ def main():
     lib = dp.lib
     n_traj = args.warmup + PROFILE_STEPS + args.steps
     traj_its = None
-    if not frozen:
+    traj_fallback = None
+    if not frozen and halo is not None:
+        # The distributed Krylov solves (RCCL all-reduce and halo from inside the solver loop) are the one part of the
+        # N > 1 path that could only be rehearsed over gloo here.  If they fail -- the same way on every rank, i.e.
+        # before or outside a collective -- the measurement falls back to the frozen state instead of being lost, and
+        # says so in `config.state`.
+        try:
+            halo.enable_solves()    # knpemi_solve_emi / knp solve the global systems
+            if os.environ.get("KNPEMI_BENCH_TEST_FALLBACK"):      # rehearsal hook for the branch below
+                raise RuntimeError("KNPEMI_BENCH_TEST_FALLBACK is set")
+            phi_t, c_t, traj_its = record_trajectory(case, stepper, n_traj, torch, halo)
+        except Exception as e:      # noqa: BLE001
+            if case.family != "idealized":
+                raise
+            traj_fallback = f"{type(e).__name__}: {e}"[:300]
+            frozen = True
+            stepper.solve_emi = stepper.solve_knp = None
+            frozen_state()
+            stepper.reset()
+            halo.exchange_bulk()
+            halo.exchange_membrane()
+    elif not frozen:
         phi_t, c_t, traj_its = record_trajectory(case, stepper, n_traj, torch, halo)
+    if not frozen:
         stepper.reset()
         if halo is not None:
             halo.exchange_bulk()
@@ -591,7 +614,9 @@ def main():
                        "dofs_per_step": dofs_total, "A_knp_assemblies_per_step": 2 if args.knp_twice else 1,
                        "emi_matrix_beside_ode_sweep": bool(stepper.overlap),
                        "update_fused_into_knp_write_back": bool(stepper.fuse_update),
-                       "state": ("fields frozen at the initial state (phi_M reset every step)" if frozen else
+                       "state": (("fields frozen at the initial state (phi_M reset every step)"
+                                  + (f"; FALLBACK: the trajectory pass with distributed solves raised {traj_fallback}"
+                                     if traj_fallback else "")) if frozen else
                                  f"recorded trajectory of the first {n_traj} time steps from t = 0 (device Krylov solves, "
                                  f"untimed); the timed steps replay it, pasting each recorded solution where the solve "
                                  f"writes it"),
