@@ -274,10 +274,11 @@ def with_solves(case, stepper, n_steps, torch, halo=None):
                     **info["knp"]}}
 
 
-def run_dg(args, torch, steps=None, warmup=None, cpu=True):
+def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, world=1):
     """The DG(P1) + interior-penalty variant (csrc/kernels_dg.hip) on the workload's mesh: one step =
     membrane ODE sweep over the facet nodes + potential-system assembly + concentration-systems assembly + end-of-step
-    update, device-resident.  Its linear solves are not on the device, so the fields stay at the initial state."""
+    update (+ the ghost-cell refresh at N > 1: x-slabs of an N times longer box, knpemi.dg.DGSlab), device-resident.
+    Its linear solves are not on the device, so the fields stay at the initial state."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import dg_time
@@ -287,8 +288,16 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True):
     family, kind, r = WORKLOADS[args.workload]
     if family != "idealized" or kind != "tet":
         raise SystemExit("--variant dg runs on the idealized tetrahedral workloads (config2, config3, r3)")
+    slab = None
     with contextlib.redirect_stdout(io.StringIO()):
-        dp = dg_time.build(r)
+        if world == 1:
+            dp = dg_time.build(r)
+        else:
+            from knpemi.dg import DGSlab
+            slab = DGSlab(r, 2 * world, rank, world, device=torch.cuda.current_device())
+            dp = dg_time.init_fields(slab.dp)
+            slab.attach()
+            slab.exchange()
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import knpemi_oracle as ko
     m = ko.MODELS["hh_si"]
@@ -307,23 +316,40 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True):
         dp.assemble_emi()
         dp.assemble_knp()
         dp.update_device(c_new.data_ptr())
+        if slab is not None:
+            slab.exchange()
+
+    def sync():
+        dp.sync()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     for k in range(warmup):
         step(k)
-    dp.sync()
+    sync()
     dp.ode_stats()
     dp.profile(True)
     t0 = time.perf_counter()
     for k in range(steps):
         step(warmup + k)
-    dp.sync()
+    sync()
     elapsed = time.perf_counter() - t0
+    n_owned_cells = dp.n_cells if slab is None else int(slab.owned_cells.sum())
+    if dist is not None:
+        red_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tot = torch.tensor([float(n_owned_cells)], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tot)
+        n_owned_cells = int(tot.item())
     dp.profile(False)
     (_, emi_us), (_, knp_us) = dp.profile_read(0), dp.profile_read(1)
     n_rhs, _, n_failed = dp.ode_stats()
     if n_failed:
         raise SystemExit("LSODA failed on the device")
-    dofs = dp.n * dp.K
+    dofs = n_owned_cells * dp.nv * dp.K
     ms = elapsed / steps * 1e3
 
     def roof(which, name, us):
@@ -340,19 +366,22 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True):
     out = {
         "metric": "assembled dofs/s (DG volume + interior-facet SIP + membrane-facet assembly + membrane ODE sweep) per "
                   "timestep; 3D idealized mesh, fp64",
-        "value": dofs / (elapsed / steps), "unit": "dofs/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+        "value": dofs / (elapsed / steps), "unit": "dofs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: make_mesh_3D geometry r={r}, {dp.n_cells} tetrahedra, broken P1: {dp.n} dofs "
                                f"per field, {dp.nnz} CSR entries per system, {dp.nmf * dp.nf} membrane facet nodes (HH), 3 ions",
                    "variant": "DG(P1) + symmetric interior penalty (gamma = 10), upwinded drift", "dofs_per_step": dofs,
+                   "partition": ("none" if slab is None else
+                                 f"x-slabs of a {32 * world} um box (config 2 per GPU), one ghost-cell layer per cut, "
+                                 f"ghost dofs refreshed once per step: {slab.mode}"),
                    "state": "fields held at the initial state (the DG systems are not solved on the device)"},
         "roofline": roof(1, "dg_knp_kernel", knp_us),
         "roofline_potential_kernel": roof(0, "dg_emi_kernel", emi_us),
         "kernels_us_per_step": {"dg_emi_kernel": emi_us, "dg_knp_kernel": knp_us},
         "ode": {"rhs_evals_per_dof_per_step": n_rhs / max(1, dp.nmf * dp.nf) / steps},
     }
-    if cpu:
+    if cpu and rank == 0 and world == 1:
         import knpemi_dg_oracle as dgo
         from knpemi.fem.idealized import make_mesh_3D
         mesh, ct, ft = make_mesh_3D(0, "tetrahedron")
@@ -428,9 +457,12 @@ def main():
     from knpemi.stepper import DeviceStepper
 
     if args.variant == "dg":
-        if world > 1:
-            raise SystemExit("the DG variant is single-GPU (no ghost-cell exchange yet): run it with --gpus 1")
-        print(json.dumps(run_dg(args, torch)))
+        out = run_dg(args, torch, dist=dist, rank=rank, world=world)
+        if rank == 0:
+            print(json.dumps(out))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
         return
     if world > 1 and args.scaling == "strong" and args.workload == "config2":
         args.workload = "config3"       # the fixed mesh of BASELINE.json configs[2]

@@ -371,6 +371,13 @@ int knpemi_dg_ode_bind(knpemi_dg* h, int model_id, int n_states, int n_params, c
 int knpemi_dg_ode_step(knpemi_dg* h, double t0, double dt, double rtol, double atol, int flags);
 int knpemi_dg_ode_get_tables(knpemi_dg* h, double* states, double* params);
 int knpemi_dg_ode_stats(knpemi_dg* h, int64_t* n_rhs, int64_t* n_steps, int64_t* n_failed);
+/* Cell-partitioned runs: every rank holds its cells plus one layer of ghost cells across the cut facets.  The ghost
+ * cells' dofs (five field doubles each: the K concentrations and the potential) are refreshed from their owners once
+ * per step: pack the listed dofs into a device buffer [n][5] / unpack it on the receiving side (device index lists,
+ * stream-ordered; the transport is the caller's: RCCL point-to-point in knpemi/dg.py, as Function.x.scatter_forward()
+ * of a DG function does under MPI in DOLFINx).  Membrane nodes of ghost cells are integrated redundantly. */
+int knpemi_dg_halo_pack(knpemi_dg* h, const int32_t* idx_dev, int n, double* buf_dev);
+int knpemi_dg_halo_unpack(knpemi_dg* h, const int32_t* idx_dev, int n, const double* buf_dev);
 int knpemi_dg_sync(knpemi_dg* h);
 /* average duration (ms) of `reps` back-to-back launches of one assembly kernel (0 = potential, 1 = concentrations),
  * measured with HIP events on the stream the kernel is launched on */

@@ -708,6 +708,16 @@ __global__ void dg_update_kernel(DgDev D, const DgConsts* __restrict__ Cp, const
   if (t < D.nq) D.phiM[t] = D.rec[(size_t)D.q2i[t] * KN_REC + 7] - D.rec[(size_t)D.q2e[t] * KN_REC + 7];
 }
 
+// ghost-cell halo: the five field slots (c3 c0 c1 c2 phi) of the listed dofs <-> a packed buffer
+__global__ void dg_halo_kernel(double* rec, const int* __restrict__ idx, int n, double* buf, int unpack) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * 5) return;
+  const int e = t / 5, c = t - e * 5;
+  double* r = rec + (size_t)idx[e] * KN_REC + 3 + c;
+  if (unpack) *r = buf[t];
+  else buf[t] = *r;
+}
+
 __global__ void dg_slot_kernel(double* rec, int slot, double* buf, int n, int to_records) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
@@ -1198,6 +1208,23 @@ extern "C" int knpemi_dg_update(knpemi_dg* h, const double* c_new, int on_device
   if (rc) return rc;
   if (!on_device) KN_HIP(hipStreamSynchronize(h->stream));
   return KNPEMI_OK;
+}
+
+extern "C" int knpemi_dg_halo_pack(knpemi_dg* h, const int32_t* idx_dev, int n, double* buf_dev) {
+  if (!h || n < 0 || (n > 0 && (!idx_dev || !buf_dev))) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_halo_pack: bad argument");
+  if (n == 0) return KNPEMI_OK;
+  KN_HIP(hipSetDevice(h->device));
+  hipLaunchKernelGGL(dg_halo_kernel, dim3((5 * (size_t)n + 255) / 256), dim3(256), 0, h->stream, h->dev.rec, idx_dev, n, buf_dev, 0);
+  return dg_check_launch("dg_halo_kernel");
+}
+
+extern "C" int knpemi_dg_halo_unpack(knpemi_dg* h, const int32_t* idx_dev, int n, const double* buf_dev) {
+  if (!h || n < 0 || (n > 0 && (!idx_dev || !buf_dev))) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_halo_unpack: bad argument");
+  if (n == 0) return KNPEMI_OK;
+  KN_HIP(hipSetDevice(h->device));
+  hipLaunchKernelGGL(dg_halo_kernel, dim3((5 * (size_t)n + 255) / 256), dim3(256), 0, h->stream, h->dev.rec, idx_dev, n,
+                     const_cast<double*>(buf_dev), 1);
+  return dg_check_launch("dg_halo_kernel");
 }
 
 extern "C" int knpemi_dg_sync(knpemi_dg* h) {

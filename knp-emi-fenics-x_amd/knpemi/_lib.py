@@ -161,6 +161,8 @@ SIGNATURES = {
     "knpemi_dg_ode_step": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]),
     "knpemi_dg_ode_get_tables": (C.c_int, [C.c_void_p, c_dbl_p, c_dbl_p]),
     "knpemi_dg_ode_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "knpemi_dg_halo_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "knpemi_dg_halo_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "knpemi_dg_sync": (C.c_int, [C.c_void_p]),
     "knpemi_dg_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_dbl_p]),
     "knpemi_dg_profile": (C.c_int, [C.c_void_p, C.c_int]),

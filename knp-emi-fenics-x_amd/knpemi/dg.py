@@ -61,6 +61,7 @@ class DGProblem:
         h = C.c_void_p()
         L.check(self.lib.knpemi_dg_create(C.byref(desc), int(device), C.byref(h)))
         self.h = h
+        self.device = int(device)
         n, nnz, nq = C.c_int64(), C.c_int64(), C.c_int64()
         L.check(self.lib.knpemi_dg_dims(self.h, C.byref(n), C.byref(nnz), C.byref(nq)))
         assert n.value == self.n and nq.value == self.nmf * self.nf
@@ -220,3 +221,77 @@ class DGProblem:
         ms = C.c_double()
         L.check(self.lib.knpemi_dg_time_kernel(self.h, which, 0 if splitting_scheme else L.NO_SPLITTING, reps, C.byref(ms)))
         return ms.value
+
+
+class DGSlab:
+    """One rank's part of the DG problem on `make_mesh_3D(r, tetrahedron, l)` cut into x-slabs of whole hexahedron
+    layers: its own layers plus ONE ghost layer on each interior side (the cells across the cut facets), generated
+    locally with the global coordinates (`make_mesh_3D_slab`) -- nothing global is ever built.
+
+    Rows of owned cells are complete: their facet neighbours are all local.  Once per step the ghost cells' dofs (K
+    concentrations + potential) are refreshed from the owning neighbour rank (`exchange`: pack kernel -> point-to-point
+    over `torch.distributed` -> unpack kernel, on the handle's stream with RCCL, host-staged with gloo).  Membrane nodes
+    on ghost cells are integrated redundantly from identical inputs (the ODE sweep is deterministic), so phi_M and I_ch
+    need no exchange -- the same arrangement as the CG path (knpemi/fem/distributed.py).
+    """
+
+    def __init__(self, r, l, rank, world, n_ions=3, device=0):
+        from .fem.idealized import make_mesh_3D_slab
+        from .fem.distributed import Halo
+        nx = l * 16 * 2 ** r
+        cuts = [(nx * k) // world for k in range(world + 1)]
+        self.a, self.b = cuts[rank], cuts[rank + 1]                 # owned hexahedron layers [a, b)
+        if self.b - self.a < 1:
+            raise ValueError("fewer hexahedron layers than ranks")
+        lo, hi = max(self.a - 1, 0), min(self.b + 1, nx)
+        mesh, ct, ft = make_mesh_3D_slab(r, "tetrahedron", l, (lo, hi))
+        self.dp = DGProblem(mesh, ct, ft, [0, 1], [1], n_ions=n_ions, device=device)
+        dp = self.dp
+        nxl = hi - lo
+        self.layer = lo + (np.arange(dp.n_cells) // 6) % nxl        # global layer of every local cell (x fastest)
+        self.owned_cells = (self.layer >= self.a) & (self.layer < self.b)
+        self.rank, self.world, self.nx = rank, world, nx
+
+        def dofs_of_layer(g):
+            c = np.flatnonzero(self.layer == g)                     # ascending local id = the same order on both ranks
+            return (c[:, None] * dp.nv + np.arange(dp.nv)[None, :]).ravel().astype(np.int64)
+        plan = {}
+        if rank > 0:
+            plan["low"] = dict(nb=rank - 1, send=dofs_of_layer(self.a), recv=dofs_of_layer(self.a - 1))
+        if rank < world - 1:
+            plan["high"] = dict(nb=rank + 1, send=dofs_of_layer(self.b - 1), recv=dofs_of_layer(self.b))
+        self.plan = plan
+        self._halo = Halo()          # reuses its packed-buffer plan and transport (mode agreed once, at attach)
+        self._d = None
+
+    def attach(self):
+        import torch
+        import torch.distributed as dist
+        h, dp = self._halo, self.dp
+        h.dp, h.L, h.torch, h.dist = dp, L, torch, dist
+        dev = torch.device("cuda", dp.device)
+        h._device = dev
+        import os
+        stream_ordered = os.environ.get("KNPEMI_HALO_SYNC") is None
+        try:
+            h._ext = torch.cuda.ExternalStream(dp.lib.knpemi_dg_stream(dp.h), device=dev)
+        except (RuntimeError, TypeError):
+            h._ext, stream_ordered = None, False
+        if dist.get_backend() == "gloo":
+            h.mode = "gloo host-staged"
+        else:
+            flag = torch.tensor([1 if stream_ordered else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            h.mode = "stream-ordered RCCL" if int(flag.item()) else "host-synchronised RCCL"
+        h._stream_ordered = h.mode == "stream-ordered RCCL"
+        self.mode = h.mode
+        self._d = h._device_plan(self.plan, 5)
+
+    def exchange(self):
+        """Refresh the ghost cells' concentrations and potential from their owners."""
+        d, dp = self._d, self.dp
+        if d is None:
+            return
+        L.check(dp.lib.knpemi_dg_halo_pack(dp.h, d["send_idx"].data_ptr(), d["send_idx"].numel(), d["send_buf"].data_ptr()))
+        self._halo._transfer(d)
+        L.check(dp.lib.knpemi_dg_halo_unpack(dp.h, d["recv_idx"].data_ptr(), d["recv_idx"].numel(), d["recv_buf"].data_ptr()))

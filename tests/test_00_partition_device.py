@@ -21,13 +21,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_ranks(args, world=2, timeout=420):
+def _run_ranks(args, world=2, timeout=420, tool="check_partition_steps.py"):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "check_partition_steps.py")] + args,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", tool)] + args,
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     try:
@@ -69,3 +69,15 @@ def test_two_rank_time_steps_with_distributed_solves(kind, method):
     rcs, outs = _run_ranks(["--kind", kind, "--steps", "4", "--method", method, "--solves"])
     assert rcs == [0, 0], "\n".join(outs)
     assert "PARTITION STEPS OK" in outs[0], outs[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_dg_variant_cell_partition_equals_single_rank_bit_for_bit(world):
+    """The DG(P1)+SIP variant on x-slabs with one ghost-cell layer (knpemi.dg.DGSlab): after three steps (facet-node ODE
+    sweep, both assemblies, update, ghost refresh through knpemi_dg_halo_pack/unpack with the ghosts poisoned before
+    every exchange) the matrix rows, right-hand sides and fields of the owned cells and the potentials, currents and
+    ODE states of the owned membrane nodes equal those of the whole box on one rank, bit for bit."""
+    rcs, outs = _run_ranks(["--steps", "3"], world=world, tool="check_dg_partition.py")
+    assert rcs == [0] * world, "\n".join(outs)
+    assert "DG PARTITION OK" in outs[0], outs[0]

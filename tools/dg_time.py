@@ -11,11 +11,8 @@ for p in ("knp-emi-fenics-x_amd", "examples/idealized_geometries"):
     sys.path.insert(0, os.path.join(ROOT, p))
 
 
-def build(r, l=2):
-    from knpemi.dg import DGProblem
-    from knpemi.fem.idealized import make_mesh_3D
-    mesh, ct, ft = make_mesh_3D(r, "tetrahedron", l=l)
-    dp = DGProblem(mesh, ct, ft, [0, 1], [1])
+def init_fields(dp):
+    """Physical parameters and a smooth initial state (functions of the coordinates: partition-independent)."""
     ions = [dict(name="Na", z=1.0, D=[1.33e-9] * 2), dict(name="K", z=1.0, D=[1.96e-9] * 2), dict(name="Cl", z=-1.0, D=[2.03e-9] * 2)]
     dp.set_params(dict(dt=1e-4, F=96485.0, psi=96485.0 / (8.314 * 300.0), C_M=0.02), ions)
     ins = (dp.cell_sub > 0)[:, None] * np.ones((1, dp.nv), bool)
@@ -24,6 +21,13 @@ def build(r, l=2):
     dp.set_potential(np.where(ins, -0.07, 0.0) + 1e-3 * np.sin(1e6 * dp.X[:, :, 0]))
     dp.set_membrane_potential(np.full((dp.nmf, dp.nf), -0.07))
     return dp
+
+
+def build(r, l=2):
+    from knpemi.dg import DGProblem
+    from knpemi.fem.idealized import make_mesh_3D
+    mesh, ct, ft = make_mesh_3D(r, "tetrahedron", l=l)
+    return init_fields(DGProblem(mesh, ct, ft, [0, 1], [1]))
 
 
 def algorithmic_bytes(dp, which):
