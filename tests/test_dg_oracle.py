@@ -91,3 +91,85 @@ def test_dg_update_and_traces():
     assert np.all(o.cell_sub[ce] == 0) and np.all(o.cell_sub[ci] == 1)
     Xe, _ = o.traces(be.X[:, :, 0])
     assert np.array_equal(Xe, be.XM[:, :, 0])
+
+
+def test_dg_and_cg_restatements_agree_up_to_the_discretisation_error():
+    """The same (not manufactured) problem through both oracles: unit square with an inner cell, smooth positive
+    concentrations that differ across the membrane (non-zero diffusive currents), a smooth phi_M and channel currents.
+    The two discretisations solve the same equations, so their potentials (up to the constant) and their updated
+    concentrations must approach each other at second order under refinement."""
+    import scipy.sparse.linalg as spla
+    import driver
+    import knpemi_oracle as o
+    import knpemi_dg_oracle as dg
+    from knpemi.fem import make_mesh_mms
+    diffs = []
+    for M in (16, 32):
+        mesh, ct, ft = make_mesh_mms(M)
+        cell_sub = ct.dense()
+        sel = ft.values == 1
+        mfac, mtag = mesh.facets[ft.indices[sel]], ft.values[sel]
+        P = o.OracleProblem(mesh.x, mesh.cells, mesh.cell_type, cell_sub, mfac, mtag, {0: [], 1: [1]})
+        D = dg.DGOracle(mesh.x, mesh.cells, mesh.cell_type, cell_sub, mfac, mtag)
+        dt = 0.02
+        params = dict(dt=dt, F=1.0, psi=1.0, C_M=1.0, C_phi=1.0 / dt)
+        zs, Ds = (1.0, -1.0, 1.0), ((1.0, 0.8), (1.3, 1.1), (0.9, 0.7))
+        ions_cg = [dict(name=n, z=z, D={0: d[0], 1: d[1]}) for n, z, d in zip("abc", zs, Ds)]
+        ions_dg = [dict(name=n, z=z, D=list(d)) for n, z, d in zip("abc", zs, Ds)]
+        u = lambda X: np.cos(np.pi * X[0]) * np.cos(2 * np.pi * X[1])
+        conc = lambda X, t: [2.0 + 0.3 * u(X) + 0.5 * t, 3.0 - 0.4 * u(X) + 0.2 * t]
+        pm_f = lambda X: 0.3 + 0.1 * np.cos(2 * np.pi * X[0])
+        phi_f = lambda X, t: 0.2 * np.sin(np.pi * X[0]) * np.cos(np.pi * X[1]) + 0.3 * t
+        # CG fields on the sub-meshes
+        c_all, phi_cg = {}, {}
+        for t in (0, 1):
+            X = P.sub[t]["x"].T
+            c0, c1 = conc(X, t)
+            c_all[t] = [c0, c1, -(zs[0] * c0 + zs[1] * c1) / zs[2]]
+            phi_cg[t] = phi_f(X, t)
+        XQ = P.mem[1]["x"].T
+        phiM = {1: pm_f(XQ)}
+        Ik = [0.2 * np.sin(2 * np.pi * XQ[1]), -0.1 * np.cos(2 * np.pi * XQ[0]), 0.05 + 0 * XQ[0]]
+        mm = {1: [dict(tag=1, I_ch_k={n: Ik[k] for k, n in enumerate("abc")})]}
+        A, _, b = o.assemble_emi(P, params, ions_cg, c_all, phiM, mm)
+        x_cg = driver.solve_singular(A, b)
+        Ak, bk = o.assemble_knp(P, params, ions_cg, c_all, phi_cg, phiM, mm, dt)
+        c_cg = spla.splu(Ak.tocsc()).solve(bk)
+        boff, _ = o.knp_block_offsets(P, 2)
+        # the same fields as broken functions
+        Xd = mesh.x[mesh.cells]                                   # (nc, nv, 2)
+        shape = Xd.shape[:2]
+        tt = np.repeat(cell_sub[:, None], shape[1], axis=1).ravel().astype(float)
+        Xf = Xd.reshape(-1, 2).T
+        c0, c1 = conc(Xf, tt)
+        cd = [c0.reshape(shape), c1.reshape(shape), (-(zs[0] * c0 + zs[1] * c1) / zs[2]).reshape(shape)]
+        XM = mesh.x[mfac]
+        pm_d = pm_f(XM.reshape(-1, 2).T).reshape(len(mfac), 2)
+        XMf = XM.reshape(-1, 2).T
+        Ik_d = [(0.2 * np.sin(2 * np.pi * XMf[1])).reshape(len(mfac), 2), (-0.1 * np.cos(2 * np.pi * XMf[0])).reshape(len(mfac), 2),
+                np.full((len(mfac), 2), 0.05)]
+        Ad, bd = D.assemble_emi(params, ions_dg, cd, pm_d, Ik_d)
+        x_dg = C.solve_pinned(Ad, bd).reshape(shape)
+        Akd, bkd = D.assemble_knp(params, ions_dg, cd, phi_f(Xf, tt).reshape(shape), pm_d, Ik_d)
+        c_dg = [C.solve(Akd[k], bkd[k]).reshape(shape) for k in range(2)]
+        # CG values at the broken dofs: vertex of the cell, on the cell's own sub-mesh
+        def at_dofs(vec_by_sub):
+            out = np.zeros(shape)
+            for t in (0, 1):
+                rows = cell_sub == t
+                out[rows] = vec_by_sub[t][np.searchsorted(P.sub[t]["pv"], mesh.cells[rows])]
+            return out
+        w = D.vol[:, None] / shape[1] * np.ones(shape)
+        xc = at_dofs({t: x_cg[P.off[t]:P.off[t] + P.N[t]] for t in (0, 1)})
+        e_phi = (x_dg - xc) - np.sum(w * (x_dg - xc)) / np.sum(w)
+        d_phi = np.sqrt(np.sum(w * e_phi ** 2)) / np.sqrt(np.sum(w * (xc - np.sum(w * xc) / np.sum(w)) ** 2))
+        d_c = []
+        for k in range(2):
+            ck = at_dofs({t: c_cg[boff[(t, k)]:boff[(t, k)] + P.N[t]] for t in (0, 1)})
+            # compare the step increments: the fields themselves agree trivially to the size of c
+            ref = cd[k]
+            d_c.append(np.sqrt(np.sum(w * (c_dg[k] - ck) ** 2)) / np.sqrt(np.sum(w * (ck - ref) ** 2)))
+        diffs.append([d_phi] + d_c)
+    diffs = np.array(diffs)
+    print("DG vs CG relative differences (phi, c_0 increment, c_1 increment):", diffs)
+    assert np.all(diffs[1] < 0.1) and np.all(diffs[0] / diffs[1] > 2.5), diffs
