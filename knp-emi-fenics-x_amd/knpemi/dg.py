@@ -178,8 +178,10 @@ class DGProblem:
         odeSolver.py:40-55); ion_param[3 k + (0, 1, 2)] = parameter columns of ion k's ECS trace, intracellular trace
         and channel current."""
         nq = self.nmf * self.nf
-        st = np.tile(np.asarray(states_row, np.float64), (nq, 1))
-        pr = np.tile(np.asarray(params_row, np.float64), (nq, 1))
+        full = lambda a: np.ascontiguousarray(a, np.float64) if np.ndim(a) == 2 else np.tile(np.asarray(a, np.float64), (nq, 1))
+        st, pr = full(states_row), full(params_row)      # a full [n_mem_nodes][n] table (e.g. a stimulus written into
+        if st.shape[0] != nq or pr.shape[0] != nq:        # the rows of some nodes) or one row for all nodes
+            raise ValueError("state / parameter tables need one row per membrane node")
         ip = np.ascontiguousarray(ion_param, np.int32)
         self._ode_shape = (st.shape[1], pr.shape[1])
         L.check(self.lib.knpemi_dg_ode_bind(self.h, model_id, st.shape[1], pr.shape[1], L.dptr(st), L.dptr(pr),

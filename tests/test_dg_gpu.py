@@ -80,6 +80,37 @@ def test_dg_assembly_matches_oracle(hip_lib, dim, M, K, splitting):
         assert np.all(np.diff(cols) > 0) and r in cols
 
 
+@pytest.mark.parametrize("dim", [2, 3])
+def test_dg_assembly_matches_oracle_at_physical_scales(hip_lib, dim):
+    """The reference's idealized geometries and SI parameters (micrometre cells, D ~ 1e-9 m^2/s, dt = 0.1 ms,
+    run_2D.py:174-251): determinants of 1e-14 .. 1e-21 and matrix entries spread over many decades must not cost the
+    kernels' closed forms and fast reciprocals any accuracy against the quadrature-based restatement."""
+    from knpemi.dg import DGProblem
+    from knpemi.fem.idealized import make_mesh_2D, make_mesh_3D
+    import knpemi_dg_oracle as dg
+    mesh, ct, ft = make_mesh_2D(1) if dim == 2 else make_mesh_3D(0, "tetrahedron")
+    dp = DGProblem(mesh, ct, ft, [0, 1], [1])
+    o = dg.DGOracle(mesh.x, mesh.cells, mesh.cell_type, dp.cell_sub, dp.mem_facets, dp.mem_tags)
+    ions = [dict(name="Na", z=1.0, D=[1.33e-9] * 2), dict(name="K", z=1.0, D=[1.96e-9] * 2), dict(name="Cl", z=-1.0, D=[2.03e-9] * 2)]
+    params = dict(dt=1e-4, F=96485.0, psi=96485.0 / (8.314 * 300.0), C_M=0.02)
+    ins = (dp.cell_sub > 0)[:, None] * np.ones((1, dp.nv), bool)
+    w = np.sin(2e5 * dp.X[:, :, 0]) * np.cos(2e6 * dp.X[:, :, 1])
+    c_all = [np.where(ins, i, e) * (1.0 + 1e-2 * w * (1 + k)) for k, (e, i) in enumerate(((100.0, 12.0), (4.0, 125.0), (104.0, 137.0)))]
+    phi = np.where(ins, -0.0744, 0.0) + 1e-3 * w
+    rng = np.random.default_rng(7)
+    phi_M = -0.0744 + 1e-3 * rng.standard_normal((dp.nmf, dp.nf))
+    I_ch = [1e-2 * rng.standard_normal((dp.nmf, dp.nf)) for _ in range(3)]
+    _push(dp, params, ions, c_all, phi, phi_M, I_ch)
+    for splitting in (True, False):
+        dp.assemble_emi(splitting)
+        dp.assemble_knp(splitting)
+        A, b = o.assemble_emi(params, ions, c_all, phi_M, I_ch, splitting_scheme=splitting)
+        assert csr_rel_err(dp.matrix(0), A) < TOL and rel_err(dp.rhs(0), b) < TOL
+        As, bs = o.assemble_knp(params, ions, c_all, phi, phi_M, I_ch, splitting_scheme=splitting)
+        for k in range(2):
+            assert csr_rel_err(dp.matrix(1 + k), As[k]) < TOL and rel_err(dp.rhs(1 + k), bs[k]) < TOL, k
+
+
 def test_dg_assembly_without_membrane_and_bit_reproducible(hip_lib):
     dp, o = _problem(3, 6, False)
     ions = C.ions_unit()
@@ -225,3 +256,29 @@ def test_dg_error_paths(hip_lib):
         dp.assemble_emi()
     with pytest.raises(ValueError):
         dp.set_potential(np.zeros(3))
+
+
+def test_dg_time_loop_on_the_device_matches_the_restatement(hip_lib):
+    """BASELINE configs[0] with the DG variant, as examples/idealized_geometries/run_2D_dg.py runs it (facet-node ODE
+    sweep, both assemblies and the update on the GPU, SciPy solves of the device-assembled systems): ten steps against
+    the loop of the CPU restatement (oracle/dg_driver.py, which tests/test_dg_oracle.py ties to the CG loop)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "idealized_geometries"))
+    import run_2D_dg
+    from test_dg_oracle import _dg_2d_run
+    ref, XM, mask = _dg_2d_run()
+    run = run_2D_dg.DGRun(1)
+    assert np.array_equal(run.dp.XM.reshape(-1, 2), XM) and np.array_equal(run.stimulated, mask)
+    for _ in range(10):
+        run.step()
+        ref.step()
+    dp = run.dp
+    assert rel_err(dp.get_membrane_potential(), ref.phiM) < 1e-8
+    st, pr = dp.ode_tables()
+    assert rel_err(st, ref.states) < 1e-8
+    p_dev, p_ref = dp.get_potential(), ref.phi
+    assert rel_err(p_dev - p_dev.mean(), p_ref - p_ref.mean()) < 1e-8
+    for k in range(3):
+        assert rel_err(dp.get_concentration(k), ref.c_all[k]) < 1e-10
+    v = dp.get_membrane_potential()
+    assert v.mean() > -0.0744 + 0.010

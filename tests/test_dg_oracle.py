@@ -173,3 +173,68 @@ def test_dg_and_cg_restatements_agree_up_to_the_discretisation_error():
     diffs = np.array(diffs)
     print("DG vs CG relative differences (phi, c_0 increment, c_1 increment):", diffs)
     assert np.all(diffs[1] < 0.1) and np.all(diffs[0] / diffs[1] > 2.5), diffs
+
+
+def _dg_2d_run(r=1, g_syn=10.0):
+    """BASELINE configs[0] on the DG restatement: 2D idealized mesh, K / Cl / Na with the reference's initial
+    concentrations (run_2D.py:190-251), HH on the membrane facets' nodes, synaptic stimulus on x < 20 um."""
+    import dg_driver
+    import knpemi_oracle as o
+    import knpemi_dg_oracle as dg
+    import setup_problem as sp_
+    from knpemi.fem.idealized import make_mesh_2D
+    mesh, ct, ft = make_mesh_2D(r)
+    sel = ft.values == 1
+    mfac = mesh.facets[ft.indices[sel]]
+    D = dg.DGOracle(mesh.x, mesh.cells, mesh.cell_type, ct.dense(), mfac, ft.values[sel])
+    ions = [dict(name="K", z=1.0, D=[sp_.D_K] * 2), dict(name="Cl", z=-1.0, D=[sp_.D_CL] * 2), dict(name="Na", z=1.0, D=[sp_.D_NA] * 2)]
+    params = dict(dt=sp_.DT, F=sp_.FARADAY, psi=sp_.PSI, C_M=sp_.C_M)
+    ins = (D.cell_sub > 0)[:, None] * np.ones((1, D.nv), bool)
+    c_all = [np.where(ins, i, e) for e, i in ((sp_.K_E, sp_.K_I), (sp_.CL_E, sp_.CL_I), (sp_.NA_E, sp_.NA_I))]
+    m = o.MODELS["hh_si"]
+    ix = m["pidx"]
+    prow = np.array(m["params"], float)
+    prow[ix["Cm"]] = sp_.C_M
+    prow[ix["z_Na"]], prow[ix["z_K"]], prow[ix["z_Cl"]], prow[ix["psi"]] = 1.0, 1.0, -1.0, sp_.PSI
+    nq = D.nmf * D.nf
+    XM = mesh.x[mfac].reshape(nq, 2)
+    mask = XM[:, 0] < 20e-6
+    run = dg_driver.DGOracleRun(D, params, ions, "hh_si", c_all, np.tile(np.array(m["states"]), (nq, 1)), np.tile(prow, (nq, 1)),
+                                mask, {ix["stim_amplitude"]: g_syn})
+    return run, XM, mask
+
+
+def test_dg_time_loop_follows_the_cg_time_loop():
+    """Ten time steps of BASELINE configs[0] with the DG restatement against the CG oracle loop (oracle/driver.py, the
+    path that is parity-tested against the GPU): the stimulated cell depolarises by the same amount -- the two
+    discretisations of one model differ by their (second-order) errors only, everything else (ODE coupling at the facet
+    nodes, splitting scheme, update, units) has to be the same."""
+    import driver
+    from helpers import Setup
+    import contextlib, io
+    run, XM, mask = _dg_2d_run()
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = Setup("2d", 1, g_syn=10.0, build_forms=False)
+    o, P, params, ions = s.oracle()
+    c_all, _, _, _ = s.oracle_fields()
+    ode = s.mem_models[0]['ode']
+    cmask = np.array([x[0] < 20e-6 for x in ode.dof_locations])
+    cg = driver.OracleRun(P, params, ions, "hh_si", c_all, ode.states.copy(), ode.parameters.copy(), ode.dof_locations, cmask,
+                          {o.MODELS["hh_si"]["pidx"]["stim_amplitude"]: 10.0}, {'z': -1, 0: 0.0, 1: 0.0})
+    for _ in range(10):
+        run.step()
+        cg.step()
+    v_dg, v_cg = run.phiM.ravel(), cg.phiM[1]
+    rest = -0.07438609374462003
+    dep_dg, dep_cg = v_dg.mean() - rest, v_cg.mean() - rest
+    print("depolarisation after 10 steps: DG", dep_dg, "CG", dep_cg)
+    assert dep_cg > 0.010 and abs(dep_dg - dep_cg) < 0.03 * dep_cg
+    # pointwise: every DG membrane node against the CG membrane dof at the same point
+    key = lambda X: tuple(np.round(np.asarray(X)[:2] * 1e12).astype(np.int64))
+    at = {key(x): v for x, v in zip(ode.dof_locations, v_cg)}
+    ref = np.array([at[key(x)] for x in XM])
+    assert np.abs(v_dg - ref).max() < 0.05 * dep_cg, np.abs(v_dg - ref).max()
+    # the concentrations moved the same way (ECS potassium next to the stimulated membrane rises in both)
+    ke_dg, _ = run.D.traces(run.c_all[0])
+    ke_cg, _ = P.trace(1, cg.c_all[0][0], cg.c_all[1][0])
+    assert abs((ke_dg.mean() - ke_cg.mean()) / (ke_cg.mean() - c_all[0][0].mean() + 1e-300)) < 0.2 or abs(ke_dg.mean() - ke_cg.mean()) < 1e-6
