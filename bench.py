@@ -572,9 +572,10 @@ def main():
     rows = {k: v for k, v in per_kernel.items() if k in ("emi_rows_kernel", "knp_rows_kernel")}
     dominant = max(rows, key=rows.get) if rows else "emi_rows_kernel"
     dom_id = L.KERNEL_NAMES.index(dominant)
-    mem_id = L.KERNEL_NAMES.index("knp_membrane_kernel")
-    # timed region: only the dominant row kernel and the membrane-facet kernel stay bracketed by HIP events
-    L.check(lib.knpemi_profile(dp.h, (1 << dom_id) | (1 << mem_id)))
+    # timed region: only the dominant row kernel stays bracketed by HIP events (it runs on the side stream).  The
+    # membrane-facet kernel sits on the critical path, where an event pair costs the step ~10 us: its duration for
+    # `roofline_membrane_facet_kernel` is the one of the profiling pass above.
+    L.check(lib.knpemi_profile(dp.h, 1 << dom_id))
     ode_stats()                                 # reset the counters
     sync()
     t0 = time.perf_counter()
@@ -587,8 +588,7 @@ def main():
     n, ms = C.c_int64(), C.c_double()
     L.check(lib.knpemi_profile_read(dp.h, dom_id, C.byref(n), C.byref(ms)))
     dom_us = ms.value / max(n.value, 1) * 1e3
-    L.check(lib.knpemi_profile_read(dp.h, mem_id, C.byref(n), C.byref(ms)))
-    mem_us = ms.value / max(n.value, 1) * 1e3
+    mem_us = per_kernel.get("knp_membrane_kernel", 0.0)
     L.check(lib.knpemi_profile(dp.h, 0))
     if n_failed:
         raise SystemExit("LSODA failed on the device")
@@ -656,7 +656,7 @@ def main():
                                  f"writes it"),
                        "partition": "x-slabs" if world > 1 else "none"},
             "roofline": roof(dominant, dom_us),
-            "roofline_membrane_facet_kernel": roof("knp_membrane_kernel", mem_us),
+            "roofline_membrane_facet_kernel": roof("knp_membrane_kernel", mem_us) if mem_us > 0 else None,
             "kernels_us_per_step": per_kernel,
             "ode": {"rhs_evals_per_dof_per_step": n_rhs / max(1, n_ode_dofs) / args.steps,
                     "lsoda_steps_per_dof_per_step": n_lsoda_steps / max(1, n_ode_dofs) / args.steps,
