@@ -282,6 +282,30 @@ int knpemi_set_distributed(knpemi_handle* h, const uint8_t* owned, void* reduce_
 int knpemi_vec_gather(knpemi_handle* h, const void* vec_dev, const int32_t* idx_dev, int n, void* buf_dev);
 int knpemi_vec_scatter(knpemi_handle* h, void* vec_dev, const int32_t* idx_dev, int n, const void* buf_dev);
 
+/* ---- RCCL transport inside the library (the reference: MPI inside DOLFINx / PETSc, Function.x.scatter_forward() and the
+ * parallel KSP of pdeSolver.py:24-35) ----------------------------------------------------------------------------------
+ * One process per GPU.  Rank 0 obtains a unique id (128 bytes), the caller distributes it over whatever rendezvous it
+ * has, every rank calls knpemi_comm_init (collective).  knpemi_comm_sendrecv posts, in ONE RCCL group on the handle's
+ * stream, for every part p: send_buf[send_off[p], +send_cnt[p]) -> peer[p] and recv_buf[recv_off[p], +recv_cnt[p]) <-
+ * peer[p] (device buffers, counts in doubles): with knpemi_halo_pack before and knpemi_halo_unpack after it this is the
+ * forward halo of a step, stream-ordered, no host synchronisation, no Python.  knpemi_comm_allreduce sums n doubles of a
+ * device buffer over the ranks.  knpemi_comm_allreduce_hook / knpemi_comm_halo_hook have the signatures of
+ * knpemi_allreduce_fn / knpemi_halo_fn and take the handle as ctx: passed to knpemi_set_distributed (after
+ * knpemi_comm_set_vector_plan for both systems) they keep the distributed Krylov solves inside the library.
+ * RCCL is resolved at run time (the copy already loaded in the process, else /opt/rocm/lib/librccl.so). */
+int knpemi_comm_unique_id(char* out, size_t len);
+int knpemi_comm_init(knpemi_handle* h, int rank, int world, const char* id_bytes, size_t len);
+int knpemi_comm_sendrecv(knpemi_handle* h, const double* send_buf_dev, double* recv_buf_dev, int n_parts,
+                         const int32_t* peer, const int64_t* send_off, const int64_t* send_cnt, const int64_t* recv_off,
+                         const int64_t* recv_cnt);
+int knpemi_comm_allreduce(knpemi_handle* h, double* buf_dev, int n);
+int knpemi_comm_set_vector_plan(knpemi_handle* h, int which, const int32_t* send_idx_dev, int n_send,
+                                const int32_t* recv_idx_dev, int n_recv, double* send_buf_dev, double* recv_buf_dev,
+                                int n_parts, const int32_t* peer, const int64_t* send_off, const int64_t* send_cnt,
+                                const int64_t* recv_off, const int64_t* recv_cnt);
+int knpemi_comm_allreduce_hook(void* ctx, int n);
+int knpemi_comm_halo_hook(void* ctx, void* vec_dev, int which);
+
 /* Per-kernel HIP-event profiling on the handle's stream: every launch of a kernel whose bit is set
  * in `kernel_mask` is bracketed by an event pair; knpemi_profile_read() synchronises, returns the
  * number of bracketed launches and their summed duration, and resets the accumulator. */

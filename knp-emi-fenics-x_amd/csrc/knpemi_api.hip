@@ -628,6 +628,7 @@ extern "C" void knpemi_destroy(knpemi_handle* h) {
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->aux) (void)hipStreamDestroy(h->aux);
+  kn_comm_destroy(h);
   kn_amg_free(h->amg_emi);
   kn_amg_free(h->amg_knp);
   if (h->graph_emi.exec) (void)hipGraphExecDestroy(h->graph_emi.exec);

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstring>
 #include <memory>
 #include <string>
 #include <vector>
@@ -157,6 +158,16 @@ struct KnDist {
   double n_owned_global = 0.0;                     // owned EMI unknowns summed over the ranks
 };
 
+// ghost refresh of a solver vector without Python (comm_rccl.hip)
+struct KnVecPlan {
+  bool set = false;
+  const int32_t* send_idx = nullptr; const int32_t* recv_idx = nullptr;
+  int n_send = 0, n_recv = 0;
+  double* send_buf = nullptr; double* recv_buf = nullptr;
+  std::vector<int32_t> peer;
+  std::vector<int64_t> send_off, send_cnt, recv_off, recv_cnt;
+};
+
 struct knpemi_handle {
   int device = 0;
   hipStream_t stream = nullptr;          // main stream
@@ -183,6 +194,9 @@ struct knpemi_handle {
   std::vector<KnOdeModel> ode; // [moff[n_sub]]
   // host copies of patterns for export
   std::vector<int> h_rowptr, h_colind, h_rowptrL, h_colindL;
+  void* comm = nullptr;                              // RCCL communicator (comm_rccl.hip), NULL until knpemi_comm_init
+  int comm_rank = 0, comm_world = 1;
+  KnVecPlan vec_plan[2];                             // [KNPEMI_B_EMI], [KNPEMI_B_KNP]
   double* d_stage = nullptr; size_t stage_len = 0;   // staging buffer for strided field I/O
   double* kry = nullptr; size_t kry_n = 0;           // Krylov workspace (kernels_krylov.hip)
   int kry_ones_masked = 0;                           // the workspace's `ones` vector currently holds the ownership mask
@@ -238,6 +252,7 @@ struct OdeDev;
 struct OdeArgs;
 int kn_launch_ode_raw(hipStream_t st, int model_id, const OdeDev& dv, const OdeArgs& a, const void* coef);   // kernels_ode.hip
 int kn_lsoda_coef_upload(void** out);
+void kn_comm_destroy(knpemi_handle* h);   // comm_rccl.hip
 int kn_gamma_quadrature(int NF, std::vector<double>* out);   // degree-6 membrane-facet rule (knpemi_api.hip)
 
 // kernel launchers (kernels_*.hip) ------------------------------------------------------------

@@ -136,6 +136,16 @@ SIGNATURES = {
     "knpemi_set_distributed": (C.c_int, [C.c_void_p, c_u8_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "knpemi_vec_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "knpemi_vec_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "knpemi_comm_unique_id": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "knpemi_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "knpemi_comm_sendrecv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_int_p, C.POINTER(C.c_int64),
+                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "knpemi_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "knpemi_comm_set_vector_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                              C.c_void_p, C.c_int, c_int_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                              C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "knpemi_comm_allreduce_hook": (C.c_int, [C.c_void_p, C.c_int]),
+    "knpemi_comm_halo_hook": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "knpemi_profile": (C.c_int, [C.c_void_p, C.c_uint32]),
     "knpemi_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), c_dbl_p]),
     "knpemi_timer_start": (C.c_int, [C.c_void_p]),

@@ -145,16 +145,47 @@ class Halo:
             self._ext = torch.cuda.ExternalStream(dp.lib.knpemi_stream(dp.h), device=dev)
         except (RuntimeError, TypeError):
             self._ext, stream_ordered = None, False
+        self._native = False
         if dist.get_backend() == "gloo":
             self.mode = "gloo host-staged"
         else:
-            flag = torch.tensor([1 if stream_ordered else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            self.mode = "stream-ordered RCCL" if int(flag.item()) else "host-synchronised RCCL"
+            # first choice: RCCL called by the library itself (knpemi_comm_*: pack -> ncclSend/ncclRecv group -> unpack
+            # on the library's stream, a few microseconds of host time per exchange instead of ~50 through
+            # torch.distributed's Python layer).  All ranks must agree, so every step of the set-up is voted on.
+            native = os.environ.get("KNPEMI_HALO_TORCH") is None and stream_ordered is not None
+            if native:
+                native = self._native_comm_init(dp, dev)
+            if native:
+                self.mode = "library RCCL (knpemi_comm_sendrecv)"
+                self._native = True
+            else:
+                flag = torch.tensor([1 if stream_ordered else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                self.mode = "stream-ordered RCCL" if int(flag.item()) else "host-synchronised RCCL"
         self._stream_ordered = self.mode == "stream-ordered RCCL"
         self._dev = {}
         for kind in ("bulk", "mem"):
             self._dev[kind] = self._device_plan(self.plans[kind], self.width[kind])
+
+    def _vote(self, ok, dev):
+        flag = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=dev)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
+
+    def _native_comm_init(self, dp, dev):
+        """Create the library's own RCCL communicator: rank 0 draws the unique id, torch.distributed carries it."""
+        dist, L = self.dist, self.L
+        rank, world = dist.get_rank(), dist.get_world_size()
+        buf = C.create_string_buffer(128)
+        ok = True
+        if rank == 0:
+            ok = dp.lib.knpemi_comm_unique_id(buf, 128) == 0
+        box = [buf.raw if ok else None]
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            return False
+        rc = dp.lib.knpemi_comm_init(dp.h, rank, world, box[0], 128)
+        return self._vote(rc == 0, dev)
 
     def _device_plan(self, plan, w, index_map=None):
         """One packed buffer per direction: all neighbours' entries are packed / unpacked by a single kernel launch,
@@ -175,12 +206,24 @@ class Halo:
             ns, nr = len(pl["send"]) * w * m, len(pl["recv"]) * w * m
             d["parts"].append((pl["nb"], slice(so, so + ns), slice(ro, ro + nr)))
             so, ro = so + ns, ro + nr
+        # the same parts as flat arrays for knpemi_comm_sendrecv
+        d["peer"] = np.array([p[0] for p in d["parts"]], np.int32)
+        for key, idx, attr in (("send_off", 1, "start"), ("recv_off", 2, "start")):
+            d[key] = np.array([getattr(p[idx], attr) for p in d["parts"]], np.int64)
+        d["send_cnt"] = np.array([p[1].stop - p[1].start for p in d["parts"]], np.int64)
+        d["recv_cnt"] = np.array([p[2].stop - p[2].start for p in d["parts"]], np.int64)
         return d
 
     def _transfer(self, d):
         """send_buf -> neighbours -> recv_buf, ordered on the library's stream (see `mode`)."""
         dp, dist, torch = self.dp, self.dist, self.torch
-        if dist.get_backend() != "gloo":
+        if getattr(self, "_native", False):
+            i64 = C.POINTER(C.c_int64)
+            self.L.check(dp.lib.knpemi_comm_sendrecv(
+                dp.h, d["send_buf"].data_ptr(), d["recv_buf"].data_ptr(), len(d["peer"]), self.L.iptr(d["peer"]),
+                d["send_off"].ctypes.data_as(i64), d["send_cnt"].ctypes.data_as(i64),
+                d["recv_off"].ctypes.data_as(i64), d["recv_cnt"].ctypes.data_as(i64)))
+        elif dist.get_backend() != "gloo":
             ops = []
             for nb, ss, rs in d["parts"]:
                 ops += [dist.P2POp(dist.isend, d["send_buf"][ss], nb), dist.P2POp(dist.irecv, d["recv_buf"][rs], nb)]
@@ -267,10 +310,31 @@ class Halo:
             except Exception as exc:       # noqa: BLE001
                 self._hook_error = exc
                 return -1
-        self._cb = (L.ALLREDUCE_FN(allreduce), L.HALO_FN(halo))    # keep the callbacks alive
         own = np.ascontiguousarray(self.owned_mask())
-        L.check(dp.lib.knpemi_set_distributed(dp.h, own.ctypes.data_as(L.c_u8_p), self._red.data_ptr(),
-                                              C.cast(self._cb[0], C.c_void_p), C.cast(self._cb[1], C.c_void_p), None))
+        if getattr(self, "_native", False):
+            # the solves stay inside the library: its own all-reduce and vector halo are the hooks, the handle the context
+            i64 = C.POINTER(C.c_int64)
+            for which, d in self._vec.items():
+                if d is None:
+                    d = dict(send_idx=torch.zeros(0, dtype=torch.int32, device=self._device),
+                             recv_idx=torch.zeros(0, dtype=torch.int32, device=self._device),
+                             send_buf=torch.zeros(1, dtype=torch.float64, device=self._device),
+                             recv_buf=torch.zeros(1, dtype=torch.float64, device=self._device),
+                             peer=np.zeros(0, np.int32), send_off=np.zeros(0, np.int64), send_cnt=np.zeros(0, np.int64),
+                             recv_off=np.zeros(0, np.int64), recv_cnt=np.zeros(0, np.int64))
+                    self._vec[which] = d
+                L.check(dp.lib.knpemi_comm_set_vector_plan(
+                    dp.h, which, d["send_idx"].data_ptr(), d["send_idx"].numel(), d["recv_idx"].data_ptr(),
+                    d["recv_idx"].numel(), d["send_buf"].data_ptr(), d["recv_buf"].data_ptr(), len(d["peer"]),
+                    L.iptr(d["peer"]), d["send_off"].ctypes.data_as(i64), d["send_cnt"].ctypes.data_as(i64),
+                    d["recv_off"].ctypes.data_as(i64), d["recv_cnt"].ctypes.data_as(i64)))
+            hooks = (C.cast(dp.lib.knpemi_comm_allreduce_hook, C.c_void_p), C.cast(dp.lib.knpemi_comm_halo_hook, C.c_void_p))
+            L.check(dp.lib.knpemi_set_distributed(dp.h, own.ctypes.data_as(L.c_u8_p), self._red.data_ptr(),
+                                                  hooks[0], hooks[1], dp.h))
+        else:
+            self._cb = (L.ALLREDUCE_FN(allreduce), L.HALO_FN(halo))    # keep the callbacks alive
+            L.check(dp.lib.knpemi_set_distributed(dp.h, own.ctypes.data_as(L.c_u8_p), self._red.data_ptr(),
+                                                  C.cast(self._cb[0], C.c_void_p), C.cast(self._cb[1], C.c_void_p), None))
         self.supports_solves = True
 
     def _device_plan_knp(self, knp_index):

@@ -81,3 +81,18 @@ def test_dg_variant_cell_partition_equals_single_rank_bit_for_bit(world):
     rcs, outs = _run_ranks(["--steps", "3"], world=world, tool="check_dg_partition.py")
     assert rcs == [0] * world, "\n".join(outs)
     assert "DG PARTITION OK" in outs[0], outs[0]
+
+
+@pytest.mark.gpu
+def test_rccl_halo_transport_rehearsal_on_one_gpu():
+    """Real RCCL on one GPU (a world-size-1 group sending the packed halo to itself, tools/check_async_halo.py): the
+    stream-ordered exchange through torch.distributed and the library's own transport (knpemi_comm_init / _sendrecv /
+    _allreduce) deliver the packed halo without any host synchronisation, over 300 + 5 exchanges; the Krylov solves run
+    through the library's own hooks (knpemi_comm_allreduce_hook / knpemi_comm_halo_hook) and solve the same systems."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_async_halo.py")], env=env, capture_output=True,
+                       text=True, timeout=420)
+    out = p.stdout + p.stderr
+    assert p.returncode == 0 and "ALL OK" in out, out[-3000:]
+    assert out.count("library RCCL exchange") == 5 and "correct: False" not in out, out[-3000:]
+    assert "distributed solves through the library's hooks" in out and "WRONG" not in out, out[-3000:]
