@@ -140,6 +140,17 @@ int knpemi_get_field(knpemi_handle* h, int field, int sub, int idx, double* host
 int knpemi_assemble_emi(knpemi_handle* h, int flags);
 int knpemi_assemble_knp(knpemi_handle* h, int flags);
 int knpemi_assemble_emi_membrane_rhs(knpemi_handle* h, int flags);
+/* The membrane-facet integrals of b_knp (knpWeakForm.py:168-214) in two parts.  Everything of the integrand that does
+ * not depend on the potential -- the rational factors alpha_k, C_k g_k with phi_M and I_ch from the ODE step -- is
+ * integrated by knpemi_assemble_knp_membrane_early(flags [| KNPEMI_ON_AUX_STREAM]) as soon as the ODE sweep has
+ * finished, i.e. BESIDE the EMI solve; knpemi_assemble_knp(flags | KNPEMI_MEMBRANE_EARLY) then only applies the small
+ * facet matrices to the jump of the potential just solved for.  Same integrals as the one-part form (1e-15 apart:
+ * another summation order), one kernel less between the two solves.  Measured on MI355X it does not pay at the
+ * BASELINE sizes: the membrane rows of the KNP row kernel get longer (facet -> vertex -> record loads per entry) by more
+ * than the facet kernel's 13-19 us (config 2: 0.187 -> 0.193 ms per step; 995 k tets: 0.262 -> 0.275), so the
+ * stepper keeps the one-part form by default. */
+#define KNPEMI_MEMBRANE_EARLY 16
+int knpemi_assemble_knp_membrane_early(knpemi_handle* h, int flags);
 int knpemi_join(knpemi_handle* h);
 
 /* CSR access.  A_EMI/P_EMI: square, unknown order [phi_0, phi_1, ...] (pdeSolver.py:42).

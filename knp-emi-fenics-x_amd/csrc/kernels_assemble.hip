@@ -169,6 +169,26 @@ template <int NF, int KS>
 __device__ __forceinline__ void membrane_entries_to_lds(const KnDev& D, const KnConsts& C, int e0, int ne, bool cell_side,
                                                         int splitting, int tid, double* gam);
 
+// Early membrane integrals (knp_membrane_pre_kernel): b_knp contribution of membrane entry e from the potential that
+// now sits in the vertex records.
+template <int NF, int KS>
+__device__ __forceinline__ void membrane_entry_early(const KnDev& D, int e, double (&bk)[KS]) {
+  constexpr int GS = (1 + NF) * KS;
+  const double* g = D.gpre + (size_t)GS * e;
+  const int fg = D.mentry[e] >> 3;
+  double jump[NF];
+#pragma unroll
+  for (int b = 0; b < NF; ++b)
+    jump[b] = D.VR[(size_t)D.fi[(size_t)fg * NF + b] * KN_REC + 7] - D.VR[(size_t)D.fe[(size_t)fg * NF + b] * KN_REC + 7];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    double v = g[k];
+#pragma unroll
+    for (int b = 0; b < NF; ++b) v -= g[(1 + b) * KS + k] * jump[b];
+    bk[k] += v;
+  }
+}
+
 // staged record of a KNP row block: coordinates, f_k = c_prev_k / dt (+ f_source_k) of the KS solved ions, phi
 template <int KS>
 struct RecK {
@@ -403,7 +423,7 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
 
 template <int GDIM, int LPR, int KS>
 __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n, int rec_n,
-                                                        int gam_n, int splitting) {
+                                                        int gam_n, int splitting, int pre) {
   constexpr int NV = GDIM + 1;
   const KnConsts& C = *Cp;
   extern __shared__ __align__(16) double lds[];
@@ -489,8 +509,11 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
     if (sub == 0) {
       const int ne = (unsigned)ri.y >> 16;
       for (int e = ri.w; e < ri.w + ne; ++e) {
+        if (pre) membrane_entry_early<GDIM, KS>(D, e, bk);
+        else {
 #pragma unroll
-        for (int k = 0; k < KS; ++k) bk[k] += gam_n > 0 ? gam[(size_t)(e - B.me0) * KS + k] : D.gam_e[(size_t)KS * e + k];
+          for (int k = 0; k < KS; ++k) bk[k] += gam_n > 0 ? gam[(size_t)(e - B.me0) * KS + k] : D.gam_e[(size_t)KS * e + k];
+        }
       }
     }
   }
@@ -800,7 +823,7 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
 
 template <int LPR, bool AFFINE, int KS>
 __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n, int rec_n,
-                                                                            int gam_n, int splitting) {
+                                                                            int gam_n, int splitting, int pre) {
   const KnConsts& C = *Cp;
   extern __shared__ __align__(16) double lds[];
   double* acc = lds;
@@ -867,8 +890,11 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDe
     if (sub == 0) {
       const int ne = (unsigned)ri.y >> 16;
       for (int e = ri.w; e < ri.w + ne; ++e) {
+        if (pre) membrane_entry_early<4, KS>(D, e, bk);
+        else {
 #pragma unroll
-        for (int k = 0; k < KS; ++k) bk[k] += gam_n > 0 ? gam[(size_t)(e - B.me0) * KS + k] : D.gam_e[(size_t)KS * e + k];
+          for (int k = 0; k < KS; ++k) bk[k] += gam_n > 0 ? gam[(size_t)(e - B.me0) * KS + k] : D.gam_e[(size_t)KS * e + k];
+        }
       }
     }
   }
@@ -987,6 +1013,54 @@ __device__ __forceinline__ void facet_point(const FacetData<NF>& f, const KnCons
   }
 }
 
+// The same point for the early form: cw[k] = w sgn C_k (the factor of -[phi]) and pg[k] = w sgn C_k g_k.
+template <int NF>
+__device__ __forceinline__ void facet_point_split(const FacetData<NF>& f, const KnConsts& C, int q, const double* qw,
+                                                  const double* qN, const double* qdN, int splitting,
+                                                  double (&cw)[KN_MAXK - 1], double (&pg)[KN_MAXK - 1]) {
+  const int KS = C.K - 1;
+  double cq[KN_MAXK], iq[KN_MAXK], pmq = 0, it = 0;
+#pragma unroll
+  for (int k = 0; k < KN_MAXK; ++k) { cq[k] = 0.0; iq[k] = 0.0; }
+#pragma unroll
+  for (int bb = 0; bb < NF; ++bb) {
+    const double N = qN[q * NF + bb];
+    const Rec& o = f.cell_side ? f.pi[bb] : f.pe[bb];
+#pragma unroll
+    for (int k = 0; k < KN_MAXK; ++k) { cq[k] += N * o.c[k]; iq[k] += N * f.Ik[bb][k]; }
+    pmq += N * f.pm[bb]; it += N * f.It[bb];
+  }
+  double wq;
+  if constexpr (NF == 4) {
+    double ux = 0, uy = 0, uz = 0, vx = 0, vy = 0, vz = 0;
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      const double da = qdN[(q * 4 + bb) * 2], db = qdN[(q * 4 + bb) * 2 + 1];
+      ux += da * f.pe[bb].x; uy += da * f.pe[bb].y; uz += da * f.pe[bb].z;
+      vx += db * f.pe[bb].x; vy += db * f.pe[bb].y; vz += db * f.pe[bb].z;
+    }
+    const double nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+    wq = qw[q] * sqrt(nx * nx + ny * ny + nz * nz);
+  } else {
+    wq = qw[q] * f.meas * (NF == 2 ? 1.0 : 2.0);
+  }
+  double asum = 0.0;
+#pragma unroll
+  for (int k = 0; k < KN_MAXK; ++k) asum += f.so->az2D[k] * cq[k];
+#pragma unroll
+  for (int k = 0; k < KN_MAXK - 1; ++k) {
+    cw[k] = 0.0; pg[k] = 0.0;
+    if (k < KS) {
+      const double al = f.so->az2D[k] * cq[k] / asum;
+      const double Cc = al * C.C_M / (C.F * C.z[k] * C.dt);
+      double gr = pmq - C.dt / (C.C_M * al) * iq[k];
+      if (splitting) gr += (C.dt / C.C_M) * it;
+      cw[k] = wq * f.sgn * Cc;
+      pg[k] = cw[k] * gr;
+    }
+  }
+}
+
 // Stand-alone form (diagnostics, KNPEMI_OPT_FUSE_MEMBRANE = 0): one thread per (facet, side) tests the integrand
 // against all NF facet functions and writes NF x (K - 1) partial integrals to gam_e.
 template <int NF>
@@ -1033,6 +1107,74 @@ __global__ __launch_bounds__(256) void knp_membrane_kernel(KnDev D, const KnCons
 #pragma unroll
     for (int k = 0; k < KN_MAXK - 1; ++k)
       if (k < KS) D.gam_e[(size_t)KS * pos[a] + k] = acc[a][k];
+}
+
+// Early form (KNPEMI_MEMBRANE_EARLY): everything of the integrand that does not depend on the potential is integrated
+// BEFORE the EMI solve, beside it on the auxiliary stream.  With  [phi](q) = sum_b N_b(q) [phi]_b  the integrand
+//   w sgn (C_k g_k - C_k [phi])  tested with N_a  splits into
+//   P[a][k] = sum_q N_a w sgn C_k g_k      and      W[a][b][k] = sum_q N_a N_b w sgn C_k,
+// so that the KNP row kernel only has to form  P[a][k] - sum_b W[a][b][k] [phi]_b  from the potential just solved for:
+// the degree-6 quadrature leaves the chain  EMI solve -> KNP assembly.  (1 + NF) (K - 1) doubles per entry in gpre.
+template <int NF>
+__global__ __launch_bounds__(256) void knp_membrane_pre_kernel(KnDev D, const KnConsts* __restrict__ Cp, int splitting) {
+  const KnConsts& C = *Cp;
+  extern __shared__ double qt[];
+  const int nq = D.nq_gamma;
+  const int ntab = nq * (1 + NF + (NF == 4 ? 2 * NF : 0));
+  for (int i = threadIdx.x; i < ntab; i += blockDim.x) qt[i] = D.qtab[i];
+  __syncthreads();
+  const double* qw = qt;
+  const double* qN = qt + nq;
+  const double* qdN = qt + nq * (1 + NF);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * D.nftot) return;
+  const int KS = C.K - 1, GS = (1 + NF) * KS;
+  const int fg = t >> 1;
+  const bool cell_side = t & 1;
+  const int ms = D.fmodel[fg];
+  const int* pos = D.gam_pos + (size_t)t * NF;
+  if (ms < 0) {
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+      for (int j = 0; j < GS; ++j) D.gpre[(size_t)GS * pos[a] + j] = 0.0;
+    return;
+  }
+  FacetData<NF> f;
+  load_facet<NF>(D, C, fg, cell_side, ms, f);
+  double P[NF][KN_MAXK - 1], W[NF][NF][KN_MAXK - 1];
+#pragma unroll
+  for (int a = 0; a < NF; ++a)
+#pragma unroll
+    for (int k = 0; k < KN_MAXK - 1; ++k) {
+      P[a][k] = 0.0;
+#pragma unroll
+      for (int b = 0; b < NF; ++b) W[a][b][k] = 0.0;
+    }
+  for (int q = 0; q < nq; ++q) {
+    double cw[KN_MAXK - 1], pg[KN_MAXK - 1];
+    facet_point_split<NF>(f, C, q, qw, qN, qdN, splitting, cw, pg);
+#pragma unroll
+    for (int a = 0; a < NF; ++a) {
+      const double Na = qN[q * NF + a];
+#pragma unroll
+      for (int k = 0; k < KN_MAXK - 1; ++k) {
+        P[a][k] += Na * pg[k];
+#pragma unroll
+        for (int b = 0; b < NF; ++b) W[a][b][k] += Na * qN[q * NF + b] * cw[k];
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NF; ++a) {
+    double* g = D.gpre + (size_t)GS * pos[a];
+#pragma unroll
+    for (int k = 0; k < KN_MAXK - 1; ++k)
+      if (k < KS) {
+        g[k] = P[a][k];
+#pragma unroll
+        for (int b = 0; b < NF; ++b) g[(1 + b) * KS + k] = W[a][b][k];
+      }
+  }
 }
 
 // Fused form: the KNP row kernels call this before their barrier.  The membrane entries (row, facet, local vertex a)
@@ -1242,7 +1384,7 @@ static int launch_emi_v2(knpemi_handle* h, int want_p, int split) {
 }
 
 template <int GDIM>
-static int launch_knp_v2(knpemi_handle* h, int split) {
+static int launch_knp_v2(knpemi_handle* h, int split, int pre) {
   const KnDev& D = h->dev;
   const int acc_n = (h->lds_doubles_knp + 1) & ~1, rec_n = h->lds_uniq_max;
   const int KS = h->K - 1;
@@ -1256,7 +1398,7 @@ static int launch_knp_v2(knpemi_handle* h, int split) {
   if (h->lpr == L && KS == S) {                                                                     \
     if ((rc = set_lds_limit(knp_rows_v2<GDIM, L, S>, lds))) return rc;                              \
     KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                         \
-    hipLaunchKernelGGL((knp_rows_v2<GDIM, L, S>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n, gam_n, split); \
+    hipLaunchKernelGGL((knp_rows_v2<GDIM, L, S>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n, gam_n, split, pre); \
     return check_launch("knp_rows_v2");                                                             \
   }
   // lanes per row: 2 (triangles) or 4 by default, KNPEMI_LPR for experiments; K - 1 = 1..3 solved ions
@@ -1290,7 +1432,7 @@ static int launch_emi_hex_v2(knpemi_handle* h, int want_p, int split) {
   return check_launch("emi_rows_hex_v2");
 }
 
-static int launch_knp_hex_v2(knpemi_handle* h, int split) {
+static int launch_knp_hex_v2(knpemi_handle* h, int split, int pre) {
   const KnDev& D = h->dev;
   const int acc_n = (h->lds_doubles_knp + 1) & ~1, rec_n = h->lds_uniq_max;
   const int KS = h->K - 1;
@@ -1304,7 +1446,7 @@ static int launch_knp_hex_v2(knpemi_handle* h, int split) {
   if (h->lpr == L && h->hex_affine == AFF && KS == S) {                                             \
     if ((rc = set_lds_limit(knp_rows_hex_v2<L, AFF, S>, lds))) return rc;                           \
     KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                         \
-    hipLaunchKernelGGL((knp_rows_hex_v2<L, AFF, S>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n, gam_n, split); \
+    hipLaunchKernelGGL((knp_rows_hex_v2<L, AFF, S>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n, gam_n, split, pre); \
     return check_launch("knp_rows_hex_v2");                                                         \
   }
   KN_CASE(4, true, 2) KN_CASE(4, false, 2) KN_CASE(2, true, 2) KN_CASE(2, false, 2) KN_CASE(8, true, 2) KN_CASE(8, false, 2)
@@ -1327,8 +1469,9 @@ int kn_launch_knp_rows(knpemi_handle* h, int flags) {
   const KnDev& D = h->dev;
   if (D.nblocks == 0) return KNPEMI_OK;
   const int split = (flags & KNPEMI_NO_SPLITTING) ? 0 : 1;
-  if (h->NV == 8) return launch_knp_hex_v2(h, split);
-  return h->gdim == 2 ? launch_knp_v2<2>(h, split) : launch_knp_v2<3>(h, split);
+  const int pre = (flags & KNPEMI_MEMBRANE_EARLY) ? 1 : 0;   // membrane integrals from knp_membrane_pre_kernel
+  if (h->NV == 8) return launch_knp_hex_v2(h, split, pre);
+  return h->gdim == 2 ? launch_knp_v2<2>(h, split, pre) : launch_knp_v2<3>(h, split, pre);
 }
 
 int kn_launch_membrane_mass(knpemi_handle* h, int n_entries, const int* d_entry_row, double* d_out) {
@@ -1354,6 +1497,20 @@ int kn_launch_knp_membrane(knpemi_handle* h, int flags) {
   else if (NF == 3) hipLaunchKernelGGL((knp_membrane_kernel<3>), grid, block, lds, h->cur, D, h->d_consts, split);
   else hipLaunchKernelGGL((knp_membrane_kernel<4>), grid, block, lds, h->cur, D, h->d_consts, split);
   return check_launch("knp_membrane_kernel");
+}
+
+int kn_launch_knp_membrane_pre(knpemi_handle* h, int flags) {
+  const KnDev& D = h->dev;
+  if (D.nftot == 0) return KNPEMI_OK;
+  const int split = (flags & KNPEMI_NO_SPLITTING) ? 0 : 1;
+  const int NF = h->NF;
+  const size_t lds = (size_t)D.nq_gamma * (1 + NF + (NF == 4 ? 2 * NF : 0)) * sizeof(double);
+  dim3 grid((2 * D.nftot + 255) / 256), block(256);
+  KnProfScope prof(h, KNPEMI_K_KNP_MEMBRANE);
+  if (NF == 2) hipLaunchKernelGGL((knp_membrane_pre_kernel<2>), grid, block, lds, h->cur, D, h->d_consts, split);
+  else if (NF == 3) hipLaunchKernelGGL((knp_membrane_pre_kernel<3>), grid, block, lds, h->cur, D, h->d_consts, split);
+  else hipLaunchKernelGGL((knp_membrane_pre_kernel<4>), grid, block, lds, h->cur, D, h->d_consts, split);
+  return check_launch("knp_membrane_pre_kernel");
 }
 
 int kn_launch_emi_membrane_rhs(knpemi_handle* h, int flags) {

@@ -128,6 +128,8 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   KN_HIP(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
   KN_HIP(hipStreamCreateWithFlags(&h->aux2, hipStreamNonBlocking));
   KN_HIP(hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
+  KN_HIP(hipEventCreateWithFlags(&h->ev_pre_fork, hipEventDisableTiming));
+  KN_HIP(hipEventCreateWithFlags(&h->ev_pre, hipEventDisableTiming));
   h->cur = h->stream;
   KN_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   KN_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
@@ -570,6 +572,7 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   if ((rc = dev_zeros(h, (size_t)(K - 1) * Ntot, &D.b_knp))) return rc;
   if ((rc = dev_zeros(h, (size_t)NQtot, &D.phiM))) return rc;
   if ((rc = dev_zeros(h, std::max<size_t>(1, mentry.size()) * (size_t)(K - 1), &D.gam_e))) return rc;
+  if ((rc = dev_zeros(h, std::max<size_t>(1, mentry.size()) * (size_t)(K - 1) * (1 + NF), &D.gpre))) return rc;
   if ((rc = dev_zeros(h, (size_t)std::max(1, h->moff[S]) * KN_MAXK * std::max(1, NQtot), &D.Ich))) return rc;
   {
     std::vector<int> krp((size_t)(K - 1) * Ntot + 1, 0), kci((size_t)(K - 1) * colindL.size());
@@ -624,6 +627,8 @@ extern "C" void knpemi_destroy(knpemi_handle* h) {
   if (h->aux2) (void)hipStreamSynchronize(h->aux2);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
+  if (h->ev_pre_fork) (void)hipEventDestroy(h->ev_pre_fork);
+  if (h->ev_pre) (void)hipEventDestroy(h->ev_pre);
   if (h->aux2) (void)hipStreamDestroy(h->aux2);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -828,10 +833,37 @@ extern "C" int knpemi_assemble_emi_membrane_rhs(knpemi_handle* h, int flags) {
   return kn_launch_emi_membrane_rhs(h, flags);
 }
 
+extern "C" int knpemi_assemble_knp_membrane_early(knpemi_handle* h, int flags) {
+  if (!h) return fail(KNPEMI_EINVAL, "null handle");
+  if (!h->have_params) return fail(KNPEMI_EINVAL, "knpemi_assemble_knp_membrane_early: knpemi_set_params not called");
+  KN_HIP(hipSetDevice(h->device));
+  int rc;
+  if (flags & KNPEMI_ON_AUX_STREAM) {
+    // after everything the main stream holds (the ODE output, the previous update), beside what comes next on it
+    KN_HIP(hipEventRecord(h->ev_pre_fork, h->stream));
+    KN_HIP(hipStreamWaitEvent(h->aux, h->ev_pre_fork, 0));
+    h->cur = h->aux;
+    rc = kn_launch_knp_membrane_pre(h, flags);
+    h->cur = h->stream;
+    if (rc) return rc;
+    KN_HIP(hipEventRecord(h->ev_pre, h->aux));
+    h->pre_pending = 1;
+    return KNPEMI_OK;
+  }
+  return kn_launch_knp_membrane_pre(h, flags);
+}
+
 extern "C" int knpemi_assemble_knp(knpemi_handle* h, int flags) {
   if (!h) return fail(KNPEMI_EINVAL, "null handle");
   if (!h->have_params) return fail(KNPEMI_EINVAL, "knpemi_assemble_knp: knpemi_set_params not called");
   KN_HIP(hipSetDevice(h->device));
+  if (flags & KNPEMI_MEMBRANE_EARLY) {   // the integrals were prepared by knpemi_assemble_knp_membrane_early
+    if (h->pre_pending) {
+      KN_HIP(hipStreamWaitEvent(h->stream, h->ev_pre, 0));
+      h->pre_pending = 0;
+    }
+    return kn_launch_knp_rows(h, flags);
+  }
   if (!h->fuse_membrane) {   // stand-alone facet kernel: partial integrals through gam_e, the row kernel adds them
     int rc = kn_launch_knp_membrane(h, flags);
     if (rc) return rc;

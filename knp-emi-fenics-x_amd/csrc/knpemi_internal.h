@@ -90,7 +90,8 @@ struct KnDev {
   const int* q2e; const int* q2i;                // [NQtot] global vertex ids
   const double* P_mass;       // [nnz - pmass0] static ICS mass entries of P_emi (rows of the cell sub-domains)
   int64_t pmass0;             // rowptr[first cell-side row]
-  double* gam_e;              // [E][2 ions] membrane partial integrals of b_knp, in entry order
+  double* gam_e;              // [E][K-1] membrane partial integrals of b_knp, in entry order
+  double* gpre;               // [E][(1 + NF)(K-1)] early form: phi-independent part + facet matrix (knp_membrane_pre_kernel)
   double* phiM;               // [NQtot]
   double* Ich;                // [n_model_slots][K][stride NQtot] (indexed by global q)
   int M;
@@ -174,6 +175,8 @@ struct knpemi_handle {
   hipStream_t aux = nullptr;             // auxiliary stream (EMI matrix assembly beside the ODE sweep)
   hipStream_t aux2 = nullptr;            // second auxiliary stream (ODE sweeps of further membrane models)
   hipEvent_t ev_join2 = nullptr;
+  hipEvent_t ev_pre_fork = nullptr, ev_pre = nullptr;   // early membrane integrals on the auxiliary stream
+  int pre_pending = 0;
   hipStream_t cur = nullptr;             // stream the row-kernel launchers enqueue on (stream or aux)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -258,6 +261,7 @@ int kn_gamma_quadrature(int NF, std::vector<double>* out);   // degree-6 membran
 // kernel launchers (kernels_*.hip) ------------------------------------------------------------
 int kn_launch_emi_rows(knpemi_handle* h, int flags);
 int kn_launch_knp_rows(knpemi_handle* h, int flags);
+int kn_launch_knp_membrane_pre(knpemi_handle* h, int flags);
 int kn_launch_emi_membrane_rhs(knpemi_handle* h, int flags);
 int kn_launch_knp_membrane(knpemi_handle* h, int flags);
 int kn_launch_membrane_mass(knpemi_handle* h, int n_entries, const int* d_entry_row, double* d_out);

@@ -21,7 +21,7 @@ MAX_IONS, MAX_SUB, MAX_MODELS = 4, 8, 4
 F_PHI, F_C, F_C_PREV, F_C_ELIM, F_PHI_M, F_I_CH, F_SOURCE = range(7)
 A_EMI, P_EMI, A_KNP = 0, 1, 2
 B_EMI, B_KNP = 0, 1
-WANT_P, NO_SPLITTING, SKIP_MEMBRANE_RHS, ON_AUX_STREAM = 1, 2, 4, 8
+WANT_P, NO_SPLITTING, SKIP_MEMBRANE_RHS, ON_AUX_STREAM, MEMBRANE_EARLY = 1, 2, 4, 8, 16
 ODE_SET_V, ODE_SET_TRACES, ODE_ON_AUX, ODE_ON_AUX2 = 1, 2, 4, 8
 OPT_FUSE_UPDATE, OPT_FUSE_MEMBRANE = 1, 2
 K_ODE, K_EMI_ROWS, K_KNP_ROWS, K_KNP_MEMBRANE, K_UPDATE, K_EMI_MEMBRANE = range(6)
@@ -101,6 +101,7 @@ SIGNATURES = {
     "knpemi_assemble_emi": (C.c_int, [C.c_void_p, C.c_int]),
     "knpemi_assemble_knp": (C.c_int, [C.c_void_p, C.c_int]),
     "knpemi_assemble_emi_membrane_rhs": (C.c_int, [C.c_void_p, C.c_int]),
+    "knpemi_assemble_knp_membrane_early": (C.c_int, [C.c_void_p, C.c_int]),
     "knpemi_join": (C.c_int, [C.c_void_p]),
     "knpemi_solve_emi": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int), c_dbl_p]),
     "knpemi_solve_knp": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int), c_dbl_p]),

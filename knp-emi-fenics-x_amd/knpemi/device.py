@@ -240,8 +240,15 @@ class DeviceProblem:
         flags = (L.WANT_P if want_p else 0) | (0 if splitting_scheme else L.NO_SPLITTING)
         L.check(self.lib.knpemi_assemble_emi(self.h, flags))
 
-    def assemble_knp(self, splitting_scheme=True):
-        L.check(self.lib.knpemi_assemble_knp(self.h, 0 if splitting_scheme else L.NO_SPLITTING))
+    def assemble_knp(self, splitting_scheme=True, early_membrane=False):
+        """A_knp and b_knp.  `early_membrane`: the two-part form of the membrane integrals
+        (knpemi_assemble_knp_membrane_early + KNPEMI_MEMBRANE_EARLY, here back to back on one stream; the stepper can
+        run the first part beside the EMI solve); default: the one-part facet kernel."""
+        flags = 0 if splitting_scheme else L.NO_SPLITTING
+        if early_membrane:
+            L.check(self.lib.knpemi_assemble_knp_membrane_early(self.h, flags))
+            flags |= L.MEMBRANE_EARLY
+        L.check(self.lib.knpemi_assemble_knp(self.h, flags))
 
     def _pattern(self, which):
         key = which if which != L.P_EMI else L.A_EMI

@@ -24,7 +24,7 @@ from . import _lib as L
 class DeviceStepper:
     def __init__(self, forms_emi, forms_knp, c, c_prev, phi, phi_M_prev, solve_emi=None, solve_knp=None,
                  assemble_knp_twice=False, overlap=True, device_solves=None, extrapolate_guess=True,
-                 fuse_update=None, fuse_membrane=False):
+                 fuse_update=None, fuse_membrane=False, early_membrane=False):
         a = forms_emi[0]
         self.dp = a.dp
         self.a = a
@@ -62,6 +62,10 @@ class DeviceStepper:
         L.check(self.lib.knpemi_set_option(dp.h, L.OPT_FUSE_UPDATE, 1 if self.fuse_update else 0))
         # membrane-facet integrals of b_knp inside the KNP row kernel (default) or as a launch of their own
         self.fuse_membrane = bool(fuse_membrane)
+        # membrane-facet integrals of b_knp prepared beside the EMI solve (knpemi_assemble_knp_membrane_early): takes the
+        # facet kernel off the chain between the two solves but lengthens the membrane rows of the KNP row kernel by
+        # more than it saves (config 2: 0.187 -> 0.193 ms per step), hence off by default
+        self.early_membrane = bool(early_membrane) and not self.fuse_membrane
         L.check(self.lib.knpemi_set_option(dp.h, L.OPT_FUSE_MEMBRANE, 1 if self.fuse_membrane else 0))
         self.dt = float(a.dt)
         self.flags_emi = L.WANT_P | (0 if a.splitting_scheme else L.NO_SPLITTING)
@@ -211,13 +215,18 @@ class DeviceStepper:
                     self.overlap = False
         else:
             L.check(lib.knpemi_assemble_emi(dp.h, self.flags_emi))
+        knp_flags = self.flags_knp
+        if self.early_membrane:
+            # everything of the membrane integrals that does not need the new potential: now, beside the EMI solve
+            L.check(lib.knpemi_assemble_knp_membrane_early(dp.h, self.flags_knp | (L.ON_AUX_STREAM if self.overlap else 0)))
+            knp_flags |= L.MEMBRANE_EARLY
         if self.solve_emi is not None:
             self.solve_emi(dp)
             if halo is not None:
                 halo.exchange_bulk()
-        L.check(lib.knpemi_assemble_knp(dp.h, self.flags_knp))
+        L.check(lib.knpemi_assemble_knp(dp.h, knp_flags))
         if self.assemble_knp_twice:   # the reference assembles p = a a second time (knpWeakForm.py:319)
-            L.check(lib.knpemi_assemble_knp(dp.h, self.flags_knp))
+            L.check(lib.knpemi_assemble_knp(dp.h, knp_flags))
         if self.solve_knp is not None:
             self.solve_knp(dp)
         if not (self.fuse_update and self.solve_knp is not None):

@@ -1014,20 +1014,24 @@ def test_device_resident_time_loop_matches_oracle(hip_lib):
 
 def test_fused_update_and_overlap_variants_are_bit_identical(hip_lib):
     """The stepper's launch-saving variants change no bit: update_pde_variables fused into the write-back kernel of the
-    KNP solve (KNPEMI_OPT_FUSE_UPDATE) vs the separate launch, and the EMI matrix assembled beside the ODE sweep (aux
-    stream, separate Robin-term launch) vs after it (fused Robin term), and the membrane-facet integrals of b_knp inside
-    the KNP row kernel (KNPEMI_OPT_FUSE_MEMBRANE) vs the stand-alone facet kernel -- fields, membrane potential, currents and ODE
-    tables after six whole steps with the device solves."""
+    KNP solve (KNPEMI_OPT_FUSE_UPDATE) vs the separate launch; the EMI matrix assembled beside the ODE sweep (aux
+    stream, separate Robin-term launch) vs after it (fused Robin term); the early part of the membrane-facet integrals
+    beside the EMI solve (aux stream) vs in line -- fields, membrane potential, currents and ODE tables after six whole
+    steps with the device solves.  The one-part forms of the membrane integrals (stand-alone facet kernel, or inside
+    the KNP row kernel: KNPEMI_OPT_FUSE_MEMBRANE) are bit-identical to each other and agree with the two-part form to
+    rounding (another summation order)."""
     from knpemi.stepper import DeviceStepper
     out = []
-    for fuse, overlap, thr, fuse_mem in ((True, True, 0.025, True), (False, True, 0.0, True), (False, False, 0.025, False)):
+    variants = ((True, True, 0.025, False, True), (False, True, 0.0, False, True), (False, False, 0.025, False, True),
+                (False, False, 0.025, True, False), (True, True, 0.025, False, False))
+    for fuse, overlap, thr, fuse_mem, early in variants:
         s = Setup("tet", 0, g_syn=10.0)
         for t in s.subdomain_list:
             for k in range(2):
                 s.c[t][k].x.array[:] = s.c_prev[t][k].x._a
         st = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp), s.c, s.c_prev, s.phi,
                            s.phi_M_prev, device_solves=(1e-9, 1e-10), fuse_update=fuse, overlap=overlap,
-                           fuse_membrane=fuse_mem)
+                           fuse_membrane=fuse_mem, early_membrane=early)
         st.overlap_threshold_ms = thr
         ode = s.mem_models[0]['ode']
         st.add_membrane_model(ode, s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
@@ -1037,9 +1041,13 @@ def test_fused_update_and_overlap_variants_are_bit_identical(hip_lib):
         out.append([s.phi[0].x._a.copy(), s.phi[1].x._a.copy(), s.phi_M_prev[1].x._a.copy(), ode.states.copy(),
                     ode.parameters.copy()] + [f.x._a.copy() for t in (0, 1) for f in s.c_prev[t]]
                    + [s.ion_list[-1][f'c_{t}'].x._a.copy() for t in (0, 1)])
-    for other in out[1:]:
-        for a, b in zip(out[0], other):
-            assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    same = lambda x, y: all(np.array_equal(a.view(np.uint64), b.view(np.uint64)) for a, b in zip(x, y))
+    assert same(out[0], out[1]) and same(out[0], out[2])          # two-part form: fused update / overlap / in line
+    assert same(out[3], out[4])                                   # one-part forms
+    phi = lambda o: np.concatenate([o[0], o[1]])
+    assert rel_err(phi(out[3]) - phi(out[3]).mean(), phi(out[0]) - phi(out[0]).mean()) < 1e-8   # solver tolerance 1e-9
+    for a, b in zip(out[0][2:4] + out[0][5:], out[3][2:4] + out[3][5:]):
+        assert rel_err(b, a) < 1e-9
 
 
 def test_stepper_reports_lsoda_failures(hip_lib):
