@@ -413,6 +413,11 @@ int knpemi_dg_ode_stats(knpemi_dg* h, int64_t* n_rhs, int64_t* n_steps, int64_t*
  * of a DG function does under MPI in DOLFINx).  Membrane nodes of ghost cells are integrated redundantly. */
 int knpemi_dg_halo_pack(knpemi_dg* h, const int32_t* idx_dev, int n, double* buf_dev);
 int knpemi_dg_halo_unpack(knpemi_dg* h, const int32_t* idx_dev, int n, const double* buf_dev);
+/* the library's RCCL transport for that halo, on the DG handle's stream (see knpemi_comm_init / knpemi_comm_sendrecv) */
+int knpemi_dg_comm_init(knpemi_dg* h, int rank, int world, const char* id_bytes, size_t len);
+int knpemi_dg_comm_sendrecv(knpemi_dg* h, const double* send_buf_dev, double* recv_buf_dev, int n_parts,
+                            const int32_t* peer, const int64_t* send_off, const int64_t* send_cnt, const int64_t* recv_off,
+                            const int64_t* recv_cnt);
 int knpemi_dg_sync(knpemi_dg* h);
 /* average duration (ms) of `reps` back-to-back launches of one assembly kernel (0 = potential, 1 = concentrations),
  * measured with HIP events on the stream the kernel is launched on */

@@ -83,25 +83,19 @@ extern "C" int knpemi_comm_unique_id(char* out, size_t len) {
   return KNPEMI_OK;
 }
 
+int kn_comm_create(int device, int rank, int world, const char* id_bytes, size_t len, void** out);
+
 extern "C" int knpemi_comm_init(knpemi_handle* h, int rank, int world, const char* id_bytes, size_t len) {
-  if (!h || !id_bytes || len < sizeof(ncclUniqueId) || world < 1 || rank < 0 || rank >= world) {
-    kn_set_error("knpemi_comm_init: bad argument");
+  if (!h) {
+    kn_set_error("knpemi_comm_init: null handle");
     return KNPEMI_EINVAL;
-  }
-  if (!rccl().ok) {
-    kn_set_error("knpemi_comm_init: RCCL is not available in this process");
-    return KNPEMI_EHIP;
   }
   if (h->comm) {
     kn_set_error("knpemi_comm_init: communicator already created");
     return KNPEMI_EINVAL;
   }
-  KN_HIP(hipSetDevice(h->device));
-  ncclUniqueId id;
-  std::memcpy(&id, id_bytes, sizeof(id));
-  ncclComm_t c = nullptr;
-  KN_NCCL(rccl().CommInitRank(&c, world, id, rank));
-  h->comm = c;
+  int rc = kn_comm_create(h->device, rank, world, id_bytes, len, &h->comm);
+  if (rc) return rc;
   h->comm_rank = rank;
   h->comm_world = world;
   return KNPEMI_OK;
@@ -113,10 +107,10 @@ void kn_comm_destroy(knpemi_handle* h) {
 }
 
 // send_buf[send_off[p] .. + send_cnt[p]) -> peer[p], recv_buf[recv_off[p] .. + recv_cnt[p]) <- peer[p], one group
-extern "C" int knpemi_comm_sendrecv(knpemi_handle* h, const double* send_buf_dev, double* recv_buf_dev, int n_parts,
-                                    const int32_t* peer, const int64_t* send_off, const int64_t* send_cnt,
-                                    const int64_t* recv_off, const int64_t* recv_cnt) {
-  if (!h || !h->comm) {
+int kn_comm_sendrecv(void* comm, int world, int device, hipStream_t stream, const double* send_buf_dev, double* recv_buf_dev,
+                     int n_parts, const int32_t* peer, const int64_t* send_off, const int64_t* send_cnt,
+                     const int64_t* recv_off, const int64_t* recv_cnt) {
+  if (!comm) {
     kn_set_error("knpemi_comm_sendrecv: no communicator (knpemi_comm_init)");
     return KNPEMI_EINVAL;
   }
@@ -125,20 +119,57 @@ extern "C" int knpemi_comm_sendrecv(knpemi_handle* h, const double* send_buf_dev
     return KNPEMI_EINVAL;
   }
   for (int p = 0; p < n_parts; ++p)
-    if (peer[p] < 0 || peer[p] >= h->comm_world || send_cnt[p] < 0 || recv_cnt[p] < 0 ||
+    if (peer[p] < 0 || peer[p] >= world || send_cnt[p] < 0 || recv_cnt[p] < 0 ||
         (send_cnt[p] > 0 && !send_buf_dev) || (recv_cnt[p] > 0 && !recv_buf_dev)) {
       kn_set_error("knpemi_comm_sendrecv: bad part");
       return KNPEMI_EINVAL;
     }
-  KN_HIP(hipSetDevice(h->device));
-  ncclComm_t c = static_cast<ncclComm_t>(h->comm);
+  KN_HIP(hipSetDevice(device));
+  ncclComm_t c = static_cast<ncclComm_t>(comm);
   KN_NCCL(rccl().GroupStart());
-  for (int p = 0; p < n_parts; ++p) {
-    if (send_cnt[p] > 0) KN_NCCL(rccl().Send(send_buf_dev + send_off[p], (size_t)send_cnt[p], ncclDouble, peer[p], c, h->stream));
-    if (recv_cnt[p] > 0) KN_NCCL(rccl().Recv(recv_buf_dev + recv_off[p], (size_t)recv_cnt[p], ncclDouble, peer[p], c, h->stream));
+  ncclResult_t first = ncclSuccess;   // an error inside the group must not leave it open
+  for (int p = 0; p < n_parts && first == ncclSuccess; ++p) {
+    if (send_cnt[p] > 0) first = rccl().Send(send_buf_dev + send_off[p], (size_t)send_cnt[p], ncclDouble, peer[p], c, stream);
+    if (first == ncclSuccess && recv_cnt[p] > 0)
+      first = rccl().Recv(recv_buf_dev + recv_off[p], (size_t)recv_cnt[p], ncclDouble, peer[p], c, stream);
   }
-  KN_NCCL(rccl().GroupEnd());
+  const ncclResult_t end = rccl().GroupEnd();
+  if (first != ncclSuccess) return comm_fail("ncclSend / ncclRecv", first);
+  if (end != ncclSuccess) return comm_fail("ncclGroupEnd", end);
   return KNPEMI_OK;
+}
+
+int kn_comm_create(int device, int rank, int world, const char* id_bytes, size_t len, void** out) {
+  if (!id_bytes || len < sizeof(ncclUniqueId) || world < 1 || rank < 0 || rank >= world || !out) {
+    kn_set_error("knpemi_comm_init: bad argument");
+    return KNPEMI_EINVAL;
+  }
+  if (!rccl().ok) {
+    kn_set_error("knpemi_comm_init: RCCL is not available in this process");
+    return KNPEMI_EHIP;
+  }
+  KN_HIP(hipSetDevice(device));
+  ncclUniqueId id;
+  std::memcpy(&id, id_bytes, sizeof(id));
+  ncclComm_t c = nullptr;
+  KN_NCCL(rccl().CommInitRank(&c, world, id, rank));
+  *out = c;
+  return KNPEMI_OK;
+}
+
+void kn_comm_free(void* comm) {
+  if (comm && rccl().ok) (void)rccl().CommDestroy(static_cast<ncclComm_t>(comm));
+}
+
+extern "C" int knpemi_comm_sendrecv(knpemi_handle* h, const double* send_buf_dev, double* recv_buf_dev, int n_parts,
+                                    const int32_t* peer, const int64_t* send_off, const int64_t* send_cnt,
+                                    const int64_t* recv_off, const int64_t* recv_cnt) {
+  if (!h) {
+    kn_set_error("knpemi_comm_sendrecv: null handle");
+    return KNPEMI_EINVAL;
+  }
+  return kn_comm_sendrecv(h->comm, h->comm_world, h->device, h->stream, send_buf_dev, recv_buf_dev, n_parts, peer, send_off,
+                          send_cnt, recv_off, recv_cnt);
 }
 
 extern "C" int knpemi_comm_allreduce(knpemi_handle* h, double* buf_dev, int n) {

@@ -744,6 +744,8 @@ struct knpemi_dg {
   size_t stage_len = 0;
   double* d_fsrc = nullptr;
   const int* d_colind = nullptr;
+  void* comm = nullptr;            // the library's RCCL communicator for the ghost-cell halo (comm_rccl.hip)
+  int comm_world = 1;
   // per-launch event brackets of the two assembly kernels (knpemi_dg_profile)
   int prof_on = 0;
   std::vector<hipEvent_t> prof_ev[2];
@@ -852,6 +854,7 @@ extern "C" void knpemi_dg_destroy(knpemi_dg* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : h->allocs) (void)hipFree(p);
+  kn_comm_free(h->comm);
   if (h->d_coef) (void)hipFree(h->d_coef);
   for (auto& v : h->prof_ev) for (hipEvent_t e : v) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1225,6 +1228,23 @@ extern "C" int knpemi_dg_halo_unpack(knpemi_dg* h, const int32_t* idx_dev, int n
   hipLaunchKernelGGL(dg_halo_kernel, dim3((5 * (size_t)n + 255) / 256), dim3(256), 0, h->stream, h->dev.rec, idx_dev, n,
                      const_cast<double*>(buf_dev), 1);
   return dg_check_launch("dg_halo_kernel");
+}
+
+extern "C" int knpemi_dg_comm_init(knpemi_dg* h, int rank, int world, const char* id_bytes, size_t len) {
+  if (!h) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_comm_init: null handle");
+  if (h->comm) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_comm_init: communicator already created");
+  int rc = kn_comm_create(h->device, rank, world, id_bytes, len, &h->comm);
+  if (rc) return rc;
+  h->comm_world = world;
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_dg_comm_sendrecv(knpemi_dg* h, const double* send_buf_dev, double* recv_buf_dev, int n_parts,
+                                       const int32_t* peer, const int64_t* send_off, const int64_t* send_cnt,
+                                       const int64_t* recv_off, const int64_t* recv_cnt) {
+  if (!h) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_comm_sendrecv: null handle");
+  return kn_comm_sendrecv(h->comm, h->comm_world, h->device, h->stream, send_buf_dev, recv_buf_dev, n_parts, peer, send_off,
+                          send_cnt, recv_off, recv_cnt);
 }
 
 extern "C" int knpemi_dg_sync(knpemi_dg* h) {

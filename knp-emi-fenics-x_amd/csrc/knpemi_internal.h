@@ -256,6 +256,11 @@ struct OdeArgs;
 int kn_launch_ode_raw(hipStream_t st, int model_id, const OdeDev& dv, const OdeArgs& a, const void* coef);   // kernels_ode.hip
 int kn_lsoda_coef_upload(void** out);
 void kn_comm_destroy(knpemi_handle* h);   // comm_rccl.hip
+int kn_comm_create(int device, int rank, int world, const char* id_bytes, size_t len, void** out);
+void kn_comm_free(void* comm);
+int kn_comm_sendrecv(void* comm, int world, int device, hipStream_t stream, const double* send_buf_dev, double* recv_buf_dev,
+                     int n_parts, const int32_t* peer, const int64_t* send_off, const int64_t* send_cnt,
+                     const int64_t* recv_off, const int64_t* recv_cnt);
 int kn_gamma_quadrature(int NF, std::vector<double>* out);   // degree-6 membrane-facet rule (knpemi_api.hip)
 
 // kernel launchers (kernels_*.hip) ------------------------------------------------------------

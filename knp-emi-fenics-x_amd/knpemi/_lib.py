@@ -174,6 +174,9 @@ SIGNATURES = {
     "knpemi_dg_ode_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "knpemi_dg_halo_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "knpemi_dg_halo_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "knpemi_dg_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "knpemi_dg_comm_sendrecv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_int_p, C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "knpemi_dg_sync": (C.c_int, [C.c_void_p]),
     "knpemi_dg_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_dbl_p]),
     "knpemi_dg_profile": (C.c_int, [C.c_void_p, C.c_int]),

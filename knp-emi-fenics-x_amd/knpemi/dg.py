@@ -14,6 +14,7 @@ Broken dof (cell c, local vertex j) = c * nv + j; fields are arrays of shape (n_
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import scipy.sparse as sp
@@ -273,18 +274,35 @@ class DGSlab:
         h.dp, h.L, h.torch, h.dist = dp, L, torch, dist
         dev = torch.device("cuda", dp.device)
         h._device = dev
-        import os
         stream_ordered = os.environ.get("KNPEMI_HALO_SYNC") is None
         try:
             h._ext = torch.cuda.ExternalStream(dp.lib.knpemi_dg_stream(dp.h), device=dev)
         except (RuntimeError, TypeError):
             h._ext, stream_ordered = None, False
+        self._native = False
         if dist.get_backend() == "gloo":
             h.mode = "gloo host-staged"
         else:
-            flag = torch.tensor([1 if stream_ordered else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            h.mode = "stream-ordered RCCL" if int(flag.item()) else "host-synchronised RCCL"
+            # first choice: the library's own RCCL communicator on the DG handle's stream (knpemi_dg_comm_*), voted on
+            native = os.environ.get("KNPEMI_HALO_TORCH") is None
+            if native:
+                buf = C.create_string_buffer(128)
+                ok = dp.lib.knpemi_comm_unique_id(buf, 128) == 0 if dist.get_rank() == 0 else True
+                box = [buf.raw if ok else None]
+                dist.broadcast_object_list(box, src=0)
+                native = box[0] is not None
+                if native:
+                    rc = dp.lib.knpemi_dg_comm_init(dp.h, dist.get_rank(), dist.get_world_size(), box[0], 128)
+                    flag = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    native = bool(int(flag.item()))
+            if native:
+                self._native = True
+                h.mode = "library RCCL (knpemi_dg_comm_sendrecv)"
+            else:
+                flag = torch.tensor([1 if stream_ordered else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                h.mode = "stream-ordered RCCL" if int(flag.item()) else "host-synchronised RCCL"
         h._stream_ordered = h.mode == "stream-ordered RCCL"
         self.mode = h.mode
         self._d = h._device_plan(self.plan, 5)
@@ -295,5 +313,12 @@ class DGSlab:
         if d is None:
             return
         L.check(dp.lib.knpemi_dg_halo_pack(dp.h, d["send_idx"].data_ptr(), d["send_idx"].numel(), d["send_buf"].data_ptr()))
-        self._halo._transfer(d)
+        if self._native:
+            i64 = C.POINTER(C.c_int64)
+            L.check(dp.lib.knpemi_dg_comm_sendrecv(
+                dp.h, d["send_buf"].data_ptr(), d["recv_buf"].data_ptr(), len(d["peer"]), L.iptr(d["peer"]),
+                d["send_off"].ctypes.data_as(i64), d["send_cnt"].ctypes.data_as(i64),
+                d["recv_off"].ctypes.data_as(i64), d["recv_cnt"].ctypes.data_as(i64)))
+        else:
+            self._halo._transfer(d)
         L.check(dp.lib.knpemi_dg_halo_unpack(dp.h, d["recv_idx"].data_ptr(), d["recv_idx"].numel(), d["recv_buf"].data_ptr()))
