@@ -298,15 +298,14 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, wo
             dp = dg_time.init_fields(slab.dp)
             slab.attach()
             slab.exchange()
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import knpemi_oracle as ko
-    m = ko.MODELS["hh_si"]
-    ix = m["pidx"]
-    prow = np.array(m["params"], float)
-    prow[ix["Cm"]] = 0.02
-    prow[ix["z_Na"]], prow[ix["z_K"]], prow[ix["z_Cl"]], prow[ix["psi"]] = 1.0, 1.0, -1.0, 96485.0 / (8.314 * 300.0)
+    import mm_hh                                   # the driver's membrane model module (examples/idealized_geometries)
+    pi = mm_hh.parameter_indices
+    prow = np.asarray(mm_hh.init_parameter_values(), float)
+    prow[pi("Cm")] = 0.02
+    prow[pi("z_Na")], prow[pi("z_K")], prow[pi("z_Cl")], prow[pi("psi")] = 1.0, 1.0, -1.0, 96485.0 / (8.314 * 300.0)
     names = ("Na", "K", "Cl")
-    dp.ode_bind(L.MODEL_HH_SI, m["states"], prow, sum(([ix[f"{n}_e"], ix[f"{n}_i"], ix[f"I_ch_{n}"]] for n in names), []), m["V"])
+    dp.ode_bind(L.MODEL_HH_SI, np.asarray(mm_hh.init_state_values(), float), prow,
+                sum(([pi(f"{n}_e"), pi(f"{n}_i"), pi(f"I_ch_{n}")] for n in names), []), mm_hh.state_indices("V"))
     c_new = torch.tensor(np.stack([dp.get_concentration(k).ravel() for k in range(2)]), device="cuda")
     torch.cuda.synchronize()
     dt = 1e-4
@@ -381,7 +380,8 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, wo
         "kernels_us_per_step": {"dg_emi_kernel": emi_us, "dg_knp_kernel": knp_us},
         "ode": {"rhs_evals_per_dof_per_step": n_rhs / max(1, dp.nmf * dp.nf) / steps},
     }
-    if cpu and rank == 0 and world == 1:
+    if cpu and rank == 0 and world == 1:      # the only use of oracle/ in this function: the timed CPU restatement
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import knpemi_dg_oracle as dgo
         from knpemi.fem.idealized import make_mesh_3D
         mesh, ct, ft = make_mesh_3D(0, "tetrahedron")

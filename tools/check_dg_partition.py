@@ -15,11 +15,10 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "knp-emi-fenics-x_amd"))
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "examples", "idealized_geometries"))
 
 
 def setup(dp):
-    import knpemi_oracle as ko
     from knpemi import _lib as L
     ions = [dict(name="Na", z=1.0, D=[1.33e-9] * 2), dict(name="K", z=1.0, D=[1.96e-9] * 2), dict(name="Cl", z=-1.0, D=[2.03e-9] * 2)]
     dp.set_params(dict(dt=1e-4, F=96485.0, psi=96485.0 / (8.314 * 300.0), C_M=0.02), ions)
@@ -29,13 +28,14 @@ def setup(dp):
         dp.set_concentration(k, np.where(ins, i, e) * (1.0 + 1e-3 * w * (1 + k)))
     dp.set_potential(np.where(ins, -0.0744, 0.0) + 1e-3 * w)
     dp.set_membrane_potential(np.full((dp.nmf, dp.nf), -0.0744))
-    m = ko.MODELS["hh_si"]
-    ix = m["pidx"]
-    prow = np.array(m["params"], float)
-    prow[ix["Cm"]] = 0.02
-    prow[ix["z_Na"]], prow[ix["z_K"]], prow[ix["z_Cl"]], prow[ix["psi"]] = 1.0, 1.0, -1.0, 96485.0 / (8.314 * 300.0)
+    import mm_hh
+    pi = mm_hh.parameter_indices
+    prow = np.asarray(mm_hh.init_parameter_values(), float)
+    prow[pi("Cm")] = 0.02
+    prow[pi("z_Na")], prow[pi("z_K")], prow[pi("z_Cl")], prow[pi("psi")] = 1.0, 1.0, -1.0, 96485.0 / (8.314 * 300.0)
     names = ("Na", "K", "Cl")
-    dp.ode_bind(L.MODEL_HH_SI, m["states"], prow, sum(([ix[f"{n}_e"], ix[f"{n}_i"], ix[f"I_ch_{n}"]] for n in names), []), m["V"])
+    dp.ode_bind(L.MODEL_HH_SI, np.asarray(mm_hh.init_state_values(), float), prow,
+                sum(([pi(f"{n}_e"), pi(f"{n}_i"), pi(f"I_ch_{n}")] for n in names), []), mm_hh.state_indices("V"))
 
 
 def run(dp, K, slab=None):
