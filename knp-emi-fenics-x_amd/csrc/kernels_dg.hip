@@ -955,10 +955,13 @@ extern "C" int knpemi_dg_create(const knpemi_dg_desc* d, int device, knpemi_dg**
       for (int a = 0; a < NV; ++a) {
         if (a == f) continue;
         const int v = d->cells[(size_t)c * NV + a];
-        w |= (unsigned)local_of(o, v) << (4 + 2 * a);
+        const int lo_ = local_of(o, v);
+        if (lo_ < 0) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: two cells share a facet key but not its vertices");
+        w |= (unsigned)lo_ << (4 + 2 * a);
         if (mem >= 0) {
           int node = -1;
           for (int t = 0; t < NF; ++t) if (d->mem_facets[(size_t)mem * NF + t] == v) node = t;
+          if (node < 0) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: membrane facet vertices do not match the cells'");
           w |= (unsigned)node << (12 + 2 * a);
           (d->cell_sub[c] == 0 ? h->h_q2e : h->h_q2i)[(size_t)mem * NF + node] = c * NV + a;
         }
