@@ -311,7 +311,11 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_emi_kernel(DgDev D, const DgConst
 #pragma unroll
       for (int b = 0; b < NV; ++b) {
         const int jn = b == 0 ? (fi[0] >> 2) & 3 : (fi[0] >> (4 + 2 * p[b])) & 3;
-        const DofRec r = load_rec(D.rec, N * NV + jn);
+        // a neighbour inside this workgroup's cells is already staged in LDS (half of them are, for Kuhn-split meshes:
+        // the tetrahedra of one hexahedron follow each other): only the others are gathered from memory
+        const int ln = N * NV + jn - row0;
+        const double* rp = (ln >= 0 && ln < nrows) ? img + ln * DG_RPITCH : D.rec + (size_t)(N * NV + jn) * KN_REC;
+        const DofRec r = load_rec(rp, 0);      // one address, LDS or global: generic loads
         if (b == 0) {
 #pragma unroll
           for (int d = 0; d < GD; ++d) dfar[d] = r.x[d] - X[1][d];
@@ -514,7 +518,9 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_knp_kernel(DgDev D, const DgConst
 #pragma unroll
       for (int b = 0; b < NV; ++b) {
         const int jn = b == 0 ? (fi[0] >> 2) & 3 : (fi[0] >> (4 + 2 * p[b])) & 3;
-        const double* r = D.rec + (size_t)(N * NV + jn) * KN_REC;
+        const int ln = N * NV + jn - row0;      // staged in LDS if the neighbour belongs to this workgroup
+        const bool local = ln >= 0 && ln < nrows;
+        const double* r = local ? img + ln * DG_RPITCH : D.rec + (size_t)(N * NV + jn) * KN_REC;
         phN[b] = r[7];
         if (b == 0) {
 #pragma unroll
