@@ -282,3 +282,46 @@ def test_dg_time_loop_on_the_device_matches_the_restatement(hip_lib):
         assert rel_err(dp.get_concentration(k), ref.c_all[k]) < 1e-10
     v = dp.get_membrane_potential()
     assert v.mean() > -0.0744 + 0.010
+
+
+@pytest.mark.parametrize("r,label", [(1, "config2: 124 416 tetrahedra"), (2, "config3: 995 328 tetrahedra")])
+def test_dg_full_size_properties(hip_lib, r, label):
+    """BASELINE sizes, checked through what needs no oracle: the potential matrix is symmetric with the constants in
+    its kernel and a compatible right-hand side; every column of A_k - M/dt sums to zero (the SIP and the upwinded drift
+    fluxes only move mass between cells; membrane fluxes are right-hand-side terms); rows are sorted and hold one
+    nv-wide block per cell and neighbour; a second assembly reproduces every bit."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import dg_time
+    dp = dg_time.build(r)
+    n = dp.n
+    assert dp.n_cells == 124416 * 8 ** (r - 1)
+    dp.assemble_emi()
+    dp.assemble_knp()
+    A = dp.matrix(0)
+    scale = abs(A.data).max()
+    assert abs(A - A.T).max() < 1e-12 * scale
+    assert np.abs(A @ np.ones(n)).max() < 1e-10 * scale
+    b = dp.rhs(0)
+    assert abs(b.sum()) < 1e-9 * np.abs(b).sum()
+    assert np.all(np.diff(dp.indptr) % dp.nv == 0) and int(np.diff(dp.indptr).max()) == dp.nv * (dp.nv + 1)
+    rows = np.random.default_rng(0).integers(0, n, 2000)
+    for i in rows:
+        cols = dp.indices[dp.indptr[i]:dp.indptr[i + 1]]
+        assert np.all(np.diff(cols) > 0) and i in cols
+    # cell volumes from the coordinates
+    X = dp.X
+    e = X[:, 1:] - X[:, :1]
+    vol = np.abs(np.einsum("ci,ci->c", e[:, 0], np.cross(e[:, 1], e[:, 2]))) / 6.0
+    mass_col = np.repeat(vol / dp.nv, dp.nv) / 1e-4
+    sums, datas = [], []
+    for k in range(2):
+        Ak = dp.matrix(1 + k)
+        col = np.asarray(Ak.sum(axis=0)).ravel()
+        assert np.abs(col - mass_col).max() < 1e-9 * abs(Ak.data).max(), k
+        datas.append(Ak.data.copy())
+    dp.assemble_emi()
+    dp.assemble_knp()
+    assert np.array_equal(dp.matrix(0).data, A.data)
+    for k in range(2):
+        assert np.array_equal(dp.matrix(1 + k).data, datas[k])
