@@ -487,7 +487,8 @@ def main():
 
     stepper = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp),
                             s.c, s.c_prev, s.phi, s.phi_M_prev, assemble_knp_twice=args.knp_twice,
-                            overlap=not args.no_overlap, fuse_update=not args.frozen_state)
+                            overlap=not args.no_overlap, fuse_update=not args.frozen_state,
+                            early_membrane=bool(os.environ.get("KNPEMI_EARLY_MEMBRANE")))
     dp = stepper.dp
     for m, stim, loc in case.models:
         stepper.add_membrane_model(m, stim, loc)

@@ -506,9 +506,9 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
       for (int k = 0; k < KS; ++k) unsafeAtomicAdd(&acc[(size_t)k * acc_n + rL + diag], dk[k]);
     }
     // membrane Robin/coupling contributions, written per (row, facet) entry by knp_membrane_kernel
-    if (sub == 0) {
+    {   // the row's LPR lanes share its membrane entries (the sums meet in the reduction below)
       const int ne = (unsigned)ri.y >> 16;
-      for (int e = ri.w; e < ri.w + ne; ++e) {
+      for (int e = ri.w + sub; e < ri.w + ne; e += LPR) {
         if (pre) membrane_entry_early<GDIM, KS>(D, e, bk);
         else {
 #pragma unroll
@@ -887,9 +887,9 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDe
       const int pc = D.pair_cell[ent];
       if (pc >= 0) do_pair(pc, *reinterpret_cast<const uint2*>(D.pair_slots + 2 * ent));
     }
-    if (sub == 0) {
+    {   // the row's LPR lanes share its membrane entries (the sums meet in the reduction below)
       const int ne = (unsigned)ri.y >> 16;
-      for (int e = ri.w; e < ri.w + ne; ++e) {
+      for (int e = ri.w + sub; e < ri.w + ne; e += LPR) {
         if (pre) membrane_entry_early<4, KS>(D, e, bk);
         else {
 #pragma unroll
