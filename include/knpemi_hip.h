@@ -256,6 +256,8 @@ int knpemi_update_pde(knpemi_handle* h);
  *   107 us fused) the stand-alone kernel costs spread over all CUs.  Kept as an option for small, launch-bound cases. */
 #define KNPEMI_OPT_FUSE_UPDATE 1
 #define KNPEMI_OPT_FUSE_MEMBRANE 2
+/* KNPEMI_OPT_PROFILE_STRIDE (n >= 1, default 1): knpemi_profile brackets every n-th launch of a selected kernel only. */
+#define KNPEMI_OPT_PROFILE_STRIDE 3
 int knpemi_set_option(knpemi_handle* h, int option, int value);
 
 /* Nodal trace of an (ECS, cell) pair of bulk functions onto Q_sub: interpolate_to_membrane
@@ -422,7 +424,8 @@ int knpemi_dg_sync(knpemi_dg* h);
 /* average duration (ms) of `reps` back-to-back launches of one assembly kernel (0 = potential, 1 = concentrations),
  * measured with HIP events on the stream the kernel is launched on */
 int knpemi_dg_time_kernel(knpemi_dg* h, int which, int flags, int reps, double* avg_ms);
-/* per-launch HIP event brackets of the assembly kernels inside a running time loop (as knpemi_profile):
+/* HIP event brackets of the assembly kernels inside a running time loop (as knpemi_profile): on = n >= 1 brackets
+ * every n-th launch of each kernel, 0 switches them off;
  * profile_read synchronises, returns the number of bracketed launches of kernel `which` and their summed duration,
  * and resets the accumulator */
 int knpemi_dg_profile(knpemi_dg* h, int on);

@@ -753,7 +753,8 @@ struct knpemi_dg {
   void* comm = nullptr;            // the library's RCCL communicator for the ghost-cell halo (comm_rccl.hip)
   int comm_world = 1;
   // per-launch event brackets of the two assembly kernels (knpemi_dg_profile)
-  int prof_on = 0;
+  int prof_on = 0;                 // 0 off, n >= 1: every n-th launch is bracketed
+  unsigned prof_count[2] = {0, 0};
   std::vector<hipEvent_t> prof_ev[2];
   size_t prof_used[2] = {0, 0};
   // membrane ODE sweep
@@ -804,6 +805,7 @@ int dg_check_launch(const char* what) {
 struct DgProf {   // brackets one launch with an event pair on the handle's stream
   knpemi_dg* h; int k; bool on;
   DgProf(knpemi_dg* h_, int k_) : h(h_), k(k_), on(h_->prof_on != 0) {
+    if (on && h->prof_on > 1 && (h->prof_count[k]++ % (unsigned)h->prof_on) != 0) on = false;   // every n-th launch
     if (!on) return;
     auto& v = h->prof_ev[k];
     if (h->prof_used[k] + 2 > v.size()) {
@@ -1284,7 +1286,8 @@ extern "C" void* knpemi_dg_stream(knpemi_dg* h) { return h ? (void*)h->stream : 
 
 extern "C" int knpemi_dg_profile(knpemi_dg* h, int on) {
   if (!h) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_profile: null handle");
-  h->prof_on = on ? 1 : 0;
+  h->prof_on = on > 0 ? on : 0;
+  h->prof_count[0] = h->prof_count[1] = 0;
   return KNPEMI_OK;
 }
 

@@ -1313,6 +1313,11 @@ extern "C" int knpemi_set_option(knpemi_handle* h, int option, int value) {
   if (!h) return fail(KNPEMI_EINVAL, "null handle");
   if (option == KNPEMI_OPT_FUSE_UPDATE) { h->fuse_update = value ? 1 : 0; return KNPEMI_OK; }
   if (option == KNPEMI_OPT_FUSE_MEMBRANE) { h->fuse_membrane = value ? 1 : 0; return KNPEMI_OK; }
+  if (option == KNPEMI_OPT_PROFILE_STRIDE) {   // the next launch of every kernel is a bracketed one
+    h->prof_stride = value > 1 ? value : 1;
+    for (unsigned& c : h->prof_count) c = 0;
+    return KNPEMI_OK;
+  }
   return fail(KNPEMI_EINVAL, "knpemi_set_option: unknown option");
 }
 

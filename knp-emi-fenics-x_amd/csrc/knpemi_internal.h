@@ -212,6 +212,8 @@ struct knpemi_handle {
   int pc_emi = KNPEMI_PC_AMG, pc_knp = KNPEMI_PC_AMG;
   int fuse_update = 0;                 // KNPEMI_OPT_FUSE_UPDATE
   int fuse_membrane = 0;               // KNPEMI_OPT_FUSE_MEMBRANE
+  int prof_stride = 1;                 // KNPEMI_OPT_PROFILE_STRIDE
+  unsigned prof_count[16] = {0};
   int lds_gam_max = 0;                 // most membrane entries of one row block
   KnDist dist;
   // per-kernel event profiling (knpemi_profile)
@@ -224,6 +226,9 @@ struct knpemi_handle {
 struct KnProfScope {
   knpemi_handle* h; int k; bool on;
   KnProfScope(knpemi_handle* h_, int k_) : h(h_), k(k_), on((h_->prof_mask >> k_) & 1u) {
+    // KNPEMI_OPT_PROFILE_STRIDE: bracket every n-th launch only (an event pair around a kernel on the critical path
+    // costs the step several microseconds)
+    if (on && h->prof_stride > 1 && (h->prof_count[k]++ % h->prof_stride) != 0) on = false;
     if (!on) return;
     auto& v = h->prof_ev[k];
     if (h->prof_used[k] + 2 > v.size()) {

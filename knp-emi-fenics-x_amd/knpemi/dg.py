@@ -209,7 +209,7 @@ class DGProblem:
         L.check(self.lib.knpemi_dg_update(self.h, C.c_void_p(c_new_ptr), 1))
 
     def profile(self, on):
-        L.check(self.lib.knpemi_dg_profile(self.h, 1 if on else 0))
+        L.check(self.lib.knpemi_dg_profile(self.h, int(on)))      # True / 1: every launch, n: every n-th, 0: off
 
     def profile_read(self, which):
         """(launches, average microseconds) of the bracketed launches of kernel `which` since the last read."""
