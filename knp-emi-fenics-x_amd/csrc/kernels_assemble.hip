@@ -114,9 +114,11 @@ __device__ __forceinline__ double emi_membrane_entry_rhs(const KnDev& D, const K
 }
 
 template <int NF>
-__device__ __forceinline__ void emi_membrane_row(const KnDev& D, const KnConsts& C, int e0, int ne, bool cell_side,
-                                                 int rowbase, double* accA, int splitting, double& gam) {
-  for (int e = e0; e < e0 + ne; ++e) {
+__device__ __forceinline__ void emi_membrane_row(const KnDev& D, const KnConsts& C, int e0, int ne, int first, int stride,
+                                                 bool cell_side, int rowbase, double* accA, int splitting, double& gam) {
+  // the lanes of a row share its membrane entries: lane `first` of `stride` takes every stride-th one; the partial
+  // Robin sums meet in the caller's shuffle reduction (emi_membrane_rhs_kernel forms the same partial sums)
+  for (int e = e0 + first; e < e0 + ne; e += stride) {
     const int ms = D.me_model[e];
     if (ms < 0) continue;
     const uint64_t sl = D.mslots[e];
@@ -408,10 +410,10 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
       if (sl != 0xFFFFFFFFu) do_pair(sl);
     }
     if (diag >= 0) unsafeAtomicAdd(&accA[lap + diag], dA);
-    if (sub == 0 && ne > 0) emi_membrane_row<NF>(D, C, ri.w, ne, cell_side, rowbase, accA, splitting, gam);
+    if (ne > 0) emi_membrane_row<NF>(D, C, ri.w, ne, sub, LPR, cell_side, rowbase, accA, splitting, gam);
   }
 #pragma unroll
-  for (int m = 1; m < LPR; m <<= 1) bacc += __shfl_xor(bacc, m);
+  for (int m = 1; m < LPR; m <<= 1) { bacc += __shfl_xor(bacc, m); gam += __shfl_xor(gam, m); }
   if (valid && sub == 0) D.b_emi[g] = bacc + gam;
   __syncthreads();
   for (int i = tid; i < seglen; i += KN_BLOCK) {
@@ -808,10 +810,10 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
       const int pc = D.pair_cell[ent];
       if (pc >= 0) do_pair(pc, *reinterpret_cast<const uint2*>(D.pair_slots + 2 * ent));
     }
-    if (sub == 0 && ne > 0) emi_membrane_row<NF>(D, C, ri.w, ne, cell_side, rowbase, accA, splitting, gam);
+    if (ne > 0) emi_membrane_row<NF>(D, C, ri.w, ne, sub, LPR, cell_side, rowbase, accA, splitting, gam);
   }
 #pragma unroll
-  for (int m = 1; m < LPR; m <<= 1) bacc += __shfl_xor(bacc, m);
+  for (int m = 1; m < LPR; m <<= 1) { bacc += __shfl_xor(bacc, m); gam += __shfl_xor(gam, m); }
   if (valid && sub == 0) D.b_emi[g] = bacc + gam;
   __syncthreads();
   for (int i = tid; i < seglen; i += KN_BLOCK) {
@@ -1063,6 +1065,13 @@ __device__ __forceinline__ void facet_point_split(const FacetData<NF>& f, const 
 
 // Stand-alone form (diagnostics, KNPEMI_OPT_FUSE_MEMBRANE = 0): one thread per (facet, side) tests the integrand
 // against all NF facet functions and writes NF x (K - 1) partial integrals to gam_e.
+// KN_MEM_LQ adjacent lanes share one (facet, side): each takes every KN_MEM_LQ-th quadrature point and the partial
+// integrals meet in a shuffle reduction.  The membrane is a 2-D set: with one thread per (facet, side) a config-2 launch
+// has 46 workgroups whose threads walk 12 points of ~150 instructions one after the other; spreading the points
+// turns that latency chain into four times as many, four times shorter waves.
+#ifndef KN_MEM_LQ
+#define KN_MEM_LQ 4
+#endif
 template <int NF>
 __global__ __launch_bounds__(256) void knp_membrane_kernel(KnDev D, const KnConsts* __restrict__ Cp, int splitting) {
   const KnConsts& C = *Cp;
@@ -1074,39 +1083,46 @@ __global__ __launch_bounds__(256) void knp_membrane_kernel(KnDev D, const KnCons
   const double* qw = qt;
   const double* qN = qt + nq;
   const double* qdN = qt + nq * (1 + NF);
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= 2 * D.nftot) return;
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = gt / KN_MEM_LQ, lq = gt % KN_MEM_LQ;
+  // lanes past the last (facet, side) repeat the last one and drop their results: the shuffles below see whole groups
+  const bool live = t < 2 * D.nftot;
+  const int tt = live ? t : 2 * D.nftot - 1;
   const int KS = C.K - 1;
-  const int fg = t >> 1;
-  const bool cell_side = t & 1;
+  const int fg = tt >> 1;
+  const bool cell_side = tt & 1;
   const int ms = D.fmodel[fg];
-  const int* pos = D.gam_pos + (size_t)t * NF;   // entry of (facet, side, local vertex) in the membrane row lists
-  if (ms < 0) {
-#pragma unroll
-    for (int a = 0; a < NF; ++a)
-      for (int k = 0; k < KS; ++k) D.gam_e[(size_t)KS * pos[a] + k] = 0.0;
-    return;
-  }
-  FacetData<NF> f;
-  load_facet<NF>(D, C, fg, cell_side, ms, f);
+  const int* pos = D.gam_pos + (size_t)tt * NF;   // entry of (facet, side, local vertex) in the membrane row lists
   double acc[NF][KN_MAXK - 1];
 #pragma unroll
   for (int a = 0; a < NF; ++a)
 #pragma unroll
     for (int k = 0; k < KN_MAXK - 1; ++k) acc[a][k] = 0.0;
-  for (int q = 0; q < nq; ++q) {
-    double fk[KN_MAXK - 1];
-    facet_point<NF>(f, C, q, qw, qN, qdN, splitting, fk);
+  if (ms >= 0) {
+    FacetData<NF> f;
+    load_facet<NF>(D, C, fg, cell_side, ms, f);
+    for (int q = lq; q < nq; q += KN_MEM_LQ) {
+      double fk[KN_MAXK - 1];
+      facet_point<NF>(f, C, q, qw, qN, qdN, splitting, fk);
+#pragma unroll
+      for (int a = 0; a < NF; ++a)
+#pragma unroll
+        for (int k = 0; k < KN_MAXK - 1; ++k) acc[a][k] += qN[q * NF + a] * fk[k];
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < KN_MEM_LQ; m <<= 1)
 #pragma unroll
     for (int a = 0; a < NF; ++a)
 #pragma unroll
-      for (int k = 0; k < KN_MAXK - 1; ++k) acc[a][k] += qN[q * NF + a] * fk[k];
+      for (int k = 0; k < KN_MAXK - 1; ++k) acc[a][k] += __shfl_xor(acc[a][k], m);
+  if (live && lq == 0) {
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+      for (int k = 0; k < KN_MAXK - 1; ++k)
+        if (k < KS) D.gam_e[(size_t)KS * pos[a] + k] = acc[a][k];
   }
-#pragma unroll
-  for (int a = 0; a < NF; ++a)
-#pragma unroll
-    for (int k = 0; k < KN_MAXK - 1; ++k)
-      if (k < KS) D.gam_e[(size_t)KS * pos[a] + k] = acc[a][k];
 }
 
 // Early form (KNPEMI_MEMBRANE_EARLY): everything of the integrand that does not depend on the potential is integrated
@@ -1321,20 +1337,24 @@ __global__ void halo_kernel(KnDev D, int kind, int pack, const int* __restrict__
 // Membrane Robin term of b_emi alone (emiWeakForm.py:228-239), for the runs that assemble the EMI
 // matrix beside the ODE sweep: one thread per membrane row, same arithmetic and entry order as the
 // row kernels, so b_emi is bit-identical to the fused path.
-template <int NF>
+template <int NF, int LPR>
 __global__ __launch_bounds__(256) void emi_membrane_rhs_kernel(KnDev D, const KnConsts* __restrict__ Cp, int splitting) {
   const KnConsts& C = *Cp;
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= D.M) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int mm = t / LPR, sub = t % LPR;
+  const bool live = mm < D.M;                  // lanes past the last row repeat it: the shuffles see whole groups
+  const int m = live ? mm : D.M - 1;
   const int g = D.mrow[m];
   const bool cell_side = g >= C.voff[1];
   double gam = 0.0;
-  for (int e = D.mptr[m]; e < D.mptr[m + 1]; ++e) {
+  for (int e = D.mptr[m] + sub; e < D.mptr[m + 1]; e += LPR) {
     const int ms = D.me_model[e];
     if (ms < 0) continue;
     gam += (cell_side ? 1.0 : -1.0) * C.C_phi * emi_membrane_entry_rhs<NF>(D, C, e, ms, splitting);
   }
-  D.b_emi[g] = D.b_emi[g] + gam;
+#pragma unroll
+  for (int k = 1; k < LPR; k <<= 1) gam += __shfl_xor(gam, k);
+  if (live && sub == 0) D.b_emi[g] = D.b_emi[g] + gam;
 }
 
 int check_launch(const char* what) {
@@ -1491,7 +1511,7 @@ int kn_launch_knp_membrane(knpemi_handle* h, int flags) {
   const int split = (flags & KNPEMI_NO_SPLITTING) ? 0 : 1;
   const int NF = h->NF;
   const size_t lds = (size_t)D.nq_gamma * (1 + NF + (NF == 4 ? 2 * NF : 0)) * sizeof(double);
-  dim3 grid((2 * D.nftot + 255) / 256), block(256);
+  dim3 grid((2 * (size_t)D.nftot * KN_MEM_LQ + 255) / 256), block(256);
   KnProfScope prof(h, KNPEMI_K_KNP_MEMBRANE);
   if (NF == 2) hipLaunchKernelGGL((knp_membrane_kernel<2>), grid, block, lds, h->cur, D, h->d_consts, split);
   else if (NF == 3) hipLaunchKernelGGL((knp_membrane_kernel<3>), grid, block, lds, h->cur, D, h->d_consts, split);
@@ -1517,11 +1537,16 @@ int kn_launch_emi_membrane_rhs(knpemi_handle* h, int flags) {
   const KnDev& D = h->dev;
   if (D.M == 0) return KNPEMI_OK;
   const int split = (flags & KNPEMI_NO_SPLITTING) ? 0 : 1;
-  dim3 grid((D.M + 255) / 256), block(256);
+  const int lpr = h->lpr;      // the same lane groups as the row kernels, so that both forms produce the same bits
+  dim3 grid(((size_t)D.M * lpr + 255) / 256), block(256);
   KnProfScope prof(h, KNPEMI_K_EMI_MEMBRANE);
-  if (h->NF == 2) hipLaunchKernelGGL((emi_membrane_rhs_kernel<2>), grid, block, 0, h->stream, D, h->d_consts, split);
-  else if (h->NF == 3) hipLaunchKernelGGL((emi_membrane_rhs_kernel<3>), grid, block, 0, h->stream, D, h->d_consts, split);
-  else hipLaunchKernelGGL((emi_membrane_rhs_kernel<4>), grid, block, 0, h->stream, D, h->d_consts, split);
+#define KN_ROBIN(NFV, L) hipLaunchKernelGGL((emi_membrane_rhs_kernel<NFV, L>), grid, block, 0, h->stream, D, h->d_consts, split)
+#define KN_ROBIN_L(NFV) \
+  switch (lpr) { case 1: KN_ROBIN(NFV, 1); break; case 2: KN_ROBIN(NFV, 2); break; case 8: KN_ROBIN(NFV, 8); break; \
+                 default: KN_ROBIN(NFV, 4); }
+  if (h->NF == 2) { KN_ROBIN_L(2) } else if (h->NF == 3) { KN_ROBIN_L(3) } else { KN_ROBIN_L(4) }
+#undef KN_ROBIN_L
+#undef KN_ROBIN
   return check_launch("emi_membrane_rhs_kernel");
 }
 
