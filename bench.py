@@ -489,6 +489,8 @@ def main():
                             s.c, s.c_prev, s.phi, s.phi_M_prev, assemble_knp_twice=args.knp_twice,
                             overlap=not args.no_overlap, fuse_update=not args.frozen_state,
                             early_membrane=bool(os.environ.get("KNPEMI_EARLY_MEMBRANE")))
+    if os.environ.get("KNPEMI_OVERLAP_THRESHOLD_US"):      # experiment: when the stepper gives up running the EMI assembly beside the sweep
+        stepper.overlap_threshold_ms = float(os.environ["KNPEMI_OVERLAP_THRESHOLD_US"]) * 1e-3
     dp = stepper.dp
     for m, stim, loc in case.models:
         stepper.add_membrane_model(m, stim, loc)

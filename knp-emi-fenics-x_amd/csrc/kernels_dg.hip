@@ -236,7 +236,8 @@ __device__ __forceinline__ void copy_out(double* __restrict__ dst, const double*
 }
 
 template <int NV> constexpr int dg_fs_emi() { return (6 + 2 * NV) | 1; }   // n[3] area inv_h JNn | gNn[nv] | kN[nv]
-template <int NV> constexpr int dg_fs_knp() { return (6 + NV) | 1; }       // n[3] area inv_h gphiNn | gNn[nv]
+// n[3] area inv_h gphiNn | interior facet: gNn[nv]; membrane facet: G[facet vertex][k], the membrane integrals
+template <int NV, int KS> constexpr int dg_fs_knp() { return (6 + ((NV - 1) * KS > NV ? (NV - 1) * KS : NV)) | 1; }
 
 template <int NV>
 __global__ __launch_bounds__(DG_BLOCK) void dg_emi_kernel(DgDev D, const DgConsts* __restrict__ Cp, int chunk, int splitting) {
@@ -455,7 +456,7 @@ template <int NV, int KS>
 __global__ __launch_bounds__(DG_BLOCK) void dg_knp_kernel(DgDev D, const DgConsts* __restrict__ Cp, int chunk, int splitting) {
   constexpr int GD = NV - 1, NF = NV - 1;
   constexpr int RPB = (DG_BLOCK / NV) * NV;
-  constexpr int FS = dg_fs_knp<NV>();
+  constexpr int FS = dg_fs_knp<NV, KS>();
   extern __shared__ double lds[];
   double* fs = lds;
   double* img = lds + RPB * FS;
@@ -537,6 +538,69 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_knp_kernel(DgDev D, const DgConst
         my[6 + p[b]] = gn;
       }
       my[5] = gphiNn;
+    } else if (nb[0] >= 0) {
+      // membrane facet (knpWeakForm.py:168-214), degree-6 rule, evaluated ONCE per (cell, facet) by this lane for the
+      // three rows that see the facet.  With alpha_k = D_k z_k^2 c_k / sum_j D_j z_j^2 c_j of this side the integrand
+      //   -/+ (C_k g_k - C_k [phi])  is
+      //   sgn * [ alpha_k C_M / (F z_k dt) ([phi] - phi_M - (dt / C_M) I_ch) + I_ch_k / (F z_k) ],  sgn = +1 on the ECS side
+      const int N = nb[0], kind = fi[0] & 3;
+      const int mf = D.mfid[T * NV + p[0]];
+      const double area = GD * G.vol * gf;
+      double jm[NV], pm[NV], It[NV], Ik[NV][KN_MAXK], Gk[NV][KS];
+#pragma unroll
+      for (int a = 1; a < NV; ++a) {
+        const int jn = (fi[0] >> (4 + 2 * p[a])) & 3;
+        const int ln = N * NV + jn - row0;
+        const double phn = (ln >= 0 && ln < nrows) ? img[ln * DG_RPITCH + 7] : D.rec[(size_t)(N * NV + jn) * KN_REC + 7];
+        jm[a] = kind == 2 ? phn - ph[a] : ph[a] - phn;
+        const int q = mf * NF + ((fi[0] >> (12 + 2 * p[a])) & 3);
+        pm[a] = D.phiM[q];
+        double it = 0.0;
+#pragma unroll
+        for (int k = 0; k < KN_MAXK; ++k) {
+          Ik[a][k] = k < C.K ? D.Ich[(size_t)k * D.nq + q] : 0.0;
+          it += Ik[a][k];
+        }
+        It[a] = it;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) Gk[a][k] = 0.0;
+      }
+      const double sgn = kind == 2 ? 1.0 : -1.0;
+      const double* qw = D.qtab;
+      const double* qN = D.qtab + D.nquad;
+      for (int q = 0; q < D.nquad; ++q) {
+        double cq[KN_MAXK], iq[KN_MAXK], jq = 0.0, pq = 0.0, itq = 0.0, Nq[NV];
+#pragma unroll
+        for (int k = 0; k < KN_MAXK; ++k) { cq[k] = 0.0; iq[k] = 0.0; }
+#pragma unroll
+        for (int a = 1; a < NV; ++a) {
+          Nq[a] = qN[q * NF + (a - 1)];
+#pragma unroll
+          for (int k = 0; k < KN_MAXK; ++k) { cq[k] += Nq[a] * cc[a][k]; iq[k] += Nq[a] * Ik[a][k]; }
+          jq += Nq[a] * jm[a]; pq += Nq[a] * pm[a]; itq += Nq[a] * It[a];
+        }
+        double asum = 0.0;
+#pragma unroll
+        for (int k = 0; k < KN_MAXK; ++k) asum += C.az2D[s][k] * cq[k];
+        const double w = sgn * qw[q] * area * (NF == 2 ? 1.0 : 2.0);
+        double drive = jq - pq;
+        if (splitting) drive -= (C.dt / C.C_M) * itq;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const double al = C.az2D[s][k] * cq[k] / asum;
+          const double fz = 1.0 / (C.F * C.z[k]);
+          const double fq = w * (al * C.C_M * fz * C.inv_dt * drive + iq[k] * fz);
+#pragma unroll
+          for (int a = 1; a < NV; ++a) Gk[a][k] += Nq[a] * fq;
+        }
+      }
+      // by the vertex's position among the facet's vertices in the cell's ORIGINAL numbering (the facet is opposite i)
+#pragma unroll
+      for (int a = 1; a < NV; ++a) {
+        const int loc = p[a] < i ? p[a] : p[a] - 1;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) my[6 + loc * KS + k] = Gk[a][k];
+      }
     }
   }
   __syncthreads();
@@ -598,58 +662,11 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_knp_kernel(DgDev D, const DgConst
         }
         bf[f] = -0.5 * (dot<GD>(gphi, n) + gphiNn);   // beta_k = z_k psi D_k bf: drift speed out of this cell
         c2f[f] = on0 ? c2 : 0.0;
-      } else if (on0) {
-        // membrane flux (knpWeakForm.py:168-214), degree-6 rule; with alpha_k = D_k z_k^2 c_k / sum_j D_j z_j^2 c_j of this
-        // side the integrand  -/+ (C_k g_k - C_k [phi])  is
-        //   sgn * [ alpha_k C_M / (F z_k dt) ([phi] - phi_M - (dt / C_M) I_ch) + I_ch_k / (F z_k) ],  sgn = +1 on the ECS side
-        const int N = nb[f];
-        const int mf = D.mfid[T * NV + p[f]];
-        double jm[NV], pm[NV], It[NV], Ik[NV][KN_MAXK];
+      } else if (on0) {   // membrane facet: the integrals of this row's function, prepared by the facet's lane
+        const int fo = p[f];                          // original local vertex opposite the facet
+        const int loc = i < fo ? i : i - 1;
 #pragma unroll
-        for (int a = 0; a < NV; ++a) {
-          if (a == f) continue;
-          const int jn = (fi[f] >> (4 + 2 * p[a])) & 3;
-          const double phn = D.rec[(size_t)(N * NV + jn) * KN_REC + 7];
-          jm[a] = kind == 2 ? phn - ph[a] : ph[a] - phn;
-          const int q = mf * NF + ((fi[f] >> (12 + 2 * p[a])) & 3);
-          pm[a] = D.phiM[q];
-          double it = 0.0;
-#pragma unroll
-          for (int k = 0; k < KN_MAXK; ++k) {
-            Ik[a][k] = k < C.K ? D.Ich[(size_t)k * D.nq + q] : 0.0;
-            it += Ik[a][k];
-          }
-          It[a] = it;
-        }
-        const double sgn = kind == 2 ? 1.0 : -1.0;
-        const double* qw = D.qtab;
-        const double* qN = D.qtab + D.nquad;
-        for (int q = 0; q < D.nquad; ++q) {
-          double cq[KN_MAXK], iq[KN_MAXK], jq = 0.0, pq = 0.0, itq = 0.0, lam0 = 0.0;
-#pragma unroll
-          for (int k = 0; k < KN_MAXK; ++k) { cq[k] = 0.0; iq[k] = 0.0; }
-#pragma unroll
-          for (int a = 0; a < NV; ++a) {
-            if (a == f) continue;
-            const double Nq = qN[q * NF + (a < f ? a : a - 1)];
-            if (a == 0) lam0 = Nq;
-#pragma unroll
-            for (int k = 0; k < KN_MAXK; ++k) { cq[k] += Nq * cc[a][k]; iq[k] += Nq * Ik[a][k]; }
-            jq += Nq * jm[a]; pq += Nq * pm[a]; itq += Nq * It[a];
-          }
-          double asum = 0.0;
-#pragma unroll
-          for (int k = 0; k < KN_MAXK; ++k) asum += C.az2D[s][k] * cq[k];
-          const double w = sgn * qw[q] * area * (NF == 2 ? 1.0 : 2.0) * lam0;
-          double drive = jq - pq;
-          if (splitting) drive -= (C.dt / C.C_M) * itq;
-#pragma unroll
-          for (int k = 0; k < KS; ++k) {
-            const double al = C.az2D[s][k] * cq[k] / asum;
-            const double fz = 1.0 / (C.F * C.z[k]);
-            rhs[k] += w * (al * C.C_M * fz * C.inv_dt * drive + iq[k] * fz);
-          }
-        }
+        for (int k = 0; k < KS; ++k) rhs[k] += fd[6 + loc * KS + k];
       }
     }
     block_slots<NV>(T, nb, slot_self, slot);
@@ -837,12 +854,11 @@ int launch_emi(knpemi_dg* h, int flags) {
 template <int NV>
 int launch_knp_nv(knpemi_dg* h, int chunk, int split) {
   constexpr int rpb = (DG_BLOCK / NV) * NV;
-  const size_t fsb = (size_t)rpb * dg_fs_knp<NV>();
   const dim3 grid(8 * chunk), block(DG_BLOCK);
   switch (h->K - 1) {
-    case 1: hipLaunchKernelGGL((dg_knp_kernel<NV, 1>), grid, block, (fsb + dg_scratch_doubles<NV, 1>()) * sizeof(double), h->stream, h->dev, h->d_consts, chunk, split); break;
-    case 2: hipLaunchKernelGGL((dg_knp_kernel<NV, 2>), grid, block, (fsb + dg_scratch_doubles<NV, 1>()) * sizeof(double), h->stream, h->dev, h->d_consts, chunk, split); break;
-    default: hipLaunchKernelGGL((dg_knp_kernel<NV, 3>), grid, block, (fsb + dg_scratch_doubles<NV, 1>()) * sizeof(double), h->stream, h->dev, h->d_consts, chunk, split); break;
+    case 1: hipLaunchKernelGGL((dg_knp_kernel<NV, 1>), grid, block, ((size_t)rpb * dg_fs_knp<NV, 1>() + dg_scratch_doubles<NV, 1>()) * sizeof(double), h->stream, h->dev, h->d_consts, chunk, split); break;
+    case 2: hipLaunchKernelGGL((dg_knp_kernel<NV, 2>), grid, block, ((size_t)rpb * dg_fs_knp<NV, 2>() + dg_scratch_doubles<NV, 1>()) * sizeof(double), h->stream, h->dev, h->d_consts, chunk, split); break;
+    default: hipLaunchKernelGGL((dg_knp_kernel<NV, 3>), grid, block, ((size_t)rpb * dg_fs_knp<NV, 3>() + dg_scratch_doubles<NV, 1>()) * sizeof(double), h->stream, h->dev, h->d_consts, chunk, split); break;
   }
   return dg_check_launch("dg_knp_kernel");
 }
