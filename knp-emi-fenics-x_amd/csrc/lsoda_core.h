@@ -184,6 +184,21 @@ KN_HD double kn_group_get(double v, int k) {   // value held by lane k of this l
   return v;
 }
 
+// a / b.  On the device: a times the hardware reciprocal estimate refined by two Newton steps (6 instructions, relative
+// error of a few 1e-16) instead of the IEEE division sequence (11 dependent instructions); the integrator is a
+// single dependent chain and divides four to eight times per trip.  The host build (the bit-for-bit comparison with the
+// sequential restatement and the nst / nfe comparison with ODEPACK) keeps the exact quotient.
+KN_HD double kn_div(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  return a * r;
+#else
+  return a / b;
+#endif
+}
+
 // x^e for x >= 0, e > 0 (the step-ratio formulas of DSTODA): exp(e log x), under half the instructions of
 // the general pow() on gfx950 and accurate to a few ulp, far inside what these heuristics resolve.
 KN_HD double kn_powr(double x, double e) { return exp(log(x) * e); }
@@ -845,13 +860,13 @@ struct Lsoda {
     if (m != 0 || meth != 1) {
       if (m != 0) {
         double rm = 1024.0;
-        if (del <= (1024.0 * delp)) rm = del / delp;
+        if (del <= (1024.0 * delp)) rm = kn_div(del, delp);
         rate = fmax(rate, rm);
         crate = fmax(0.2 * crate, rm);
       }
-      const double dcon = del * fmin(1.0, 1.5 * crate) / (tq2 * conit);
+      const double dcon = kn_div(del * fmin(1.0, 1.5 * crate), tq2 * conit);
       if (dcon <= 1.0) {
-        pdest = fmax(pdest, rate / fabs(h * el[1]));
+        pdest = fmax(pdest, kn_div(rate, fabs(h * el[1])));
         if (pdest != 0.0) pdlast = pdest;
         ph = PH_ERR;
         return;
@@ -889,8 +904,8 @@ struct Lsoda {
     const int lb = lhi + 1 > ROWS ? ROWS : lhi + 1;   // an order increase in this phase can reach lhi + 1
     jcur = 0;
     double dsm;
-    if (m == 0) dsm = del / tq2;
-    else dsm = vmnorm(acor) / tq2;
+    if (m == 0) dsm = kn_div(del, tq2);
+    else dsm = kn_div(vmnorm(acor), tq2);
     if (dsm <= 1.0) {
       kflag = 0;
       nst++;

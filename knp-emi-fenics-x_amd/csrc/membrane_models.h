@@ -74,11 +74,11 @@ struct ModelHHSI {
     const double d1 = c == 1 ? 20. : (c == 3 ? 0.002 : 10.);
     const double n2 = c == 1 ? (30. - u) : -u;
     const double d2 = c == 0 ? 18. : (c == 1 ? 10. : 80.);
-    const double e1 = exp(n1 / d1), e2 = exp(n2 / d2);
+    const double e1 = exp(kn_div(n1, d1)), e2 = exp(kn_div(n2, d2));
     const double k1 = c == 0 ? 0.1e3 : 0.01e3;
-    const double alpha = c == 1 ? 0.07e3 * e1 : k1 * n1 / (e1 - 1);
+    const double alpha = c == 1 ? 0.07e3 * e1 : kn_div(k1 * n1, e1 - 1);
     const double k2 = c == 0 ? 4.e3 : 0.125e3;
-    const double beta = c == 1 ? 1.e3 / (e2 + 1) : k2 * e2;
+    const double beta = c == 1 ? kn_div(1.e3, e2 + 1) : k2 * e2;
     const double gate = c == 0 ? m : (c == 1 ? h : n);
     const double dgate = (1 - gate) * alpha - gate * beta;
     const double i_stim = stim * e1 * (t < 125e-3 ? 1.0 : 0.0);
@@ -87,7 +87,7 @@ struct ModelHHSI {
     const double i_K = (glK + gK * (n2q * n2q)) * (V - E_K) - 2 * i_pump;
     I_Na = i_Na;
     I_K = i_K;
-    return c == 3 ? (-i_K - i_Na) / Cm : dgate;
+    return c == 3 ? kn_div(-i_K - i_Na, Cm) : dgate;
   }
   template <class Row>
   KN_HD void finish(const Row& p) const { p[15] = I_Na; p[16] = I_K; p[17] = 0.0; }
@@ -135,11 +135,11 @@ struct ModelHHMV {
     const double d1 = c == 1 ? 20. : (c == 3 ? 2.0 : 10.);
     const double n2 = c == 1 ? (30. - u) : -u;
     const double d2 = c == 0 ? 18. : (c == 1 ? 10. : 80.);
-    const double e1 = exp(n1 / d1), e2 = exp(n2 / d2);
+    const double e1 = exp(kn_div(n1, d1)), e2 = exp(kn_div(n2, d2));
     const double k1 = c == 0 ? 0.1 : 0.01;
-    const double alpha = c == 1 ? 0.07 * e1 : k1 * n1 / (e1 - 1);
+    const double alpha = c == 1 ? 0.07 * e1 : kn_div(k1 * n1, e1 - 1);
     const double k2 = c == 0 ? 4. : 0.125;
-    const double beta = c == 1 ? 1. / (e2 + 1) : k2 * e2;
+    const double beta = c == 1 ? kn_div(1., e2 + 1) : k2 * e2;
     const double gate = c == 0 ? m : (c == 1 ? h : n);
     const double dgate = (1 - gate) * alpha - gate * beta;
     const double i_stim = stim * e1 * (t < 125 ? 1.0 : 0.0);
@@ -148,7 +148,7 @@ struct ModelHHMV {
     const double i_K = (glK + gK * (n2q * n2q)) * (V - E_K) - 2 * i_pump;
     I_Na = i_Na;
     I_K = i_K;
-    return c == 3 ? (-i_K - i_Na) / Cm : dgate;
+    return c == 3 ? kn_div(-i_K - i_Na, Cm) : dgate;
   }
   template <class Row>
   KN_HD void finish(const Row& p) const { p[15] = I_Na; p[16] = I_K; p[17] = 0.0; }
