@@ -214,13 +214,21 @@ __device__ __forceinline__ RecK<KS> lds_rec(const double* recs, int i) {
   return r;
 }
 
+// 1 / a from the hardware estimate and two Newton steps (relative error of a few 1e-16): five instructions instead of the
+// eleven of the IEEE division sequence, once per (row, cell) pair and per quadrature point of the Q1 kernels.
+__device__ __forceinline__ double kn_rcp(double a) {
+  double r = __builtin_amdgcn_rcp(a);
+  r = fma(fma(-a, r, 1.0), r, r);
+  return fma(fma(-a, r, 1.0), r, r);
+}
+
 template <int GDIM, class R>
 __device__ __forceinline__ double simplex_row0(const R (&r)[GDIM + 1], double (&d)[GDIM + 1]) {
   // gradient dot products of lambda_0 with all lambda_j, and the cell measure
   if constexpr (GDIM == 2) {
     const double e1x = r[1].x - r[0].x, e1y = r[1].y - r[0].y;
     const double e2x = r[2].x - r[0].x, e2y = r[2].y - r[0].y;
-    const double det = e1x * e2y - e1y * e2x, inv = 1.0 / det;
+    const double det = e1x * e2y - e1y * e2x, inv = kn_rcp(det);
     const double g1x = e2y * inv, g1y = -e2x * inv;
     const double g2x = -e1y * inv, g2y = e1x * inv;
     const double g0x = -(g1x + g2x), g0y = -(g1y + g2y);
@@ -235,7 +243,7 @@ __device__ __forceinline__ double simplex_row0(const R (&r)[GDIM + 1], double (&
     double g1x = by * cz - bz * cy, g1y = bz * cx - bx * cz, g1z = bx * cy - by * cx;
     double g2x = cy * az - cz * ay, g2y = cz * ax - cx * az, g2z = cx * ay - cy * ax;
     double g3x = ay * bz - az * by, g3y = az * bx - ax * bz, g3z = ax * by - ay * bx;
-    const double det = ax * g1x + ay * g1y + az * g1z, inv = 1.0 / det;
+    const double det = ax * g1x + ay * g1y + az * g1z, inv = kn_rcp(det);
     g1x *= inv; g1y *= inv; g1z *= inv;
     g2x *= inv; g2y *= inv; g2z *= inv;
     g3x *= inv; g3y *= inv; g3z *= inv;
@@ -616,7 +624,7 @@ __device__ __forceinline__ HexInv hex_inverse(const HexEdges& e, const hexq::Poi
   const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
   const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
   const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-  const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02, inv = 1.0 / det;
+  const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02, inv = kn_rcp(det);
   HexInv I;
   I.i[0][0] = c00 * inv; I.i[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * inv;
   I.i[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * inv;
