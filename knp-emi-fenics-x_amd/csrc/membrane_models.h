@@ -177,9 +177,9 @@ struct ModelGlial {
     (void)t;
     const double V = y[0];
     const double dphi = V - E_K;
-    const double C = 1 + exp((dphi + 18.5) / 42.4);
-    const double D = 1 + exp(-(118.6 + V) / 44.1);
-    const double g_Kir = gfac / (C * D);
+    const double C = 1 + exp(kn_div(dphi + 18.5, 42.4));
+    const double D = 1 + exp(kn_div(-(118.6 + V), 44.1));
+    const double g_Kir = kn_div(gfac, C * D);
     const double i_Kir = glK * g_Kir * (V - E_K);
     const double i_Na = glNa * (V - E_Na) + 3 * i_pump;
     const double i_K = i_Kir - 2 * i_pump;
@@ -187,7 +187,7 @@ struct ModelGlial {
     I_Na = i_Na;
     I_K = i_K;
     I_Cl = i_Cl;
-    dy[0] = (-i_K - i_Na - i_Cl) / Cm;
+    dy[0] = kn_div(-i_K - i_Na - i_Cl, Cm);
   }
   static constexpr int CURRENT_LANE = 0;
   KN_HD double rhs_lane(int, double t, const double* y) const {
