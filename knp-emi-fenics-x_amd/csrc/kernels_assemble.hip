@@ -88,6 +88,14 @@ __device__ __forceinline__ void facet_mass_row(const Rec (&p)[NF], int a, double
   }
 }
 
+// 1 / a from the hardware estimate and two Newton steps (relative error of a few 1e-16): five instructions instead of the
+// eleven of the IEEE division sequence, once per (row, cell) pair and per quadrature point of the Q1 kernels.
+__device__ __forceinline__ double kn_rcp(double a) {
+  double r = __builtin_amdgcn_rcp(a);
+  r = fma(fma(-a, r, 1.0), r, r);
+  return fma(fma(-a, r, 1.0), r, r);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Membrane part of an EMI row: coupling C_phi (u_i - u_e)(v_i - v_e) and Robin RHS
 // (emiWeakForm.py:160-165,228-239).  Everything static about the (row, facet) entries e0 .. e0 + ne - 1 was
@@ -212,14 +220,6 @@ __device__ __forceinline__ RecK<KS> lds_rec(const double* recs, int i) {
     r.c = p[3 + KS];
   }
   return r;
-}
-
-// 1 / a from the hardware estimate and two Newton steps (relative error of a few 1e-16): five instructions instead of the
-// eleven of the IEEE division sequence, once per (row, cell) pair and per quadrature point of the Q1 kernels.
-__device__ __forceinline__ double kn_rcp(double a) {
-  double r = __builtin_amdgcn_rcp(a);
-  r = fma(fma(-a, r, 1.0), r, r);
-  return fma(fma(-a, r, 1.0), r, r);
 }
 
 template <int GDIM, class R>
@@ -1010,13 +1010,14 @@ __device__ __forceinline__ void facet_point(const FacetData<NF>& f, const KnCons
 #pragma unroll
   for (int k = 0; k < KN_MAXK; ++k) asum += f.so->az2D[k] * cq[k];
   const double jump = ph_i - ph_e;
+  const double rasum = kn_rcp(asum);
 #pragma unroll
   for (int k = 0; k < KN_MAXK - 1; ++k) {
     fk[k] = 0.0;
     if (k < KS) {
-      const double al = f.so->az2D[k] * cq[k] / asum;
-      const double Cc = al * C.C_M / (C.F * C.z[k] * C.dt);
-      double gr = pmq - C.dt / (C.C_M * al) * iq[k];
+      const double al = f.so->az2D[k] * cq[k] * rasum;
+      const double Cc = al * C.C_M * kn_rcp(C.F * C.z[k] * C.dt);
+      double gr = pmq - C.dt * kn_rcp(C.C_M * al) * iq[k];
       if (splitting) gr += (C.dt / C.C_M) * it;
       fk[k] = wq * f.sgn * (Cc * gr - Cc * jump);
     }
