@@ -337,6 +337,21 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_emi_kernel(DgDev D, const DgConst
         my[6 + NV + p[b]] = kN[b];
       }
       my[5] = JNn;
+    } else if (nb[0] >= 0) {
+      // membrane facet: the Robin datum g = phi_M (- I_ch / C_phi without the splitting scheme) at the facet's nodes, read
+      // once by this lane (two dependent loads) for the three rows that need it
+      const int mf = D.mfid[T * NV + p[0]];
+#pragma unroll
+      for (int a = 1; a < NV; ++a) {
+        const int q = mf * NF + ((fi[0] >> (12 + 2 * p[a])) & 3);
+        double g = D.phiM[q];
+        if (!splitting) {
+          double it = 0.0;
+          for (int k = 0; k < C.K; ++k) it += D.Ich[(size_t)k * D.nq + q];
+          g -= it / C.C_phi;
+        }
+        my[6 + (p[a] < i ? p[a] : p[a] - 1)] = g;
+      }
     }
   }
   __syncthreads();
@@ -398,7 +413,7 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_emi_kernel(DgDev D, const DgConst
         }
         if (on0) rhs += 0.5 * (dot<GD>(J, n) + JNn) * (area * (1.0 / GD));
       } else if (on0) {   // membrane: C_phi [u][v] and C_phi g [v]  (emiWeakForm.py:160-165, 228-239)
-        const int mf = D.mfid[T * NV + p[f]];
+        const int fo = p[f];           // original local vertex opposite the facet: g sits by facet-local position
         double gsum = 0.0;
 #pragma unroll
         for (int a = 0; a < NV; ++a) {
@@ -406,14 +421,7 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_emi_kernel(DgDev D, const DgConst
           const double m2 = C.C_phi * c2 * (a == 0 ? 2.0 : 1.0);
           self[a] += m2;
           nbv[f][a] -= m2;
-          const int q = mf * NF + ((fi[f] >> (12 + 2 * p[a])) & 3);
-          double g = D.phiM[q];
-          if (!splitting) {
-            double it = 0.0;
-            for (int k = 0; k < C.K; ++k) it += D.Ich[(size_t)k * D.nq + q];
-            g -= it / C.C_phi;
-          }
-          gsum += g * m2;
+          gsum += fd[6 + (p[a] < fo ? p[a] : p[a] - 1)] * m2;
         }
         rhs += kind == 3 ? gsum : -gsum;
       }
