@@ -292,6 +292,12 @@ typedef int (*knpemi_halo_fn)(void* ctx, void* vec_dev, int which);
 int knpemi_set_distributed(knpemi_handle* h, const uint8_t* owned, void* reduce_buf_dev, knpemi_allreduce_fn allreduce,
                            knpemi_halo_fn halo, void* ctx);
 /* gather / scatter of entries of a device vector (the pack / unpack of the halo of a solver vector) */
+/* Two-level variant of the distributed EMI preconditioner: next to every rank's AMG cycle a coarse space of one
+ * piecewise-constant function per chunk of consecutive vertices of every sub-domain of every rank (as many chunks as
+ * fit 64 functions in all) -- A_c = Phi^T A Phi is built with <= 64 SpMVs when the hierarchy is (re)built, every
+ * application costs one all-reduce of <= 64 doubles.  Call after knpemi_set_distributed; the reduction buffer then
+ * needs 8 + 64 doubles.  world <= 1 switches it off. */
+int knpemi_set_distributed_coarse(knpemi_handle* h, int rank, int world);
 int knpemi_vec_gather(knpemi_handle* h, const void* vec_dev, const int32_t* idx_dev, int n, void* buf_dev);
 int knpemi_vec_scatter(knpemi_handle* h, void* vec_dev, const int32_t* idx_dev, int n, const void* buf_dev);
 

@@ -220,6 +220,52 @@ __global__ void extrapolate_kernel(int n, double* __restrict__ cur, int stride, 
   old[i] = c;
 }
 
+// ---- coarse space of the distributed EMI preconditioner ---------------------------------------------------------
+// Aggregates (knpemi_set_distributed_coarse): the owned vertices of every sub-domain of this rank, binned into k slices
+// along the longest axis of their bounding box; agg_of[i] = local aggregate of unknown i (-1: ghost), and per aggregate
+// the list of its unknowns (agg_ptr / agg_idx).
+// restriction: one workgroup per local aggregate sums r over its list in a fixed order (reproducible) and writes its
+// entry of the coarse vector in the reduction buffer; the all-reduce fills in the other ranks' entries.
+__global__ __launch_bounds__(256) void coarse_restrict_kernel(const double* __restrict__ r, const int* __restrict__ agg_ptr,
+                                                              const int* __restrict__ agg_idx, int nl, int rank, int world,
+                                                              double* __restrict__ red) {
+  __shared__ double sh[256];
+  const int a = blockIdx.x;
+  double acc = 0.0;
+  for (int t = agg_ptr[a] + threadIdx.x; t < agg_ptr[a + 1]; t += 256) acc += r[agg_idx[t]];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int m = 128; m > 0; m >>= 1) {
+    if ((int)threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) red[KN_COARSE_OFF + rank * nl + a] = sh[0];
+  if (a == 0)   // the other ranks' entries start from zero
+    for (int j = threadIdx.x; j < world * nl; j += 256)
+      if (j / nl != rank) red[KN_COARSE_OFF + j] = 0.0;
+}
+
+// z_c = A_c^+ r_c, this rank's rows only
+__global__ void coarse_solve_kernel(const double* __restrict__ inv, const double* __restrict__ red, int nl, int rank, int nc,
+                                    double* __restrict__ zc) {
+  const int a = threadIdx.x;
+  if (a >= nl) return;
+  const double* row = inv + (size_t)(rank * nl + a) * nc;
+  double v = 0.0;
+  for (int j = 0; j < nc; ++j) v += row[j] * red[KN_COARSE_OFF + j];
+  zc[a] = v;
+}
+
+// prolongation: z += z_c[aggregate] on the owned unknowns (mode 0); mode 1: z = indicator of aggregate `pick`
+__global__ void coarse_prolong_kernel(int n, const int* __restrict__ agg_of, const double* __restrict__ zc, double* __restrict__ z,
+                                      int mode, int pick) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int a = agg_of[i];
+  if (mode == 0) { if (a >= 0) z[i] += zc[a]; }
+  else z[i] = (a >= 0 && a == pick) ? 1.0 : 0.0;
+}
+
 struct Ctx {
   knpemi_handle* h;
   int n;
@@ -333,6 +379,87 @@ static int ensure_work(knpemi_handle* h, size_t n) {
   return KNPEMI_OK;
 }
 
+// r_c = Phi^T r into the reduction buffer (all-reduced): every rank ends up with the whole coarse vector
+static void coarse_restrict(Ctx& c, const double* r) {
+  knpemi_handle* h = c.h;
+  KnDist& d = h->dist;
+  hipLaunchKernelGGL(coarse_restrict_kernel, dim3(d.nl), dim3(256), 0, h->stream, r, d.d_agg_ptr, d.d_agg_idx, d.nl, d.rank,
+                     d.world, d.d_red);
+  if (int e = d.allreduce(d.ctx, KN_COARSE_OFF + d.nc)) c.comm_rc = c.comm_rc ? c.comm_rc : e;
+}
+
+// Coarse operator A_c = Phi^T A Phi of the partitioned EMI system (one column per (rank, sub-domain): an SpMV of its
+// indicator and a restriction), then on the host the inverse of A_c + alpha 1 1^T (A_c has the constants in its kernel;
+// the residuals it is applied to have zero mean) with empty aggregates decoupled.
+static int coarse_setup(Ctx& c, double* work_phi, double* work_y) {
+  knpemi_handle* h = c.h;
+  KnDist& d = h->dist;
+  const int nc = d.nc, nl = d.nl;
+  if (!d.d_coarse_inv) {
+    void* p = nullptr;
+    KN_HIP(hipMalloc(&p, (size_t)KN_COARSE_MAX * KN_COARSE_MAX * sizeof(double))); h->allocs.push_back(p); d.d_coarse_inv = static_cast<double*>(p);
+    KN_HIP(hipMalloc(&p, KN_COARSE_MAX * sizeof(double))); h->allocs.push_back(p); d.d_coarse_z = static_cast<double*>(p);
+  }
+  std::vector<double> Ac((size_t)nc * nc, 0.0), col(nc);
+  for (int j = 0; j < nc; ++j) {
+    const int rj = j / nl, aj = j % nl;
+    // phi_j: 1 on the owned unknowns of aggregate aj of rank rj (ghost copies are filled by the SpMV's halo), 0 elsewhere
+    hipLaunchKernelGGL(coarse_prolong_kernel, grid1(c.n), dim3(256), 0, h->stream, c.n, d.d_agg_of, (const double*)nullptr,
+                       work_phi, 1, rj == d.rank ? aj : -1);
+    spmv(c, work_phi, work_y, nullptr);
+    coarse_restrict(c, work_y);
+    KN_HIP(hipMemcpyAsync(col.data(), d.d_red + KN_COARSE_OFF, nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    KN_HIP(hipStreamSynchronize(h->stream));
+    if (c.comm_rc) { kn_set_error("coarse space set-up: a communication hook failed"); return KNPEMI_EHIP; }
+    for (int i = 0; i < nc; ++i) Ac[(size_t)i * nc + j] = col[i];
+  }
+  // symmetrise (rounding), decouple empty aggregates, shift the constants' kernel, invert (Gauss-Jordan, nc <= 64)
+  double tr = 0.0;
+  for (int i = 0; i < nc; ++i) tr += Ac[(size_t)i * nc + i];
+  const double alpha = tr > 0 ? tr / ((double)nc * nc) : 1.0;
+  std::vector<double> M((size_t)nc * nc), inv((size_t)nc * nc, 0.0);
+  std::vector<char> empty(nc, 0);
+  for (int i = 0; i < nc; ++i) empty[i] = !(Ac[(size_t)i * nc + i] > 0.0);
+  for (int i = 0; i < nc; ++i)
+    for (int j = 0; j < nc; ++j) {
+      double v = 0.5 * (Ac[(size_t)i * nc + j] + Ac[(size_t)j * nc + i]);
+      if (empty[i] || empty[j]) v = i == j ? 1.0 : 0.0;
+      else v += alpha;
+      M[(size_t)i * nc + j] = v;
+    }
+  for (int i = 0; i < nc; ++i) inv[(size_t)i * nc + i] = 1.0;
+  for (int k = 0; k < nc; ++k) {
+    int piv = k;
+    for (int i = k + 1; i < nc; ++i) if (std::fabs(M[(size_t)i * nc + k]) > std::fabs(M[(size_t)piv * nc + k])) piv = i;
+    if (!(std::fabs(M[(size_t)piv * nc + k]) > 0.0)) { kn_set_error("coarse space set-up: singular coarse operator"); return KNPEMI_EINVAL; }
+    if (piv != k)
+      for (int j = 0; j < nc; ++j) { std::swap(M[(size_t)k * nc + j], M[(size_t)piv * nc + j]); std::swap(inv[(size_t)k * nc + j], inv[(size_t)piv * nc + j]); }
+    const double dk = 1.0 / M[(size_t)k * nc + k];
+    for (int j = 0; j < nc; ++j) { M[(size_t)k * nc + j] *= dk; inv[(size_t)k * nc + j] *= dk; }
+    for (int i = 0; i < nc; ++i) {
+      if (i == k) continue;
+      const double f = M[(size_t)i * nc + k];
+      if (f == 0.0) continue;
+      for (int j = 0; j < nc; ++j) { M[(size_t)i * nc + j] -= f * M[(size_t)k * nc + j]; inv[(size_t)i * nc + j] -= f * inv[(size_t)k * nc + j]; }
+    }
+  }
+  for (int i = 0; i < nc; ++i)
+    if (empty[i]) for (int j = 0; j < nc; ++j) inv[(size_t)i * nc + j] = inv[(size_t)j * nc + i] = 0.0;   // nothing to correct there
+  KN_HIP(hipMemcpy(d.d_coarse_inv, inv.data(), inv.size() * sizeof(double), hipMemcpyHostToDevice));
+  d.coarse_built = true;
+  return KNPEMI_OK;
+}
+
+// z += Phi A_c^+ Phi^T r  (additive two-level correction next to the per-rank AMG)
+static void coarse_correct(Ctx& c, const double* r, double* z) {
+  knpemi_handle* h = c.h;
+  KnDist& d = h->dist;
+  coarse_restrict(c, r);
+  hipLaunchKernelGGL(coarse_solve_kernel, dim3(1), dim3(KN_COARSE_MAX), 0, h->stream, d.d_coarse_inv, d.d_red, d.nl, d.rank, d.nc,
+                     d.d_coarse_z);
+  hipLaunchKernelGGL(coarse_prolong_kernel, grid1(c.n), dim3(256), 0, h->stream, c.n, d.d_agg_of, d.d_coarse_z, z, 0, 0);
+}
+
 // Jacobi-PCG on A_emi x = b_emi, x = phi (record component 7, gathered into a contiguous vector first).
 int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* iters, double* relres) {
   KnDev& D = h->dev;
@@ -378,8 +505,19 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     G.its_ref = -1;
     ++G.builds;
   }
+  // two-level variant on a partitioned mesh: the ranks' AMG cycles do not see each other, a coarse space of one
+  // constant per (rank, sub-domain) carries the error across the cuts (knpemi_set_distributed_coarse)
+  const bool coarse = dist.on && amg && h->dist.nc > 0;
+  if (coarse && (!h->dist.coarse_built || G.its_ref < 0)) {
+    if ((rc = coarse_setup(c, p, q))) return rc;               // p, q are free before the first search direction
+  }
   auto precond = [&]() -> int {
-    if (amg) return kn_amg_apply(h, G, D.A_emi, dinv, r, q, z);   // q = A p is free here
+    if (amg) {
+      int e = kn_amg_apply(h, G, D.A_emi, dinv, r, q, z);      // q = A p is free here
+      if (e) return e;
+      if (coarse) coarse_correct(c, r, z);
+      return KNPEMI_OK;
+    }
     vec(c, V_JACOBI, z, nullptr, r, dinv);
     return KNPEMI_OK;
   };

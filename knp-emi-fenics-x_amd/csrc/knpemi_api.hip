@@ -1297,6 +1297,60 @@ extern "C" int knpemi_set_distributed(knpemi_handle* h, const uint8_t* owned, vo
   return KNPEMI_OK;
 }
 
+extern "C" int knpemi_set_distributed_coarse(knpemi_handle* h, int rank, int world) {
+  if (!h) return fail(KNPEMI_EINVAL, "null handle");
+  KnDist& d = h->dist;
+  if (world <= 1) { d.nc = 0; d.coarse_built = false; return KNPEMI_OK; }
+  if (rank < 0 || rank >= world) return fail(KNPEMI_EINVAL, "knpemi_set_distributed_coarse: bad rank");
+  if (world * h->n_sub > KN_COARSE_MAX)
+    return fail(KNPEMI_EINVAL, "knpemi_set_distributed_coarse: more than 64 (rank, sub-domain) aggregates");
+  if (!d.on) return fail(KNPEMI_EINVAL, "knpemi_set_distributed_coarse: call knpemi_set_distributed first");
+  KN_HIP(hipSetDevice(h->device));
+  d.rank = rank; d.world = world;
+  d.k = std::max(1, KN_COARSE_MAX / (world * h->n_sub));      // as many slices per sub-domain as the coarse size allows
+  d.nl = h->n_sub * d.k;
+  d.nc = world * d.nl;
+  d.coarse_built = false;
+  // aggregates: the owned vertices of a sub-domain, binned along the longest axis of their bounding box
+  const int Ntot = h->dev.Ntot;
+  std::vector<double> rec((size_t)Ntot * KN_REC);
+  KN_HIP(hipMemcpy(rec.data(), h->dev.VR, rec.size() * sizeof(double), hipMemcpyDeviceToHost));
+  std::vector<int> agg_of(Ntot, -1);
+  for (int s = 0; s < h->n_sub; ++s) {
+    const int v0 = h->voff[s], v1 = v0 + h->n_vert[s];
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int v = v0; v < v1; ++v) {
+      if (!d.h_owned_emi[v]) continue;
+      for (int a = 0; a < h->gdim; ++a) { lo[a] = std::min(lo[a], rec[(size_t)v * KN_REC + a]); hi[a] = std::max(hi[a], rec[(size_t)v * KN_REC + a]); }
+    }
+    int ax = 0;
+    for (int a = 1; a < h->gdim; ++a) if (hi[a] - lo[a] > hi[ax] - lo[ax]) ax = a;
+    const double len = hi[ax] - lo[ax];
+    for (int v = v0; v < v1; ++v) {
+      if (!d.h_owned_emi[v]) continue;
+      int bin = len > 0 ? (int)((rec[(size_t)v * KN_REC + ax] - lo[ax]) / len * d.k) : 0;
+      agg_of[v] = s * d.k + std::min(d.k - 1, std::max(0, bin));
+    }
+  }
+  std::vector<int> ptr(d.nl + 1, 0), idx;
+  for (int v = 0; v < Ntot; ++v) if (agg_of[v] >= 0) ++ptr[agg_of[v] + 1];
+  for (int a = 0; a < d.nl; ++a) ptr[a + 1] += ptr[a];
+  idx.resize(ptr[d.nl]);
+  {
+    std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+    for (int v = 0; v < Ntot; ++v) if (agg_of[v] >= 0) idx[fill[agg_of[v]]++] = v;
+  }
+  int rc;
+  const int* p = nullptr;
+  if ((rc = dev_upload(h, agg_of, &p))) return rc;
+  d.d_agg_of = const_cast<int*>(p);
+  if ((rc = dev_upload(h, ptr, &p))) return rc;
+  d.d_agg_ptr = const_cast<int*>(p);
+  if ((rc = dev_upload(h, idx, &p))) return rc;
+  d.d_agg_idx = const_cast<int*>(p);
+  return KNPEMI_OK;
+}
+
 extern "C" int knpemi_vec_gather(knpemi_handle* h, const void* vec_dev, const int32_t* idx_dev, int n, void* buf_dev) {
   if (!h || n < 0 || (n > 0 && (!vec_dev || !idx_dev || !buf_dev))) return fail(KNPEMI_EINVAL, "knpemi_vec_gather: bad argument");
   KN_HIP(hipSetDevice(h->device));

@@ -135,6 +135,7 @@ SIGNATURES = {
     "knpemi_halo_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "knpemi_halo_unpack": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "knpemi_set_distributed": (C.c_int, [C.c_void_p, c_u8_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "knpemi_set_distributed_coarse": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "knpemi_vec_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "knpemi_vec_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "knpemi_comm_unique_id": (C.c_int, [C.c_char_p, C.c_size_t]),

@@ -292,7 +292,7 @@ class Halo:
             return np.concatenate([base + k * nvs[s] for k in range(KS)])
         self._vec = {L.B_EMI: self._device_plan(self.plans["bulk"], 1),
                      L.B_KNP: self._device_plan_knp(knp_index)}
-        self._red = torch.zeros(8, dtype=torch.float64, device=self._device)
+        self._red = torch.zeros(8 + 64, dtype=torch.float64, device=self._device)    # 8 scalars + the coarse vector
         self._hook_error = None
 
         def allreduce(ctx, n):
@@ -335,6 +335,8 @@ class Halo:
             self._cb = (L.ALLREDUCE_FN(allreduce), L.HALO_FN(halo))    # keep the callbacks alive
             L.check(dp.lib.knpemi_set_distributed(dp.h, own.ctypes.data_as(L.c_u8_p), self._red.data_ptr(),
                                                   C.cast(self._cb[0], C.c_void_p), C.cast(self._cb[1], C.c_void_p), None))
+        if os.environ.get("KNPEMI_NO_COARSE") is None and self.dist.get_world_size() * len(dp.n_vert) <= 64:
+            L.check(dp.lib.knpemi_set_distributed_coarse(dp.h, self.dist.get_rank(), self.dist.get_world_size()))
         self.supports_solves = True
 
     def _device_plan_knp(self, knp_index):
