@@ -278,7 +278,7 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, wo
     """The DG(P1) + interior-penalty variant (csrc/kernels_dg.hip) on the workload's mesh: one step =
     membrane ODE sweep over the facet nodes + potential-system assembly + concentration-systems assembly + end-of-step
     update (+ the ghost-cell refresh at N > 1: x-slabs of an N times longer box, knpemi.dg.DGSlab), device-resident.
-    Its linear solves are not on the device, so the fields stay at the initial state."""
+    The timed steps hold the fields at the initial state; `with_solves` then runs whole steps with the device solves."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import dg_time
@@ -374,12 +374,36 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, wo
                    "partition": ("none" if slab is None else
                                  f"x-slabs of a {32 * world} um box (config 2 per GPU), one ghost-cell layer per cut, "
                                  f"ghost dofs refreshed once per step: {slab.mode}"),
-                   "state": "fields held at the initial state (the DG systems are not solved on the device)"},
+                   "state": "fields held at the initial state in the timed steps; whole steps with the device solves in with_solves"},
         "roofline": roof(1, "dg_knp_kernel", knp_us),
         "roofline_potential_kernel": roof(0, "dg_emi_kernel", emi_us),
         "kernels_us_per_step": {"dg_emi_kernel": emi_us, "dg_knp_kernel": knp_us},
         "ode": {"rhs_evals_per_dof_per_step": n_rhs / max(1, dp.nmf * dp.nf) / steps},
     }
+    n_solve = getattr(args, "solve_steps", 0)
+    if world == 1 and cpu and n_solve > 0 and dp.n <= 1_000_000:
+        # whole DG time steps: the two systems solved on the device (CG / BiCGStab + auxiliary-space AMG at the reference's
+        # rtol 1e-5 / 1e-7, knpemi_dg_solve_emi/knp), the update taken from the solution without leaving the device
+        def solved_step(k):
+            dp.ode_step(k * dt, dt, set_v=k > 0)
+            dp.assemble_emi()
+            a = dp.solve_emi(rtol=1e-5)[0]
+            dp.assemble_knp()
+            b = dp.solve_knp(rtol=1e-7, update=True)[0]
+            return a, b
+        k0 = warmup + steps
+        t0 = time.perf_counter()
+        solved_step(k0)                        # builds the two hierarchies on the host
+        dp.sync()
+        t_first = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        its = [solved_step(k0 + 1 + k) for k in range(n_solve)]
+        dp.sync()
+        ts = (time.perf_counter() - t0) / n_solve
+        out["with_solves"] = {"ms_per_step": ts * 1e3, "steps": n_solve, "first_step_with_amg_setup_s": t_first,
+                              "cg_iterations_per_step": sum(a for a, _ in its) / n_solve,
+                              "bicgstab_iterations_per_step": sum(b for _, b in its) / n_solve,
+                              "rtol": [1e-5, 1e-7], "state": "membrane at rest (no stimulus), fields evolving"}
     if cpu and rank == 0 and world == 1:      # the only use of oracle/ in this function: the timed CPU restatement
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import knpemi_dg_oracle as dgo

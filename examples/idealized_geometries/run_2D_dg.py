@@ -1,9 +1,10 @@
 """The 2D idealized run (`run_2D.py:137-372` of the reference: one cell in the ECS, K / Cl / Na, Hodgkin-Huxley membrane,
 synaptic stimulus on x < 20 um) with the DG(P1) + interior-penalty variant (`knpemi.dg.DGProblem`):
-membrane ODEs at the facet nodes and both assemblies on the GPU; the two linear systems of a step are solved on the host
-with SciPy (the variant has no device solver yet) from the CSR the kernels fill.
+membrane ODEs at the facet nodes, both assemblies, both linear solves (CG / BiCGStab + auxiliary-space AMG,
+`knpemi_dg_solve_emi/knp`) and the end-of-step update on the GPU; `--host-solves` solves the two systems with SciPy
+from the CSR the kernels fill instead.
 
-    python run_2D_dg.py [--resolution 1] [--steps 100]
+    python run_2D_dg.py [--resolution 1] [--steps 100] [--host-solves]
 """
 import argparse
 import os
@@ -33,7 +34,8 @@ def solve_singular(A, b):
 
 
 class DGRun:
-    def __init__(self, resolution=1, g_syn=10.0, dt=DT):
+    def __init__(self, resolution=1, g_syn=10.0, dt=DT, device_solves=True, rtol=(1e-5, 1e-7)):
+        self.device_solves, self.rtol, self.iterations = device_solves, rtol, []
         mesh, ct, ft = make_mesh_2D(resolution)
         self.dp = dp = DGProblem(mesh, ct, ft, [0, 1], [1])
         self.ions = [dict(name="K", z=1.0, D=[D_K] * 2), dict(name="Cl", z=-1.0, D=[D_CL] * 2), dict(name="Na", z=1.0, D=[D_NA] * 2)]
@@ -61,11 +63,17 @@ class DGRun:
         dp = self.dp
         dp.ode_step(self.time, self.dt, set_v=self.k > 0)           # traces -> LSODA -> phi_M, I_ch
         dp.assemble_emi()
-        phi = solve_singular(dp.matrix(0), dp.rhs(0))
-        dp.set_potential(phi)
-        dp.assemble_knp()
-        c_new = np.stack([spla.splu(dp.matrix(1 + k).tocsc()).solve(dp.rhs(1 + k)) for k in range(2)])
-        dp.update(c_new)
+        if self.device_solves:                                       # pdeSolver.py:24-35,99-110 (rtol 1e-5 / 1e-7)
+            it_emi = dp.solve_emi(rtol=self.rtol[0])[0]
+            dp.assemble_knp()
+            it_knp = dp.solve_knp(rtol=self.rtol[1], update=True)[0]
+            self.iterations.append((it_emi, it_knp))
+        else:
+            phi = solve_singular(dp.matrix(0), dp.rhs(0))
+            dp.set_potential(phi)
+            dp.assemble_knp()
+            c_new = np.stack([spla.splu(dp.matrix(1 + k).tocsc()).solve(dp.rhs(1 + k)) for k in range(2)])
+            dp.update(c_new)
         n_rhs, n_steps, n_failed = dp.ode_stats()
         assert n_failed == 0                                         # odeSolver.py:121
         self.time += self.dt
@@ -76,10 +84,12 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--resolution", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--host-solves", action="store_true")
     a = ap.parse_args()
-    run = DGRun(a.resolution)
+    run = DGRun(a.resolution, device_solves=not a.host_solves)
     for k in range(a.steps):
         run.step()
         if (k + 1) % 10 == 0:
             v = run.dp.get_membrane_potential()
-            print(f"t = {run.time * 1e3:5.1f} ms   phi_M: mean {v.mean() * 1e3:8.3f} mV, max {v.max() * 1e3:8.3f} mV")
+            its = f"   iterations {run.iterations[-1]}" if run.iterations else ""
+            print(f"t = {run.time * 1e3:5.1f} ms   phi_M: mean {v.mean() * 1e3:8.3f} mV, max {v.max() * 1e3:8.3f} mV{its}")

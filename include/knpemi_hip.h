@@ -407,6 +407,16 @@ int knpemi_dg_device_system(knpemi_dg* h, int which, const int32_t** rowptr, con
 /* End of step (utils.py:238-295): c_prev <- c_new ([K-1][n_dofs], host or device pointer), eliminated ion from
  * electroneutrality dof by dof, phi_M <- phi_i - phi_e at the membrane nodes. */
 int knpemi_dg_update(knpemi_dg* h, const double* c_new, int on_device);
+/* Device solves of the DG systems (the KSP solves of pdeSolver.py:24-35,74-78,99-110 with the iterative options,
+ * SURVEY section 8 f1 for the f4 variant): CG on the potential system with the constants projected out, BiCGStab on the
+ * K - 1 concentration systems, both preconditioned by the library's smoothed-aggregation AMG whose first coarse level is
+ * the continuous P1 space of every sub-domain (auxiliary space) under a damped-Jacobi smoother on the broken dofs.
+ * Start from the current potential / the previous concentrations, stop at ||r|| <= max(atol, rtol ||b||),
+ * KNPEMI_ESOLVE at maxit.  solve_emi writes the potential field; solve_knp keeps the solution on the device and, with
+ * update != 0, runs knpemi_dg_update on it; knpemi_dg_get_solution copies it out ([K-1][n_dofs]).  Single rank. */
+int knpemi_dg_solve_emi(knpemi_dg* h, double rtol, double atol, int maxit, int* iters, double* relres);
+int knpemi_dg_solve_knp(knpemi_dg* h, double rtol, double atol, int maxit, int* iters, double* relres, int update);
+int knpemi_dg_get_solution(knpemi_dg* h, double* c_host);
 /* Membrane ODE sweep over the membrane nodes with one of the built-in models (KNPEMI_MODEL_*): same kernel, tables and
  * flags as knpemi_ode_step; states / params are [n_mem_nodes][n_states | n_params] row-major on the host. */
 int knpemi_dg_ode_bind(knpemi_dg* h, int model_id, int n_states, int n_params, const double* states, const double* params,

@@ -157,6 +157,74 @@ double estimate_rho(const HostCsr& A, const std::vector<double>& d) {
   return std::min(bound, 1.1 * lam);
 }
 
+// inverse of the bs x bs matrix m (row-major, destroyed); false if a pivot vanishes
+template <class T>
+bool small_inverse(T* m, T* inv, int bs) {
+  for (int i = 0; i < bs; ++i) for (int j = 0; j < bs; ++j) inv[i * bs + j] = i == j ? 1.0 : 0.0;
+  for (int k = 0; k < bs; ++k) {
+    int piv = k;
+    for (int i = k + 1; i < bs; ++i) if (fabs(m[i * bs + k]) > fabs(m[piv * bs + k])) piv = i;
+    if (m[piv * bs + k] == 0.0) return false;
+    if (piv != k)
+      for (int j = 0; j < bs; ++j) {
+        T t = m[k * bs + j]; m[k * bs + j] = m[piv * bs + j]; m[piv * bs + j] = t;
+        t = inv[k * bs + j]; inv[k * bs + j] = inv[piv * bs + j]; inv[piv * bs + j] = t;
+      }
+    const T d = 1.0 / m[k * bs + k];
+    for (int j = 0; j < bs; ++j) { m[k * bs + j] *= d; inv[k * bs + j] *= d; }
+    for (int i = 0; i < bs; ++i) {
+      if (i == k) continue;
+      const T f = m[i * bs + k];
+      for (int j = 0; j < bs; ++j) { m[i * bs + j] -= f * m[k * bs + j]; inv[i * bs + j] -= f * inv[k * bs + j]; }
+    }
+  }
+  return true;
+}
+
+// spectral radius of B^-1 A, B = the bs x bs diagonal blocks of A (power iteration, fixed seed)
+double estimate_rho_block(const HostCsr& A, int bs) {
+  const int nb = A.n / bs;
+  std::vector<double> binv((size_t)nb * bs * bs);
+  for (int c = 0; c < nb; ++c) {
+    double m[16] = {0};
+    for (int a = 0; a < bs; ++a)
+      for (int j = A.rp[c * bs + a]; j < A.rp[c * bs + a + 1]; ++j) {
+        const int b = A.ci[j] - c * bs;
+        if (b >= 0 && b < bs) m[a * bs + b] = A.v[j];
+      }
+    if (!small_inverse(m, &binv[(size_t)c * bs * bs], bs)) return -1.0;
+  }
+  std::vector<double> v(A.n), w(A.n), u(A.n);
+  uint64_t state = 0x9E3779B97F4A7C15ull;
+  for (int i = 0; i < A.n; ++i) {
+    state = state * 6364136223846793005ull + 1442695040888963407ull;
+    v[i] = (double)(state >> 11) / 9007199254740992.0 - 0.5;
+  }
+  double lam = 1.0;
+  for (int it = 0; it < 20; ++it) {
+    for (int i = 0; i < A.n; ++i) {
+      double s = 0.0;
+      for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) s += A.v[j] * v[A.ci[j]];
+      u[i] = s;
+    }
+    double nrm = 0.0;
+    for (int c = 0; c < nb; ++c)
+      for (int a = 0; a < bs; ++a) {
+        double s = 0.0;
+        for (int b = 0; b < bs; ++b) s += binv[((size_t)c * bs + a) * bs + b] * u[c * bs + b];
+        w[c * bs + a] = s;
+        nrm += s * s;
+      }
+    nrm = std::sqrt(nrm);
+    if (!(nrm > 0)) break;
+    double dot = 0.0, vv = 0.0;
+    for (int i = 0; i < A.n; ++i) { dot += w[i] * v[i]; vv += v[i] * v[i]; }
+    lam = std::fabs(dot / vv);
+    for (int i = 0; i < A.n; ++i) v[i] = w[i] / nrm;
+  }
+  return 1.1 * lam;     // the iteration approaches rho from below
+}
+
 // P = (I - w D^-1 A) T for the piecewise-constant T of `agg`
 HostCsr smoothed_prolongator(const HostCsr& A, const std::vector<double>& d, const std::vector<int>& agg, int na, double w) {
   HostCsr P;
@@ -222,13 +290,14 @@ bool dense_inverse(const HostCsr& A, bool singular, std::vector<double>& inv) {
 
 // ---- device kernels -------------------------------------------------------------------------------
 
-enum { M_AX = 0, M_PRE, M_ADD, M_JAC };
+enum { M_AX = 0, M_PRE, M_ADD, M_JAC, M_RES };
 
 // LPR lanes per row.
 //   M_AX : y = A x
 //   M_PRE: x = w dinv r (this row), y = r - A (w dinv r)      pre-smoothing from a zero guess + residual
 //   M_ADD: y += A x                                             prolongation
 //   M_JAC: y = x + w dinv (r - A x)                            post-smoothing (y != x)
+//   M_RES: y = r - A x                                          residual (block-Jacobi smoothing applies B^-1 apart)
 template <int MODE, int LPR>
 __global__ __launch_bounds__(256) void amg_spmv_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ colind,
                                                        const double* __restrict__ vals, const double* x,
@@ -250,8 +319,59 @@ __global__ __launch_bounds__(256) void amg_spmv_kernel(int n, const int* __restr
     if (MODE == M_AX) y[row] = acc;
     else if (MODE == M_PRE) { y[row] = r[row] - w * acc; xout[row] = w * dinv[row] * r[row]; }
     else if (MODE == M_ADD) y[row] += acc;
+    else if (MODE == M_RES) y[row] = r[row] - acc;
     else y[row] = x[row] + w * dinv[row] * (r[row] - acc);
   }
+}
+
+// binv[c] = inverse of the BS x BS diagonal block of cell c (rows c BS .. c BS + BS - 1)
+template <int BS>
+__global__ void amg_block_inv_kernel(int nb, const int* __restrict__ rowptr, const int* __restrict__ colind,
+                                     const double* __restrict__ vals, double* __restrict__ binv) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nb) return;
+  double m[BS * BS], inv[BS * BS];
+#pragma unroll
+  for (int i = 0; i < BS * BS; ++i) m[i] = 0.0;
+#pragma unroll
+  for (int a = 0; a < BS; ++a)
+    for (int j = rowptr[c * BS + a]; j < rowptr[c * BS + a + 1]; ++j) {
+      const int b = colind[j] - c * BS;
+#pragma unroll
+      for (int bb = 0; bb < BS; ++bb) if (b == bb) m[a * BS + bb] = vals[j];
+    }
+  // Gauss-Jordan without pivoting, fully unrolled (registers only): the diagonal blocks of the SIP / mass-dominated
+  // systems are positive definite
+#pragma unroll
+  for (int i = 0; i < BS * BS; ++i) inv[i] = (i / BS == i % BS) ? 1.0 : 0.0;
+#pragma unroll
+  for (int k = 0; k < BS; ++k) {
+    const double d = 1.0 / m[k * BS + k];
+#pragma unroll
+    for (int j = 0; j < BS; ++j) { m[k * BS + j] *= d; inv[k * BS + j] *= d; }
+#pragma unroll
+    for (int i = 0; i < BS; ++i) {
+      if (i == k) continue;
+      const double f = m[i * BS + k];
+#pragma unroll
+      for (int j = 0; j < BS; ++j) { m[i * BS + j] -= f * m[k * BS + j]; inv[i * BS + j] -= f * inv[k * BS + j]; }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < BS * BS; ++i) binv[(size_t)c * BS * BS + i] = inv[i];
+}
+
+// y = (x ? x : 0) + w B^-1 v, block by block (one thread per unknown)
+template <int BS>
+__global__ void amg_block_apply_kernel(int n, const double* __restrict__ binv, const double* __restrict__ v, const double* x,
+                                       double w, double* y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = i / BS, a = i % BS;
+  double s = 0.0;
+#pragma unroll
+  for (int b = 0; b < BS; ++b) s += binv[((size_t)c * BS + a) * BS + b] * v[c * BS + b];
+  y[i] = (x ? x[i] : 0.0) + w * s;
 }
 
 __global__ void amg_diag_inv_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ colind,
@@ -286,6 +406,13 @@ void launch_spmv(hipStream_t st, int n, int avg_row, const int* rp, const int* c
     dim3 g(((size_t)n * 4 + 255) / 256);
     hipLaunchKernelGGL((amg_spmv_kernel<MODE, 4>), g, dim3(256), 0, st, n, rp, ci, v, x, r, dinv, w, y, xout);
   }
+}
+
+// y = (x ? x : 0) + omega_block B^-1 v on the finest level
+void block_apply(hipStream_t st, const KnAmg& G, int n, const double* v, const double* x, double* y) {
+  dim3 g((n + 255) / 256);
+  if (G.block == 3) hipLaunchKernelGGL(amg_block_apply_kernel<3>, g, dim3(256), 0, st, n, G.binv, v, x, G.omega_block, y);
+  else hipLaunchKernelGGL(amg_block_apply_kernel<4>, g, dim3(256), 0, st, n, G.binv, v, x, G.omega_block, y);
 }
 
 template <class T>
@@ -361,6 +488,16 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
     const double rho = estimate_rho(cur, d);
     L.omega = 4.0 / (3.0 * rho);
     L.avg_row = cur.n ? (int)(cur.ci.size() / (size_t)cur.n) : 0;
+    if (l == 0 && G.block > 0) {
+      if (cur.n % G.block || G.block > 4) { kn_set_error("AMG set-up: bad smoother block size"); return KNPEMI_EINVAL; }
+      const double rb = estimate_rho_block(cur, G.block);
+      if (!(rb > 0)) { kn_set_error("AMG set-up: singular diagonal block"); return KNPEMI_ESOLVE; }
+      G.omega_block = 4.0 / (3.0 * rb);
+      void* pb = nullptr;
+      KN_HIP(hipMalloc(&pb, (size_t)cur.n * G.block * sizeof(double)));
+      G.allocs.push_back(pb);
+      G.binv = static_cast<double*>(pb);
+    }
     if (l == 0) {   // the finest operator is the caller's CSR of the current step
       L.A.n = L.A.m = cur.n; L.A.nnz = (int)cur.ci.size();
       L.A.rp = const_cast<int*>(d_rowptr); L.A.ci = const_cast<int*>(d_colind); L.A.v = const_cast<double*>(d_vals);
@@ -370,7 +507,10 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
     if ((rc = upload(G, dinv, &L.dinv, st))) return rc;
     std::vector<int> agg;
     int na = 0;
-    if (cur.n > n_dense) {
+    if (l == 0 && G.first_na > 0 && (int)G.first_agg.size() == cur.n) {
+      agg = G.first_agg;
+      na = G.first_na;
+    } else if (cur.n > n_dense) {
       // a threshold that leaves (almost) no strong connections stalls the coarsening: relax it for this level
       double th = theta;
       for (int attempt = 0; attempt < 6; ++attempt, th = attempt == 5 ? 0.0 : 0.5 * th) {
@@ -443,7 +583,10 @@ int kn_amg_apply(knpemi_handle* h, KnAmg& G, const double* vals, const double* d
       }
       break;
     }
-    launch_spmv<M_PRE>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, nullptr, rl, dinv, L.omega, L.t, xl);
+    if (l == 0 && G.block > 0) {   // x = w B^-1 r, t = r - A x
+      block_apply(st, G, L.n, rl, nullptr, xl);
+      launch_spmv<M_RES>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, xl, rl, nullptr, 0.0, L.t);
+    } else launch_spmv<M_PRE>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, nullptr, rl, dinv, L.omega, L.t, xl);
     launch_spmv<M_AX>(st, L.nc, L.r_row, L.R.rp, L.R.ci, L.R.v, L.t, nullptr, nullptr, 0.0, G.lev[l + 1].r);
   }
   for (int l = nl - 2; l >= 0; --l) {
@@ -453,7 +596,23 @@ int kn_amg_apply(knpemi_handle* h, KnAmg& G, const double* vals, const double* d
     const double* Av = l == 0 ? vals : L.A.v;
     const double* dinv = l == 0 ? dinv0 : L.dinv;
     launch_spmv<M_ADD>(st, L.n, L.p_row, L.P.rp, L.P.ci, L.P.v, G.lev[l + 1].t, nullptr, nullptr, 0.0, xl);
-    launch_spmv<M_JAC>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, xl, rl, dinv, L.omega, l == 0 ? out : L.t);
+    if (l == 0 && G.block > 0) {   // out = x + w B^-1 (r - A x); the level's t is free again
+      launch_spmv<M_RES>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, xl, rl, nullptr, 0.0, L.t);
+      block_apply(st, G, L.n, L.t, xl, out);
+    } else launch_spmv<M_JAC>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, xl, rl, dinv, L.omega, l == 0 ? out : L.t);
   }
+  return KNPEMI_OK;
+}
+
+int kn_amg_refresh(knpemi_handle* h, KnAmg& G, const double* vals) {
+  if (!G.built || G.block <= 0 || G.lev.empty() || G.lev[0].nc == 0) return KNPEMI_OK;
+  const KnAmgLevel& L = G.lev[0];
+  const int nb = L.n / G.block;
+  dim3 g((nb + 255) / 256);
+  if (G.block == 3) hipLaunchKernelGGL(amg_block_inv_kernel<3>, g, dim3(256), 0, h->stream, nb, L.A.rp, L.A.ci, vals, G.binv);
+  else if (G.block == 4) hipLaunchKernelGGL(amg_block_inv_kernel<4>, g, dim3(256), 0, h->stream, nb, L.A.rp, L.A.ci, vals, G.binv);
+  else { kn_set_error("AMG: smoother blocks of 3 or 4 unknowns only"); return KNPEMI_EINVAL; }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { kn_set_error(std::string("amg_block_inv_kernel: ") + hipGetErrorString(e)); return KNPEMI_EHIP; }
   return KNPEMI_OK;
 }

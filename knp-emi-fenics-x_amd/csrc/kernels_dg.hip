@@ -789,6 +789,12 @@ struct knpemi_dg {
   double* d_params = nullptr;
   unsigned long long* d_stats = nullptr;
   void* d_coef = nullptr;
+  // device solves (knpemi_dg_solve_emi / knpemi_dg_solve_knp): the Krylov + AMG code of the CG path run on the DG
+  // systems through a handle that only carries what the solvers read
+  std::vector<int> aux_of;         // continuous P1 dof (sub-domain, mesh vertex) of every broken dof
+  int n_aux = 0;
+  knpemi_handle* sol = nullptr;
+  double* d_csol = nullptr;        // [K-1][n_dofs] solved concentrations
 };
 
 namespace {
@@ -887,6 +893,14 @@ extern "C" void knpemi_dg_destroy(knpemi_dg* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : h->allocs) (void)hipFree(p);
   kn_comm_free(h->comm);
+  if (h->sol) {
+    kn_amg_free(h->sol->amg_emi);
+    kn_amg_free(h->sol->amg_knp);
+    if (h->sol->graph_emi.exec) (void)hipGraphExecDestroy(h->sol->graph_emi.exec);
+    if (h->sol->graph_knp.exec) (void)hipGraphExecDestroy(h->sol->graph_knp.exec);
+    for (void* p : h->sol->allocs) (void)hipFree(p);
+    delete h->sol;
+  }
   if (h->d_coef) (void)hipFree(h->d_coef);
   for (auto& v : h->prof_ev) for (hipEvent_t e : v) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -948,6 +962,17 @@ extern "C" int knpemi_dg_create(const knpemi_dg_desc* d, int device, knpemi_dg**
   for (int c = 0; c < nc; ++c) csub[c] = (unsigned char)d->cell_sub[c];
   h->h_q2e.assign((size_t)nmf * NF, -1);
   h->h_q2i.assign((size_t)nmf * NF, -1);
+  {   // continuous P1 numbering per sub-domain (vertices on the membrane are doubled): the solver's auxiliary space
+    std::vector<int64_t> key((size_t)n);
+    for (int c = 0; c < nc; ++c)
+      for (int a = 0; a < NV; ++a) key[(size_t)c * NV + a] = (int64_t)d->cell_sub[c] * d->n_vertices + d->cells[(size_t)c * NV + a];
+    std::vector<int64_t> uniq(key);
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    h->n_aux = (int)uniq.size();
+    h->aux_of.resize((size_t)n);
+    for (int i = 0; i < n; ++i) h->aux_of[i] = (int)(std::lower_bound(uniq.begin(), uniq.end(), key[i]) - uniq.begin());
+  }
   auto local_of = [&](int c, int v) {
     for (int a = 0; a < NV; ++a) if (d->cells[(size_t)c * NV + a] == v) return a;
     return -1;
@@ -1245,6 +1270,96 @@ extern "C" int knpemi_dg_update(knpemi_dg* h, const double* c_new, int on_device
   int rc = dg_check_launch("dg_update_kernel");
   if (rc) return rc;
   if (!on_device) KN_HIP(hipStreamSynchronize(h->stream));
+  return KNPEMI_OK;
+}
+
+namespace {
+
+// The solver handle of a DG problem: stream, systems and the potential component of the dof records (same 64-byte
+// layout as the CG vertex records), nothing else.
+int dg_solver(knpemi_dg* h, knpemi_handle** out) {
+  if (h->sol) { *out = h->sol; return KNPEMI_OK; }
+  const DgDev& D = h->dev;
+  const int n = D.n_dof, KS = h->K - 1;
+  if ((int64_t)KS * D.nnz >= ((int64_t)1 << 31) - 64)
+    return dg_fail(KNPEMI_EINVAL, "knpemi_dg_solve: the block-diagonal concentration system has more than 2^31 entries");
+  int rc;
+  if (!h->d_colind && (rc = dg_upload(h, h->h_colind, &h->d_colind))) return rc;
+  // block-diagonal pattern of the K - 1 concentration systems
+  std::vector<int> krp((size_t)KS * n + 1), kci((size_t)KS * D.nnz);
+  for (int k = 0; k < KS; ++k) {
+    for (int i = 0; i < n; ++i) krp[(size_t)k * n + i] = (int)(k * D.nnz) + h->h_rowptr[i];
+    for (int64_t j = 0; j < D.nnz; ++j) kci[(size_t)k * D.nnz + j] = k * n + h->h_colind[j];
+  }
+  krp[(size_t)KS * n] = (int)(KS * D.nnz);
+  const int *d_krp = nullptr, *d_kci = nullptr;
+  if ((rc = dg_upload(h, krp, &d_krp))) return rc;
+  if ((rc = dg_upload(h, kci, &d_kci))) return rc;
+  if ((rc = dg_alloc(h, (size_t)KS * n, &h->d_csol))) return rc;
+  auto* s = new knpemi_handle();
+  s->device = h->device;
+  s->stream = s->cur = h->stream;
+  s->K = h->K; s->n_sub = h->n_sub;
+  s->dev.Ntot = n;
+  s->dev.VR = D.rec;
+  s->dev.rowptr = D.rowptr; s->dev.colind = h->d_colind;
+  s->dev.A_emi = D.A_emi; s->dev.b_emi = D.b_emi;
+  s->dev.krowptr = d_krp; s->dev.kcolind = d_kci;
+  s->dev.A_knp = D.A_knp; s->dev.b_knp = D.b_knp;
+  s->dev.csol = h->d_csol;
+  s->plain_knp = true;
+  s->amg_emi.first_agg = h->aux_of;
+  s->amg_emi.first_na = h->n_aux;
+  s->amg_knp.first_agg.resize((size_t)KS * n);
+  for (int k = 0; k < KS; ++k)
+    for (int i = 0; i < n; ++i) s->amg_knp.first_agg[(size_t)k * n + i] = k * h->n_aux + h->aux_of[i];
+  s->amg_knp.first_na = KS * h->n_aux;
+  s->amg_emi.block = s->amg_knp.block = h->NV;       // block-Jacobi smoothing over the dofs of a cell
+  if (getenv("KNPEMI_DG_PLAIN_AMG")) { s->amg_emi.first_na = s->amg_knp.first_na = 0; }
+  if (getenv("KNPEMI_DG_POINT_JACOBI")) { s->amg_emi.block = s->amg_knp.block = 0; }
+  h->sol = s;
+  *out = s;
+  return KNPEMI_OK;
+}
+
+}  // namespace
+
+// Device solves of the two DG systems (pdeSolver.py:24-35,74-78,99-110 with the iterative options): CG on the
+// symmetric interior-penalty potential system with the constants projected out, BiCGStab on the K - 1 concentration
+// systems taken as one block-diagonal system; preconditioner = the smoothed-aggregation AMG of the CG path whose first
+// coarse level is the continuous P1 space of every sub-domain (auxiliary-space correction) under a damped-Jacobi
+// smoother on the broken dofs.  The potential goes into the dof records, the concentrations stay in the solver's
+// buffer until knpemi_dg_update (update != 0 runs it right away).
+extern "C" int knpemi_dg_solve_emi(knpemi_dg* h, double rtol, double atol, int maxit, int* iters, double* relres) {
+  if (!h) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_solve_emi: null handle");
+  KN_HIP(hipSetDevice(h->device));
+  knpemi_handle* s = nullptr;
+  int rc = dg_solver(h, &s);
+  if (rc) return rc;
+  return kn_solve_emi(s, rtol, atol, maxit, iters, relres);
+}
+
+extern "C" int knpemi_dg_solve_knp(knpemi_dg* h, double rtol, double atol, int maxit, int* iters, double* relres, int update) {
+  if (!h) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_solve_knp: null handle");
+  if (update && !h->have_params) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_solve_knp: knpemi_dg_set_params has not been called");
+  KN_HIP(hipSetDevice(h->device));
+  knpemi_handle* s = nullptr;
+  int rc = dg_solver(h, &s);
+  if (rc) return rc;
+  const int n = h->dev.n_dof;
+  for (int k = 0; k < h->K - 1; ++k)   // initial guess: the previous concentrations (ksp_initial_guess_nonzero)
+    if ((rc = kn_launch_field_gather(s, h->dev.rec + KN_CSLOT(k), KN_REC, h->d_csol + (size_t)k * n, n))) return rc;
+  if ((rc = kn_solve_knp(s, rtol, atol, maxit, iters, relres))) return rc;
+  if (update) return knpemi_dg_update(h, h->d_csol, 1);
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_dg_get_solution(knpemi_dg* h, double* c_host) {
+  if (!h || !c_host) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_get_solution: null argument");
+  if (!h->d_csol) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_get_solution: knpemi_dg_solve_knp has not been called");
+  KN_HIP(hipSetDevice(h->device));
+  KN_HIP(hipMemcpyAsync(c_host, h->d_csol, (size_t)(h->K - 1) * h->dev.n_dof * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  KN_HIP(hipStreamSynchronize(h->stream));
   return KNPEMI_OK;
 }
 

@@ -505,6 +505,7 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     G.its_ref = -1;
     ++G.builds;
   }
+  if (amg && (rc = kn_amg_refresh(h, G, D.A_emi))) return rc;
   // two-level variant on a partitioned mesh: the ranks' AMG cycles do not see each other, a coarse space of one
   // constant per (rank, sub-domain) carries the error across the cuts (knpemi_set_distributed_coarse)
   const bool coarse = dist.on && amg && h->dist.nc > 0;
@@ -594,7 +595,8 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     mask(c, D.b_knp);      // the ghost rows of the right-hand side are not assembled
   }
   // x0 = previous concentrations in the block order [c[0][0], c[0][1], c[1][0], ...]
-  hipLaunchKernelGGL(knp_order_kernel, grid1(n), dim3(256), 0, h->stream, D.Ntot, KS, h->n_sub, h->d_consts, x, D.csol, 1);
+  if (h->plain_knp) vec(c, V_COPY, x, nullptr, D.csol, nullptr);
+  else hipLaunchKernelGGL(knp_order_kernel, grid1(n), dim3(256), 0, h->stream, D.Ntot, KS, h->n_sub, h->d_consts, x, D.csol, 1);
   hipLaunchKernelGGL(diag_inv_kernel, grid1(n), dim3(256), 0, h->stream, n, c.rowptr, c.colind, c.vals, dinv);
   KnAmg& G = h->amg_knp;
   const bool amg = h->pc_knp == KNPEMI_PC_AMG;
@@ -605,6 +607,7 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     G.its_ref = -1;
     ++G.builds;
   }
+  if (amg && (rc = kn_amg_refresh(h, G, D.A_knp))) return rc;
   spmv(c, x, r, nullptr, D.b_knp);                             // r = b - A x
   vec(c, V_COPY, rhat, nullptr, r, nullptr);
   KN_HIP(hipMemsetAsync(p, 0, (size_t)n * sizeof(double), h->stream));
@@ -656,7 +659,8 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   }
   if (dist.on) if (int e = dist.halo(dist.ctx, x, KNPEMI_B_KNP)) c.comm_rc = c.comm_rc ? c.comm_rc : e;
   if (c.comm_rc) { kn_set_error("KNP solve: a communication hook failed"); return KNPEMI_EHIP; }
-  if (h->fuse_update) { if ((rc = kn_launch_knp_writeback_update(h, x))) return rc; }
+  if (h->plain_knp) vec(c, V_COPY, D.csol, nullptr, x, nullptr);
+  else if (h->fuse_update) { if ((rc = kn_launch_knp_writeback_update(h, x))) return rc; }
   else hipLaunchKernelGGL(knp_order_kernel, grid1(n), dim3(256), 0, h->stream, D.Ntot, KS, h->n_sub, h->d_consts, x, D.csol, 0);
   if (iters) *iters = it;
   if (relres) *relres = bnorm > 0 ? rn / bnorm : rn;

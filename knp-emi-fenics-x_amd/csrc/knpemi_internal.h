@@ -138,6 +138,16 @@ struct KnAmg {
   double op_complexity = 1.0;
   int its_ref = -1;                  // iterations of the first solve after the build (rebuild trigger)
   int builds = 0;
+  // Optional aggregates of the finest level (auxiliary-space variant, DG systems: the broken dofs of a (sub-domain,
+  // mesh vertex) form one aggregate, so the first coarse level is the continuous P1 space of the sub-domains and the
+  // strength-based aggregation only starts there).  first_na == 0: aggregate every level by strength.
+  std::vector<int> first_agg;
+  int first_na = 0;
+  // Optional block-Jacobi smoother on the finest level: `block` consecutive unknowns (the dofs of a DG cell) form a
+  // block whose inverse is refreshed from the current values before every solve (kn_amg_refresh).  0: point Jacobi.
+  int block = 0;
+  double* binv = nullptr;            // [n / block][block][block]
+  double omega_block = 1.0;          // damping 4 / (3 rho(B^-1 A))
 };
 void kn_amg_free(KnAmg& G);
 struct knpemi_handle;
@@ -145,6 +155,7 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
                  bool singular, const uint8_t* h_owned = nullptr);
 int kn_amg_apply(knpemi_handle* h, KnAmg& G, const double* vals, const double* dinv0, const double* r, double* scratch,
                  double* out);
+int kn_amg_refresh(knpemi_handle* h, KnAmg& G, const double* vals);   // block inverses of the current finest operator
 
 // Distributed solves (knpemi_set_distributed)
 struct KnDist {
@@ -222,6 +233,7 @@ struct knpemi_handle {
   KnGraph graph_emi, graph_knp;
   int pc_emi = KNPEMI_PC_AMG, pc_knp = KNPEMI_PC_AMG;
   int fuse_update = 0;                 // KNPEMI_OPT_FUSE_UPDATE
+  bool plain_knp = false;              // the KNP solve's unknown order is dev.csol's own ([K-1][Ntot]; DG variant)
   int fuse_membrane = 0;               // KNPEMI_OPT_FUSE_MEMBRANE
   int prof_stride = 1;                 // KNPEMI_OPT_PROFILE_STRIDE
   unsigned prof_count[16] = {0};

@@ -173,6 +173,27 @@ class DGProblem:
             raise ValueError("c_new has the wrong size")
         L.check(self.lib.knpemi_dg_update(self.h, a.ctypes.data_as(C.c_void_p), 0))
 
+    # -- device solves ------------------------------------------------------------------------------------------
+    def solve_emi(self, rtol=1e-5, atol=1e-40, maxit=1000):
+        """CG + auxiliary-space AMG on the assembled potential system, constants projected out (pdeSolver.py:24-35,
+        74-78); the potential field takes the solution.  Returns (iterations, relative residual)."""
+        it, rr = C.c_int(), C.c_double()
+        L.check(self.lib.knpemi_dg_solve_emi(self.h, rtol, atol, maxit, C.byref(it), C.byref(rr)))
+        return it.value, rr.value
+
+    def solve_knp(self, rtol=1e-7, atol=1e-40, maxit=1000, update=False):
+        """BiCGStab + AMG on the K - 1 assembled concentration systems (pdeSolver.py:99-110), starting from the previous
+        concentrations; update=True runs the end-of-step update on the solution without leaving the device."""
+        it, rr = C.c_int(), C.c_double()
+        L.check(self.lib.knpemi_dg_solve_knp(self.h, rtol, atol, maxit, C.byref(it), C.byref(rr), int(bool(update))))
+        return it.value, rr.value
+
+    def solution(self):
+        """The concentrations of the last solve_knp, (K-1, n)."""
+        c = np.zeros((self.K - 1, self.n))
+        L.check(self.lib.knpemi_dg_get_solution(self.h, L.dptr(c)))
+        return c
+
     # -- membrane ODEs -----------------------------------------------------------------------------------------
     def ode_bind(self, model_id, states_row, params_row, ion_param, v_index):
         """One state / parameter row per membrane node, all initialised to the given rows (MembraneModel.__init__,

@@ -267,7 +267,7 @@ def test_dg_time_loop_on_the_device_matches_the_restatement(hip_lib):
     import run_2D_dg
     from test_dg_oracle import _dg_2d_run
     ref, XM, mask = _dg_2d_run()
-    run = run_2D_dg.DGRun(1)
+    run = run_2D_dg.DGRun(1, device_solves=False)
     assert np.array_equal(run.dp.XM.reshape(-1, 2), XM) and np.array_equal(run.stimulated, mask)
     for _ in range(10):
         run.step()
@@ -282,6 +282,75 @@ def test_dg_time_loop_on_the_device_matches_the_restatement(hip_lib):
         assert rel_err(dp.get_concentration(k), ref.c_all[k]) < 1e-10
     v = dp.get_membrane_potential()
     assert v.mean() > -0.0744 + 0.010
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_dg_device_solves_match_direct_solves(hip_lib, dim):
+    """knpemi_dg_solve_emi / knpemi_dg_solve_knp (CG with the constants projected out / BiCGStab, AMG over the continuous
+    P1 auxiliary space; pdeSolver.py:24-35,74-78,99-110) on the systems of the idealized geometries at SI scales against
+    SciPy's sparse LU of the same device-assembled matrices."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "idealized_geometries"))
+    import scipy.sparse.linalg as spla
+    from run_2D_dg import solve_singular
+    from knpemi.dg import DGProblem
+    from knpemi.fem.idealized import make_mesh_2D, make_mesh_3D
+    mesh, ct, ft = make_mesh_2D(2) if dim == 2 else make_mesh_3D(0, "tetrahedron")
+    dp = DGProblem(mesh, ct, ft, [0, 1], [1])
+    assert dp.n > 640                                               # beyond the size the AMG inverts directly
+    ions = [dict(name="Na", z=1.0, D=[1.33e-9] * 2), dict(name="K", z=1.0, D=[1.96e-9] * 2), dict(name="Cl", z=-1.0, D=[2.03e-9] * 2)]
+    params = dict(dt=1e-4, F=96485.0, psi=96485.0 / (8.314 * 300.0), C_M=0.02)
+    ins = (dp.cell_sub > 0)[:, None] * np.ones((1, dp.nv), bool)
+    w = np.sin(2e5 * dp.X[:, :, 0]) * np.cos(2e6 * dp.X[:, :, 1])
+    c_all = [np.where(ins, i, e) * (1.0 + 1e-2 * w * (1 + k)) for k, (e, i) in enumerate(((100.0, 12.0), (4.0, 125.0), (104.0, 137.0)))]
+    rng = np.random.default_rng(11)
+    phi_M = -0.0744 + 1e-3 * rng.standard_normal((dp.nmf, dp.nf))
+    I_ch = [1e-2 * rng.standard_normal((dp.nmf, dp.nf)) for _ in range(3)]
+    _push(dp, params, ions, c_all, np.where(ins, -0.0744, 0.0), phi_M, I_ch)
+    dp.assemble_emi()
+    A, b = dp.matrix(0), dp.rhs(0)
+    rtol = 1e-11 if dim == 2 else 1e-8          # (the 3D residual stalls near 4e-10 ||b||: entries spread over decades)
+    its, rr = dp.solve_emi(rtol=rtol)
+    phi = dp.get_potential().reshape(-1)
+    assert 0 < its < 150 and rr < rtol, (its, rr)
+    assert abs(phi.mean()) < 1e-12 * np.abs(phi).max()
+    bp = b - b.mean()                                               # the solver projects b (compatible to rounding)
+    assert np.linalg.norm(A @ phi - bp) < 2 * rtol * np.linalg.norm(bp)
+    if dim == 2:                                                    # (a bordered sparse LU of the 3D system fills in)
+        ref = solve_singular(A, bp)
+        assert rel_err(phi, ref - ref.mean()) < 1e-7
+    dp.assemble_knp()                                               # with the potential just solved
+    its, rr = dp.solve_knp(rtol=1e-12)
+    assert 0 < its < 150 and rr < 1e-12, (its, rr)
+    c = dp.solution()
+    for k in range(2):
+        Ak, bk = dp.matrix(1 + k), dp.rhs(1 + k)
+        assert np.linalg.norm(Ak @ c[k] - bk) < 1e-11 * np.linalg.norm(bk), k
+        if dim == 2:
+            assert rel_err(c[k], spla.splu(Ak.tocsc()).solve(bk)) < 1e-9, k
+
+
+def test_dg_time_loop_with_device_solves_follows_the_direct_solves(hip_lib):
+    """The whole DG time step on the device (ODE sweep, assemblies, CG / BiCGStab + AMG at the reference's rtol
+    1e-5 / 1e-7, update without leaving the device) against the same loop with SciPy's direct solves: ten steps of
+    BASELINE configs[0] while the stimulated membrane depolarises."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "idealized_geometries"))
+    import run_2D_dg
+    dev, host = run_2D_dg.DGRun(1), run_2D_dg.DGRun(1, device_solves=False)
+    for _ in range(10):
+        dev.step()
+        host.step()
+    assert all(0 <= a < 60 and 0 <= b < 30 for a, b in dev.iterations), dev.iterations
+    v_dev, v_host = dev.dp.get_membrane_potential(), host.dp.get_membrane_potential()
+    assert v_host.mean() > -0.0744 + 0.010
+    assert rel_err(v_dev, v_host) < 1e-4
+    for k in range(3):
+        assert rel_err(dev.dp.get_concentration(k), host.dp.get_concentration(k)) < 1e-6
+    tight = run_2D_dg.DGRun(1, rtol=(1e-10, 1e-12))
+    for _ in range(10):
+        tight.step()
+    assert rel_err(tight.dp.get_membrane_potential(), v_host) < 1e-7
 
 
 @pytest.mark.parametrize("r,label", [(1, "config2: 124 416 tetrahedra"), (2, "config3: 995 328 tetrahedra")])
