@@ -392,6 +392,7 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, wo
             b = dp.solve_knp(rtol=1e-7, update=True)[0]
             return a, b
         k0 = warmup + steps
+        dp.set_extrapolation(True)
         t0 = time.perf_counter()
         solved_step(k0)                        # builds the two hierarchies on the host
         dp.sync()

@@ -57,6 +57,8 @@ class DGRun:
         ion_param = sum(([pi(f"{i['name']}_e"), pi(f"{i['name']}_i"), pi(f"I_ch_{i['name']}")] for i in self.ions), [])
         self.v_index = ode.state_indices("V")
         dp.ode_bind(L.MODEL_HH_SI, states, params, ion_param, self.v_index)
+        if device_solves:
+            dp.set_extrapolation(True)
         self.dt, self.time, self.k = dt, 0.0, 0
 
     def step(self):

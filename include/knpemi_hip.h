@@ -417,6 +417,9 @@ int knpemi_dg_update(knpemi_dg* h, const double* c_new, int on_device);
 int knpemi_dg_solve_emi(knpemi_dg* h, double rtol, double atol, int maxit, int* iters, double* relres);
 int knpemi_dg_solve_knp(knpemi_dg* h, double rtol, double atol, int maxit, int* iters, double* relres, int update);
 int knpemi_dg_get_solution(knpemi_dg* h, double* c_host);
+/* on != 0: both solves start from 2 x_n - x_(n-1) (the last two solutions) instead of x_n, as knpemi_extrapolate_guess
+ * does for the CG path; the stopping criterion is unchanged. */
+int knpemi_dg_set_extrapolation(knpemi_dg* h, int on);
 /* Membrane ODE sweep over the membrane nodes with one of the built-in models (KNPEMI_MODEL_*): same kernel, tables and
  * flags as knpemi_ode_step; states / params are [n_mem_nodes][n_states | n_params] row-major on the host. */
 int knpemi_dg_ode_bind(knpemi_dg* h, int model_id, int n_states, int n_params, const double* states, const double* params,

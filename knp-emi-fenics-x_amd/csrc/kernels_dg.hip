@@ -795,6 +795,7 @@ struct knpemi_dg {
   int n_aux = 0;
   knpemi_handle* sol = nullptr;
   double* d_csol = nullptr;        // [K-1][n_dofs] solved concentrations
+  int extrapolate = 0;             // knpemi_dg_set_extrapolation
 };
 
 namespace {
@@ -1336,7 +1337,17 @@ extern "C" int knpemi_dg_solve_emi(knpemi_dg* h, double rtol, double atol, int m
   knpemi_handle* s = nullptr;
   int rc = dg_solver(h, &s);
   if (rc) return rc;
+  if (h->extrapolate && (rc = kn_extrapolate_guess(s, KNPEMI_B_EMI))) return rc;   // phi <- 2 phi_n - phi_(n-1)
   return kn_solve_emi(s, rtol, atol, maxit, iters, relres);
+}
+
+// Initial guesses of the two solves: the linear extrapolation 2 x_n - x_(n-1) of the last two solutions instead of the
+// last one (knpemi_extrapolate_guess of the CG path); only the starting point changes.
+extern "C" int knpemi_dg_set_extrapolation(knpemi_dg* h, int on) {
+  if (!h) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_set_extrapolation: null handle");
+  h->extrapolate = on ? 1 : 0;
+  if (h->sol) h->sol->guess_have[0] = h->sol->guess_have[1] = false;
+  return KNPEMI_OK;
 }
 
 extern "C" int knpemi_dg_solve_knp(knpemi_dg* h, double rtol, double atol, int maxit, int* iters, double* relres, int update) {
@@ -1349,6 +1360,7 @@ extern "C" int knpemi_dg_solve_knp(knpemi_dg* h, double rtol, double atol, int m
   const int n = h->dev.n_dof;
   for (int k = 0; k < h->K - 1; ++k)   // initial guess: the previous concentrations (ksp_initial_guess_nonzero)
     if ((rc = kn_launch_field_gather(s, h->dev.rec + KN_CSLOT(k), KN_REC, h->d_csol + (size_t)k * n, n))) return rc;
+  if (h->extrapolate && (rc = kn_extrapolate_guess(s, KNPEMI_B_KNP))) return rc;
   if ((rc = kn_solve_knp(s, rtol, atol, maxit, iters, relres))) return rc;
   if (update) return knpemi_dg_update(h, h->d_csol, 1);
   return KNPEMI_OK;

@@ -172,6 +172,7 @@ SIGNATURES = {
     "knpemi_dg_solve_emi": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int), c_dbl_p]),
     "knpemi_dg_solve_knp": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int), c_dbl_p, C.c_int]),
     "knpemi_dg_get_solution": (C.c_int, [C.c_void_p, c_dbl_p]),
+    "knpemi_dg_set_extrapolation": (C.c_int, [C.c_void_p, C.c_int]),
     "knpemi_dg_ode_bind": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_dbl_p, c_dbl_p, c_int_p, C.c_int]),
     "knpemi_dg_ode_step": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]),
     "knpemi_dg_ode_get_tables": (C.c_int, [C.c_void_p, c_dbl_p, c_dbl_p]),

@@ -188,6 +188,10 @@ class DGProblem:
         L.check(self.lib.knpemi_dg_solve_knp(self.h, rtol, atol, maxit, C.byref(it), C.byref(rr), int(bool(update))))
         return it.value, rr.value
 
+    def set_extrapolation(self, on=True):
+        """Both solves start from 2 x_n - x_(n-1) instead of x_n."""
+        L.check(self.lib.knpemi_dg_set_extrapolation(self.h, int(bool(on))))
+
     def solution(self):
         """The concentrations of the last solve_knp, (K-1, n)."""
         c = np.zeros((self.K - 1, self.n))
