@@ -764,6 +764,162 @@ __device__ __forceinline__ void hex_knp_row(const R8 (&r)[8], int li, double (&M
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Parallelepipeds: closed forms instead of the 2 x 2 x 2 rule (which is exact for these integrands when the Jacobian
+// is constant, so both give the same numbers up to rounding).  The row vertex l is moved to local vertex 0 by
+// reflecting the reference cell along the axes where l has a bit set: the caller loads the records in the order
+// j' = j ^ l, the edge vectors taken from the permuted records carry the reflection, and every result of the frame
+// belongs to the cell's local vertex j' ^ l.  With l = 0 the integrals over the unit cube factor into 1D integrals of
+// two or three linear functions (1/3, 1/6; 1/4, 1/12), contracted axis by axis (sum factorisation): ~1/5 of the
+// operations of the quadrature loop on a box mesh, whose metric tensor is diagonal.
+// ---------------------------------------------------------------------------------------------
+namespace hexcf {
+constexpr double T4 = 0.25, T12 = 1.0 / 12.0, A3 = 1.0 / 3.0, A6 = 1.0 / 6.0;
+__host__ __device__ constexpr int ix(int s, int ms, int a, int ma, int b, int mb) { return (ms << s) | (ma << a) | (mb << b); }
+__host__ __device__ constexpr double a0(int j) { return j ? A6 : A3; }
+// P[ja][jb] = sum_{ma, mb} b(ma, 0, ja) b(mb, 0, jb) k[ma][mb],  b(m, 0, j) = 1/4 if m = j = 0 else 1/12
+__device__ __forceinline__ void contract_bb(const double (&k)[2][2], double (&P)[2][2]) {
+  const double r00 = T4 * k[0][0] + T12 * k[1][0], r01 = T4 * k[0][1] + T12 * k[1][1];
+  const double r10 = T12 * (k[0][0] + k[1][0]), r11 = T12 * (k[0][1] + k[1][1]);
+  P[0][0] = T4 * r00 + T12 * r01; P[0][1] = T12 * (r00 + r01);
+  P[1][0] = T4 * r10 + T12 * r11; P[1][1] = T12 * (r10 + r11);
+}
+// Q[js][ju] = sum_{ms, mu} a(ms, js) b(mu, 0, ju) k[ms][mu],  a(m, j) = 1/3 if m = j else 1/6
+__device__ __forceinline__ void contract_ab(const double (&k)[2][2], double (&Q)[2][2]) {
+  const double v00 = T4 * k[0][0] + T12 * k[0][1], v01 = T12 * (k[0][0] + k[0][1]);
+  const double v10 = T4 * k[1][0] + T12 * k[1][1], v11 = T12 * (k[1][0] + k[1][1]);
+  Q[0][0] = A3 * v00 + A6 * v10; Q[0][1] = A3 * v01 + A6 * v11;
+  Q[1][0] = A6 * v00 + A3 * v10; Q[1][1] = A6 * v01 + A3 * v11;
+}
+struct Geo { double g[3][3]; double det; bool skew; };   // g = |det J| J^-1 J^-T
+template <class R>
+__device__ __forceinline__ Geo geometry(const R (&r)[8]) {
+  double J[3][3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    J[0][t] = r[1 << t].x - r[0].x; J[1][t] = r[1 << t].y - r[0].y; J[2][t] = r[1 << t].z - r[0].z;
+  }
+  const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+  const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+  const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+  const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02, inv = kn_rcp(det);
+  double I[3][3];
+  I[0][0] = c00 * inv; I[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * inv; I[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * inv;
+  I[1][0] = c01 * inv; I[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * inv; I[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * inv;
+  I[2][0] = c02 * inv; I[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * inv; I[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * inv;
+  Geo G;
+  G.det = fabs(det);
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = a; b < 3; ++b) {
+      const double v = G.det * (I[a][0] * I[b][0] + I[a][1] * I[b][1] + I[a][2] * I[b][2]);
+      G.g[a][b] = v; G.g[b][a] = v;
+    }
+  G.skew = G.g[0][1] != 0.0 || G.g[0][2] != 0.0 || G.g[1][2] != 0.0;   // false on every cell of a box mesh
+  return G;
+}
+}  // namespace hexcf
+
+// Row of local vertex 0 (records in the reflected order, see above): kappa-stiffness ra, volume right-hand side.
+__device__ __forceinline__ void hex_emi_row0(const Rec5 (&r)[8], double (&ra)[8], double& bvol) {
+  using namespace hexcf;
+  const Geo G = geometry(r);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ra[j] = 0.0;
+  double bv = 0.0;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int a = (s + 1) % 3, b = (s + 2) % 3;
+    double kb[2][2], P[2][2], ds = 0.0;
+#pragma unroll
+    for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        kb[ma][mb] = r[ix(s, 0, a, ma, b, mb)].k + r[ix(s, 1, a, ma, b, mb)].k;
+        ds += a0(ma) * a0(mb) * (r[ix(s, 1, a, ma, b, mb)].s - r[ix(s, 0, a, ma, b, mb)].s);
+      }
+    contract_bb(kb, P);
+    const double c = 0.5 * G.g[s][s];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ra[j] += (((j >> s) & 1) ? -c : c) * P[(j >> a) & 1][(j >> b) & 1];
+    bv += G.g[s][s] * ds;
+  }
+  if (G.skew) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        if (s == t) continue;
+        const int u = 3 - s - t;
+        double kt[2][2], Q[2][2], ds = 0.0;
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+          for (int mu = 0; mu < 2; ++mu) {
+            kt[ms][mu] = A3 * r[ix(s, ms, u, mu, t, 0)].k + A6 * r[ix(s, ms, u, mu, t, 1)].k;
+            ds += a0(mu) * (r[ix(s, ms, u, mu, t, 1)].s - r[ix(s, ms, u, mu, t, 0)].s);
+          }
+        contract_ab(kt, Q);
+        const double g = G.g[s][t];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ra[j] += (((j >> t) & 1) ? -g : g) * Q[(j >> s) & 1][(j >> u) & 1];
+        bv += 0.25 * g * ds;
+      }
+  }
+  bvol += bv;
+}
+
+// Row of local vertex 0 of the KNP element matrices (records in the reflected order): mass, stiffness, drift.
+template <class R8>
+__device__ __forceinline__ void hex_knp_row0(const R8 (&r)[8], double (&M)[8], double (&S)[8], double (&Cc)[8]) {
+  using namespace hexcf;
+  const Geo G = geometry(r);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    M[j] = G.det * (a0(j & 1) * a0((j >> 1) & 1) * a0((j >> 2) & 1));
+    S[j] = 0.0; Cc[j] = 0.0;
+  }
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int a = (s + 1) % 3, b = (s + 2) % 3;
+    double dp[2][2], P[2][2];
+#pragma unroll
+    for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) dp[ma][mb] = r[ix(s, 1, a, ma, b, mb)].c - r[ix(s, 0, a, ma, b, mb)].c;
+    contract_bb(dp, P);
+    const double g = G.g[s][s];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double w = a0((j >> a) & 1) * a0((j >> b) & 1);
+      S[j] += (((j >> s) & 1) ? -g : g) * w;
+      Cc[j] -= 0.5 * g * P[(j >> a) & 1][(j >> b) & 1];
+    }
+  }
+  if (G.skew) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        if (s == t) continue;
+        const int u = 3 - s - t;
+        double dp[2][2], Q[2][2];
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+          for (int mu = 0; mu < 2; ++mu) dp[ms][mu] = r[ix(s, ms, u, mu, t, 1)].c - r[ix(s, ms, u, mu, t, 0)].c;
+        contract_ab(dp, Q);
+        const double g = G.g[s][t];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          S[j] += (((j >> t) & 1) ? -0.25 * g : 0.25 * g) * a0((j >> u) & 1);
+          Cc[j] -= g * a0((j >> t) & 1) * Q[(j >> s) & 1][(j >> u) & 1];
+        }
+      }
+  }
+}
+
 template <int LPR, bool AFFINE>
 __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n,
                                                             int rec_n, int want_p, int splitting) {
@@ -804,11 +960,17 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
       int slot[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) { slot[j] = (sl.x >> (8 * j)) & 255; slot[4 + j] = (sl.y >> (8 * j)) & 255; }
+      if constexpr (AFFINE) {   // frame of the row vertex: local vertex j ^ li takes position j
+        const uint64_t s64 = ((uint64_t)sl.y << 32) | sl.x;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) slot[j] = (int)((s64 >> (8 * (j ^ li))) & 255);
+      }
       Rec5 r[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) r[j] = lds_rec5(recs, eloc[rL + slot[j]]);
       double ra[8];
-      hex_emi_row<AFFINE>(r, li, ra, bacc);
+      if constexpr (AFFINE) hex_emi_row0(r, ra, bacc);
+      else hex_emi_row<AFFINE>(r, li, ra, bacc);
 #pragma unroll
       for (int j = 0; j < 8; ++j) unsafeAtomicAdd(&accA[lap + slot[j]], ra[j]);
     };
@@ -877,11 +1039,17 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDe
       int slot[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) { slot[j] = (sl.x >> (8 * j)) & 255; slot[4 + j] = (sl.y >> (8 * j)) & 255; }
+      if constexpr (AFFINE) {   // frame of the row vertex: local vertex j ^ li takes position j
+        const uint64_t s64 = ((uint64_t)sl.y << 32) | sl.x;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) slot[j] = (int)((s64 >> (8 * (j ^ li))) & 255);
+      }
       RecK<KS> r[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) r[j] = lds_rec<KS>(recs, eloc[rL + slot[j]]);
       double M[8], S[8], Cc[8];
-      hex_knp_row<AFFINE>(r, li, M, S, Cc);
+      if constexpr (AFFINE) hex_knp_row0(r, M, S, Cc);
+      else hex_knp_row<AFFINE>(r, li, M, S, Cc);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
 #pragma unroll

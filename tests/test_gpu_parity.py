@@ -57,6 +57,23 @@ def test_assembly_matches_oracle_on_distorted_hexahedra(hip_lib, splitting):
     assert max(errs.values()) < TOL, errs
 
 
+@pytest.mark.parametrize("mirror", [False, True])
+def test_assembly_matches_oracle_on_sheared_hexahedra(hip_lib, mirror):
+    """Parallelepipeds with a full metric tensor (the box sheared by a constant matrix; mirrored: left-handed cells):
+    the closed-form Q1 rows of the affine kernels, off-diagonal terms included, against the oracle's 2 x 2 x 2 rule."""
+    from setup_problem import make_mesh
+    mesh, ct, ft = make_mesh("hex", 0)
+    A = np.array([[1.0, 0.8, -0.5], [0.02, 1.0, 0.3], [-0.01, 0.25, 1.0]])
+    if mirror:
+        A[:, 1] *= -1.0
+    mesh.x[:] = mesh.x @ A.T
+    s = Setup("hex", 0, mesh_data=(mesh, ct, ft))
+    s.perturb()
+    for splitting in (True, False):
+        errs, _ = _assemble_both(s, splitting)
+        assert max(errs.values()) < TOL, errs
+
+
 def test_general_hexahedron_kernel_on_box_mesh(hip_lib, monkeypatch):
     """KNPEMI_HEX_GENERAL forces the general Q1 kernels (per-cell affinity test at run time) on a box mesh."""
     monkeypatch.setenv("KNPEMI_HEX_GENERAL", "1")
