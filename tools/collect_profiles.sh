@@ -14,9 +14,13 @@ echo "rocprof dg done"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_config3 -- \
     python3 $R/bench.py --workload config3 --steps 20 --warmup 3 --cpu-steps 0 --solve-steps 0 --no-dg > $O/stats_config3.json 2> $O/stats_config3.err
 echo "rocprof config3 done"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_config2h -- \
+    python3 $R/bench.py --workload config2h --steps 30 --warmup 3 --cpu-steps 0 --solve-steps 0 --no-dg --no-overlap > $O/stats_config2h.json 2> $O/stats_config2h.err
+echo "rocprof config2h done"
 cd $R
 python3 bench.py > $O/bench_config2.json 2> $O/bench_config2.err; echo "bench config2 done"
 python3 bench.py --workload config3 --steps 20 --warmup 3 --cpu-steps 0 > $O/bench_config3.json 2> $O/bench_config3.err; echo "bench config3 done"
+python3 bench.py --workload config2h --steps 30 --warmup 3 --cpu-steps 0 > $O/bench_config2h.json 2> $O/bench_config2h.err; echo "bench config2h done"
 python3 bench.py --workload config5s --steps 20 --warmup 3 --cpu-steps 0 --solve-steps 0 > $O/bench_config5s.json 2> $O/bench_config5s.err; echo "bench config5s done"
 python3 bench.py --variant dg --workload config3 --steps 20 --warmup 3 > $O/bench_dg_config3.json 2> $O/bench_dg_config3.err; echo "bench dg config3 done"
 bash tools/collect_traffic.sh config3 cg > $O/traffic_config3.txt 2>&1; echo "traffic config3 done"
