@@ -431,9 +431,13 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
   }
 }
 
-template <int GDIM, int LPR, int KS>
+// MEM: where the membrane integrals of b_knp come from -- 0: the partial integrals knp_membrane_kernel left in gam_e
+// (default), 1: evaluated here into LDS (KNPEMI_OPT_FUSE_MEMBRANE), 2: the early form (KNPEMI_MEMBRANE_EARLY).  A
+// template parameter, not a run-time switch: the two optional paths cost the default one 46 registers per lane
+// (140 instead of 94: three instead of five waves per SIMD).
+template <int GDIM, int LPR, int KS, int MEM>
 __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n, int rec_n,
-                                                        int gam_n, int splitting, int pre) {
+                                                        int gam_n, int splitting) {
   constexpr int NV = GDIM + 1;
   const KnConsts& C = *Cp;
   extern __shared__ __align__(16) double lds[];
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
     for (int k = 0; k < KS; ++k) acc[(size_t)k * acc_n + i] = 0.0;
   }
   stage_records<KS>(D, B, recs, eloc, tid, C.inv_dt, fs0, nvs);
-  if (gam_n > 0) membrane_entries_to_lds<GDIM, KS>(D, C, B.me0, B.mne, s > 0, splitting, tid, gam);
+  if constexpr (MEM == 1) membrane_entries_to_lds<GDIM, KS>(D, C, B.me0, B.mne, s > 0, splitting, tid, gam);
   __syncthreads();
 
   const KnSubConst& sc = C.sc[s];
@@ -519,10 +523,10 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
     {   // the row's LPR lanes share its membrane entries (the sums meet in the reduction below)
       const int ne = (unsigned)ri.y >> 16;
       for (int e = ri.w + sub; e < ri.w + ne; e += LPR) {
-        if (pre) membrane_entry_early<GDIM, KS>(D, e, bk);
+        if constexpr (MEM == 2) membrane_entry_early<GDIM, KS>(D, e, bk);
         else {
 #pragma unroll
-          for (int k = 0; k < KS; ++k) bk[k] += gam_n > 0 ? gam[(size_t)(e - B.me0) * KS + k] : D.gam_e[(size_t)KS * e + k];
+          for (int k = 0; k < KS; ++k) bk[k] += MEM == 1 ? gam[(size_t)(e - B.me0) * KS + k] : D.gam_e[(size_t)KS * e + k];
         }
       }
     }
@@ -993,9 +997,9 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
   }
 }
 
-template <int LPR, bool AFFINE, int KS>
+template <int LPR, bool AFFINE, int KS, int MEM>
 __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n, int rec_n,
-                                                                            int gam_n, int splitting, int pre) {
+                                                                            int gam_n, int splitting) {
   const KnConsts& C = *Cp;
   extern __shared__ __align__(16) double lds[];
   double* acc = lds;
@@ -1025,7 +1029,7 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDe
     for (int k = 0; k < KS; ++k) acc[(size_t)k * acc_n + i] = 0.0;
   }
   stage_records<KS>(D, B, recs, eloc, tid, C.inv_dt, fs0, nvs);
-  if (gam_n > 0) membrane_entries_to_lds<4, KS>(D, C, B.me0, B.mne, s > 0, splitting, tid, gam);
+  if constexpr (MEM == 1) membrane_entries_to_lds<4, KS>(D, C, B.me0, B.mne, s > 0, splitting, tid, gam);
   __syncthreads();
 
   const KnSubConst& sc = C.sc[s];
@@ -1068,10 +1072,10 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDe
     {   // the row's LPR lanes share its membrane entries (the sums meet in the reduction below)
       const int ne = (unsigned)ri.y >> 16;
       for (int e = ri.w + sub; e < ri.w + ne; e += LPR) {
-        if (pre) membrane_entry_early<4, KS>(D, e, bk);
+        if constexpr (MEM == 2) membrane_entry_early<4, KS>(D, e, bk);
         else {
 #pragma unroll
-          for (int k = 0; k < KS; ++k) bk[k] += gam_n > 0 ? gam[(size_t)(e - B.me0) * KS + k] : D.gam_e[(size_t)KS * e + k];
+          for (int k = 0; k < KS; ++k) bk[k] += MEM == 1 ? gam[(size_t)(e - B.me0) * KS + k] : D.gam_e[(size_t)KS * e + k];
         }
       }
     }
@@ -1591,17 +1595,21 @@ static int launch_knp_v2(knpemi_handle* h, int split, int pre) {
   if (lds > 160 * 1024) { kn_set_error("KNP row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   dim3 grid(D.nblocks), block(KN_BLOCK);
   int rc = 0;
-#define KN_CASE(L, S)                                                                               \
-  if (h->lpr == L && KS == S) {                                                                     \
-    if ((rc = set_lds_limit(knp_rows_v2<GDIM, L, S>, lds))) return rc;                              \
+  const int mem = pre ? 2 : (gam_n > 0 ? 1 : 0);
+#define KN_CASE(L, S, M)                                                                            \
+  if (h->lpr == L && KS == S && mem == M) {                                                         \
+    if ((rc = set_lds_limit(knp_rows_v2<GDIM, L, S, M>, lds))) return rc;                           \
     KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                         \
-    hipLaunchKernelGGL((knp_rows_v2<GDIM, L, S>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n, gam_n, split, pre); \
+    hipLaunchKernelGGL((knp_rows_v2<GDIM, L, S, M>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n, gam_n, split); \
     return check_launch("knp_rows_v2");                                                             \
   }
-  // lanes per row: 2 (triangles) or 4 by default, KNPEMI_LPR for experiments; K - 1 = 1..3 solved ions
-  KN_CASE(2, 2) KN_CASE(4, 2) KN_CASE(1, 2) KN_CASE(8, 2) KN_CASE(2, 1) KN_CASE(4, 1) KN_CASE(2, 3) KN_CASE(4, 3)
+  // lanes per row: 2 (triangles) or 4 by default, KNPEMI_LPR for experiments; K - 1 = 1..3 solved ions; the optional
+  // membrane paths (fused, early) for the default lanes-per-row only
+  KN_CASE(2, 2, 0) KN_CASE(4, 2, 0) KN_CASE(1, 2, 0) KN_CASE(8, 2, 0) KN_CASE(2, 1, 0) KN_CASE(4, 1, 0) KN_CASE(2, 3, 0) KN_CASE(4, 3, 0)
+  KN_CASE(2, 2, 1) KN_CASE(4, 2, 1) KN_CASE(2, 1, 1) KN_CASE(4, 1, 1) KN_CASE(2, 3, 1) KN_CASE(4, 3, 1)
+  KN_CASE(2, 2, 2) KN_CASE(4, 2, 2) KN_CASE(2, 1, 2) KN_CASE(4, 1, 2) KN_CASE(2, 3, 2) KN_CASE(4, 3, 2)
 #undef KN_CASE
-  kn_set_error("knp_rows: unsupported lanes-per-row / ion-count combination");
+  kn_set_error("knp_rows: unsupported lanes-per-row / ion-count / membrane-option combination");
   return KNPEMI_EINVAL;
 }
 
@@ -1639,17 +1647,20 @@ static int launch_knp_hex_v2(knpemi_handle* h, int split, int pre) {
   if (lds > 160 * 1024) { kn_set_error("KNP row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   dim3 grid(D.nblocks), block(KN_BLOCK);
   int rc = 0;
-#define KN_CASE(L, AFF, S)                                                                          \
-  if (h->lpr == L && h->hex_affine == AFF && KS == S) {                                             \
-    if ((rc = set_lds_limit(knp_rows_hex_v2<L, AFF, S>, lds))) return rc;                           \
+  const int mem = pre ? 2 : (gam_n > 0 ? 1 : 0);
+#define KN_CASE(L, AFF, S, M)                                                                       \
+  if (h->lpr == L && h->hex_affine == AFF && KS == S && mem == M) {                                 \
+    if ((rc = set_lds_limit(knp_rows_hex_v2<L, AFF, S, M>, lds))) return rc;                        \
     KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                         \
-    hipLaunchKernelGGL((knp_rows_hex_v2<L, AFF, S>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n, gam_n, split, pre); \
+    hipLaunchKernelGGL((knp_rows_hex_v2<L, AFF, S, M>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n, gam_n, split); \
     return check_launch("knp_rows_hex_v2");                                                         \
   }
-  KN_CASE(4, true, 2) KN_CASE(4, false, 2) KN_CASE(2, true, 2) KN_CASE(2, false, 2) KN_CASE(8, true, 2) KN_CASE(8, false, 2)
-  KN_CASE(1, true, 2) KN_CASE(1, false, 2) KN_CASE(4, true, 1) KN_CASE(4, false, 1) KN_CASE(4, true, 3) KN_CASE(4, false, 3)
+  KN_CASE(4, true, 2, 0) KN_CASE(4, false, 2, 0) KN_CASE(2, true, 2, 0) KN_CASE(2, false, 2, 0) KN_CASE(8, true, 2, 0) KN_CASE(8, false, 2, 0)
+  KN_CASE(1, true, 2, 0) KN_CASE(1, false, 2, 0) KN_CASE(4, true, 1, 0) KN_CASE(4, false, 1, 0) KN_CASE(4, true, 3, 0) KN_CASE(4, false, 3, 0)
+  KN_CASE(4, true, 2, 1) KN_CASE(4, false, 2, 1) KN_CASE(4, true, 1, 1) KN_CASE(4, false, 1, 1) KN_CASE(4, true, 3, 1) KN_CASE(4, false, 3, 1)
+  KN_CASE(4, true, 2, 2) KN_CASE(4, false, 2, 2) KN_CASE(4, true, 1, 2) KN_CASE(4, false, 1, 2) KN_CASE(4, true, 3, 2) KN_CASE(4, false, 3, 2)
 #undef KN_CASE
-  kn_set_error("knp_rows (hexahedra): unsupported lanes-per-row / ion-count combination");
+  kn_set_error("knp_rows (hexahedra): unsupported lanes-per-row / ion-count / membrane-option combination");
   return KNPEMI_EINVAL;
 }
 
