@@ -276,6 +276,38 @@ __device__ __forceinline__ BlkInfo load_blk(const KnDev& D, int b, int wave) {
   return B;
 }
 
+// Rows of a block: KN_BLOCK / LPR / KN_CHUNK chunks of (up to) KN_CHUNK consecutive rows each (D.blk_rng, six ints per
+// chunk: first row, rows, end of the chunk's entries in the block's concatenated EMI segment, global EMI position minus
+// concatenated position, the same two for the Laplacian pattern).  A block of consecutive rows is the special case of
+// consecutive chunks; clustered chunks (knpemi_create) touch fewer distinct vertices.
+template <int LPR>
+struct BlkRows {
+  static constexpr int NR = KN_BLOCK / LPR / KN_CHUNK;
+  const int* rng;
+  __device__ __forceinline__ BlkRows(const KnDev& D, int b) : rng(D.blk_rng + (size_t)b * (6 * NR)) {}
+  // global row of block-local row rloc (valid = false: a lane without a row; it takes the block's first row)
+  __device__ __forceinline__ int row(int rloc, bool& valid) const {
+    const int2 c = *reinterpret_cast<const int2*>(rng + 6 * (rloc / KN_CHUNK));
+    valid = (rloc % KN_CHUNK) < c.y;
+    return valid ? c.x + (rloc % KN_CHUNK) : rng[0];
+  }
+  // f(i, global CSR position) for every position i of the block's concatenated segment (which = 0: EMI pattern,
+  // 1: Laplacian pattern), two chunks per pass: bounds and offsets are wave-uniform, the stores of a pass cover two
+  // contiguous pieces of the global array
+  template <class F>
+  __device__ __forceinline__ void for_each_entry(int tid, int which, F&& f) const {
+    static_assert(NR % 2 == 0, "chunks are walked in pairs");
+    int lo = 0;
+#pragma unroll
+    for (int r = 0; r < NR; r += 2) {
+      const int mid = rng[6 * r + 2 + 2 * which], hi = rng[6 * (r + 1) + 2 + 2 * which];
+      const int d0 = rng[6 * r + 3 + 2 * which], d1 = rng[6 * (r + 1) + 3 + 2 * which];
+      for (int i = lo + tid; i < hi; i += KN_BLOCK) f(i, (int64_t)i + (i >= mid ? d1 : d0));
+      lo = hi;
+    }
+  }
+};
+
 #define KN_STAGE 3   // distinct vertices per thread staged with batched loads (256 threads x 3 = 768)
 
 // Phase A of the v2 kernels: the 48-byte records of the block's distinct vertices go to `recs`, the
@@ -363,11 +395,12 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
   const BlkInfo B = load_blk(D, b, tid >> 6);
-  const int row0 = B.row0, nrows = B.nrows, s = B.sub, seg0 = B.seg0, seglen = B.seglen;
+  const int s = B.sub, seglen = B.seglen;
   // this lane's pair entries and row descriptor: issued first, their latency overlaps phase A
   const int rloc = tid / LPR, sub = tid % LPR;
-  const bool valid = rloc < nrows;
-  const int g = row0 + (valid ? rloc : 0);
+  const BlkRows<LPR> rows(D, b);
+  bool valid;
+  const int g = rows.row(rloc, valid);
   const int64_t base = (int64_t)B.slbase * KN_SLICE + (tid & 63);
   const int np = B.np;
   uint32_t slr[KN_PREFETCH];
@@ -424,11 +457,11 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
   for (int m = 1; m < LPR; m <<= 1) { bacc += __shfl_xor(bacc, m); gam += __shfl_xor(gam, m); }
   if (valid && sub == 0) D.b_emi[g] = bacc + gam;
   __syncthreads();
-  for (int i = tid; i < seglen; i += KN_BLOCK) {
+  rows.for_each_entry(tid, 0, [&](int i, int64_t gp) {
     const double a = accA[i];
-    D.A_emi[seg0 + i] = a;
-    if (want_p) D.P_emi[seg0 + i] = cell_side ? a + D.P_mass[seg0 + i - D.pmass0] : a;
-  }
+    D.A_emi[gp] = a;
+    if (want_p) D.P_emi[gp] = cell_side ? a + D.P_mass[gp - D.pmass0] : a;
+  });
 }
 
 // MEM: where the membrane integrals of b_knp come from -- 0: the partial integrals knp_membrane_kernel left in gam_e
@@ -448,12 +481,13 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
   const BlkInfo B = load_blk(D, b, tid >> 6);
-  const int row0 = B.row0, nrows = B.nrows, s = B.sub, segL0 = B.segL0, nnzLb = B.nnzLb;
+  const int s = B.sub, nnzLb = B.nnzLb;
   const int v0 = C.voff[s], nvs = C.voff[s + 1] - v0;
   const double* fs0 = (D.fsrc && s == 0) ? D.fsrc : nullptr;
   const int rloc = tid / LPR, sub = tid % LPR;
-  const bool valid = rloc < nrows;
-  const int g = row0 + (valid ? rloc : 0);
+  const BlkRows<LPR> rows(D, b);
+  bool valid;
+  const int g = rows.row(rloc, valid);
   const int64_t base = (int64_t)B.slbase * KN_SLICE + (tid & 63);
   const int np = B.np;
   uint32_t slr[KN_PREFETCH];
@@ -543,11 +577,11 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
   }
   __syncthreads();
   const int64_t subnnz0 = D.rowptrL[v0], subnnz = D.rowptrL[v0 + nvs] - subnnz0;
-  double* out0 = D.A_knp + (size_t)KS * subnnz0 + (segL0 - subnnz0);
-  for (int i = tid; i < nnzLb; i += KN_BLOCK) {
+  double* out0 = D.A_knp + (size_t)KS * subnnz0 - subnnz0;
+  rows.for_each_entry(tid, 1, [&](int i, int64_t gp) {
 #pragma unroll
-    for (int k = 0; k < KS; ++k) out0[(size_t)k * subnnz + i] = acc[(size_t)k * acc_n + i];
-  }
+    for (int k = 0; k < KS; ++k) out0[(size_t)k * subnnz + gp] = acc[(size_t)k * acc_n + i];
+  });
 }
 
 // =============================================================================================
@@ -936,10 +970,11 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
   const BlkInfo B = load_blk(D, b, tid >> 6);
-  const int row0 = B.row0, nrows = B.nrows, s = B.sub, seg0 = B.seg0, seglen = B.seglen;
+  const int s = B.sub, seglen = B.seglen;
   const int rloc = tid / LPR, sub = tid % LPR;
-  const bool valid = rloc < nrows;
-  const int g = row0 + (valid ? rloc : 0);
+  const BlkRows<LPR> rows(D, b);
+  bool valid;
+  const int g = rows.row(rloc, valid);
   const int64_t base = (int64_t)B.slbase * KN_SLICE + (tid & 63);
   const int np = B.np;
   // first pair entry of this lane: issued before phase A so that its latency overlaps the staging
@@ -990,11 +1025,11 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
   for (int m = 1; m < LPR; m <<= 1) { bacc += __shfl_xor(bacc, m); gam += __shfl_xor(gam, m); }
   if (valid && sub == 0) D.b_emi[g] = bacc + gam;
   __syncthreads();
-  for (int i = tid; i < seglen; i += KN_BLOCK) {
+  rows.for_each_entry(tid, 0, [&](int i, int64_t gp) {
     const double a = accA[i];
-    D.A_emi[seg0 + i] = a;
-    if (want_p) D.P_emi[seg0 + i] = cell_side ? a + D.P_mass[seg0 + i - D.pmass0] : a;
-  }
+    D.A_emi[gp] = a;
+    if (want_p) D.P_emi[gp] = cell_side ? a + D.P_mass[gp - D.pmass0] : a;
+  });
 }
 
 template <int LPR, bool AFFINE, int KS, int MEM>
@@ -1009,12 +1044,13 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDe
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
   const BlkInfo B = load_blk(D, b, tid >> 6);
-  const int row0 = B.row0, nrows = B.nrows, s = B.sub, segL0 = B.segL0, nnzLb = B.nnzLb;
+  const int s = B.sub, nnzLb = B.nnzLb;
   const int v0 = C.voff[s], nvs = C.voff[s + 1] - v0;
   const double* fs0 = (D.fsrc && s == 0) ? D.fsrc : nullptr;
   const int rloc = tid / LPR, sub = tid % LPR;
-  const bool valid = rloc < nrows;
-  const int g = row0 + (valid ? rloc : 0);
+  const BlkRows<LPR> rows(D, b);
+  bool valid;
+  const int g = rows.row(rloc, valid);
   const int64_t base = (int64_t)B.slbase * KN_SLICE + (tid & 63);
   const int np = B.np;
   int pc0 = -1;
@@ -1092,11 +1128,11 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDe
   }
   __syncthreads();
   const int64_t subnnz0 = D.rowptrL[v0], subnnz = D.rowptrL[v0 + nvs] - subnnz0;
-  double* out0 = D.A_knp + (size_t)KS * subnnz0 + (segL0 - subnnz0);
-  for (int i = tid; i < nnzLb; i += KN_BLOCK) {
+  double* out0 = D.A_knp + (size_t)KS * subnnz0 - subnnz0;
+  rows.for_each_entry(tid, 1, [&](int i, int64_t gp) {
 #pragma unroll
-    for (int k = 0; k < KS; ++k) out0[(size_t)k * subnnz + i] = acc[(size_t)k * acc_n + i];
-  }
+    for (int k = 0; k < KS; ++k) out0[(size_t)k * subnnz + gp] = acc[(size_t)k * acc_n + i];
+  });
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -358,22 +358,88 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   const int LPR = h->lpr, RPB = KN_BLOCK / LPR, RPS = KN_SLICE / LPR;
 
   // ---- row blocks (never straddle a sub-domain) and sliced ELL of (row, cell) pairs ----------------
-  std::vector<int> blk_row0, blk_nrows, blk_sub;
+  // A block holds NR chunks of up to KN_CHUNK consecutive rows (kernels_assemble.hip: BlkRows).  Chunks are clustered
+  // greedily by the number of Laplacian entries that connect them, so that the rows of a block share neighbours: on
+  // the x-fastest numbering of the box meshes 64 consecutive rows are a line of vertices that touches 456 distinct
+  // vertices, a bundle of eight 8-vertex pieces of neighbouring lines ~200.  KNPEMI_BLOCK_CLASSIC=1: consecutive chunks.
+  const int CH = KN_CHUNK, NR = RPB / CH;
+  struct Chunk { int start, len, sub; };
+  std::vector<Chunk> chunks;
+  std::vector<int> chunk_of(Ntot, -1);
   for (int s = 0; s < S; ++s)
-    for (int r0 = h->voff[s]; r0 < h->voff[s + 1]; r0 += RPB) {
-      blk_row0.push_back(r0);
-      blk_nrows.push_back(std::min(RPB, h->voff[s + 1] - r0));
-      blk_sub.push_back(s);
+    for (int r0 = h->voff[s]; r0 < h->voff[s + 1]; r0 += CH) {
+      const int len = std::min(CH, h->voff[s + 1] - r0);
+      for (int g = r0; g < r0 + len; ++g) chunk_of[g] = (int)chunks.size();
+      chunks.push_back({r0, len, s});
     }
-  const int nblocks = (int)blk_row0.size();
+  const int nchunks = (int)chunks.size();
+  std::vector<std::vector<int>> blocks;
+  h->blocks_clustered = getenv("KNPEMI_BLOCK_CLASSIC") == nullptr;
+  if (!h->blocks_clustered) {
+    for (int c = 0; c < nchunks;) {
+      std::vector<int> blk;
+      const int s = chunks[c].sub;
+      while (c < nchunks && chunks[c].sub == s && (int)blk.size() < NR) blk.push_back(c++);
+      blocks.push_back(blk);
+    }
+  } else {
+    std::vector<char> taken(nchunks, 0);
+    std::vector<int> weight(nchunks, 0), cand;
+    int next_free = 0;
+    for (int c0 = 0; c0 < nchunks; ++c0) {
+      if (taken[c0]) continue;
+      const int s = chunks[c0].sub;
+      std::vector<int> blk;
+      cand.clear();
+      auto take = [&](int c) {
+        taken[c] = 1;
+        blk.push_back(c);
+        for (int g = chunks[c].start; g < chunks[c].start + chunks[c].len; ++g)
+          for (int p = rowptrL[g]; p < rowptrL[g + 1]; ++p) {
+            const int d = chunk_of[colindL[p]];
+            if (taken[d] || chunks[d].sub != s) continue;
+            if (weight[d]++ == 0) cand.push_back(d);
+          }
+      };
+      take(c0);
+      while ((int)blk.size() < NR) {
+        int best = -1;
+        for (int d : cand)
+          if (!taken[d] && (best < 0 || weight[d] > weight[best] || (weight[d] == weight[best] && d < best))) best = d;
+        if (best < 0) {   // no free neighbour left: continue with the next free chunk of the sub-domain
+          int f = std::max(next_free, c0 + 1);      // every chunk below next_free is taken
+          while (f < nchunks && chunks[f].sub == s && taken[f]) ++f;
+          next_free = f;
+          if (f >= nchunks || chunks[f].sub != s) break;
+          best = f;
+        }
+        take(best);
+      }
+      for (int d : cand) weight[d] = 0;
+      std::sort(blk.begin(), blk.end());
+      blocks.push_back(blk);
+    }
+  }
+  const int nblocks = (int)blocks.size();
+  std::vector<int> blk_sub(nblocks);
+  // row of slot t of block b (-1: none), slots t = r * CH + o
+  auto slot_row = [&](int b, int t) {
+    const int r = t / CH, o = t % CH;
+    if (r >= (int)blocks[b].size()) return -1;
+    const Chunk& c = chunks[blocks[b][r]];
+    return o < c.len ? c.start + o : -1;
+  };
+  for (int b = 0; b < nblocks; ++b) blk_sub[b] = chunks[blocks[b][0]].sub;
   const int SPB = KN_BLOCK / KN_SLICE;  // slices (wavefronts) per block
   const int SW = NV == 8 ? 2 : 1;
   std::vector<int64_t> sl_ptr((size_t)nblocks * SPB + 1, 0);
   for (int b = 0; b < nblocks; ++b)
     for (int w = 0; w < SPB; ++w) {
       int64_t mx = 0;
-      int ga = blk_row0[b] + w * RPS, gb = std::min(blk_row0[b] + blk_nrows[b], ga + RPS);
-      for (int g = ga; g < gb; ++g) mx = std::max(mx, (v2c_ptr[g + 1] - v2c_ptr[g] + LPR - 1) / LPR);
+      for (int t = w * RPS; t < (w + 1) * RPS; ++t) {
+        const int g = slot_row(b, t);
+        if (g >= 0) mx = std::max(mx, (v2c_ptr[g + 1] - v2c_ptr[g] + LPR - 1) / LPR);
+      }
       sl_ptr[(size_t)b * SPB + w + 1] = sl_ptr[(size_t)b * SPB + w] + mx * KN_SLICE;
     }
   const bool simplex = NV != 8;
@@ -381,8 +447,9 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   std::vector<uint32_t> pair_slots(simplex ? 0 : (size_t)sl_ptr.back() * SW, 0);
   std::vector<uint32_t> pair_sl(simplex ? (size_t)sl_ptr.back() : 0, 0xFFFFFFFFu);
   for (int b = 0; b < nblocks; ++b)
-    for (int t = 0; t < blk_nrows[b]; ++t) {
-      const int g = blk_row0[b] + t, w = t / RPS, rs = t % RPS;
+    for (int t = 0; t < RPB; ++t) {
+      const int g = slot_row(b, t), w = t / RPS, rs = t % RPS;
+      if (g < 0) continue;
       const int* rb = &colindL[rowptrL[g]];
       const int* re = &colindL[rowptrL[g + 1]];
       for (int64_t p = v2c_ptr[g]; p < v2c_ptr[g + 1]; ++p) {
@@ -442,12 +509,42 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
 
   // ---- per-block / per-row descriptors: one scalar load per block, one 16-byte load per row ----------
   std::vector<int> blk_info((size_t)nblocks * 16, 0), row_info((size_t)Ntot * 4, 0), blk_uverts;
+  std::vector<int> blk_rng((size_t)nblocks * NR * 6, 0);
   std::vector<uint16_t> ent_loc(colindL.size(), 0);
+  size_t ent_base = 0;
   for (int b = 0; b < nblocks; ++b) {
     int* bi = &blk_info[(size_t)b * 16];
-    const int g0 = blk_row0[b], g1 = g0 + blk_nrows[b];
-    bi[0] = g0; bi[1] = blk_nrows[b]; bi[2] = blk_sub[b]; bi[3] = rowptr[g0];
-    bi[4] = rowptr[g1] - rowptr[g0]; bi[5] = rowptrL[g0]; bi[6] = rowptrL[g1] - rowptrL[g0];
+    int* rg = &blk_rng[(size_t)b * NR * 6];
+    int offE = 0, offL = 0, nrows = 0;
+    for (int r = 0; r < NR; ++r) {
+      int* q = rg + 6 * r;
+      if (r < (int)blocks[b].size()) {
+        const Chunk& c = chunks[blocks[b][r]];
+        const int g0 = c.start, g1 = c.start + c.len;
+        q[0] = g0; q[1] = c.len;
+        q[3] = rowptr[g0] - offE; q[5] = rowptrL[g0] - offL;
+        for (int g = g0; g < g1; ++g) {
+          int* ri = &row_info[(size_t)g * 4];
+          const int m = gam_idx[g];
+          const int ne = m < 0 ? 0 : mptr[m + 1] - mptr[m];
+          ri[0] = offE + (rowptr[g] - rowptr[g0]);
+          ri[1] = ri[0] + lapoff[g];
+          if (ri[1] > 0xFFFF || ne > 0x7FFF) return fail(KNPEMI_EINVAL, "row block too large for the packed row descriptor");
+          ri[1] |= ne << 16;
+          ri[2] = offL + (rowptrL[g] - rowptrL[g0]);
+          ri[3] = m < 0 ? 0 : mptr[m];
+        }
+        offE += rowptr[g1] - rowptr[g0];
+        offL += rowptrL[g1] - rowptrL[g0];
+        nrows += c.len;
+      } else {
+        q[0] = chunks[blocks[b][0]].start; q[1] = 0;
+        q[3] = rg[6 * (r - 1) + 3]; q[5] = rg[6 * (r - 1) + 5];
+      }
+      q[2] = offE; q[4] = offL;
+    }
+    bi[0] = chunks[blocks[b][0]].start; bi[1] = nrows; bi[2] = blk_sub[b]; bi[3] = 0;
+    bi[4] = offE; bi[5] = (int)ent_base; bi[6] = offL;
     uint32_t steps = 0;
     for (int w = 0; w < SPB; ++w) {
       bi[8 + w] = (int)(sl_ptr[(size_t)b * SPB + w] / KN_SLICE);
@@ -456,10 +553,11 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
       steps |= (uint32_t)np << (8 * w);
     }
     bi[12] = (int)steps;
-    {   // membrane entries of the block's rows (entries are sorted by row, so they form one range)
+    if (!h->blocks_clustered) {   // membrane entries of the block's rows (entries are sorted by row: one range)
       int me0 = 0, mne = 0;
-      for (int g = g0; g < g1; ++g) {
-        const int m = gam_idx[g];
+      for (int t = 0; t < RPB; ++t) {
+        const int g = slot_row(b, t);
+        const int m = g < 0 ? -1 : gam_idx[g];
         if (m < 0) continue;
         if (mne == 0) me0 = mptr[m];
         mne = mptr[m + 1] - me0;
@@ -467,54 +565,43 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
       bi[14] = me0; bi[15] = mne;
       h->lds_gam_max = std::max(h->lds_gam_max, mne);
     }
-    // distinct vertices touched by the block's rows (sorted: consecutive ids = contiguous records)
+    // distinct vertices touched by the block's rows (sorted: consecutive ids = contiguous records); the local index
+    // of every Laplacian entry, in the order of the block's concatenated segment
     {
-      std::vector<int> u(colindL.begin() + rowptrL[g0], colindL.begin() + rowptrL[g1]);
+      std::vector<int> u;
+      for (int c : blocks[b])
+        u.insert(u.end(), colindL.begin() + rowptrL[chunks[c].start], colindL.begin() + rowptrL[chunks[c].start + chunks[c].len]);
+      std::vector<int> ordered(u);
       std::sort(u.begin(), u.end());
       u.erase(std::unique(u.begin(), u.end()), u.end());
       if (u.size() > 65535) return fail(KNPEMI_EINVAL, "row block touches more than 65535 vertices");
       bi[7] = (int)blk_uverts.size();
       bi[13] = (int)u.size();
       h->lds_uniq_max = std::max(h->lds_uniq_max, (int)u.size());
-      for (int p = rowptrL[g0]; p < rowptrL[g1]; ++p)
-        ent_loc[p] = (uint16_t)(std::lower_bound(u.begin(), u.end(), colindL[p]) - u.begin());
+      for (size_t i = 0; i < ordered.size(); ++i)
+        ent_loc[ent_base + i] = (uint16_t)(std::lower_bound(u.begin(), u.end(), ordered[i]) - u.begin());
+      ent_base += ordered.size();
+      if (ent_base > (size_t)INT32_MAX) return fail(KNPEMI_EINVAL, "mesh too large for int32 block lists");
       blk_uverts.insert(blk_uverts.end(), u.begin(), u.end());
       if (blk_uverts.size() > (size_t)INT32_MAX) return fail(KNPEMI_EINVAL, "mesh too large for int32 block lists");
     }
-    for (int g = g0; g < g1; ++g) {
-      int* ri = &row_info[(size_t)g * 4];
-      const int m = gam_idx[g];
-      const int ne = m < 0 ? 0 : mptr[m + 1] - mptr[m];
-      ri[0] = rowptr[g] - rowptr[g0];
-      ri[1] = ri[0] + lapoff[g];
-      if (ri[1] > 0xFFFF || ne > 0x7FFF) return fail(KNPEMI_EINVAL, "row block too large for the packed row descriptor");
-      ri[1] |= ne << 16;
-      ri[2] = rowptrL[g] - rowptrL[g0];
-      ri[3] = m < 0 ? 0 : mptr[m];
-    }
-  }
-
-  // ---- LDS segment sizes ----------------------------------------------------------------------------------
-  for (int b = 0; b < nblocks; ++b) {
-    int g0 = blk_row0[b], g1 = g0 + blk_nrows[b];
-    h->lds_doubles_emi = std::max(h->lds_doubles_emi, rowptr[g1] - rowptr[g0]);
-    h->lds_doubles_knp = std::max(h->lds_doubles_knp, rowptrL[g1] - rowptrL[g0]);
+    h->lds_doubles_emi = std::max(h->lds_doubles_emi, offE);
+    h->lds_doubles_knp = std::max(h->lds_doubles_knp, offL);
   }
 
   if (getenv("KNPEMI_DEBUG_LDS")) {
     // distribution of the per-block LDS needs (the launch uses the maxima)
     std::vector<int> segs, uniq;
     for (int b = 0; b < nblocks; ++b) {
-      int g0 = blk_row0[b], g1 = g0 + blk_nrows[b];
-      segs.push_back(rowptr[g1] - rowptr[g0]);
+      segs.push_back(blk_info[(size_t)b * 16 + 4]);
       uniq.push_back(blk_info[(size_t)b * 16 + 13]);
     }
     std::sort(segs.begin(), segs.end());
     std::sort(uniq.begin(), uniq.end());
     auto pct = [&](const std::vector<int>& v, double p) { return v[(size_t)(p * (v.size() - 1))]; };
-    fprintf(stderr, "[knpemi] blocks %d lpr %d | EMI segment doubles: p50 %d p90 %d p99 %d max %d | distinct vertices: p50 %d p90 %d p99 %d max %d\n",
-            nblocks, LPR, pct(segs, .5), pct(segs, .9), pct(segs, .99), segs.back(), pct(uniq, .5), pct(uniq, .9), pct(uniq, .99),
-            uniq.back());
+    fprintf(stderr, "[knpemi] blocks %d (%s) lpr %d | EMI segment doubles: p50 %d p90 %d p99 %d max %d | distinct vertices: p50 %d p90 %d p99 %d max %d\n",
+            nblocks, h->blocks_clustered ? "clustered chunks" : "consecutive rows", LPR, pct(segs, .5), pct(segs, .9), pct(segs, .99),
+            segs.back(), pct(uniq, .5), pct(uniq, .9), pct(uniq, .99), uniq.back());
   }
 
   // ---- upload --------------------------------------------------------------------------------------------
@@ -527,8 +614,7 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   if ((rc = dev_upload(h, VR, &vr_c))) return rc;
   D.VR = const_cast<double*>(vr_c);
   if ((rc = dev_upload(h, cells, &D.cells))) return rc;
-  if ((rc = dev_upload(h, blk_row0, &D.blk_row0))) return rc;
-  if ((rc = dev_upload(h, blk_nrows, &D.blk_nrows))) return rc;
+  if ((rc = dev_upload(h, blk_rng, &D.blk_rng))) return rc;
   if ((rc = dev_upload(h, blk_sub, &D.blk_sub))) return rc;
   {
     const int* bi = nullptr; const int* ri = nullptr;
@@ -1366,7 +1452,12 @@ extern "C" int knpemi_vec_scatter(knpemi_handle* h, void* vec_dev, const int32_t
 extern "C" int knpemi_set_option(knpemi_handle* h, int option, int value) {
   if (!h) return fail(KNPEMI_EINVAL, "null handle");
   if (option == KNPEMI_OPT_FUSE_UPDATE) { h->fuse_update = value ? 1 : 0; return KNPEMI_OK; }
-  if (option == KNPEMI_OPT_FUSE_MEMBRANE) { h->fuse_membrane = value ? 1 : 0; return KNPEMI_OK; }
+  if (option == KNPEMI_OPT_FUSE_MEMBRANE) {
+    if (value && h->blocks_clustered)
+      return fail(KNPEMI_EINVAL, "KNPEMI_OPT_FUSE_MEMBRANE needs row blocks of consecutive rows (create the handle with KNPEMI_BLOCK_CLASSIC=1)");
+    h->fuse_membrane = value ? 1 : 0;
+    return KNPEMI_OK;
+  }
   if (option == KNPEMI_OPT_PROFILE_STRIDE) {   // the next launch of every kernel is a bracketed one
     h->prof_stride = value > 1 ? value : 1;
     for (unsigned& c : h->prof_count) c = 0;

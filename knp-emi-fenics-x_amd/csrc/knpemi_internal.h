@@ -19,6 +19,7 @@
 #define KN_CSLOT(k) ((k) < 3 ? 4 + (k) : 3)
 #define KN_BLOCK 256          // threads per row-kernel workgroup (rows per block = KN_BLOCK / lanes-per-row)
 #define KN_SLICE 64       // rows per sliced-ELL slice == wavefront width on gfx950
+#define KN_CHUNK 8        // consecutive rows per chunk of a row block (kernels_assemble.hip: BlkRows)
 
 // Per-sub-domain constants folded on the host from knpemi_params (double arithmetic identical
 // to what the kernels would do per cell).
@@ -46,16 +47,16 @@ struct KnConsts {
 struct KnDev {
   int Ntot, nctot, NQtot, nftot;
   int nblocks;                // row blocks; a block never straddles two sub-domains
-  const int* blk_row0;        // [nblocks] first global row of the block
-  const int* blk_nrows;       // [nblocks] rows in the block (<= KN_BLOCK / lpr)
+  const int* blk_rng;         // [nblocks][KN_BLOCK / lpr / KN_CHUNK][6] chunks of consecutive rows (BlkRows)
   const int* blk_sub;         // [nblocks] sub-domain of the block
-  const int4* blk_info;       // [nblocks][4]: {row0, nrows, sub, rowptr[row0]} {EMI seg length, rowptrL[row0],
+  const int4* blk_info;       // [nblocks][4]: {first row, rows, sub, 0} {EMI seg length, offset into ent_loc,
                               //   Laplacian seg length, offset into blk_uverts} {slice entry bases / 64}
                               //   {4 x uint8 slice steps, #distinct vertices, 0, 0}
   const int* blk_uverts;      // concatenated per-block sorted lists of the distinct vertices its rows touch
-  const uint16_t* ent_loc;    // [nnzL] position of every Laplacian entry's vertex in its block's list
-  const int4* row_info;       // [Ntot]: {rowptr[g] - seg0, (that + lapoff[g]) | n_membrane_entries << 16, rowptrL[g] - segL0,
-                              //          first membrane entry}
+  const uint16_t* ent_loc;    // [nnzL] position of every Laplacian entry's vertex in its block's list, stored in the
+                              //   order of the blocks' concatenated Laplacian segments
+  const int4* row_info;       // [Ntot]: offsets in the block's concatenated segments {EMI row start, (that + lapoff[g]) |
+                              //          n_membrane_entries << 16, Laplacian row start, first membrane entry}
   double* VR;                 // [Ntot][KN_REC]
   double* csol;               // [K-1][Ntot]  solver output c (block order handled by offsets)
   double* fsrc;               // [K-1][N_0] optional ECS source term (NULL when unused)
@@ -238,6 +239,7 @@ struct knpemi_handle {
   int prof_stride = 1;                 // KNPEMI_OPT_PROFILE_STRIDE
   unsigned prof_count[16] = {0};
   int lds_gam_max = 0;                 // most membrane entries of one row block
+  bool blocks_clustered = false;       // row blocks are clusters of row chunks (default), not consecutive rows
   KnDist dist;
   // per-kernel event profiling (knpemi_profile)
   uint32_t prof_mask = 0;

@@ -83,6 +83,28 @@ def test_general_hexahedron_kernel_on_box_mesh(hip_lib, monkeypatch):
     assert max(errs.values()) < TOL, errs
 
 
+@pytest.mark.parametrize("kind", ["2d", "tet", "hex"])
+def test_clustered_row_blocks_equal_blocks_of_consecutive_rows_bit_for_bit(hip_lib, monkeypatch, kind):
+    """The row blocks are clusters of 8-row chunks chosen by the Laplacian graph (fewer distinct vertices to stage per
+    block); KNPEMI_BLOCK_CLASSIC=1 takes 64 consecutive rows.  A row's pairs, their order and its lanes do not depend on
+    the block it sits in: all five assembled objects agree bit for bit."""
+    res = []
+    for classic in (False, True):
+        if classic:
+            monkeypatch.setenv("KNPEMI_BLOCK_CLASSIC", "1")
+        else:
+            monkeypatch.delenv("KNPEMI_BLOCK_CLASSIC", raising=False)
+        s = Setup(kind, 1 if kind == "2d" else 0)
+        s.perturb()
+        errs, objs = _assemble_both(s)
+        assert max(errs.values()) < TOL, errs
+        res.append(objs)
+    for a, b in zip(*res):
+        a = a.data if hasattr(a, "data") and not isinstance(a, np.ndarray) else a
+        b = b.data if hasattr(b, "data") and not isinstance(b, np.ndarray) else b
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
 def test_assembly_is_bit_reproducible(hip_lib):
     s = Setup("tet", 0)
     s.perturb()
@@ -1029,7 +1051,7 @@ def test_device_resident_time_loop_matches_oracle(hip_lib):
     assert all(it[1] <= 1000 for it in st.iterations)
 
 
-def test_fused_update_and_overlap_variants_are_bit_identical(hip_lib):
+def test_fused_update_and_overlap_variants_are_bit_identical(hip_lib, monkeypatch):
     """The stepper's launch-saving variants change no bit: update_pde_variables fused into the write-back kernel of the
     KNP solve (KNPEMI_OPT_FUSE_UPDATE) vs the separate launch; the EMI matrix assembled beside the ODE sweep (aux
     stream, separate Robin-term launch) vs after it (fused Robin term); the early part of the membrane-facet integrals
@@ -1042,6 +1064,10 @@ def test_fused_update_and_overlap_variants_are_bit_identical(hip_lib):
     variants = ((True, True, 0.025, False, True), (False, True, 0.0, False, True), (False, False, 0.025, False, True),
                 (False, False, 0.025, True, False), (True, True, 0.025, False, False))
     for fuse, overlap, thr, fuse_mem, early in variants:
+        if fuse_mem:      # the in-row form needs row blocks of consecutive rows (one range of membrane entries per block)
+            monkeypatch.setenv("KNPEMI_BLOCK_CLASSIC", "1")
+        else:
+            monkeypatch.delenv("KNPEMI_BLOCK_CLASSIC", raising=False)
         s = Setup("tet", 0, g_syn=10.0)
         for t in s.subdomain_list:
             for k in range(2):
