@@ -319,7 +319,7 @@ struct Lsoda {
     _Pragma("unroll") for (int i = 0; i < NI; ++i) {
       const double e = rtol * fabs(yc[i]) + atol;
       if (!(e > 0.0)) bad = 1.0;
-      ewt[i] = 1.0 / e;
+      ewt[i] = kn_div(1.0, e);
     }
     return kn_group_max<LANES>(bad) == 0.0;
   }
@@ -616,10 +616,10 @@ struct Lsoda {
         nqm2 = nq < MXORDS ? nq : MXORDS;
       } else {
         exsm = 1.0 / (double)l;
-        rh1 = 1.0 / (1.2 * kn_powr(dsm, exsm) + 0.0000012);
+        rh1 = kn_div(1.0, 1.2 * kn_powr(dsm, exsm) + 0.0000012);
         rh1it = 2.0 * rh1;
         pdh = pdlast * fabs(h);
-        if ((pdh * rh1) > 0.00001) rh1it = sm1(nq) / pdh;
+        if ((pdh * rh1) > 0.00001) rh1it = kn_div(sm1(nq), pdh);
         rh1 = fmin(rh1, rh1it);
         if (nq > MXORDS) {   // (unreachable behind `nq > 5` above; kept as in DSTODA)
           nqm2 = MXORDS;
@@ -630,7 +630,7 @@ struct Lsoda {
           rh2 = 1.0 / (1.2 * kn_powr(dm2, exm2) + 0.0000012);
         } else {
           dm2 = dsm * (cf->cm1[nq] / cf->cm2[nq]);
-          rh2 = 1.0 / (1.2 * kn_powr(dm2, exsm) + 0.0000012);
+          rh2 = kn_div(1.0, 1.2 * kn_powr(dm2, exsm) + 0.0000012);
           nqm2 = nq;
         }
         if (rh2 < ratio * rh1) return;
@@ -684,23 +684,23 @@ struct Lsoda {
     double dup = 1.0, ddn = 1.0;
     if (up) {
       _Pragma("unroll") for (int i = 0; i < NI; ++i) savf[i] = acor[i] - ysave[i];
-      dup = vmnorm(savf) / tq3;
+      dup = kn_div(vmnorm(savf), tq3);
     }
     if (dn) {
       double row[NI];
       get_row(l, lb, row);
-      ddn = vmnorm(row) / tq1;
+      ddn = kn_div(vmnorm(row), tq1);
     }
     double psm, pdn, pup;
     pow3(dsm, exsm, ddn, 1.0 / (double)nq, dup, 1.0 / (double)(l + 1), psm, pdn, pup);
-    double rhup = up ? 1.0 / (1.4 * pup + 0.0000014) : 0.0;
-    double rhsm = 1.0 / (1.2 * psm + 0.0000012);
-    double rhdn = dn ? 1.0 / (1.3 * pdn + 0.0000013) : 0.0;
+    double rhup = up ? kn_div(1.0, 1.4 * pup + 0.0000014) : 0.0;
+    double rhsm = kn_div(1.0, 1.2 * psm + 0.0000012);
+    double rhdn = dn ? kn_div(1.0, 1.3 * pdn + 0.0000013) : 0.0;
     if (meth == 1) {
       pdh = fmax(fabs(h) * pdlast, 0.000001);
-      if (l < lmax) rhup = fmin(rhup, sm1(l) / pdh);
-      rhsm = fmin(rhsm, sm1(nq) / pdh);
-      if (nq > 1) rhdn = fmin(rhdn, sm1(nq - 1) / pdh);
+      if (l < lmax) rhup = fmin(rhup, kn_div(sm1(l), pdh));
+      rhsm = fmin(rhsm, kn_div(sm1(nq), pdh));
+      if (nq > 1) rhdn = fmin(rhdn, kn_div(sm1(nq - 1), pdh));
       pdest = 0.0;
     }
     if (rhsm >= rhup) {
