@@ -383,41 +383,74 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
       blocks.push_back(blk);
     }
   } else {
-    std::vector<char> taken(nchunks, 0);
-    std::vector<int> weight(nchunks, 0), cand;
-    int next_free = 0;
-    for (int c0 = 0; c0 < nchunks; ++c0) {
-      if (taken[c0]) continue;
-      const int s = chunks[c0].sub;
-      std::vector<int> blk;
-      cand.clear();
-      auto take = [&](int c) {
-        taken[c] = 1;
-        blk.push_back(c);
-        for (int g = chunks[c].start; g < chunks[c].start + chunks[c].len; ++g)
-          for (int p = rowptrL[g]; p < rowptrL[g + 1]; ++p) {
-            const int d = chunk_of[colindL[p]];
-            if (taken[d] || chunks[d].sub != s) continue;
-            if (weight[d]++ == 0) cand.push_back(d);
+    // greedy clustering; `cap` bounds the distinct vertices of a block (the LDS of a launch is sized by the largest
+    // block): a first pass without a bound gives the distribution, the second pass cuts its tail at 9/8 of the 90th
+    // percentile by closing a block early
+    std::vector<int> seen(Ntot, -1);
+    auto cluster = [&](int cap, std::vector<int>* uniq_out) {
+      blocks.clear();
+      std::fill(seen.begin(), seen.end(), -1);
+      std::vector<char> taken(nchunks, 0);
+      std::vector<int> weight(nchunks, 0), cand;
+      int next_free = 0;
+      for (int c0 = 0; c0 < nchunks; ++c0) {
+        if (taken[c0]) continue;
+        const int s = chunks[c0].sub, id = (int)blocks.size();
+        std::vector<int> blk;
+        cand.clear();
+        int uniq = 0;
+        auto fresh = [&](int c, bool mark) {   // distinct vertices chunk c would add to the block
+          int n = 0;
+          for (int p = rowptrL[chunks[c].start]; p < rowptrL[chunks[c].start + chunks[c].len]; ++p) {
+            const int v = colindL[p];
+            if (seen[v] == id) continue;
+            if (mark) seen[v] = id;
+            else { seen[v] = -2 - id; }         // counted once within this probe, undone below
+            ++n;
           }
-      };
-      take(c0);
-      while ((int)blk.size() < NR) {
-        int best = -1;
-        for (int d : cand)
-          if (!taken[d] && (best < 0 || weight[d] > weight[best] || (weight[d] == weight[best] && d < best))) best = d;
-        if (best < 0) {   // no free neighbour left: continue with the next free chunk of the sub-domain
-          int f = std::max(next_free, c0 + 1);      // every chunk below next_free is taken
-          while (f < nchunks && chunks[f].sub == s && taken[f]) ++f;
-          next_free = f;
-          if (f >= nchunks || chunks[f].sub != s) break;
-          best = f;
+          if (!mark)
+            for (int p = rowptrL[chunks[c].start]; p < rowptrL[chunks[c].start + chunks[c].len]; ++p)
+              if (seen[colindL[p]] == -2 - id) seen[colindL[p]] = -1;
+          return n;
+        };
+        auto take = [&](int c) {
+          taken[c] = 1;
+          blk.push_back(c);
+          uniq += fresh(c, true);
+          for (int g = chunks[c].start; g < chunks[c].start + chunks[c].len; ++g)
+            for (int p = rowptrL[g]; p < rowptrL[g + 1]; ++p) {
+              const int d = chunk_of[colindL[p]];
+              if (taken[d] || chunks[d].sub != s) continue;
+              if (weight[d]++ == 0) cand.push_back(d);
+            }
+        };
+        take(c0);
+        while ((int)blk.size() < NR) {
+          int best = -1;
+          for (int d : cand)
+            if (!taken[d] && (best < 0 || weight[d] > weight[best] || (weight[d] == weight[best] && d < best))) best = d;
+          if (best < 0) {   // no free neighbour left: continue with the next free chunk of the sub-domain
+            int f = std::max(next_free, c0 + 1);      // every chunk below next_free is taken
+            while (f < nchunks && chunks[f].sub == s && taken[f]) ++f;
+            next_free = f;
+            if (f >= nchunks || chunks[f].sub != s) break;
+            best = f;
+          }
+          if (uniq + fresh(best, false) > cap) break;
+          take(best);
         }
-        take(best);
+        for (int d : cand) weight[d] = 0;
+        std::sort(blk.begin(), blk.end());
+        blocks.push_back(blk);
+        if (uniq_out) uniq_out->push_back(uniq);
       }
-      for (int d : cand) weight[d] = 0;
-      std::sort(blk.begin(), blk.end());
-      blocks.push_back(blk);
+    };
+    std::vector<int> uq;
+    cluster(INT32_MAX, &uq);
+    if (!uq.empty()) {
+      std::sort(uq.begin(), uq.end());
+      const int p90 = uq[(size_t)(0.9 * (uq.size() - 1))];
+      if (uq.back() > p90 + p90 / 8) cluster(p90 + p90 / 8, nullptr);
     }
   }
   const int nblocks = (int)blocks.size();
@@ -591,13 +624,17 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
 
   if (getenv("KNPEMI_DEBUG_LDS")) {
     // distribution of the per-block LDS needs (the launch uses the maxima)
-    std::vector<int> segs, uniq;
+    std::vector<int> segs, uniq, lsegs;
     for (int b = 0; b < nblocks; ++b) {
       segs.push_back(blk_info[(size_t)b * 16 + 4]);
+      lsegs.push_back(blk_info[(size_t)b * 16 + 6]);
       uniq.push_back(blk_info[(size_t)b * 16 + 13]);
     }
     std::sort(segs.begin(), segs.end());
+    std::sort(lsegs.begin(), lsegs.end());
     std::sort(uniq.begin(), uniq.end());
+    fprintf(stderr, "[knpemi] Laplacian segment doubles: p50 %d p90 %d p99 %d max %d\n", lsegs[lsegs.size() / 2],
+            lsegs[(size_t)(0.9 * (lsegs.size() - 1))], lsegs[(size_t)(0.99 * (lsegs.size() - 1))], lsegs.back());
     auto pct = [&](const std::vector<int>& v, double p) { return v[(size_t)(p * (v.size() - 1))]; };
     fprintf(stderr, "[knpemi] blocks %d (%s) lpr %d | EMI segment doubles: p50 %d p90 %d p99 %d max %d | distinct vertices: p50 %d p90 %d p99 %d max %d\n",
             nblocks, h->blocks_clustered ? "clustered chunks" : "consecutive rows", LPR, pct(segs, .5), pct(segs, .9), pct(segs, .99),
