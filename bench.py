@@ -533,7 +533,7 @@ def main():
         torch.cuda.synchronize()
 
     lib = dp.lib
-    n_traj = args.warmup + PROFILE_STEPS + args.steps
+    n_traj = args.warmup + PROFILE_STEPS + args.steps + 8      # + the short pass that times the row kernels alone
     traj_its = None
     traj_fallback = None
     if not frozen and halo is not None:
@@ -625,6 +625,24 @@ def main():
     L.check(lib.knpemi_set_option(dp.h, L.OPT_PROFILE_STRIDE, 1))
     if n_failed:
         raise SystemExit("LSODA failed on the device")
+    # The row kernels by themselves: while the EMI assembly shares the chip with the ODE sweep its launches are
+    # stretched by the sweep's waves.  A short untimed pass with everything on one stream gives the durations the
+    # kernels reach alone (`roofline_row_kernels_alone`); the step time above is the overlapped schedule's.
+    alone = {}
+    overlapped = bool(stepper.overlap)
+    if overlapped and not frozen and len(phi_t) >= args.warmup + PROFILE_STEPS + args.steps + 8:
+        stepper.overlap = False
+        L.check(lib.knpemi_profile(dp.h, (1 << L.KERNEL_NAMES.index("emi_rows_kernel")) | (1 << L.KERNEL_NAMES.index("knp_rows_kernel"))))
+        for _ in range(8):
+            stepper.step(halo)
+        sync()
+        for name in ("emi_rows_kernel", "knp_rows_kernel"):
+            n, ms = C.c_int64(), C.c_double()
+            L.check(lib.knpemi_profile_read(dp.h, L.KERNEL_NAMES.index(name), C.byref(n), C.byref(ms)))
+            if n.value:
+                alone[name] = ms.value / n.value * 1e3
+        L.check(lib.knpemi_profile(dp.h, 0))
+        stepper.overlap = True
     if dist is not None:
         red_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -679,7 +697,7 @@ def main():
                                    f"{len(s.subdomain_list)} sub-domains, {n_ode_dofs} membrane ODE dofs/GPU, 3 ions "
                                    f"(K, Cl, Na eliminated), {case.describe}",
                        "dofs_per_step": dofs_total, "A_knp_assemblies_per_step": 2 if args.knp_twice else 1,
-                       "emi_matrix_beside_ode_sweep": bool(stepper.overlap),
+                       "emi_matrix_beside_ode_sweep": overlapped,
                        "update_fused_into_knp_write_back": bool(stepper.fuse_update),
                        "state": (("fields frozen at the initial state (phi_M reset every step)"
                                   + (f"; FALLBACK: the trajectory pass with distributed solves raised {traj_fallback}"
@@ -690,6 +708,7 @@ def main():
                        "partition": "x-slabs" if world > 1 else "none"},
             "roofline": roof(dominant, dom_us),
             "roofline_membrane_facet_kernel": roof("knp_membrane_kernel", mem_us) if mem_us > 0 else None,
+            "roofline_row_kernels_alone": {k: roof(k, v) for k, v in alone.items()} or None,
             "kernels_us_per_step": per_kernel,
             "ode": {"rhs_evals_per_dof_per_step": n_rhs / max(1, n_ode_dofs) / args.steps,
                     "lsoda_steps_per_dof_per_step": n_lsoda_steps / max(1, n_ode_dofs) / args.steps,
