@@ -78,13 +78,15 @@ def test_coarse_space_of_the_distributed_emi_solve_lowers_the_iteration_count(mo
     at resolution 0 both counts are equal), solved to the reference's tolerances (pdeSolver.py:9,84: rtol 1e-5, the example drivers pass 1e-7 for KNP;
     the correction removes the smooth error the first iterations spend their time on, at 1e-8 the interface modes of
     the non-overlapping blocks set the count and the gain is 10 %): fewer CG iterations than the block-Jacobi AMG
-    alone, fields within what those tolerances leave (I_K is a small remainder of channel and pump currents)."""
+    alone, fields within what those tolerances leave (I_K is a small remainder of channel and pump currents).  Six steps:
+    the first two solves start cold and need 52 against 57 iterations, from the third on 31, 29, 28, 19 against
+    51, 49, 49, 47."""
     import re
     mean = {}
     for off in ("", "1"):
         if off:
             monkeypatch.setenv("KNPEMI_NO_COARSE", "1")
-        rcs, outs = _run_ranks(["--kind", "tet", "--steps", "3", "--method", "slabgen", "--solves", "--resolution", "1",
+        rcs, outs = _run_ranks(["--kind", "tet", "--steps", "6", "--method", "slabgen", "--solves", "--resolution", "1",
                            "--rtol", "1e-5", "1e-7", "--tol", "1e-2"],
                                world=3)
         assert rcs == [0, 0, 0], "\n".join(outs)
