@@ -253,7 +253,9 @@ int knpemi_update_pde(knpemi_handle* h);
  *   instead of in a launch of their own that hands them over through HBM.  Measured on MI355X it does not pay: the
  *   degree-6 facet quadrature lands on the few row blocks that own membrane rows, so the row kernel's tail grows by as
  *   much as (24,794 dofs: 17.0 + 16.3 us apart, 34.2 us fused) or more than (219,542 dofs: 59.3 + 18.7 us apart,
- *   107 us fused) the stand-alone kernel costs spread over all CUs.  Kept as an option for small, launch-bound cases. */
+ *   107 us fused) the stand-alone kernel costs spread over all CUs.  Kept as an option for small, launch-bound cases.
+ *   It needs row blocks of consecutive rows (the membrane entries of a block are then one range): create the handle
+ *   with KNPEMI_BLOCK_CLASSIC=1 in the environment, otherwise the option is refused with KNPEMI_EINVAL. */
 #define KNPEMI_OPT_FUSE_UPDATE 1
 #define KNPEMI_OPT_FUSE_MEMBRANE 2
 /* KNPEMI_OPT_PROFILE_STRIDE (n >= 1, default 1): knpemi_profile brackets every n-th launch of a selected kernel only. */
