@@ -256,6 +256,24 @@ def test_dg_error_paths(hip_lib):
         dp.assemble_emi()
     with pytest.raises(ValueError):
         dp.set_potential(np.zeros(3))
+    with pytest.raises(KnpemiError, match="solve_knp has not been called"):
+        dp.solution()
+    with pytest.raises(KnpemiError, match="set_params"):
+        dp.solve_knp(update=True)
+    # a solve that cannot reach its tolerance in maxit iterations reports it (ksp_error_if_not_converged)
+    params = dict(dt=0.05, F=1.0, psi=1.0, C_M=1.0)
+    ions = [dict(z=z, D=[1.0, 0.7]) for z in (1.0, -1.0, 1.0)]
+    c_all, phi, phi_M, I_ch, _ = _random_state(dp, 3, 5)
+    _push(dp, params, ions, c_all, phi, phi_M, I_ch)
+    big = DGProblem(create_unit_square(None, 24, 24), *_tag(create_unit_square(None, 24, 24), [([0.25] * 2, [0.75] * 2)], [1],
+                                                            full_facet_tags=False), [0, 1], [1])
+    c_all, phi, phi_M, I_ch, _ = _random_state(big, 3, 5)
+    _push(big, params, ions, c_all, phi, phi_M, I_ch)
+    big.assemble_emi()
+    with pytest.raises(KnpemiError, match="did not converge"):
+        big.solve_emi(rtol=1e-14, maxit=2)
+    its, rr = big.solve_emi(rtol=1e-9)
+    assert 0 < its < 100 and rr < 1e-9
 
 
 def test_dg_time_loop_on_the_device_matches_the_restatement(hip_lib):
