@@ -427,6 +427,9 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
 #pragma unroll
       for (int j = 0; j < NV; ++j) slot[j] = (sl >> (8 * j)) & 255;
       if (diag < 0) { diag = slot[0]; r[0] = lds_rec5(recs, eloc[rL + diag]); }   // the row's own vertex, once
+      // (The host orders a lane's pairs in strips that share all but one vertex; knp_rows_v2 keeps the shared records
+      // in registers.  Here that costs the fifth block per CU -- 104 instead of 84 registers -- and the LDS pipe is
+      // less loaded, 36 % against 51 %: measured 49.4 against 47.7 us at 995 k tets, so every record is read again.)
 #pragma unroll
       for (int j = 1; j < NV; ++j) r[j] = lds_rec5(recs, eloc[rL + slot[j]]);
       double d[NV];
@@ -514,13 +517,20 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
 #pragma unroll
     for (int k = 0; k < KS; ++k) dk[k] = 0.0;
     RecK<KS> r[NV];
+    // The host orders a lane's pairs in strips: consecutive cells share all but one vertex, at the same byte positions
+    // of the pair entry.  The records of the shared vertices stay in registers; only a slot that changed is read from
+    // LDS again (one 48-byte record per pair instead of three: knp_rows 53.6 -> 46.9 us at 995 k tets, with four
+    // instead of five blocks per CU -- 112 registers; capping them at 96 spills and gives the gain back).
+    uint32_t have = 0xFFFFFFFFu;     // slots of the records r[1..] currently hold
     auto do_pair = [&](uint32_t sl) {
       int slot[NV];
 #pragma unroll
       for (int j = 0; j < NV; ++j) slot[j] = (sl >> (8 * j)) & 255;
       if (diag < 0) { diag = slot[0]; r[0] = lds_rec<KS>(recs, eloc[rL + diag]); }
 #pragma unroll
-      for (int j = 1; j < NV; ++j) r[j] = lds_rec<KS>(recs, eloc[rL + slot[j]]);
+      for (int j = 1; j < NV; ++j)
+        if (slot[j] != (int)((have >> (8 * j)) & 255)) r[j] = lds_rec<KS>(recs, eloc[rL + slot[j]]);
+      have = sl;
       double d[NV];
       const double vol = simplex_row0<GDIM>(r, d);
       double gp = 0;

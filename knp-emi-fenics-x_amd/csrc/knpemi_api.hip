@@ -5,6 +5,7 @@
 // (src/knpemi/pdeSolver.py:46-66,121-139: sparsity patterns, dof maps, entity maps) and inside
 // scifem.compute_interface_data (src/knpemi/emiWeakForm.py:39-42).
 #include <algorithm>
+#include <array>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -485,6 +486,62 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
       if (g < 0) continue;
       const int* rb = &colindL[rowptrL[g]];
       const int* re = &colindL[rowptrL[g + 1]];
+      if (simplex) {
+        // The LPR lanes of the row take strips of its incident cells: consecutive cells of a lane share a face (an
+        // edge in 2D) that contains the row vertex, and the shared vertices keep their byte position in the pair
+        // entry, so the kernel re-reads from LDS only the record whose slot changed (one per pair instead of NV - 1).
+        // Ties are broken by the cell order, vertex positions start from the cell's own vertex order: the same on
+        // every partition of the mesh.
+        const int n = (int)(v2c_ptr[g + 1] - v2c_ptr[g]), NO = NV - 1, Lmax = (n + LPR - 1) / LPR;
+        std::vector<std::array<int, 3>> ov(n);
+        for (int q = 0; q < n; ++q) {
+          const int vc = v2c[v2c_ptr[g] + q], li = vc & 7;
+          const int* cv = &cells[(size_t)(vc >> 3) * NV];
+          for (int j = 1; j < NV; ++j) ov[q][j - 1] = cv[(li + j) % NV];
+        }
+        std::vector<char> used(n, 0);
+        int remaining = n;
+        for (int sub = 0; sub < LPR && remaining > 0; ++sub) {
+          std::array<int, 3> prev{};
+          bool have_prev = false;
+          for (int len = 0; len < Lmax && remaining > 0; ++len) {
+            auto shared = [&](const std::array<int, 3>& a) {
+              int c = 0;
+              for (int x = 0; x < NO; ++x) for (int y = 0; y < NO; ++y) c += a[x] == prev[y];
+              return c;
+            };
+            int pick = -1;
+            if (have_prev)
+              for (int q = 0; q < n && pick < 0; ++q) if (!used[q] && shared(ov[q]) == NO - 1) pick = q;
+            const bool strip = pick >= 0;
+            for (int q = 0; q < n && pick < 0; ++q) if (!used[q]) pick = q;
+            std::array<int, 3> cur = ov[pick];
+            if (strip) {   // the vertices shared with the previous pair stay where they are, the new one takes the free place
+              cur = prev;
+              int fresh = -1;
+              for (int x = 0; x < NO; ++x) {
+                bool in_prev = false;
+                for (int y = 0; y < NO; ++y) in_prev |= ov[pick][x] == prev[y];
+                if (!in_prev) fresh = ov[pick][x];
+              }
+              for (int y = 0; y < NO; ++y) {
+                bool kept = false;
+                for (int x = 0; x < NO; ++x) kept |= ov[pick][x] == prev[y];
+                if (!kept) cur[y] = fresh;
+              }
+            }
+            uint32_t slots = (uint32_t)(std::lower_bound(rb, re, g) - rb);
+            for (int j = 1; j < NV; ++j) slots |= (uint32_t)(std::lower_bound(rb, re, cur[j - 1]) - rb) << (8 * j);
+            const size_t ent = (size_t)sl_ptr[(size_t)b * SPB + w] + (size_t)len * KN_SLICE + (rs * LPR + sub);
+            pair_sl[ent] = slots;
+            used[pick] = 1;
+            prev = cur;
+            have_prev = true;
+            --remaining;
+          }
+        }
+        continue;
+      }
       for (int64_t p = v2c_ptr[g]; p < v2c_ptr[g + 1]; ++p) {
         const int64_t pi = p - v2c_ptr[g];
         const int lane = rs * LPR + (int)(pi % LPR);
