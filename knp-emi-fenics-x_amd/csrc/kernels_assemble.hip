@@ -422,6 +422,10 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
     int diag = -1;
     double dA = 0.0;
     Rec5 r[NV];
+    uint32_t have = 0xFFFFFFFFu;     // slots whose contributions pend[1..] currently hold (255: none)
+    double pend[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) pend[j] = 0.0;
     auto do_pair = [&](uint32_t sl) {
       int slot[NV];
 #pragma unroll
@@ -443,8 +447,18 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
       const double kbar = ksum * (1.0 / NV);
       bacc -= vol * sd;
       dA += vol * kbar * d[0];
+      // Off-diagonal entries: in the strip order a vertex keeps its position over consecutive pairs, so its
+      // contributions are summed in a register and go to LDS when another vertex takes the position.
 #pragma unroll
-      for (int j = 1; j < NV; ++j) unsafeAtomicAdd(&accA[lap + slot[j]], vol * kbar * d[j]);
+      for (int j = 1; j < NV; ++j) {
+        const int hs = (int)((have >> (8 * j)) & 255);
+        if (slot[j] != hs) {
+          if (hs != 255) unsafeAtomicAdd(&accA[lap + hs], pend[j]);
+          pend[j] = 0.0;
+        }
+        pend[j] += vol * kbar * d[j];
+      }
+      have = sl;
     };
 #pragma unroll
     for (int p = 0; p < KN_PREFETCH; ++p)
@@ -452,6 +466,11 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
     for (int p = KN_PREFETCH; p < np; ++p) {
       const uint32_t sl = D.pair_sl[base + (int64_t)p * KN_SLICE];
       if (sl != 0xFFFFFFFFu) do_pair(sl);
+    }
+#pragma unroll
+    for (int j = 1; j < NV; ++j) {
+      const int hs = (int)((have >> (8 * j)) & 255);
+      if (hs != 255) unsafeAtomicAdd(&accA[lap + hs], pend[j]);
     }
     if (diag >= 0) unsafeAtomicAdd(&accA[lap + diag], dA);
     if (ne > 0) emi_membrane_row<NF>(D, C, ri.w, ne, sub, LPR, cell_side, rowbase, accA, splitting, gam);
@@ -521,7 +540,12 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
     // of the pair entry.  The records of the shared vertices stay in registers; only a slot that changed is read from
     // LDS again (one 48-byte record per pair instead of three: knp_rows 53.6 -> 46.9 us at 995 k tets, with four
     // instead of five blocks per CU -- 112 registers; capping them at 96 spills and gives the gain back).
-    uint32_t have = 0xFFFFFFFFu;     // slots of the records r[1..] currently hold
+    uint32_t have = 0xFFFFFFFFu;     // slots of the records r[1..] (and of the pending sums) currently held; 255: none
+    double pend[NV][KS];
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int k = 0; k < KS; ++k) pend[j][k] = 0.0;
     auto do_pair = [&](uint32_t sl) {
       int slot[NV];
 #pragma unroll
@@ -530,7 +554,6 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
 #pragma unroll
       for (int j = 1; j < NV; ++j)
         if (slot[j] != (int)((have >> (8 * j)) & 255)) r[j] = lds_rec<KS>(recs, eloc[rL + slot[j]]);
-      have = sl;
       double d[NV];
       const double vol = simplex_row0<GDIM>(r, d);
       double gp = 0;
@@ -543,14 +566,22 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
         dk[k] += 2.0 * m * C.inv_dt + sc.D[k] * vol * d[0] + sc.zpsiD[k] * drift;
         bk[k] += 2.0 * m * r[0].f[k];
       }
+      // off-diagonal entries: summed in registers while a vertex keeps its position, to LDS when it leaves (emi_rows_v2)
 #pragma unroll
       for (int j = 1; j < NV; ++j) {
+        const int hs = (int)((have >> (8 * j)) & 255);
+        const bool moved = slot[j] != hs;
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-          unsafeAtomicAdd(&acc[(size_t)k * acc_n + rL + slot[j]], m * C.inv_dt + sc.D[k] * vol * d[j] + sc.zpsiD[k] * drift);
+          if (moved) {
+            if (hs != 255) unsafeAtomicAdd(&acc[(size_t)k * acc_n + rL + hs], pend[j][k]);
+            pend[j][k] = 0.0;
+          }
+          pend[j][k] += m * C.inv_dt + sc.D[k] * vol * d[j] + sc.zpsiD[k] * drift;
           bk[k] += m * r[j].f[k];
         }
       }
+      have = sl;
     };
 #pragma unroll
     for (int p = 0; p < KN_PREFETCH; ++p)
@@ -558,6 +589,13 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
     for (int p = KN_PREFETCH; p < np; ++p) {
       const uint32_t sl = D.pair_sl[base + (int64_t)p * KN_SLICE];
       if (sl != 0xFFFFFFFFu) do_pair(sl);
+    }
+#pragma unroll
+    for (int j = 1; j < NV; ++j) {
+      const int hs = (int)((have >> (8 * j)) & 255);
+#pragma unroll
+      for (int k = 0; k < KS; ++k)
+        if (hs != 255) unsafeAtomicAdd(&acc[(size_t)k * acc_n + rL + hs], pend[j][k]);
     }
     if (diag >= 0) {
 #pragma unroll
