@@ -897,6 +897,7 @@ extern "C" void knpemi_dg_destroy(knpemi_dg* h) {
   if (h->sol) {
     kn_amg_free(h->sol->amg_emi);
     kn_amg_free(h->sol->amg_knp);
+    if (h->sol->kry_pinned) (void)hipHostFree(h->sol->kry_pinned);
     if (h->sol->graph_emi.exec) (void)hipGraphExecDestroy(h->sol->graph_emi.exec);
     if (h->sol->graph_knp.exec) (void)hipGraphExecDestroy(h->sol->graph_knp.exec);
     for (void* p : h->sol->allocs) (void)hipFree(p);

@@ -312,10 +312,21 @@ void vec(const Ctx& c, int op, double* a, double* b, const double* cc, const dou
   hipLaunchKernelGGL(vec_kernel, grid1(c.n), dim3(256), 0, c.h->stream, c.n, op, c.sc, a, b, cc, d, (const double*)nullptr);
 }
 
+// the solver's scalars on the host: through a pinned buffer (a copy into pageable memory is staged by the runtime)
 int read_scalars(const Ctx& c, double* host, int count) {
-  KN_HIP(hipMemcpyAsync(host, c.sc, count * sizeof(double), hipMemcpyDeviceToHost, c.h->stream));
-  KN_HIP(hipStreamSynchronize(c.h->stream));
+  knpemi_handle* h = c.h;
+  if (!h->kry_pinned) KN_HIP(hipHostMalloc(&h->kry_pinned, 64 * sizeof(double), hipHostMallocDefault));
+  KN_HIP(hipMemcpyAsync(h->kry_pinned, c.sc, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < count; ++i) host[i] = static_cast<double*>(h->kry_pinned)[i];
   return KNPEMI_OK;
+}
+
+// BiCGStab start: p = v = 0, rho = alpha = omega = 1, everything else 0 (one launch instead of two fills and a copy)
+__global__ void bicg_init_kernel(int n, double* __restrict__ p, double* __restrict__ v, double* __restrict__ sc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { p[i] = 0.0; v[i] = 0.0; }
+  if (i < S_N) sc[i] = (i == S_RHO || i == S_ALPHA || i == S_OMEGA) ? 1.0 : 0.0;
 }
 
 // Run `chunk` iterations of `body`: captured once into a hipGraph (the launch-bound inner loop of small
@@ -610,11 +621,7 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   if (amg && (rc = kn_amg_refresh(h, G, D.A_knp))) return rc;
   spmv(c, x, r, nullptr, D.b_knp);                             // r = b - A x
   vec(c, V_COPY, rhat, nullptr, r, nullptr);
-  KN_HIP(hipMemsetAsync(p, 0, (size_t)n * sizeof(double), h->stream));
-  KN_HIP(hipMemsetAsync(v, 0, (size_t)n * sizeof(double), h->stream));
-  double init[S_N] = {0};
-  init[S_RHO] = init[S_ALPHA] = init[S_OMEGA] = 1.0;
-  KN_HIP(hipMemcpyAsync(c.sc, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(bicg_init_kernel, grid1(std::max(n, (int)S_N)), dim3(256), 0, h->stream, n, p, v, c.sc);
   dots(c, 2, r, r, D.b_knp, D.b_knp, nullptr, nullptr, OP_STORE3, S_RR, S_BB);
   double sc[S_N];
   if ((rc = read_scalars(c, sc, S_N))) return rc;

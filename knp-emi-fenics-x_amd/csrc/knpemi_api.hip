@@ -816,6 +816,7 @@ extern "C" void knpemi_destroy(knpemi_handle* h) {
   kn_comm_destroy(h);
   kn_amg_free(h->amg_emi);
   kn_amg_free(h->amg_knp);
+  if (h->kry_pinned) (void)hipHostFree(h->kry_pinned);
   if (h->graph_emi.exec) (void)hipGraphExecDestroy(h->graph_emi.exec);
   if (h->graph_knp.exec) (void)hipGraphExecDestroy(h->graph_knp.exec);
   for (void* p : h->allocs) (void)hipFree(p);

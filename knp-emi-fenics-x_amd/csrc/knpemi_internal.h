@@ -226,6 +226,7 @@ struct knpemi_handle {
   double* d_stage = nullptr; size_t stage_len = 0;   // staging buffer for strided field I/O
   double* kry = nullptr; size_t kry_n = 0;           // Krylov workspace (kernels_krylov.hip)
   int kry_ones_masked = 0;                           // the workspace's `ones` vector currently holds the ownership mask
+  void* kry_pinned = nullptr;                        // pinned host buffer the solvers' scalars are read through
   double* guess_old[2] = {nullptr, nullptr};         // previous solutions (EMI, KNP) for knpemi_extrapolate_guess
   bool guess_have[2] = {false, false};
   KnAmg amg_emi, amg_knp;
