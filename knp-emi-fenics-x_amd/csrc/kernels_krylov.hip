@@ -24,10 +24,11 @@ __global__ __launch_bounds__(256) void spmv_kernel(int n, const int* __restrict_
                                                    const double* __restrict__ vals, const double* __restrict__ x,
                                                    const double* __restrict__ dinv, double* __restrict__ y,
                                                    const double* __restrict__ b = nullptr,
-                                                   const uint8_t* __restrict__ owned = nullptr) {
+                                                   const uint8_t* __restrict__ owned = nullptr,
+                                                   double* __restrict__ dinv_out = nullptr) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int row = t >> 4, l = t & 15;
-  double acc = 0.0;
+  double acc = 0.0, diag = 0.0;
   // partitioned problem: only the rows of owned unknowns are assembled completely; ghost rows give 0
   const bool live = row < n && (!owned || owned[row]);
   if (live) {
@@ -35,10 +36,16 @@ __global__ __launch_bounds__(256) void spmv_kernel(int n, const int* __restrict_
     for (int j = a + l; j < b; j += 16) {
       const int c = colind[j];
       acc += vals[j] * (SCALED ? x[c] * dinv[c] : x[c]);
+      if (!SCALED && c == row) diag = vals[j];
     }
   }
 #pragma unroll
   for (int m = 8; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+  if (!SCALED && dinv_out) {   // the inverse diagonal as a by-product of the first residual (diag_inv_kernel's rule)
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) diag += __shfl_xor(diag, m);
+    if (row < n && l == 0) dinv_out[row] = diag != 0.0 ? 1.0 / diag : 1.0;
+  }
   if (row < n && l == 0) y[row] = live ? ((!SCALED && b) ? b[row] - acc : acc) : 0.0;
 }
 
@@ -279,7 +286,7 @@ struct Ctx {
 
 inline dim3 grid1(int n) { return dim3((n + 255) / 256); }
 
-void spmv(Ctx& c, const double* x, double* y, const double* dinv, const double* b = nullptr) {
+void spmv(Ctx& c, const double* x, double* y, const double* dinv, const double* b = nullptr, double* dinv_out = nullptr) {
   dim3 g(((size_t)c.n * 16 + 255) / 256);
   if (c.owned) {   // the argument's ghost entries take their owners' values first
     const KnDist& d = c.h->dist;
@@ -288,7 +295,7 @@ void spmv(Ctx& c, const double* x, double* y, const double* dinv, const double* 
   if (dinv) hipLaunchKernelGGL((spmv_kernel<true>), g, dim3(256), 0, c.h->stream, c.n, c.rowptr, c.colind, c.vals, x, dinv, y,
                                (const double*)nullptr, c.owned);
   else hipLaunchKernelGGL((spmv_kernel<false>), g, dim3(256), 0, c.h->stream, c.n, c.rowptr, c.colind, c.vals, x, dinv, y, b,
-                          c.owned);
+                          c.owned, dinv_out);
 }
 
 void dots(Ctx& c, int nd, const double* a0, const double* b0, const double* a1, const double* b1, const double* a2,
@@ -505,7 +512,8 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   dots(c, 1, b, ones, nullptr, nullptr, nullptr, nullptr, OP_MEAN, 0, 0, 0, 1.0 / n_mean);
   vec(c, V_SHIFT, b, nullptr, nullptr, nullptr);
   mask(c, b);
-  hipLaunchKernelGGL(diag_inv_kernel, grid1(n), dim3(256), 0, h->stream, n, c.rowptr, c.colind, c.vals, dinv);
+  // (single rank: the inverse diagonal comes out of the first residual below)
+  if (dist.on) hipLaunchKernelGGL(diag_inv_kernel, grid1(n), dim3(256), 0, h->stream, n, c.rowptr, c.colind, c.vals, dinv);
   KnAmg& G = h->amg_emi;
   const bool amg = h->pc_emi == KNPEMI_PC_AMG;
   if (amg && (!G.built || G.n != n)) {
@@ -534,7 +542,7 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     return KNPEMI_OK;
   };
   const int chunk = amg ? 1 : 8;   // a V-cycle costs ~15 launches: test convergence after every iteration
-  spmv(c, x, r, nullptr, b);                                   // r = b - A x
+  spmv(c, x, r, nullptr, b, dist.on ? nullptr : dinv);         // r = b - A x
   dots(c, 2, r, r, b, b, nullptr, nullptr, OP_STORE3, S_RR, S_BB);
   double sc[S_N];
   if ((rc = read_scalars(c, sc, S_N))) return rc;
@@ -608,7 +616,7 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   // x0 = previous concentrations in the block order [c[0][0], c[0][1], c[1][0], ...]
   if (h->plain_knp) vec(c, V_COPY, x, nullptr, D.csol, nullptr);
   else hipLaunchKernelGGL(knp_order_kernel, grid1(n), dim3(256), 0, h->stream, D.Ntot, KS, h->n_sub, h->d_consts, x, D.csol, 1);
-  hipLaunchKernelGGL(diag_inv_kernel, grid1(n), dim3(256), 0, h->stream, n, c.rowptr, c.colind, c.vals, dinv);
+  if (dist.on) hipLaunchKernelGGL(diag_inv_kernel, grid1(n), dim3(256), 0, h->stream, n, c.rowptr, c.colind, c.vals, dinv);
   KnAmg& G = h->amg_knp;
   const bool amg = h->pc_knp == KNPEMI_PC_AMG;
   if (amg && (!G.built || G.n != n)) {
@@ -619,7 +627,7 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     ++G.builds;
   }
   if (amg && (rc = kn_amg_refresh(h, G, D.A_knp))) return rc;
-  spmv(c, x, r, nullptr, D.b_knp);                             // r = b - A x
+  spmv(c, x, r, nullptr, D.b_knp, dist.on ? nullptr : dinv);   // r = b - A x
   vec(c, V_COPY, rhat, nullptr, r, nullptr);
   hipLaunchKernelGGL(bicg_init_kernel, grid1(std::max(n, (int)S_N)), dim3(256), 0, h->stream, n, p, v, c.sc);
   dots(c, 2, r, r, D.b_knp, D.b_knp, nullptr, nullptr, OP_STORE3, S_RR, S_BB);
