@@ -173,7 +173,7 @@ __global__ void dots_apply_kernel(double* __restrict__ sc, const double* __restr
 }
 #endif
 
-enum { V_RESID = 0, V_SHIFT, V_CG_XR, V_CG_P, V_JACOBI, V_BI_P, V_BI_S, V_COPY };
+enum { V_RESID = 0, V_SHIFT, V_CG_XR, V_CG_P, V_JACOBI, V_BI_P, V_BI_S, V_COPY, V_COPY_SHIFT };
 
 // small fused vector updates; scalars are read from device memory
 __global__ void vec_kernel(int n, int op, const double* __restrict__ sc, double* __restrict__ a, double* __restrict__ b,
@@ -189,7 +189,15 @@ __global__ void vec_kernel(int n, int op, const double* __restrict__ sc, double*
     case V_BI_P: a[i] = c[i] + sc[S_BETA] * (a[i] - sc[S_OMEGA] * d[i]); break;  // p = r + beta (p - omega v)
     case V_BI_S: a[i] = c[i] - sc[S_ALPHA] * d[i]; break;                      // s = r - alpha v
     case V_COPY: a[i] = c[i]; break;
+    case V_COPY_SHIFT: a[i] = c[i] - sc[S_MEAN]; break;                        // copy and shift in one pass
   }
+}
+
+// dst[i * stride] = src[i] - mean: the solution made orthogonal to the constants on its way into the vertex records
+__global__ void scatter_shift_kernel(const double* __restrict__ src, double* __restrict__ dst, int n, int stride,
+                                     const double* __restrict__ sc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[(size_t)i * stride] = src[i] - sc[S_MEAN];
 }
 
 // dinv != NULL: p, s are the unpreconditioned directions (Jacobi applied here); else they are M^-1 p, M^-1 s
@@ -507,11 +515,16 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   }
   // x0 = current phi (ksp_initial_guess_nonzero), b = b_emi projected onto zero mean (constant null space)
   if ((rc = kn_launch_field_gather(h, D.VR + 7, KN_REC, x, n))) return rc;
-  vec(c, V_COPY, b, nullptr, D.b_emi, nullptr);
-  mask(c, b);
-  dots(c, 1, b, ones, nullptr, nullptr, nullptr, nullptr, OP_MEAN, 0, 0, 0, 1.0 / n_mean);
-  vec(c, V_SHIFT, b, nullptr, nullptr, nullptr);
-  mask(c, b);
+  if (dist.on) {
+    vec(c, V_COPY, b, nullptr, D.b_emi, nullptr);
+    mask(c, b);
+    dots(c, 1, b, ones, nullptr, nullptr, nullptr, nullptr, OP_MEAN, 0, 0, 0, 1.0 / n_mean);
+    vec(c, V_SHIFT, b, nullptr, nullptr, nullptr);
+    mask(c, b);
+  } else {   // single rank: the mean of b_emi itself, then copy and shift in one pass (same arithmetic)
+    dots(c, 1, D.b_emi, ones, nullptr, nullptr, nullptr, nullptr, OP_MEAN, 0, 0, 0, 1.0 / n_mean);
+    vec(c, V_COPY_SHIFT, b, nullptr, D.b_emi, nullptr);
+  }
   // (single rank: the inverse diagonal comes out of the first residual below)
   if (dist.on) hipLaunchKernelGGL(diag_inv_kernel, grid1(n), dim3(256), 0, h->stream, n, c.rowptr, c.colind, c.vals, dinv);
   KnAmg& G = h->amg_emi;
@@ -578,9 +591,13 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   // solution orthogonal to constants, then into the phi component of the vertex records (ghosts included: they
   // take their owners' values first)
   dots(c, 1, x, ones, nullptr, nullptr, nullptr, nullptr, OP_MEAN, 0, 0, 0, 1.0 / n_mean);
-  if (dist.on) if (int e = dist.halo(dist.ctx, x, KNPEMI_B_EMI)) c.comm_rc = c.comm_rc ? c.comm_rc : e;
-  vec(c, V_SHIFT, x, nullptr, nullptr, nullptr);
-  if ((rc = kn_launch_field_scatter(h, x, D.VR + 7, n, KN_REC))) return rc;
+  if (dist.on) {
+    if (int e = dist.halo(dist.ctx, x, KNPEMI_B_EMI)) c.comm_rc = c.comm_rc ? c.comm_rc : e;
+    vec(c, V_SHIFT, x, nullptr, nullptr, nullptr);
+    if ((rc = kn_launch_field_scatter(h, x, D.VR + 7, n, KN_REC))) return rc;
+  } else if (n > 0) {
+    hipLaunchKernelGGL(scatter_shift_kernel, grid1(n), dim3(256), 0, h->stream, x, D.VR + 7, n, KN_REC, c.sc);
+  }
   if (c.comm_rc) { kn_set_error("EMI solve: a communication hook failed"); return KNPEMI_EHIP; }
   if (iters) *iters = it;
   if (relres) *relres = bnorm > 0 ? rn / bnorm : rn;
