@@ -276,11 +276,12 @@ __device__ __forceinline__ BlkInfo load_blk(const KnDev& D, int b, int wave) {
   return B;
 }
 
-// Rows of a block: KN_BLOCK / LPR / KN_CHUNK chunks of (up to) KN_CHUNK consecutive rows each (D.blk_rng, six ints per
+// Rows of a block: KN_BLOCK / LPR / KN_CHUNK chunks of (up to) KN_CHUNK consecutive rows each (KN_CHUNK_SIMPLEX or
+// KN_CHUNK_HEX; D.blk_rng, six ints per
 // chunk: first row, rows, end of the chunk's entries in the block's concatenated EMI segment, global EMI position minus
 // concatenated position, the same two for the Laplacian pattern).  A block of consecutive rows is the special case of
 // consecutive chunks; clustered chunks (knpemi_create) touch fewer distinct vertices.
-template <int LPR>
+template <int LPR, int KN_CHUNK>
 struct BlkRows {
   static constexpr int NR = KN_BLOCK / LPR / KN_CHUNK;
   const int* rng;
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
   const int s = B.sub, seglen = B.seglen;
   // this lane's pair entries and row descriptor: issued first, their latency overlaps phase A
   const int rloc = tid / LPR, sub = tid % LPR;
-  const BlkRows<LPR> rows(D, b);
+  const BlkRows<LPR, KN_CHUNK_SIMPLEX> rows(D, b);
   bool valid;
   const int g = rows.row(rloc, valid);
   const int64_t base = (int64_t)B.slbase * KN_SLICE + (tid & 63);
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
   const int v0 = C.voff[s], nvs = C.voff[s + 1] - v0;
   const double* fs0 = (D.fsrc && s == 0) ? D.fsrc : nullptr;
   const int rloc = tid / LPR, sub = tid % LPR;
-  const BlkRows<LPR> rows(D, b);
+  const BlkRows<LPR, KN_CHUNK_SIMPLEX> rows(D, b);
   bool valid;
   const int g = rows.row(rloc, valid);
   const int64_t base = (int64_t)B.slbase * KN_SLICE + (tid & 63);
@@ -1020,7 +1021,7 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
   const BlkInfo B = load_blk(D, b, tid >> 6);
   const int s = B.sub, seglen = B.seglen;
   const int rloc = tid / LPR, sub = tid % LPR;
-  const BlkRows<LPR> rows(D, b);
+  const BlkRows<LPR, KN_CHUNK_HEX> rows(D, b);
   bool valid;
   const int g = rows.row(rloc, valid);
   const int64_t base = (int64_t)B.slbase * KN_SLICE + (tid & 63);
@@ -1096,7 +1097,7 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDe
   const int v0 = C.voff[s], nvs = C.voff[s + 1] - v0;
   const double* fs0 = (D.fsrc && s == 0) ? D.fsrc : nullptr;
   const int rloc = tid / LPR, sub = tid % LPR;
-  const BlkRows<LPR> rows(D, b);
+  const BlkRows<LPR, KN_CHUNK_HEX> rows(D, b);
   bool valid;
   const int g = rows.row(rloc, valid);
   const int64_t base = (int64_t)B.slbase * KN_SLICE + (tid & 63);

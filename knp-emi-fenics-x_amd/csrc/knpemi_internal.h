@@ -19,7 +19,12 @@
 #define KN_CSLOT(k) ((k) < 3 ? 4 + (k) : 3)
 #define KN_BLOCK 256          // threads per row-kernel workgroup (rows per block = KN_BLOCK / lanes-per-row)
 #define KN_SLICE 64       // rows per sliced-ELL slice == wavefront width on gfx950
-#define KN_CHUNK 8        // consecutive rows per chunk of a row block (kernels_assemble.hip: BlkRows)
+// consecutive rows per chunk of a row block (kernels_assemble.hip: BlkRows).  Measured at 995 k tets / 166 k hexahedra:
+// 16-row chunks give the simplex kernels fewer, longer output pieces (emi_rows 46.6 -> 43.3 us, knp_rows 45.8 -> 44.7 us;
+// 266 instead of 233 distinct vertices per block), the hexahedral ones lose with them (blocks closed early by the bound on
+// the distinct vertices are half empty: knp_rows_hex 61 -> 71 us); 4-row chunks lose everywhere.
+#define KN_CHUNK_SIMPLEX 16
+#define KN_CHUNK_HEX 8
 
 // Per-sub-domain constants folded on the host from knpemi_params (double arithmetic identical
 // to what the kernels would do per cell).
@@ -47,7 +52,7 @@ struct KnConsts {
 struct KnDev {
   int Ntot, nctot, NQtot, nftot;
   int nblocks;                // row blocks; a block never straddles two sub-domains
-  const int* blk_rng;         // [nblocks][KN_BLOCK / lpr / KN_CHUNK][6] chunks of consecutive rows (BlkRows)
+  const int* blk_rng;         // [nblocks][KN_BLOCK / lpr / chunk][6] chunks of consecutive rows (BlkRows)
   const int* blk_sub;         // [nblocks] sub-domain of the block
   const int4* blk_info;       // [nblocks][4]: {first row, rows, sub, 0} {EMI seg length, offset into ent_loc,
                               //   Laplacian seg length, offset into blk_uverts} {slice entry bases / 64}
