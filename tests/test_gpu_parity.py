@@ -85,7 +85,7 @@ def test_general_hexahedron_kernel_on_box_mesh(hip_lib, monkeypatch):
 
 @pytest.mark.parametrize("kind", ["2d", "tet", "hex"])
 def test_clustered_row_blocks_equal_blocks_of_consecutive_rows_bit_for_bit(hip_lib, monkeypatch, kind):
-    """The row blocks are clusters of 8-row chunks chosen by the Laplacian graph (fewer distinct vertices to stage per
+    """The row blocks are clusters of 16-row (hexahedra: 8-row) chunks chosen by the Laplacian graph (fewer distinct vertices to stage per
     block); KNPEMI_BLOCK_CLASSIC=1 takes 64 consecutive rows.  A row's pairs, their order and its lanes do not depend on
     the block it sits in: all five assembled objects agree bit for bit."""
     res = []
