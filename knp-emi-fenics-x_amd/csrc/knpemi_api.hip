@@ -362,7 +362,7 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   // A block holds NR chunks of up to KN_CHUNK consecutive rows (kernels_assemble.hip: BlkRows).  Chunks are clustered
   // greedily by the number of Laplacian entries that connect them, so that the rows of a block share neighbours: on
   // the x-fastest numbering of the box meshes 64 consecutive rows are a line of vertices that touches 456 distinct
-  // vertices, a bundle of eight 8-vertex pieces of neighbouring lines ~200.  KNPEMI_BLOCK_CLASSIC=1: consecutive chunks.
+  // vertices, a bundle of pieces of neighbouring lines 230-270.  KNPEMI_BLOCK_CLASSIC=1: consecutive chunks.
   const int CH = NV == 8 ? KN_CHUNK_HEX : KN_CHUNK_SIMPLEX, NR = RPB / CH;
   struct Chunk { int start, len, sub; };
   std::vector<Chunk> chunks;
