@@ -5,17 +5,24 @@ One "step" = one pass of the hot path over one field state, device-resident (SUR
 BASELINE.md section 2): fused ODE launch (trace refresh + LSODA sweep + copy-back), EMI assembly (A, P, b in one
 pass), KNP assembly (A once, b incl. the membrane kernel), end-of-step update.  Krylov solves and file output are
 excluded from the timed region -- but the state the timed steps run on is a REAL trajectory: an untimed pass first
-integrates the same problem with the device Krylov solves and records the solution of every step; the timed steps
-start again from t = 0 and paste the recorded solution where the solve would write it (one launch per system, as the
-solve's own write-back).  The membrane therefore depolarises and fires as in a real run and the ODE sweep does the
-work a real run gives it (`ode_rhs_evals_per_dof_per_step`).
+integrates the same problem with the device Krylov solves from t = 0 and records the solution of every step; the timed
+steps replay it, pasting the recorded solution where the solve would write it (one launch per system, as the solve's
+own write-back).  The membrane therefore depolarises and fires as in a real run and the ODE sweep does the work a real
+run gives it.
+
+`value` = dofs of one step / (MEDIAN over --repeats windows of the time of exactly --steps steps), the window being
+trajectory steps [--warmup, --warmup + --steps); the device is put back to the start of the window before every repeat.
+`spike_window` is the same measurement around the step where the membrane fires (most ODE work), `with_solves` whole
+time steps including the device Krylov solves from a fixed trajectory step, `config3_leg` the same measurement on the
+995 328-tet mesh (where the row kernels are HBM-bound, not launch-bound), `dg_variant` a short run of the DG variant.
+Any failure (a solve that does not converge, a communication hook, LSODA) exits non-zero: there is no fallback state.
 
 At N > 1 the mesh is partitioned into x-slabs (weak: N times longer box; --scaling strong: the fixed config-3 box),
 every step exchanges the ghost-dof halo of the bulk fields (stream-ordered RCCL point-to-point; ghost membrane dofs
 are integrated redundantly), and the recorded trajectory comes from the distributed Krylov solves
 (knpemi_set_distributed: halo'd SpMV, all-reduced dot products, per-GPU AMG).
 
-    python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -36,6 +43,8 @@ for p in (os.path.join(ROOT, "knp-emi-fenics-x_amd"), os.path.join(ROOT, "exampl
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
 LAUNCH_FLOOR_US = 5.0      # duration of a trivial streaming kernel in the same event brackets on this stack
 PROFILE_STEPS = 5
+SPIKE_SEARCH = 72        # trajectory steps recorded at least: contains the action potential of the stimulated cell end
+WITH_SOLVES_START = 10   # trajectory step the with_solves pass starts from, whatever --steps / --warmup are
 
 WORKLOADS = {
     # name: (family, mesh kind, resolution factor) -- geometry of make_mesh_3D.py, 6 tets per hexahedron
@@ -155,15 +164,21 @@ def algorithmic_bytes(case, dp):
     return survey, design, dict(nc=nc, N=N, nF=nF, NQ=NQ, nnz=nnz, nnzL=nnzL, n_model_slots=n_slots)
 
 
-def cpu_baseline(s, n_steps, threads=1):
+def cpu_baseline(s, n_steps, threads=1, traj=None, start=0):
     """C++ port of the reference path (oracle/knpemi_cpu.cpp: scalar element loops with CSR scatter-add, one
     LSODA integration per membrane dof; checked against the numpy oracle by tests/test_cpu_port.py), timed
     on `threads` cores of this host (OpenMP over cells / facets / membrane dofs) for `n_steps` whole steps of the
-    same workload.  The CSR patterns come from one untimed oracle assembly."""
+    same workload.  The CSR patterns come from one untimed oracle assembly.
+
+    `traj` = (phi_t, c_t), the recorded solutions of the GPU's trajectory pass (host arrays): the CPU loop replays the
+    same trajectory -- the recorded solution is pasted where a solve would write it, as in the GPU's timed steps -- so
+    both legs integrate the same firing membrane.  Steps 0 .. start-1 bring the state to the start of the timed window
+    and are not timed."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import adapters
     import cpu_port
+    import knpemi_oracle as ko
     o, P, params, ions = adapters.oracle_problem(s)
     c_all, phi, phiM, mm = adapters.oracle_fields(s)
     A, _, _ = o.assemble_emi(P, params, ions, c_all, phiM, mm)
@@ -173,31 +188,47 @@ def cpu_baseline(s, n_steps, threads=1):
     ode = s.mem_models[0]['ode']
     model = ode.ode.MODEL_ID
     ix = o.MODELS[model]["pidx"]
+    vi = o.MODELS[model]["V"]
     st, pa = np.ascontiguousarray(ode.states.copy()), np.ascontiguousarray(ode.parameters.copy())
     mask = np.fromiter(map(s.stim_params['stimulus_locator'], ode.dof_locations), dtype=bool)
     sidx = [ix[k] for k in s.stim_params['stimulus']]
     sval = [float(v) for v in s.stim_params['stimulus'].values()]
-    Ich = np.stack([mm[1][0]["I_ch_k"][n] for n in ("K", "Cl", "Na")])
+    names = ("K", "Cl", "Na")
+    Ich = np.stack([mm[1][0]["I_ch_k"][n] for n in names]).copy()
     mid = {"hh_si": 0, "hh_mv": 1, "glial": 2}[model]
+    boff, _ = ko.knp_block_offsets(P, 2)
     t_asm = t_ode = 0.0
-    for k in range(n_steps):
+    for k in range(start + n_steps):
         t0 = time.perf_counter()
-        for name, kk in (("K", 0), ("Cl", 1), ("Na", 2)):
+        for name, kk in zip(names, range(3)):               # update_ode_variables (utils.py:210-235)
             te, ti = P.trace(1, c_all[0][kk], c_all[1][kk])
             pa[:, ix[f"{name}_e"]] = te
             pa[:, ix[f"{name}_i"]] = ti
+        if k > 0:
+            st[:, vi] = phiM[1]
         failed, _ = port.ode_sweep(mid, st, pa, k * s.dt, s.dt, mask, sidx, sval)
         assert failed == 0
+        phiM[1][:] = st[:, vi]                               # run_3D.py:104-109
+        for j, name in enumerate(names):
+            Ich[j] = pa[:, ix[f"I_ch_{name}"]]
         t1 = time.perf_counter()
         port.assemble_emi(c_all, phiM, Ich)
+        if traj is not None:                                 # where the EMI solve writes
+            for t in P.tags:
+                phi[t][:] = traj[0][k][P.off[t]:P.off[t] + P.N[t]]
         port.assemble_knp(c_all, phi, phiM, Ich)
-        te, ti = P.trace(1, phi[0], phi[1])      # end-of-step update (vector copies + trace)
+        if traj is not None:                                 # where the KNP solve writes, then c_prev <- c
+            for t in P.tags:
+                for kk in range(2):
+                    c_all[t][kk][:] = traj[1][k][boff[(t, kk)]:boff[(t, kk)] + P.N[t]]
+        te, ti = P.trace(1, phi[0], phi[1])      # end-of-step update (utils.py:238-295)
         phiM[1][:] = ti - te
         for t in c_all:
             c_all[t][2][:] = -(ions[0]["z"] * c_all[t][0] + ions[1]["z"] * c_all[t][1]) / ions[2]["z"]
         t2 = time.perf_counter()
-        t_ode += t1 - t0
-        t_asm += t2 - t1
+        if k >= start:
+            t_ode += t1 - t0
+            t_asm += t2 - t1
     return (t_asm + t_ode) / n_steps, t_asm / n_steps, t_ode / n_steps, ode.nodes
 
 
@@ -215,9 +246,20 @@ def device_solvers(case, its, maxit=1000):
     return solver(L.B_EMI, "emi", rtol_emi, 1e-40), solver(L.B_KNP, "knp", rtol_knp, 2e-40)
 
 
-def record_trajectory(case, stepper, n_steps, torch, halo=None):
-    """Untimed: n_steps whole time steps with the device Krylov solves; returns the solutions (phi, c in the unknown
-    order of the two systems) of every step as device tensors [n_steps, n]."""
+def ode_counters(case, dp):
+    """(rhs evaluations, LSODA steps, failed dofs) since the last call, summed over the membrane models (synchronises)."""
+    nr = ns = nf = 0
+    for m, _, _ in case.models:
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int32()
+        dp.lib.knpemi_ode_stats(dp.h, m._sub, m._model, C.byref(a), C.byref(b), C.byref(c))
+        nr, ns, nf = nr + a.value, ns + b.value, nf + c.value
+    return nr, ns, nf
+
+
+def record_trajectory(case, stepper, n_steps, halo=None):
+    """Untimed: n_steps whole time steps from t = 0 with the device Krylov solves.  Returns the solutions (phi, c in the
+    unknown order of the two systems) of every step as host arrays [n_steps, n], the iteration counts and the RHS
+    evaluations per membrane dof of every step (where the cell fires)."""
     import numpy as np
     from knpemi import _lib as L
     dp = stepper.dp
@@ -238,24 +280,76 @@ def record_trajectory(case, stepper, n_steps, torch, halo=None):
         L.check(d.lib.knpemi_get_solution(d.h, L.B_KNP, L.dptr(c_t[k[0]])))
         k[0] += 1
     stepper.solve_emi, stepper.solve_knp = emi, knp
+    n_dofs = max(1, sum(m.nodes for m, _, _ in case.models))
+    ode_counters(case, dp)
+    rhs = []
     for _ in range(n_steps):
         stepper.step(halo)
+        nr, _, nf = ode_counters(case, dp)
+        if nf:
+            raise SystemExit("LSODA failed on the device (trajectory pass)")
+        rhs.append(nr / n_dofs)
     dp.sync()
     stepper.solve_emi = stepper.solve_knp = None
-    dev = torch.device("cuda", dp.device)
-    return torch.from_numpy(phi_t).to(dev), torch.from_numpy(c_t).to(dev), its
+    return phi_t, c_t, its, rhs
 
 
-def with_solves(case, stepper, n_steps, torch, halo=None):
+class Replay:
+    """The timed steps: the stepper with the recorded solutions pasted where the solves would write them (one launch
+    per system, as a solve's own write-back).  `restart(i)` puts the device back to the state before trajectory step i:
+    start state re-uploaded, steps 0 .. i-1 replayed untimed."""
+
+    def __init__(self, case, stepper, halo, phi_t, c_t, torch):
+        from knpemi import _lib as L
+        self.case, self.stepper, self.halo = case, stepper, halo
+        dev = torch.device("cuda", stepper.dp.device)
+        self.phi_t, self.c_t = torch.from_numpy(phi_t).to(dev), torch.from_numpy(c_t).to(dev)
+        self.n = len(phi_t)
+        self.cursor = 0
+        lib = stepper.dp.lib
+
+        def paste_emi(d):
+            L.check(lib.knpemi_set_solution(d.h, L.B_EMI, self.phi_t[self.cursor].data_ptr(), 1))
+
+        def paste_knp(d):
+            L.check(lib.knpemi_set_solution(d.h, L.B_KNP, self.c_t[self.cursor].data_ptr(), 1))
+            self.cursor += 1
+        self.paste = (paste_emi, paste_knp)
+
+    def restart(self, i):
+        st = self.stepper
+        st.solve_emi = st.solve_knp = None
+        st.reset()
+        if self.halo is not None:
+            self.halo.exchange_bulk()
+            self.halo.exchange_membrane()
+        if self.case.source is not None:
+            st.set_source(0, self.case.source)
+        st.solve_emi, st.solve_knp = self.paste
+        self.cursor = 0
+        self.steps(i)
+
+    def steps(self, n):
+        if self.cursor + n > self.n:
+            raise SystemExit(f"bench: trajectory of {self.n} steps is too short for step {self.cursor + n}")
+        for _ in range(n):
+            self.stepper.step(self.halo)
+
+
+def with_solves(case, replay, start, n_steps, torch):
     """Whole time steps of run_3D.py:345-368 on the device, Krylov solves included: the
-    same stepper with `knpemi_solve_emi` (CG + AMG) and `knpemi_solve_knp` (BiCGStab + AMG) between the assemblies,
-    continuing from the end of the timed trajectory.  Not part of `value`."""
+    same stepper with `knpemi_solve_emi` (CG + AMG) and `knpemi_solve_knp` (BiCGStab + AMG) between the assemblies.
+    Starts at the FIXED trajectory step `start` (whatever --steps / --warmup are): steps start, start + 1 are untimed
+    (initial guesses settle), steps start + 2 .. start + 2 + n_steps are timed.  Not part of `value`."""
     from knpemi import _lib as L
+    stepper, halo = replay.stepper, replay.halo
     dp = stepper.dp
+    replay.restart(start)
     its = {"emi": [], "knp": []}
     stepper.solve_emi, stepper.solve_knp = device_solvers(case, its)
     for _ in range(2):
         stepper.step(halo)
+    dp.sync()
     torch.cuda.synchronize()
     its["emi"].clear()
     its["knp"].clear()
@@ -268,10 +362,12 @@ def with_solves(case, stepper, n_steps, torch, halo=None):
     stepper.solve_emi = stepper.solve_knp = None
     info = {k: dp.solver_info(w) for k, w in (("emi", L.B_EMI), ("knp", L.B_KNP))}
     re, rk = case.solver_rtol
-    return {"ms_per_step": ms, "steps": n_steps, "initial_guess": "2 x_n - x_(n-1) (knpemi_extrapolate_guess)",
-            "emi": {"solver": f"CG + SA-AMG V(1,1), rtol {re:g}", "iterations_avg": sum(its["emi"]) / n_steps, **info["emi"]},
+    return {"ms_per_step": ms, "steps": n_steps, "trajectory_steps": [start + 2, start + 2 + n_steps],
+            "initial_guess": "2 x_n - x_(n-1) (knpemi_extrapolate_guess)",
+            "emi": {"solver": f"CG + SA-AMG V(1,1), rtol {re:g}", "iterations_avg": sum(its["emi"]) / n_steps,
+                    "iterations_max": max(its["emi"]), **info["emi"]},
             "knp": {"solver": f"BiCGStab + SA-AMG V(1,1), rtol {rk:g}", "iterations_avg": sum(its["knp"]) / n_steps,
-                    **info["knp"]}}
+                    "iterations_max": max(its["knp"]), **info["knp"]}}
 
 
 def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, world=1):
@@ -353,12 +449,9 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, wo
 
     def roof(which, name, us):
         by = dg_time.algorithmic_bytes(dp, which)
-        traffic = None      # PMC counters of this build, collected in their own profiler passes (tools/collect_traffic.sh)
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))[args.workload][name]
-            traffic = (2.0 * tr["FETCH_SIZE_KiB"] + tr["WRITE_SIZE_KiB"]) * 1024.0
-        except (OSError, KeyError, ValueError):
-            pass
+        # PMC counters of this build, collected in their own profiler passes (tools/collect_traffic.sh)
+        tr = load_traffic(args.workload)[1].get(name)
+        traffic = (2.0 * tr["FETCH_SIZE_KiB"] + tr["WRITE_SIZE_KiB"]) * 1024.0 if tr else None
         return {"bound": "hbm", "kernel": name, "achieved": by / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": by,
                 "avg_launch_us": us}
@@ -430,11 +523,294 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, wo
     return out
 
 
+def build_problem(workload, args, rank, world):
+    """Case + device stepper (+ halo at N > 1) of one workload."""
+    from knpemi.stepper import DeviceStepper
+    case = Case(workload, rank, world, args.scaling)
+    s = case.s
+    stepper = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp),
+                            s.c, s.c_prev, s.phi, s.phi_M_prev, assemble_knp_twice=args.knp_twice,
+                            overlap=not args.no_overlap, fuse_update=not args.frozen_state,
+                            early_membrane=bool(os.environ.get("KNPEMI_EARLY_MEMBRANE")))
+    if os.environ.get("KNPEMI_OVERLAP_THRESHOLD_US"):      # experiment: when the stepper gives up running the EMI assembly beside the sweep
+        stepper.overlap_threshold_ms = float(os.environ["KNPEMI_OVERLAP_THRESHOLD_US"]) * 1e-3
+    for m, stim, loc in case.models:
+        stepper.add_membrane_model(m, stim, loc)
+    if case.source is not None:
+        stepper.set_source(0, case.source)
+    halo = getattr(s, "halo", None)
+    if halo is not None:
+        halo.attach(stepper.dp)
+        halo.exchange_bulk()        # ghosts start from their owners' values
+        halo.exchange_membrane()    # once: afterwards the ghost membrane dofs are integrated redundantly
+    return case, stepper, halo
+
+
+def load_traffic(workload):
+    """HBM-side bytes per launch from the PMC passes of this build (tools/collect_traffic.sh -> profiles/rNN_traffic.json,
+    collected and corrected as MI355X_MICROARCH.md prescribes); the newest round's file that has the workload."""
+    for name in ("r03_traffic.json", "r02_traffic.json"):
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", name)))[workload]
+            return name, tr
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, {}
+
+
+def measure(workload, args, torch, dist, rank, world, steps, warmup, repeats, spike=True, traj_min=0):
+    """One workload on the recorded trajectory: median-timed window, per-kernel durations, row kernels alone.  Returns
+    (line fragment for rank 0, replay, case)."""
+    import numpy as np
+    from knpemi import _lib as L
+    case, stepper, halo = build_problem(workload, args, rank, world)
+    s, dp, lib = case.s, stepper.dp, stepper.dp.lib
+    frozen = args.frozen_state
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def rank_max(x):
+        if dist is None:
+            return x
+        red_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([x], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    if frozen:
+        if case.family != "idealized":
+            raise SystemExit("--frozen-state is defined for the idealized workloads")
+        # synthetic stationary state: c = c_prev (the update keeps the fields), rest potential + a smooth perturbation
+        s.perturb(seed=12345 + rank)
+        for tag in s.subdomain_list:
+            for k in range(2):
+                s.c[tag][k].x.array[:] = s.c_prev[tag][k].x._a
+            s.ion_list[-1][f'c_{tag}'].x.array[:] = -(1.0 / s.ion_list[-1]['z']) * sum(
+                ion['z'] * f.x._a for ion, f in zip(s.ion_list[:-1], s.c_prev[tag]))
+        L_x = s.mesh.x[:, 0].max() if world == 1 else s.global_length
+        for tag in s.subdomain_list:
+            x = s.subdomain_list[tag]['mesh_sub'].x
+            s.phi[tag].x.array[:] = (-0.0744 if tag > 0 else 0.0) + 1e-3 * np.sin(2 * np.pi * x[:, 0] / L_x)
+        stepper.reset()
+
+    # ---- untimed trajectory pass: whole steps with the device Krylov solves from t = 0.  A failure here (a solve that
+    # does not converge, a communication hook) ends the bench with a non-zero exit code: there is no fallback state.
+    n_traj = max(warmup + steps + 8, traj_min)
+    traj_its = rhs_per_step = None
+    replay = None
+    if not frozen:
+        if halo is not None:
+            halo.enable_solves()    # knpemi_solve_emi / knp solve the global systems
+        phi_t, c_t, traj_its, rhs_per_step = record_trajectory(case, stepper, n_traj, halo)
+        replay = Replay(case, stepper, halo, phi_t, c_t, torch)
+
+    def restart(i):
+        if replay is not None:
+            replay.restart(i)
+        else:
+            stepper.reset()
+            for _ in range(i):
+                stepper.step(halo)
+
+    def run_steps(n):
+        if replay is not None:
+            replay.steps(n)
+        else:
+            for _ in range(n):
+                stepper.step(halo)
+
+    # ---- untimed profiling pass over the first steps of the window: every kernel bracketed by HIP events
+    restart(warmup)
+    sync()
+    L.check(lib.knpemi_profile(dp.h, (1 << len(L.KERNEL_NAMES)) - 1))
+    n_prof = min(PROFILE_STEPS, steps)
+    run_steps(n_prof)
+    sync()
+    per_kernel = {}
+    for kid, name in enumerate(L.KERNEL_NAMES):
+        n, ms = C.c_int64(), C.c_double()
+        L.check(lib.knpemi_profile_read(dp.h, kid, C.byref(n), C.byref(ms)))
+        if n.value:
+            per_kernel[name] = ms.value / n.value * 1e3 * (n.value / n_prof)   # us per step (all launches)
+    L.check(lib.knpemi_profile(dp.h, 0))
+    rows = {k: v for k, v in per_kernel.items() if k in ("emi_rows_kernel", "knp_rows_kernel")}
+    dominant = max(rows, key=rows.get) if rows else "emi_rows_kernel"
+    dom_id = L.KERNEL_NAMES.index(dominant)
+    stride = int(os.environ.get("KNPEMI_BENCH_PROFILE_STRIDE", "8"))
+
+    # ---- timed windows.  One window = EXACTLY `steps` steps, trajectory steps [first, first + steps), between
+    # barrier + synchronize on both sides; the state is put back to the start of the window before every repeat and
+    # `value` comes from the MEDIAN window (BASELINE.md section 2).  Only the dominant row kernel keeps an event pair,
+    # on every 8th launch (an event pair on the critical path costs the step several microseconds).
+    def timed_windows(first, reps):
+        times, enq = [], []
+        dom_n, dom_ms, n_rhs, n_lsoda = 0, 0.0, 0, 0
+        for _ in range(reps):
+            restart(first)
+            L.check(lib.knpemi_profile(dp.h, 1 << dom_id))
+            L.check(lib.knpemi_set_option(dp.h, L.OPT_PROFILE_STRIDE, stride))
+            ode_counters(case, dp)                      # reset
+            sync()
+            t0 = time.perf_counter()
+            run_steps(steps)
+            t_enq = time.perf_counter() - t0           # host side: all launches of the window are enqueued
+            sync()
+            elapsed = time.perf_counter() - t0
+            times.append(rank_max(elapsed))
+            enq.append(t_enq)
+            nr, ns, nf = ode_counters(case, dp)
+            if nf:
+                raise SystemExit("LSODA failed on the device")
+            n_rhs, n_lsoda = n_rhs + nr, n_lsoda + ns
+            n, ms = C.c_int64(), C.c_double()
+            L.check(lib.knpemi_profile_read(dp.h, dom_id, C.byref(n), C.byref(ms)))
+            dom_n, dom_ms = dom_n + n.value, dom_ms + ms.value
+            L.check(lib.knpemi_profile(dp.h, 0))
+            L.check(lib.knpemi_set_option(dp.h, L.OPT_PROFILE_STRIDE, 1))
+        return dict(times=times, median=float(np.median(times)), enqueue=float(np.median(enq)),
+                    dom_us=dom_ms / max(dom_n, 1) * 1e3, rhs=n_rhs / reps, lsoda=n_lsoda / reps)
+
+    main_w = timed_windows(warmup, repeats)
+    # second window: the same number of steps around the step whose ODE sweep takes longest (the action potential passes
+    # the wave that integrates it: the sweep is as slow as its slowest wave).  Found with an untimed replay of the whole
+    # trajectory, the sweep bracketed by events and read back after every step.
+    spike_w = spike_first = ode_us_per_step = None
+    if spike and replay is not None and replay.n >= steps:
+        kid = L.KERNEL_NAMES.index("ode_step_kernel")
+        restart(0)
+        L.check(lib.knpemi_profile(dp.h, 1 << kid))
+        ode_us_per_step = []
+        for _ in range(replay.n):
+            run_steps(1)
+            n, ms = C.c_int64(), C.c_double()
+            L.check(lib.knpemi_profile_read(dp.h, kid, C.byref(n), C.byref(ms)))      # synchronises, clears the brackets
+            ode_us_per_step.append(ms.value * 1e3)
+        L.check(lib.knpemi_profile(dp.h, 0))
+        peak = int(np.argmax(ode_us_per_step))
+        spike_first = int(min(max(0, peak - steps // 2), len(rhs_per_step) - steps))
+        spike_w = timed_windows(spike_first, max(3, repeats // 2))
+        # the sweep's duration inside that window (every launch bracketed, untimed pass)
+        restart(spike_first)
+        L.check(lib.knpemi_profile(dp.h, 1 << L.KERNEL_NAMES.index("ode_step_kernel")))
+        run_steps(steps)
+        sync()
+        n, ms = C.c_int64(), C.c_double()
+        L.check(lib.knpemi_profile_read(dp.h, L.KERNEL_NAMES.index("ode_step_kernel"), C.byref(n), C.byref(ms)))
+        spike_w["ode_us"] = ms.value / max(n.value, 1) * 1e3 * (n.value / steps)
+        L.check(lib.knpemi_profile(dp.h, 0))
+
+    # ---- the row kernels by themselves: while the EMI assembly shares the chip with the ODE sweep its launches are
+    # stretched by the sweep's waves.  A short untimed pass with everything on one stream gives the durations the
+    # kernels reach alone (`roofline_row_kernels_alone`); the step times above are the overlapped schedule's.
+    alone = {}
+    overlapped = bool(stepper.overlap)
+    restart(warmup)
+    stepper.overlap = False
+    L.check(lib.knpemi_profile(dp.h, (1 << L.KERNEL_NAMES.index("emi_rows_kernel")) | (1 << L.KERNEL_NAMES.index("knp_rows_kernel"))))
+    run_steps(min(8, steps))
+    sync()
+    for name in ("emi_rows_kernel", "knp_rows_kernel"):
+        n, ms = C.c_int64(), C.c_double()
+        L.check(lib.knpemi_profile_read(dp.h, L.KERNEL_NAMES.index(name), C.byref(n), C.byref(ms)))
+        if n.value:
+            alone[name] = ms.value / n.value * 1e3
+    L.check(lib.knpemi_profile(dp.h, 0))
+    stepper.overlap = overlapped
+
+    owned = getattr(s, "owned_dofs", None)
+    dofs_local = 3 * (owned if owned is not None else int(dp.n_vert.sum()))
+    if dist is not None:
+        red_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        tot = torch.tensor([dofs_local], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(tot)
+        dofs_total = int(tot.item())
+    else:
+        dofs_total = dofs_local
+    out = None
+    if rank == 0:
+        survey_b, design_b, sizes = algorithmic_bytes(case, dp)
+        n_ode_dofs = sum(m.nodes for m, _, _ in case.models)
+        traffic_file, traffic = load_traffic(workload) if world == 1 else (None, {})
+
+        def roof(kernel, us):
+            tr = traffic.get(kernel)
+            by_counters = (2.0 * tr["FETCH_SIZE_KiB"] + tr["WRITE_SIZE_KiB"]) * 1024.0 if tr else None
+            ach = survey_b[kernel] / (us * 1e-6) / 1e9
+            return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": by_counters, "traffic_source": traffic_file if tr else None,
+                    # the same launch priced with the bytes the PMC counters saw instead of the SURVEY accounting
+                    "frac_by_counters": by_counters / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if by_counters else None,
+                    "algorithmic_bytes_per_launch": survey_b[kernel], "avg_launch_us": us,
+                    "bytes_this_design_touches": design_b[kernel],
+                    "frac_of_design_bytes": design_b[kernel] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                    # a launch cannot be shorter than the launch floor: the fraction of peak a perfect kernel would
+                    # reach at this size (1.0 = large enough for HBM to be the bound)
+                    "launch_floor_us": LAUNCH_FLOOR_US,
+                    "frac_at_launch_floor": min(1.0, survey_b[kernel] / (LAUNCH_FLOOR_US * 1e-6) / 1e9 / HBM_PEAK_GBS)}
+        med = main_w["median"]
+        mem_us = per_kernel.get("knp_membrane_kernel", 0.0)
+        out = {
+            "value": dofs_total / (med / steps), "unit": "dofs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": med / steps * 1e3,
+            "timing": {"what": f"median of {len(main_w['times'])} repeats of the timed window; one window = {steps} steps, "
+                               f"trajectory steps [{warmup}, {warmup + steps}) (t = {warmup * case.dt:g} .. "
+                               f"{(warmup + steps) * case.dt:g}), state restored before every repeat",
+                       "repeats_ms_per_step": [t / steps * 1e3 for t in main_w["times"]],
+                       "min_ms_per_step": min(main_w["times"]) / steps * 1e3,
+                       "max_ms_per_step": max(main_w["times"]) / steps * 1e3},
+            "host_enqueue_ms_per_step": main_w["enqueue"] / steps * 1e3,
+            "config": {"workload": f"{workload}: make_mesh_3D geometry r={case.r}, {case.kind}, "
+                                   f"{sizes['nc']} cells/GPU, {sizes['N']} sub-mesh vertices/GPU in "
+                                   f"{len(s.subdomain_list)} sub-domains, {n_ode_dofs} membrane ODE dofs/GPU, 3 ions "
+                                   f"(K, Cl, Na eliminated), {case.describe}",
+                       "dofs_per_step": dofs_total, "A_knp_assemblies_per_step": 2 if args.knp_twice else 1,
+                       "emi_matrix_beside_ode_sweep": overlapped,
+                       "update_fused_into_knp_write_back": bool(stepper.fuse_update),
+                       "state": ("fields frozen at the initial state (phi_M reset every step)" if frozen else
+                                 f"recorded trajectory of the first {n_traj} time steps from t = 0 (device Krylov solves, "
+                                 f"untimed); the timed steps replay it, pasting each recorded solution where the solve "
+                                 f"writes it"),
+                       "partition": "x-slabs" if world > 1 else "none"},
+            "roofline": roof(dominant, main_w["dom_us"]),
+            "roofline_membrane_facet_kernel": roof("knp_membrane_kernel", mem_us) if mem_us > 0 else None,
+            "roofline_row_kernels_alone": {k: roof(k, v) for k, v in alone.items()} or None,
+            "kernels_us_per_step": per_kernel,
+            "ode": {"rhs_evals_per_dof_per_step": main_w["rhs"] / max(1, n_ode_dofs) / steps,
+                    "lsoda_steps_per_dof_per_step": main_w["lsoda"] / max(1, n_ode_dofs) / steps,
+                    "kernel_us_per_step": per_kernel.get("ode_step_kernel"),
+                    "share_of_step": per_kernel.get("ode_step_kernel", 0.0) / (med / steps * 1e6)},
+        }
+        if spike_w is not None:
+            sm = spike_w["median"]
+            out["spike_window"] = {
+                "what": f"the same measurement on the {steps} steps around the step with the longest ODE sweep (step "
+                        f"{int(np.argmax(ode_us_per_step))}: {max(ode_us_per_step):.0f} us): trajectory steps "
+                        f"[{spike_first}, {spike_first + steps})",
+                "ode_kernel_us_max": max(ode_us_per_step),
+                "ode_kernel_us_along_the_trajectory": [round(x, 1) for x in ode_us_per_step],
+                "ms_per_step": sm / steps * 1e3, "value": dofs_total / (sm / steps),
+                "repeats_ms_per_step": [t / steps * 1e3 for t in spike_w["times"]],
+                "ode_kernel_us_per_step": spike_w["ode_us"],
+                "rhs_evals_per_dof_per_step": spike_w["rhs"] / max(1, n_ode_dofs) / steps}
+        if rhs_per_step is not None:
+            out["ode"]["rhs_evals_per_dof_along_the_trajectory"] = [round(x, 1) for x in rhs_per_step]
+        if halo is not None:
+            out["config"]["halo"] = halo.mode
+        if traj_its is not None:
+            out["config"]["trajectory_iterations_avg"] = {k: sum(v) / max(1, len(v)) for k, v in traj_its.items()}
+    return out, replay, case, dofs_total
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=7,
+                    help="repeats of the timed window (state restored before each); `value` is the median")
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = box length proportional to N (config 2 per GPU), strong = the fixed config-3 box "
@@ -444,7 +820,7 @@ def main():
                          "(0 = skip)")
     ap.add_argument("--solve-steps", type=int, default=20,
                     help="extra untimed-for-`value` pass: whole time steps including the device Krylov solves, reported "
-                         "as `with_solves` (0 = skip; N = 1 only)")
+                         "as `with_solves` (0 = skip)")
     ap.add_argument("--frozen-state", action="store_true",
                     help="hold the fields at their initial state instead of replaying a recorded trajectory (the "
                          "round-1 measurement: phi_M is reset every step and the cell never fires)")
@@ -452,14 +828,15 @@ def main():
                     help="run the EMI matrix assembly after the ODE sweep instead of beside it (aux stream)")
     ap.add_argument("--variant", default="cg", choices=["cg", "dg"],
                     help="cg: the reference's formulation (CG on sub-meshes, the parity path); dg: the DG(P1) + interior "
-                         "penalty variant of SURVEY.md section 8 f4 on the same mesh (assembly + ODE sweep + update, fields "
-                         "held at the initial state: its linear solves are not on the device)")
+                         "penalty variant of SURVEY.md section 8 f4 on the same mesh")
     ap.add_argument("--no-dg", action="store_true", help="skip the short DG-variant measurement appended to the cg line")
+    ap.add_argument("--no-config3", action="store_true",
+                    help="skip the 995 328-tet leg appended to the default line (`config3_leg`: the size at which the "
+                         "row kernels are HBM-bound rather than launch-bound)")
     ap.add_argument("--knp-twice", action="store_true",
                     help="assemble A_knp twice per step as the reference does (p = a, knpWeakForm.py:319)")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -478,9 +855,6 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from knpemi import _lib as L
-    from knpemi.stepper import DeviceStepper
-
     if args.variant == "dg":
         out = run_dg(args, torch, dist=dist, rank=rank, world=world)
         if rank == 0:
@@ -491,270 +865,65 @@ def main():
         return
     if world > 1 and args.scaling == "strong" and args.workload == "config2":
         args.workload = "config3"       # the fixed mesh of BASELINE.json configs[2]
-    case = Case(args.workload, rank, world, args.scaling)
-    s = case.s
-    frozen = args.frozen_state
-    def frozen_state():
-        # synthetic stationary state: c = c_prev (the update keeps the fields), rest potential + a smooth perturbation
-        s.perturb(seed=12345 + rank)
-        for tag in s.subdomain_list:
-            for k in range(2):
-                s.c[tag][k].x.array[:] = s.c_prev[tag][k].x._a
-            s.ion_list[-1][f'c_{tag}'].x.array[:] = -(1.0 / s.ion_list[-1]['z']) * sum(
-                ion['z'] * f.x._a for ion, f in zip(s.ion_list[:-1], s.c_prev[tag]))
-        L_x = s.mesh.x[:, 0].max() if world == 1 else s.global_length
-        for tag in s.subdomain_list:
-            x = s.subdomain_list[tag]['mesh_sub'].x
-            s.phi[tag].x.array[:] = (-0.0744 if tag > 0 else 0.0) + 1e-3 * np.sin(2 * np.pi * x[:, 0] / L_x)
 
-    if frozen and case.family == "idealized":
-        frozen_state()
-
-    stepper = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp),
-                            s.c, s.c_prev, s.phi, s.phi_M_prev, assemble_knp_twice=args.knp_twice,
-                            overlap=not args.no_overlap, fuse_update=not args.frozen_state,
-                            early_membrane=bool(os.environ.get("KNPEMI_EARLY_MEMBRANE")))
-    if os.environ.get("KNPEMI_OVERLAP_THRESHOLD_US"):      # experiment: when the stepper gives up running the EMI assembly beside the sweep
-        stepper.overlap_threshold_ms = float(os.environ["KNPEMI_OVERLAP_THRESHOLD_US"]) * 1e-3
-    dp = stepper.dp
-    for m, stim, loc in case.models:
-        stepper.add_membrane_model(m, stim, loc)
-    if case.source is not None:
-        stepper.set_source(0, case.source)
-    halo = getattr(s, "halo", None)
-    if halo is not None:
-        halo.attach(dp)
-        halo.exchange_bulk()        # ghosts start from their owners' values
-        halo.exchange_membrane()    # once: afterwards the ghost membrane dofs are integrated redundantly
-
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    lib = dp.lib
-    n_traj = args.warmup + PROFILE_STEPS + args.steps + 8      # + the short pass that times the row kernels alone
-    traj_its = None
-    traj_fallback = None
-    if not frozen and halo is not None:
-        # The distributed Krylov solves (RCCL all-reduce and halo from inside the solver loop) are the one part of the
-        # N > 1 path that could only be rehearsed over gloo here.  If they fail -- the same way on every rank, i.e.
-        # before or outside a collective -- the measurement falls back to the frozen state instead of being lost, and
-        # says so in `config.state`.
-        try:
-            halo.enable_solves()    # knpemi_solve_emi / knp solve the global systems
-            if os.environ.get("KNPEMI_BENCH_TEST_FALLBACK"):      # rehearsal hook for the branch below
-                raise RuntimeError("KNPEMI_BENCH_TEST_FALLBACK is set")
-            phi_t, c_t, traj_its = record_trajectory(case, stepper, n_traj, torch, halo)
-        except Exception as e:      # noqa: BLE001
-            if case.family != "idealized":
-                raise
-            traj_fallback = f"{type(e).__name__}: {e}"[:300]
-            frozen = True
-            stepper.solve_emi = stepper.solve_knp = None
-            frozen_state()
-            stepper.reset()
-            halo.exchange_bulk()
-            halo.exchange_membrane()
-    elif not frozen:
-        phi_t, c_t, traj_its = record_trajectory(case, stepper, n_traj, torch, halo)
-    if not frozen:
-        stepper.reset()
-        if halo is not None:
-            halo.exchange_bulk()
-            halo.exchange_membrane()
-        if case.source is not None:
-            stepper.set_source(0, case.source)
-        cursor = [0]
-
-        def paste_emi(d):
-            L.check(d.lib.knpemi_set_solution(d.h, L.B_EMI, phi_t[cursor[0]].data_ptr(), 1))
-
-        def paste_knp(d):
-            L.check(d.lib.knpemi_set_solution(d.h, L.B_KNP, c_t[cursor[0]].data_ptr(), 1))
-            cursor[0] += 1
-        stepper.solve_emi, stepper.solve_knp = paste_emi, paste_knp
-
-    def ode_stats():
-        nr = ns = nf = 0
-        for m, _, _ in case.models:
-            a, b, c = C.c_int64(), C.c_int64(), C.c_int32()
-            lib.knpemi_ode_stats(dp.h, m._sub, m._model, C.byref(a), C.byref(b), C.byref(c))
-            nr, ns, nf = nr + a.value, ns + b.value, nf + c.value
-        return nr, ns, nf
-
-    for _ in range(args.warmup):
-        stepper.step(halo)
-    sync()
-    # untimed profiling pass: every kernel bracketed by HIP events -> per-kernel averages, dominant kernel
-    L.check(lib.knpemi_profile(dp.h, (1 << len(L.KERNEL_NAMES)) - 1))
-    for _ in range(PROFILE_STEPS):
-        stepper.step(halo)
-    sync()
-    per_kernel = {}
-    for kid, name in enumerate(L.KERNEL_NAMES):
-        n, ms = C.c_int64(), C.c_double()
-        L.check(lib.knpemi_profile_read(dp.h, kid, C.byref(n), C.byref(ms)))
-        if n.value:
-            per_kernel[name] = ms.value / n.value * 1e3 * (n.value / PROFILE_STEPS)   # us per step (all launches)
-    rows = {k: v for k, v in per_kernel.items() if k in ("emi_rows_kernel", "knp_rows_kernel")}
-    dominant = max(rows, key=rows.get) if rows else "emi_rows_kernel"
-    dom_id = L.KERNEL_NAMES.index(dominant)
-    # timed region: only the dominant row kernel stays bracketed by HIP events (it runs on the side stream).  The
-    # membrane-facet kernel sits on the critical path, where an event pair costs the step ~10 us: its duration for
-    # `roofline_membrane_facet_kernel` is the one of the profiling pass above.
-    L.check(lib.knpemi_profile(dp.h, 1 << dom_id))
-    # ... and only every 8th of its launches: at the small sizes the stepper runs everything on one stream and the
-    # event pair would sit on the critical path of every step
-    stride = int(os.environ.get("KNPEMI_BENCH_PROFILE_STRIDE", "8"))
-    L.check(lib.knpemi_set_option(dp.h, L.OPT_PROFILE_STRIDE, stride))
-    ode_stats()                                 # reset the counters
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        stepper.step(halo)
-    t_enqueue = time.perf_counter() - t0      # host side: all launches of the timed steps are enqueued
-    sync()
-    elapsed = time.perf_counter() - t0
-    n_rhs, n_lsoda_steps, n_failed = ode_stats()
-    n, ms = C.c_int64(), C.c_double()
-    L.check(lib.knpemi_profile_read(dp.h, dom_id, C.byref(n), C.byref(ms)))
-    dom_us = ms.value / max(n.value, 1) * 1e3
-    mem_us = per_kernel.get("knp_membrane_kernel", 0.0)
-    L.check(lib.knpemi_profile(dp.h, 0))
-    L.check(lib.knpemi_set_option(dp.h, L.OPT_PROFILE_STRIDE, 1))
-    if n_failed:
-        raise SystemExit("LSODA failed on the device")
-    # The row kernels by themselves: while the EMI assembly shares the chip with the ODE sweep its launches are
-    # stretched by the sweep's waves.  A short untimed pass with everything on one stream gives the durations the
-    # kernels reach alone (`roofline_row_kernels_alone`); the step time above is the overlapped schedule's.
-    alone = {}
-    overlapped = bool(stepper.overlap)
-    if overlapped and not frozen and len(phi_t) >= args.warmup + PROFILE_STEPS + args.steps + 8:
-        stepper.overlap = False
-        L.check(lib.knpemi_profile(dp.h, (1 << L.KERNEL_NAMES.index("emi_rows_kernel")) | (1 << L.KERNEL_NAMES.index("knp_rows_kernel"))))
-        for _ in range(8):
-            stepper.step(halo)
-        sync()
-        for name in ("emi_rows_kernel", "knp_rows_kernel"):
-            n, ms = C.c_int64(), C.c_double()
-            L.check(lib.knpemi_profile_read(dp.h, L.KERNEL_NAMES.index(name), C.byref(n), C.byref(ms)))
-            if n.value:
-                alone[name] = ms.value / n.value * 1e3
-        L.check(lib.knpemi_profile(dp.h, 0))
-        stepper.overlap = True
-    if dist is not None:
-        red_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    owned = getattr(s, "owned_dofs", None)
-    dofs_local = 3 * (owned if owned is not None else int(dp.n_vert.sum()))
-    if dist is not None:
-        tot = torch.tensor([dofs_local], dtype=torch.int64, device=red_dev)
-        dist.all_reduce(tot)
-        dofs_total = int(tot.item())
-    else:
-        dofs_total = dofs_local
-    ms_per_step = elapsed / args.steps * 1e3
-    value = dofs_total / (elapsed / args.steps)
-
+    # the trajectory is long enough to contain the action potential of the stimulated end of the cell (SPIKE_SEARCH)
+    out, replay, case, dofs_total = measure(args.workload, args, torch, dist, rank, world, args.steps, args.warmup,
+                                            args.repeats, spike=not args.frozen_state, traj_min=SPIKE_SEARCH)
     if rank == 0:
-        survey_b, design_b, sizes = algorithmic_bytes(case, dp)
-        n_ode_dofs = sum(m.nodes for m, _, _ in case.models)
-
-        def roof(kernel, us):
-            # HBM bytes per launch measured with rocprofv3 PMC counters on THIS build, if they were collected
-            # (tools/collect_traffic.sh -> profiles/r02_traffic.json); PMC collection needs its own profiler passes
-            traffic = None
-            try:
-                tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))[args.workload][kernel]
-                if world == 1:
-                    traffic = (2.0 * tr["FETCH_SIZE_KiB"] + tr["WRITE_SIZE_KiB"]) * 1024.0
-            except (OSError, KeyError, ValueError):
-                pass
-            ach = survey_b[kernel] / (us * 1e-6) / 1e9
-            return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                    "algorithmic_bytes_per_launch": survey_b[kernel], "avg_launch_us": us,
-                    "bytes_this_design_touches": design_b[kernel],
-                    "frac_of_design_bytes": design_b[kernel] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                    # a launch cannot be shorter than the launch floor: the fraction of peak a perfect kernel would
-                    # reach at this size (1.0 = large enough for HBM to be the bound)
-                    "launch_floor_us": LAUNCH_FLOOR_US,
-                    "frac_at_launch_floor": min(1.0, survey_b[kernel] / (LAUNCH_FLOOR_US * 1e-6) / 1e9 / HBM_PEAK_GBS)}
-        out = {
-            "metric": "assembled dofs/s (volume + membrane-facet assembly + membrane ODE sweep) per timestep; "
-                      "3D idealized mesh, fp64",
-            "value": value, "unit": "dofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: make_mesh_3D geometry r={case.r}, {case.kind}, "
-                                   f"{sizes['nc']} cells/GPU, {sizes['N']} sub-mesh vertices/GPU in "
-                                   f"{len(s.subdomain_list)} sub-domains, {n_ode_dofs} membrane ODE dofs/GPU, 3 ions "
-                                   f"(K, Cl, Na eliminated), {case.describe}",
-                       "dofs_per_step": dofs_total, "A_knp_assemblies_per_step": 2 if args.knp_twice else 1,
-                       "emi_matrix_beside_ode_sweep": overlapped,
-                       "update_fused_into_knp_write_back": bool(stepper.fuse_update),
-                       "state": (("fields frozen at the initial state (phi_M reset every step)"
-                                  + (f"; FALLBACK: the trajectory pass with distributed solves raised {traj_fallback}"
-                                     if traj_fallback else "")) if frozen else
-                                 f"recorded trajectory of the first {n_traj} time steps from t = 0 (device Krylov solves, "
-                                 f"untimed); the timed steps replay it, pasting each recorded solution where the solve "
-                                 f"writes it"),
-                       "partition": "x-slabs" if world > 1 else "none"},
-            "roofline": roof(dominant, dom_us),
-            "roofline_membrane_facet_kernel": roof("knp_membrane_kernel", mem_us) if mem_us > 0 else None,
-            "roofline_row_kernels_alone": {k: roof(k, v) for k, v in alone.items()} or None,
-            "kernels_us_per_step": per_kernel,
-            "ode": {"rhs_evals_per_dof_per_step": n_rhs / max(1, n_ode_dofs) / args.steps,
-                    "lsoda_steps_per_dof_per_step": n_lsoda_steps / max(1, n_ode_dofs) / args.steps,
-                    "kernel_us_per_step": per_kernel.get("ode_step_kernel"),
-                    "share_of_step": per_kernel.get("ode_step_kernel", 0.0) / (ms_per_step * 1e3)},
-        }
-        if halo is not None:
-            out["config"]["halo"] = halo.mode
-        if traj_its is not None:
-            out["config"]["trajectory_iterations_avg"] = {k: sum(v) / max(1, len(v)) for k, v in traj_its.items()}
+        out = {"metric": "assembled dofs/s (volume + membrane-facet assembly + membrane ODE sweep) per timestep; "
+                         "3D idealized mesh, fp64",
+               **{k: out[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")},
+               "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic",
+               **{k: v for k, v in out.items() if k not in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")}}
     ws = None
-    if args.solve_steps > 0 and not frozen:      # collective at N > 1: every rank takes part
-        stepper.solve_emi = stepper.solve_knp = None
-        ws = with_solves(case, stepper, args.solve_steps, torch, halo)
+    if args.solve_steps > 0 and replay is not None:      # collective at N > 1: every rank takes part
+        ws = with_solves(case, replay, WITH_SOLVES_START, args.solve_steps, torch)
     if rank == 0:
         if ws is not None:
             out["with_solves"] = ws
+        s = case.s
         if args.cpu_steps > 0 and world == 1 and case.family == "idealized":
             avail = len(os.sched_getaffinity(0))
             # bounded sample: --cpu-steps refers to the config-2 size and shrinks with the problem size
             n_all = max(3, int(round(args.cpu_steps * min(1.0, 79251.0 / dofs_total))))
+            n_all = min(n_all, replay.n - args.warmup) if replay is not None else n_all
             n1 = max(2, int(0.4 * n_all))
+            traj = (replay.phi_t.cpu().numpy(), replay.c_t.cpu().numpy()) if replay is not None else None
             quiet = io.StringIO()
             with contextlib.redirect_stdout(quiet):
-                t_one, a_one, o_one, _ = cpu_baseline(s, n1, threads=1)     # before any OpenMP team exists
+                t_one, a_one, o_one, _ = cpu_baseline(s, n1, threads=1, traj=traj, start=args.warmup)   # before any OpenMP team exists
                 # thread count: a fully subscribed host can be slower than a partly subscribed one (spinning OpenMP
                 # team + the Python thread, CPU shares below the visible core count): probe and time the best
                 cand = sorted({min(avail, c) for c in (4, 8, 16, 32, avail)})
                 probes = {c: cpu_baseline(s, 3, threads=c)[0] for c in cand}
                 cores = min(probes, key=probes.get)
-                t_all, a_all, o_all, nrows = cpu_baseline(s, n_all, threads=cores)
+                t_all, a_all, o_all, nrows = cpu_baseline(s, n_all, threads=cores, traj=traj, start=args.warmup)
             what = ("whole steps of the C++ port (oracle/knpemi_cpu.cpp, sequential ODEPACK restatement "
-                    "oracle/lsoda_seq.h) on the same mesh from the initial state: EMI (A, P, b) + KNP (A, b) assembly "
-                    "and update {a:.0f} ms/step, LSODA sweep over all {n} membrane dofs {o:.0f} ms/step; "
-                    "the reference itself cannot run here")
+                    "oracle/lsoda_seq.h) on the same mesh, replaying the same recorded trajectory from step {w} (the "
+                    "window the GPU's value is timed on): EMI (A, P, b) + KNP (A, b) assembly and update {a:.1f} ms/step, "
+                    "LSODA sweep over all {n} membrane dofs {o:.1f} ms/step; the reference itself cannot run here")
             out["cpu_baseline"] = {
                 "value": dofs_total / t_all, "unit": "dofs/s", "cores": cores, "kind": "port",
-                "sample": f"{n_all} " + what.format(a=a_all * 1e3, o=o_all * 1e3, n=nrows)
+                "sample": f"{n_all} " + what.format(a=a_all * 1e3, o=o_all * 1e3, n=nrows, w=args.warmup)
                           + f"; OpenMP over cells / facets / membrane dofs, {cores} threads (fastest of "
                             f"{cand} on the {avail} cores visible to this process)"}
             out["cpu_baseline_1core"] = {
                 "value": dofs_total / t_one, "unit": "dofs/s", "cores": 1, "kind": "port",
-                "sample": f"{n1} " + what.format(a=a_one * 1e3, o=o_one * 1e3, n=nrows)
+                "sample": f"{n1} " + what.format(a=a_one * 1e3, o=o_one * 1e3, n=nrows, w=args.warmup)
                           + "; one thread, as the reference's serial run"}
-        if world == 1 and not args.no_dg and case.family == "idealized" and case.kind == "tet":
-            del stepper, s, case          # free the CG problem first
+    tet = case.family == "idealized" and case.kind == "tet"
+    del replay, case
+    if world == 1 and tet and args.workload == "config2" and not args.no_config3 and not args.frozen_state:
+        # The 995 328-tet mesh of BASELINE configs[2] on this one GPU: config 2 is launch-bound (a perfect row kernel
+        # reaches < 0.5 of the HBM peak at the launch floor), this is the size at which the roofline fraction says
+        # something about the kernels.  Same measurement, shorter: no spike window, no solves pass, no CPU leg.
+        leg, _, _, _ = measure("config3", args, torch, None, 0, 1, steps=10, warmup=5, repeats=5, spike=False)
+        out["config3_leg"] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "timing", "config", "roofline",
+                                                   "roofline_membrane_facet_kernel", "roofline_row_kernels_alone",
+                                                   "kernels_us_per_step", "ode")}
+    if rank == 0:
+        if world == 1 and not args.no_dg and tet:
             dg = run_dg(args, torch, steps=10, warmup=2, cpu=False)
             out["dg_variant"] = {k: dg[k] for k in ("value", "unit", "ms_per_step", "config", "roofline",
                                                      "roofline_potential_kernel", "kernels_us_per_step")}

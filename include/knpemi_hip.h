@@ -159,6 +159,11 @@ int knpemi_csr_dims(knpemi_handle* h, int which, int64_t* n_rows, int64_t* nnz);
 int knpemi_get_csr_pattern(knpemi_handle* h, int which, int32_t* rowptr, int32_t* colind);
 int knpemi_get_csr_values(knpemi_handle* h, int which, double* vals);
 int knpemi_get_rhs(knpemi_handle* h, int which, double* b);
+/* Caller-supplied values of an operator / right-hand side, in the layout of knpemi_get_csr_values / knpemi_get_rhs
+ * (petsc4py Mat.setValuesCSR / Vec.setArray on `problem.A` / `problem.b`, pdeSolver.py:56-66 expose both objects).
+ * Synchronous. */
+int knpemi_set_csr_values(knpemi_handle* h, int which, const double* vals);
+int knpemi_set_rhs(knpemi_handle* h, int which, const double* b);
 /* Device-resident views for on-GPU consumers (solvers, RCCL halo exchange through torch). */
 int knpemi_device_csr(knpemi_handle* h, int which, const int32_t** rowptr, const int32_t** colind,
                       const double** vals);

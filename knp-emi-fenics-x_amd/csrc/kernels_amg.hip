@@ -472,8 +472,15 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
         else if (!h_owned[c]) A.v[j] = 0.0;
       }
   }
-  for (double x : A.v)
-    if (!(x == x)) { kn_set_error("AMG set-up: operator contains NaN"); return KNPEMI_EINVAL; }
+  // The hierarchy is only as good as the values it is built from: one non-finite (or absurdly large) entry does not stop the
+  // set-up -- it collapses the damping of a level (rho -> inf), changes the aggregation of every coarser level and reaches
+  // the Krylov loop as a NaN several launches later.  Refuse it here, naming the entry.
+  for (int i = 0; i < n; ++i)
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j)
+      if (!std::isfinite(A.v[j])) {
+        kn_set_error("AMG set-up: operator entry (" + std::to_string(i) + ", " + std::to_string(A.ci[j]) + ") is not finite");
+        return KNPEMI_EINVAL;
+      }
 
   const double theta = G.theta;
   const int n_dense = 640, max_levels = 12;
@@ -485,7 +492,16 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
     KnAmgLevel L;
     L.n = cur.n;
     std::vector<double> d = diagonal(cur);
+    for (int i = 0; i < cur.n; ++i)
+      if (!std::isfinite(d[i]) || d[i] == 0.0) {
+        kn_set_error("AMG set-up: level " + std::to_string(l) + " has a zero or non-finite diagonal entry in row " + std::to_string(i));
+        return KNPEMI_ESOLVE;
+      }
     const double rho = estimate_rho(cur, d);
+    if (!std::isfinite(rho) || !(rho > 0.0)) {
+      kn_set_error("AMG set-up: spectral radius estimate of level " + std::to_string(l) + " is not a positive finite number");
+      return KNPEMI_ESOLVE;
+    }
     L.omega = 4.0 / (3.0 * rho);
     L.avg_row = cur.n ? (int)(cur.ci.size() / (size_t)cur.n) : 0;
     if (l == 0 && G.block > 0) {

@@ -9,6 +9,9 @@
 // All vectors and scalars stay on the device; the host reads back one residual norm per chunk of iterations
 // (one iteration with AMG) to test convergence.  A dot product, its block partials and the scalar update it
 // feeds are one launch with a fixed summation order, so the solves are bit-reproducible.
+#include <cmath>
+#include <cstdio>
+
 #include "knpemi_internal.h"
 
 namespace {
@@ -16,7 +19,11 @@ namespace {
 constexpr int RED_BLOCKS = 512, RED_THREADS = 256;
 
 // sc[] layout (device scalars)
-enum { S_RHO = 0, S_RHO_OLD, S_PAP, S_ALPHA, S_BETA, S_OMEGA, S_RR, S_BB, S_TS, S_TT, S_MEAN, S_TMP, S_N };
+enum { S_RHO = 0, S_RHO_OLD, S_PAP, S_ALPHA, S_BETA, S_OMEGA, S_RR, S_BB, S_TS, S_TT, S_MEAN, S_FLAG, S_RV, S_N };
+// S_FLAG: breakdown events of the current chunk of iterations (bit set, stored as a double): a vanishing denominator never
+// reaches a division -- the quotient is replaced by 0 and the event is recorded, so a breakdown surfaces as a flag the host
+// acts on (converged / restart / error with the scalars in the message), not as a NaN that has already overwritten x.
+enum { F_RHO_ZERO = 1, F_RV_ZERO = 2, F_OMEGA_ZERO = 4, F_PAP_ZERO = 8 };
 
 // y = A * (x .* dinv?), or (dinv == NULL, b != NULL) the residual y = b - A x : 16 lanes per row
 template <bool SCALED>
@@ -76,22 +83,42 @@ __global__ void diag_inv_kernel(int n, const int* __restrict__ rowptr, const int
 }
 
 // second-stage scalar algebra of the algorithm step `op`
-enum { OP_STORE3 = 0, OP_CG_INIT, OP_CG_PAP, OP_CG_RHO, OP_BI_RHO, OP_BI_ALPHA, OP_BI_OMEGA, OP_MEAN };
+enum { OP_STORE3 = 0, OP_CG_INIT, OP_CG_PAP, OP_CG_RHO, OP_BI_RHO, OP_BI_ALPHA, OP_BI_OMEGA, OP_MEAN, OP_START };
+
+__device__ __forceinline__ void raise_flag(double* __restrict__ sc, int bit) { sc[S_FLAG] = (double)((int)sc[S_FLAG] | bit); }
 
 __device__ __forceinline__ void apply_dot_op(double* __restrict__ sc, int op, int nd, double v0, double v1, double v2, int d0,
                                              int d1, int d2, double scale) {
   switch (op) {
     case OP_STORE3: sc[d0] = v0; if (nd > 1) sc[d1] = v1; if (nd > 2) sc[d2] = v2; break;
     case OP_MEAN: sc[S_MEAN] = v0 * scale; break;
+    case OP_START: sc[S_RR] = v0; sc[S_BB] = v1; sc[S_FLAG] = 0.0; break;                        // r.r, b.b of a new solve
     case OP_CG_INIT: sc[S_RHO] = v0; sc[S_RR] = v1; if (nd > 2) sc[S_BB] = v2; break;          // r.z, r.r[, b.b]
-    case OP_CG_PAP: sc[S_PAP] = v0; sc[S_ALPHA] = sc[S_RHO] / v0; break;                     // p.Ap
-    case OP_CG_RHO: sc[S_BETA] = v0 / sc[S_RHO]; sc[S_RHO] = v0; sc[S_RR] = v1; break;       // r.z, r.r
+    case OP_CG_PAP:                                                                          // p.Ap
+      sc[S_PAP] = v0;
+      if (v0 != 0.0) sc[S_ALPHA] = sc[S_RHO] / v0;
+      else { sc[S_ALPHA] = 0.0; raise_flag(sc, F_PAP_ZERO); }                                // p = 0: nothing left to correct
+      break;
+    case OP_CG_RHO:                                                                          // r.z, r.r
+      sc[S_BETA] = sc[S_RHO] != 0.0 ? v0 / sc[S_RHO] : 0.0;
+      sc[S_RHO] = v0; sc[S_RR] = v1;
+      break;
     case OP_BI_RHO:                                                                          // rhat.r
-      sc[S_BETA] = (v0 / sc[S_RHO]) * (sc[S_ALPHA] / sc[S_OMEGA]);
+      // rho_(i-1) = 0 or omega_(i-1) = 0 with a residual left is BiCGStab's breakdown: beta = 0 restarts the recurrence
+      // from p = r (the host re-bases rhat as well when it sees the flag)
+      if (sc[S_RHO] != 0.0 && sc[S_OMEGA] != 0.0) sc[S_BETA] = (v0 / sc[S_RHO]) * (sc[S_ALPHA] / sc[S_OMEGA]);
+      else { sc[S_BETA] = 0.0; raise_flag(sc, sc[S_RHO] != 0.0 ? F_OMEGA_ZERO : F_RHO_ZERO); }
       sc[S_RHO] = v0;
       break;
-    case OP_BI_ALPHA: sc[S_ALPHA] = sc[S_RHO] / v0; break;                                   // rhat.v
-    case OP_BI_OMEGA: sc[S_OMEGA] = v1 != 0.0 ? v0 / v1 : 0.0; break;                        // t.s, t.t
+    case OP_BI_ALPHA:                                                                        // rhat.v
+      sc[S_RV] = v0;
+      if (v0 != 0.0) sc[S_ALPHA] = sc[S_RHO] / v0;
+      else { sc[S_ALPHA] = 0.0; raise_flag(sc, F_RV_ZERO); }
+      break;
+    case OP_BI_OMEGA:                                                                        // t.s, t.t
+      sc[S_TS] = v0; sc[S_TT] = v1;
+      sc[S_OMEGA] = v1 != 0.0 ? v0 / v1 : 0.0;      // t = 0 <=> s = 0: the half step x += alpha p was exact, r = s
+      break;
   }
 }
 
@@ -156,22 +183,6 @@ __global__ void dots_apply_kernel(double* __restrict__ sc, const double* __restr
   apply_dot_op(sc, op, nd, red[0], nd > 1 ? red[1] : 0.0, nd > 2 ? red[2] : 0.0, d0, d1, d2, scale);
 }
 
-#if 0
-  switch (op) {
-    case OP_STORE3: sc[d0] = v0; if (nd > 1) sc[d1] = v1; if (nd > 2) sc[d2] = v2; break;
-    case OP_MEAN: sc[S_MEAN] = v0 * scale; break;
-    case OP_CG_INIT: sc[S_RHO] = v0; sc[S_RR] = v1; if (nd > 2) sc[S_BB] = v2; break;          // r.z, r.r[, b.b]
-    case OP_CG_PAP: sc[S_PAP] = v0; sc[S_ALPHA] = sc[S_RHO] / v0; break;                     // p.Ap
-    case OP_CG_RHO: sc[S_BETA] = v0 / sc[S_RHO]; sc[S_RHO] = v0; sc[S_RR] = v1; break;       // r.z, r.r
-    case OP_BI_RHO:                                                                          // rhat.r
-      sc[S_BETA] = (v0 / sc[S_RHO]) * (sc[S_ALPHA] / sc[S_OMEGA]);
-      sc[S_RHO] = v0;
-      break;
-    case OP_BI_ALPHA: sc[S_ALPHA] = sc[S_RHO] / v0; break;                                   // rhat.v
-    case OP_BI_OMEGA: sc[S_OMEGA] = v1 != 0.0 ? v0 / v1 : 0.0; break;                        // t.s, t.t
-  }
-}
-#endif
 
 enum { V_RESID = 0, V_SHIFT, V_CG_XR, V_CG_P, V_JACOBI, V_BI_P, V_BI_S, V_COPY, V_COPY_SHIFT };
 
@@ -387,6 +398,32 @@ inline uint64_t graph_key(const knpemi_handle* h, const KnAmg& G, bool amg, int 
   return k | 1u;
 }
 
+// the solver's scalars for an error message
+std::string describe_scalars(const double* sc, int it) {
+  char buf[320];
+  snprintf(buf, sizeof buf,
+           "[iteration %d: |r|^2 = %.6e, |b|^2 = %.6e, rho = %.6e, alpha = %.6e, beta = %.6e, omega = %.6e, rhat.v = %.6e, "
+           "t.s = %.6e, t.t = %.6e, p.Ap = %.6e, breakdown flags = %d]",
+           it, sc[S_RR], sc[S_BB], sc[S_RHO], sc[S_ALPHA], sc[S_BETA], sc[S_OMEGA], sc[S_RV], sc[S_TS], sc[S_TT], sc[S_PAP],
+           (int)sc[S_FLAG]);
+  return buf;
+}
+
+// A solve that starts from non-finite data is an input error, not a breakdown: say which operand it is before the first
+// iteration has overwritten the iterate (|b| from the right-hand side alone; |r0| = |b - A x0| brings in the matrix and
+// the initial guess).
+int check_start(const char* who, const double* sc) {
+  if (!std::isfinite(sc[S_BB])) {
+    kn_set_error(std::string(who) + ": the right-hand side contains non-finite values");
+    return KNPEMI_EINVAL;
+  }
+  if (!std::isfinite(sc[S_RR])) {
+    kn_set_error(std::string(who) + ": the initial residual b - A x0 is not finite (matrix values or initial guess)");
+    return KNPEMI_EINVAL;
+  }
+  return KNPEMI_OK;
+}
+
 }  // namespace
 
 // Workspace: 10 vectors of the larger system + ones + scalars + partials (allocated on first use).
@@ -556,10 +593,11 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   };
   const int chunk = amg ? 1 : 8;   // a V-cycle costs ~15 launches: test convergence after every iteration
   spmv(c, x, r, nullptr, b, dist.on ? nullptr : dinv);         // r = b - A x
-  dots(c, 2, r, r, b, b, nullptr, nullptr, OP_STORE3, S_RR, S_BB);
+  dots(c, 2, r, r, b, b, nullptr, nullptr, OP_START);
   double sc[S_N];
   if ((rc = read_scalars(c, sc, S_N))) return rc;
   const double bnorm = std::sqrt(sc[S_BB]);
+  if ((rc = check_start("EMI CG", sc))) return rc;
   const double target = std::max(atol, rtol * (bnorm > 0 ? bnorm : 1.0));
   int it = 0;
   double rn = std::sqrt(sc[S_RR]);
@@ -586,7 +624,7 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     if ((rc = read_scalars(c, sc, S_N))) return rc;
     rn = std::sqrt(sc[S_RR]);
     if (debug_krylov()) fprintf(stderr, "[knpemi] emi cg it %d |r| %.3e target %.3e alpha %.3e beta %.3e\n", it, rn, target, sc[S_ALPHA], sc[S_BETA]);
-    if (!(rn == rn)) { kn_set_error("EMI CG broke down (NaN residual)"); return KNPEMI_EINVAL; }
+    if (!std::isfinite(rn)) { kn_set_error("EMI CG broke down (non-finite residual) " + describe_scalars(sc, it)); return KNPEMI_ESOLVE; }
   }
   // solution orthogonal to constants, then into the phi component of the vertex records (ghosts included: they
   // take their owners' values first)
@@ -633,9 +671,14 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   // x0 = previous concentrations in the block order [c[0][0], c[0][1], c[1][0], ...]
   if (h->plain_knp) vec(c, V_COPY, x, nullptr, D.csol, nullptr);
   else hipLaunchKernelGGL(knp_order_kernel, grid1(n), dim3(256), 0, h->stream, D.Ntot, KS, h->n_sub, h->d_consts, x, D.csol, 1);
-  if (dist.on) hipLaunchKernelGGL(diag_inv_kernel, grid1(n), dim3(256), 0, h->stream, n, c.rowptr, c.colind, c.vals, dinv);
   KnAmg& G = h->amg_knp;
   const bool amg = h->pc_knp == KNPEMI_PC_AMG;
+  if (dist.on) {
+    hipLaunchKernelGGL(diag_inv_kernel, grid1(n), dim3(256), 0, h->stream, n, c.rowptr, c.colind, c.vals, dinv);
+    // Jacobi: the scaled SpMV A (dinv .* p) reads dinv on ghost columns, where the identity rows above left 1: take the
+    // owners' 1 / a_ii instead, so that the recurrence residual stays b - A x (x is updated with the owners' dinv)
+    if (!amg) if (int e = dist.halo(dist.ctx, dinv, KNPEMI_B_KNP)) c.comm_rc = c.comm_rc ? c.comm_rc : e;
+  }
   if (amg && (!G.built || G.n != n)) {
     G.negative_strength = true;
     if ((rc = kn_amg_setup(h, G, n, D.krowptr, D.kcolind, D.A_knp, false,
@@ -647,13 +690,14 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   spmv(c, x, r, nullptr, D.b_knp, dist.on ? nullptr : dinv);   // r = b - A x
   vec(c, V_COPY, rhat, nullptr, r, nullptr);
   hipLaunchKernelGGL(bicg_init_kernel, grid1(std::max(n, (int)S_N)), dim3(256), 0, h->stream, n, p, v, c.sc);
-  dots(c, 2, r, r, D.b_knp, D.b_knp, nullptr, nullptr, OP_STORE3, S_RR, S_BB);
+  dots(c, 2, r, r, D.b_knp, D.b_knp, nullptr, nullptr, OP_START);
   double sc[S_N];
   if ((rc = read_scalars(c, sc, S_N))) return rc;
+  if ((rc = check_start("KNP BiCGStab", sc))) return rc;
   const double bnorm = std::sqrt(sc[S_BB]);
   const double target = std::max(atol, rtol * (bnorm > 0 ? bnorm : 1.0));
   double rn = std::sqrt(sc[S_RR]);
-  int it = 0;
+  int it = 0, restarts = 0;
   const int chunk = amg ? 1 : 4;
   auto iteration = [&]() -> int {
     int rc = KNPEMI_OK;
@@ -687,7 +731,21 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     it += todo;
     if ((rc = read_scalars(c, sc, S_N))) return rc;
     rn = std::sqrt(sc[S_RR]);
-    if (!(rn == rn)) { kn_set_error("KNP BiCGStab broke down (NaN residual)"); return KNPEMI_EINVAL; }
+    if (!std::isfinite(rn)) {
+      kn_set_error("KNP BiCGStab broke down (non-finite residual) " + describe_scalars(sc, it));
+      return KNPEMI_ESOLVE;
+    }
+    const int flag = (int)sc[S_FLAG];
+    if ((flag & (F_RHO_ZERO | F_OMEGA_ZERO | F_RV_ZERO)) && rn > target) {
+      // a true breakdown (rhat has become orthogonal to the recurrence, or the stabilising step vanished) with a
+      // residual left: restart from the current iterate with rhat = r, as PETSc's KSPBCGS does
+      if (++restarts > 3) {
+        kn_set_error("KNP BiCGStab broke down repeatedly " + describe_scalars(sc, it));
+        return KNPEMI_ESOLVE;
+      }
+      vec(c, V_COPY, rhat, nullptr, r, nullptr);
+      hipLaunchKernelGGL(bicg_init_kernel, grid1(std::max(n, (int)S_N)), dim3(256), 0, h->stream, n, p, v, c.sc);
+    }
   }
   if (dist.on) if (int e = dist.halo(dist.ctx, x, KNPEMI_B_KNP)) c.comm_rc = c.comm_rc ? c.comm_rc : e;
   if (c.comm_rc) { kn_set_error("KNP solve: a communication hook failed"); return KNPEMI_EHIP; }

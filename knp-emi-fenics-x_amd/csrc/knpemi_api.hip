@@ -1161,6 +1161,36 @@ extern "C" int knpemi_get_csr_values(knpemi_handle* h, int which, double* vals) 
   return KNPEMI_OK;
 }
 
+// Values of an operator / right-hand side supplied by the caller (host arrays in the layout knpemi_get_csr_values /
+// knpemi_get_rhs return): the counterpart of PETSc's MatSetValues / VecSetValues for a caller that brings its own system
+// to the device solves of this library, and what the solver tests use to put the Krylov loops on prescribed systems.
+extern "C" int knpemi_set_csr_values(knpemi_handle* h, int which, const double* vals) {
+  if (!h || !vals) return fail(KNPEMI_EINVAL, "knpemi_set_csr_values: null argument");
+  double* dst; size_t n;
+  if (which == KNPEMI_A_EMI) { dst = h->dev.A_emi; n = h->dev.nnz; }
+  else if (which == KNPEMI_P_EMI) { dst = h->dev.P_emi; n = h->dev.nnz; }
+  else if (which == KNPEMI_A_KNP) { dst = h->dev.A_knp; n = (size_t)(h->K - 1) * h->dev.nnzL; }
+  else return fail(KNPEMI_EINVAL, "knpemi_set_csr_values: unknown matrix");
+  KN_HIP(hipSetDevice(h->device));
+  KN_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));   // an assembly on the auxiliary stream writes the same array
+  KN_HIP(hipMemcpyAsync(dst, vals, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_set_rhs(knpemi_handle* h, int which, const double* b) {
+  if (!h || !b) return fail(KNPEMI_EINVAL, "knpemi_set_rhs: null argument");
+  double* dst; size_t n;
+  if (which == KNPEMI_B_EMI) { dst = h->dev.b_emi; n = h->dev.Ntot; }
+  else if (which == KNPEMI_B_KNP) { dst = h->dev.b_knp; n = (size_t)(h->K - 1) * h->dev.Ntot; }
+  else return fail(KNPEMI_EINVAL, "knpemi_set_rhs: unknown vector");
+  KN_HIP(hipSetDevice(h->device));
+  KN_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  KN_HIP(hipMemcpyAsync(dst, b, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  return KNPEMI_OK;
+}
+
 extern "C" int knpemi_device_rhs(knpemi_handle* h, int which, const double** b) {
   if (!h || !b) return fail(KNPEMI_EINVAL, "null argument");
   if (which == KNPEMI_B_EMI) *b = h->dev.b_emi;

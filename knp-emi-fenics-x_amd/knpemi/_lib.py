@@ -112,6 +112,8 @@ SIGNATURES = {
     "knpemi_get_csr_pattern": (C.c_int, [C.c_void_p, C.c_int, c_int_p, c_int_p]),
     "knpemi_get_csr_values": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p]),
     "knpemi_get_rhs": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p]),
+    "knpemi_set_csr_values": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p]),
+    "knpemi_set_rhs": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p]),
     "knpemi_device_csr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                     C.POINTER(C.c_void_p)]),
     "knpemi_device_rhs": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),

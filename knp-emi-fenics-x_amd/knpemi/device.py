@@ -273,6 +273,17 @@ class DeviceProblem:
         L.check(self.lib.knpemi_get_rhs(self.h, which, L.dptr(b)))
         return b
 
+    def set_csr_values(self, which, vals):
+        """Caller-supplied operator values in the layout `csr(which).data` has (knpemi_set_csr_values)."""
+        vals = np.ascontiguousarray(vals, np.float64)
+        assert vals.size == self._pattern(which)[1]
+        L.check(self.lib.knpemi_set_csr_values(self.h, which, L.dptr(vals)))
+
+    def set_rhs(self, which, b):
+        b = np.ascontiguousarray(b, np.float64)
+        assert b.size == self._pattern(L.A_EMI if which == L.B_EMI else L.A_KNP)[0]
+        L.check(self.lib.knpemi_set_rhs(self.h, which, L.dptr(b)))
+
     def set_solution(self, which, x):
         x = np.ascontiguousarray(x, np.float64)
         L.check(self.lib.knpemi_set_solution(self.h, which, x.ctypes.data_as(C.c_void_p), 0))
