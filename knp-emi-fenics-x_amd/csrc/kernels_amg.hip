@@ -483,7 +483,10 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
       }
 
   const double theta = G.theta;
-  const int n_dense = 640, max_levels = 12;
+  // fused cycle: one level fewer is worth more than a cheaper coarsest solve (every level costs two launches per cycle)
+  const bool fused = G.want_fused && G.block == 0 && !h_owned && G.first_na == 0;
+  const int n_dense = fused ? 1024 : 640, max_levels = 12;
+  G.fused_ok = false;
   int rc;
   G.singular = singular;
   size_t work = 0;
@@ -554,6 +557,22 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
     L.r_row = std::max(1, (int)(R.ci.size() / (size_t)R.n));
     if ((rc = upload_csr(G, P, L.P, st))) return rc;
     if ((rc = upload_csr(G, R, L.R, st))) return rc;
+    if (fused) {
+      // V(1,1) from a zero guess is  x = w D^-1 (r + t) + Pm e_c,  t = (I - w A D^-1) r,  e_c = cycle(Rm r)  with the
+      // smoother folded into the transfer operators: restriction and residual, prolongation and post-smoothing become
+      // one SpMV each (kernels_fused.hip)
+      HostCsr Sl = cur, Sr = cur;     // I - w D^-1 A (rows scaled), I - w A D^-1 (columns scaled)
+      for (int i = 0; i < cur.n; ++i)
+        for (int j = cur.rp[i]; j < cur.rp[i + 1]; ++j) {
+          const int c = cur.ci[j];
+          Sl.v[j] = (c == i ? 1.0 : 0.0) - L.omega * cur.v[j] / d[i];
+          Sr.v[j] = (c == i ? 1.0 : 0.0) - L.omega * cur.v[j] / d[c];
+        }
+      const HostCsr Pm = spgemm(Sl, P), Rm = spgemm(R, Sr);
+      if ((rc = upload_csr(G, Pm, L.Pm, st))) return rc;
+      if ((rc = upload_csr(G, Rm, L.Rm, st))) return rc;
+      if (l == 0 && (rc = upload(G, cur.v, &L.frozen_v, st))) return rc;
+    }
     G.lev.push_back(L);
     work += 3 * (size_t)cur.n;
     cur = spgemm(R, spgemm(cur, P));
@@ -570,6 +589,7 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
   size_t tot = 0;
   for (auto& L : G.lev) tot += L.A.nnz;
   G.op_complexity = G.lev[0].A.nnz ? (double)tot / G.lev[0].A.nnz : 1.0;
+  G.fused_ok = fused && G.lev.size() >= 2 && G.lev.back().dense_inv != nullptr;
   return KNPEMI_OK;
 }
 

@@ -384,6 +384,12 @@ int run_chunk(knpemi_handle* h, knpemi_handle::KnGraph& g, uint64_t key, int chu
   return KNPEMI_OK;
 }
 
+// KNPEMI_NO_FUSED=1: the plain loops (one launch per operation) instead of kernels_fused.hip
+inline bool use_fused() {
+  static const bool off = getenv("KNPEMI_NO_FUSED") != nullptr;
+  return !off;
+}
+
 inline bool debug_krylov() {
   static const bool on = getenv("KNPEMI_DEBUG_KRYLOV") != nullptr;
   return on;
@@ -568,6 +574,7 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   const bool amg = h->pc_emi == KNPEMI_PC_AMG;
   if (amg && (!G.built || G.n != n)) {
     G.negative_strength = true;
+    G.want_fused = !dist.on && use_fused();
     // the diagonal block of a rank that has ghosts has lost couplings: it is non-singular
     if ((rc = kn_amg_setup(h, G, n, D.rowptr, D.colind, D.A_emi, !has_ghosts,
                            dist.on ? dist.h_owned_emi.data() : nullptr))) return rc;
@@ -592,16 +599,22 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     return KNPEMI_OK;
   };
   const int chunk = amg ? 1 : 8;   // a V-cycle costs ~15 launches: test convergence after every iteration
-  spmv(c, x, r, nullptr, b, dist.on ? nullptr : dinv);         // r = b - A x
-  dots(c, 2, r, r, b, b, nullptr, nullptr, OP_START);
   double sc[S_N];
-  if ((rc = read_scalars(c, sc, S_N))) return rc;
-  const double bnorm = std::sqrt(sc[S_BB]);
-  if ((rc = check_start("EMI CG", sc))) return rc;
-  const double target = std::max(atol, rtol * (bnorm > 0 ? bnorm : 1.0));
+  const bool fused = amg && G.fused_ok && !dist.on && use_fused();
   int it = 0;
+  if (fused) {   // residual, target and the loop in 2 + (2 levels - 1) launches per iteration (kernels_fused.hip)
+    const KnFusedSys S{n, c.rowptr, c.colind, c.vals, c.sc, h->kry, N};
+    if ((rc = kn_fused_cg(h, G, S, b, rtol, atol, maxit, &it, &sc[S_RR], &sc[S_BB]))) return rc;
+  } else {
+    spmv(c, x, r, nullptr, b, dist.on ? nullptr : dinv);         // r = b - A x
+    dots(c, 2, r, r, b, b, nullptr, nullptr, OP_START);
+    if ((rc = read_scalars(c, sc, S_N))) return rc;
+    if ((rc = check_start("EMI CG", sc))) return rc;
+  }
+  const double bnorm = std::sqrt(sc[S_BB]);
+  const double target = std::max(atol, rtol * (bnorm > 0 ? bnorm : 1.0));
   double rn = std::sqrt(sc[S_RR]);
-  if (rn > target) {   // the (extrapolated) initial guess is not good enough: first search direction
+  if (!fused && rn > target) {   // the (extrapolated) initial guess is not good enough: first search direction
     if ((rc = precond())) return rc;
     vec(c, V_COPY, p, nullptr, z, nullptr);
     dots(c, 2, r, z, r, r, nullptr, nullptr, OP_CG_INIT);      // r.z, r.r
@@ -616,7 +629,7 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     return KNPEMI_OK;
   };
   const uint64_t gkey = graph_key(h, G, amg, chunk, n);
-  while (rn > target && it < maxit) {
+  while (!fused && rn > target && it < maxit) {
     const int todo = std::min(chunk, maxit - it);
     if (todo == chunk) { if ((rc = run_chunk(h, h->graph_emi, gkey, chunk, iteration))) return rc; }
     else for (int k = 0; k < todo; ++k) if ((rc = iteration())) return rc;
@@ -681,23 +694,30 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   }
   if (amg && (!G.built || G.n != n)) {
     G.negative_strength = true;
+    G.want_fused = !dist.on && use_fused();
     if ((rc = kn_amg_setup(h, G, n, D.krowptr, D.kcolind, D.A_knp, false,
                            dist.on ? dist.h_owned_knp.data() : nullptr))) return rc;
     G.its_ref = -1;
     ++G.builds;
   }
   if (amg && (rc = kn_amg_refresh(h, G, D.A_knp))) return rc;
-  spmv(c, x, r, nullptr, D.b_knp, dist.on ? nullptr : dinv);   // r = b - A x
-  vec(c, V_COPY, rhat, nullptr, r, nullptr);
-  hipLaunchKernelGGL(bicg_init_kernel, grid1(std::max(n, (int)S_N)), dim3(256), 0, h->stream, n, p, v, c.sc);
-  dots(c, 2, r, r, D.b_knp, D.b_knp, nullptr, nullptr, OP_START);
   double sc[S_N];
-  if ((rc = read_scalars(c, sc, S_N))) return rc;
-  if ((rc = check_start("KNP BiCGStab", sc))) return rc;
+  const bool fused = amg && G.fused_ok && !dist.on && use_fused();
+  int it = 0, restarts = 0;
+  if (fused) {   // residual, target and 3 + 2 cycles launches per iteration (kernels_fused.hip)
+    const KnFusedSys S{n, c.rowptr, c.colind, c.vals, c.sc, h->kry, N};
+    if ((rc = kn_fused_bicgstab(h, G, S, D.b_knp, rtol, atol, maxit, &it, &sc[S_RR], &sc[S_BB]))) return rc;
+  } else {
+    spmv(c, x, r, nullptr, D.b_knp, dist.on ? nullptr : dinv);   // r = b - A x
+    vec(c, V_COPY, rhat, nullptr, r, nullptr);
+    hipLaunchKernelGGL(bicg_init_kernel, grid1(std::max(n, (int)S_N)), dim3(256), 0, h->stream, n, p, v, c.sc);
+    dots(c, 2, r, r, D.b_knp, D.b_knp, nullptr, nullptr, OP_START);
+    if ((rc = read_scalars(c, sc, S_N))) return rc;
+    if ((rc = check_start("KNP BiCGStab", sc))) return rc;
+  }
   const double bnorm = std::sqrt(sc[S_BB]);
   const double target = std::max(atol, rtol * (bnorm > 0 ? bnorm : 1.0));
   double rn = std::sqrt(sc[S_RR]);
-  int it = 0, restarts = 0;
   const int chunk = amg ? 1 : 4;
   auto iteration = [&]() -> int {
     int rc = KNPEMI_OK;
@@ -724,7 +744,7 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     return rc;
   };
   const uint64_t gkey = graph_key(h, G, amg, chunk, n);
-  while (rn > target && it < maxit) {
+  while (!fused && rn > target && it < maxit) {
     const int todo = std::min(chunk, maxit - it);
     if (todo == chunk) { if ((rc = run_chunk(h, h->graph_knp, gkey, chunk, iteration))) return rc; }
     else for (int k = 0; k < todo; ++k) if ((rc = iteration())) return rc;

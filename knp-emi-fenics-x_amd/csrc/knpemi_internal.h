@@ -130,6 +130,11 @@ struct KnAmgLevel {
   int avg_row = 0, p_row = 0, r_row = 0;
   double omega = 0.0;                // Jacobi damping 4 / (3 rho)
   KnAmgCsr A, P, R;
+  // merged transfer operators of the fused cycle (kernels_fused.hip): Rm = R (I - omega A D^-1), Pm = (I - omega D^-1 A) P,
+  // built from the operator the hierarchy was set up with; frozen_v: that operator's values on the finest level (the
+  // coarser levels' A.v are frozen copies already)
+  KnAmgCsr Rm, Pm;
+  double* frozen_v = nullptr;
   double* dinv = nullptr;
   double* dense_inv = nullptr;       // [n][n] explicit inverse on the coarsest level
   double *x = nullptr, *r = nullptr, *t = nullptr;
@@ -142,7 +147,10 @@ struct KnAmg {
   int n = 0;
   double theta = 0.08;               // strength threshold
   double op_complexity = 1.0;
+  bool want_fused = false;           // also build the merged operators of the fused cycle (single rank, point smoother)
+  bool fused_ok = false;             // ... and they exist: every level but the last has Rm / Pm, the last one a dense inverse
   int its_ref = -1;                  // iterations of the first solve after the build (rebuild trigger)
+  int its_last = 4;                  // iterations of the last fused solve: size of the next solve's first chunk
   int builds = 0;
   // Optional aggregates of the finest level (auxiliary-space variant, DG systems: the broken dofs of a (sub-domain,
   // mesh vertex) form one aggregate, so the first coarse level is the continuous P1 space of the sub-domains and the
@@ -162,6 +170,16 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
 int kn_amg_apply(knpemi_handle* h, KnAmg& G, const double* vals, const double* dinv0, const double* r, double* scratch,
                  double* out);
 int kn_amg_refresh(knpemi_handle* h, KnAmg& G, const double* vals);   // block inverses of the current finest operator
+// fused solver loops (kernels_fused.hip): the iteration of kn_solve_emi / kn_solve_knp in 6 / 13 launches
+struct KnFusedSys {
+  int n; const int* rowptr; const int* colind; const double* vals;   // the system of the current time step
+  double* sc; double* work;   // the solver's device scalars and vector workspace (kernels_krylov.hip layout)
+  size_t N;                   // stride of the workspace vectors
+};
+int kn_fused_cg(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const double* b, double rtol, double atol, int maxit,
+                int* iters, double* rr, double* bb);
+int kn_fused_bicgstab(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const double* b, double rtol, double atol, int maxit,
+                      int* iters, double* rr, double* bb);
 
 // Distributed solves (knpemi_set_distributed)
 struct KnDist {
@@ -232,6 +250,7 @@ struct knpemi_handle {
   double* kry = nullptr; size_t kry_n = 0;           // Krylov workspace (kernels_krylov.hip)
   int kry_ones_masked = 0;                           // the workspace's `ones` vector currently holds the ownership mask
   void* kry_pinned = nullptr;                        // pinned host buffer the solvers' scalars are read through
+  double* fused_part = nullptr; size_t fused_part_n = 0;   // block partials of the dot products fused into the solver kernels
   double* guess_old[2] = {nullptr, nullptr};         // previous solutions (EMI, KNP) for knpemi_extrapolate_guess
   bool guess_have[2] = {false, false};
   KnAmg amg_emi, amg_knp;
