@@ -234,7 +234,7 @@ def cpu_baseline(s, n_steps, threads=1, traj=None, start=0):
 
 def device_solvers(case, its, maxit=1000):
     """Solve callbacks of the stepper: knpemi_solve_emi (CG + AMG) / knpemi_solve_knp (BiCGStab + AMG) at the
-    reference's tolerances, starting from 2 x_n - x_(n-1)."""
+    reference's tolerances, starting from the extrapolated previous solutions."""
     from knpemi import _lib as L
     rtol_emi, rtol_knp = case.solver_rtol
 
@@ -363,7 +363,7 @@ def with_solves(case, replay, start, n_steps, torch):
     info = {k: dp.solver_info(w) for k, w in (("emi", L.B_EMI), ("knp", L.B_KNP))}
     re, rk = case.solver_rtol
     return {"ms_per_step": ms, "steps": n_steps, "trajectory_steps": [start + 2, start + 2 + n_steps],
-            "initial_guess": "2 x_n - x_(n-1) (knpemi_extrapolate_guess)",
+            "initial_guess": "3 x_n - 3 x_(n-1) + x_(n-2) (knpemi_extrapolate_guess)",
             "emi": {"solver": f"CG + SA-AMG V(1,1), rtol {re:g}", "iterations_avg": sum(its["emi"]) / n_steps,
                     "iterations_max": max(its["emi"]), **info["emi"]},
             "knp": {"solver": f"BiCGStab + SA-AMG V(1,1), rtol {rk:g}", "iterations_avg": sum(its["knp"]) / n_steps,

@@ -113,11 +113,14 @@ typedef struct {
 
 /* Physical parameters: the `physical_params` / `ion_list` dictionaries (run_3D.py:180-256). */
 typedef struct {
-  double dt, F, psi, C_M;                               /* C_phi = C_M / dt (run_3D.py:189) */
+  double dt, F, psi, C_M;
   double z[KNPEMI_MAX_IONS];                            /* ion['z'] */
   double D[KNPEMI_MAX_SUB][KNPEMI_MAX_IONS];            /* ion['D'][tag] */
   double rho_z;                                         /* rho['z'] (utils.py:249) */
   double rho[KNPEMI_MAX_SUB];                           /* rho[tag] */
+  double C_phi;                                         /* physical_parameters['C_phi'], its own entry in the reference
+                                                           (run_2D.py:187,208; emiWeakForm.py:164,231-236): the membrane
+                                                           coupling and Robin datum of the EMI forms.  <= 0: C_M / dt */
 } knpemi_params;
 
 const char* knpemi_last_error(void);
@@ -184,8 +187,9 @@ enum { KNPEMI_PC_JACOBI = 0, KNPEMI_PC_AMG = 1 };
 int knpemi_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* iters, double* relres);
 int knpemi_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* iters, double* relres);
 /* Replace the initial guess of the next solve of `which` (the current phi / c, i.e. the previous solution:
- * ksp_initial_guess_nonzero, pdeSolver.py:26,101) by the linear extrapolation 2 x_n - x_(n-1) of the last two
- * solutions; the first call only records x_n.  Call once per time step, before the solve. */
+ * ksp_initial_guess_nonzero, pdeSolver.py:26,101) by the extrapolation of the last solutions: 3 x_n - 3 x_(n-1) + x_(n-2)
+ * once three are known, 2 x_n - x_(n-1) after two; the first call only records x_n.  Call once per time step, before
+ * the solve. */
 int knpemi_extrapolate_guess(knpemi_handle* h, int which);
 /* Preconditioner of the device solve of system `which` (KNPEMI_B_EMI / KNPEMI_B_KNP): the counterpart of
  * pc_type / pc_hypre_type in pdeSolver.py:27-34,102-109.  KNPEMI_PC_AMG: smoothed-aggregation V(1,1) cycle,

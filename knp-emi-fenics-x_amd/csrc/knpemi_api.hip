@@ -834,7 +834,7 @@ extern "C" int knpemi_set_params(knpemi_handle* h, const knpemi_params* p) {
     return fail(KNPEMI_EINVAL, "knpemi_set_params: dt, C_M must be positive and z_K non-zero");
   KnConsts& C = h->consts;
   C.dt = p->dt; C.inv_dt = 1.0 / p->dt; C.F = p->F; C.psi = p->psi; C.C_M = p->C_M;
-  C.C_phi = p->C_M / p->dt;
+  C.C_phi = p->C_phi > 0.0 ? p->C_phi : p->C_M / p->dt;
   const int K = h->K;
   for (int k = 0; k < K; ++k) {
     C.z[k] = p->z[k];

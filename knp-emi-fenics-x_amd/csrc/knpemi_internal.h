@@ -252,7 +252,7 @@ struct knpemi_handle {
   void* kry_pinned = nullptr;                        // pinned host buffer the solvers' scalars are read through
   double* fused_part = nullptr; size_t fused_part_n = 0;   // block partials of the dot products fused into the solver kernels
   double* guess_old[2] = {nullptr, nullptr};         // previous solutions (EMI, KNP) for knpemi_extrapolate_guess
-  bool guess_have[2] = {false, false};
+  int guess_have[2] = {0, 0};                        // previous solutions stored so far (0, 1, 2)
   KnAmg amg_emi, amg_knp;
   // captured iteration bodies of the Krylov loops (kernels_krylov.hip); key = configuration they were captured for
   struct KnGraph { hipGraphExec_t exec = nullptr; uint64_t key = 0; };

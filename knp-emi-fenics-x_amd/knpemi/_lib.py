@@ -53,6 +53,7 @@ class Params(C.Structure):
         ("D", (C.c_double * MAX_IONS) * MAX_SUB),
         ("rho_z", C.c_double),
         ("rho", C.c_double * MAX_SUB),
+        ("C_phi", C.c_double),
     ]
 
 

@@ -165,17 +165,19 @@ class DeviceProblem:
         dt = as_float(dt)
         F, psi = as_float(physical_params["F"]), as_float(physical_params["psi"])
         C_M = as_float(physical_params["C_M"])
-        C_phi = as_float(physical_params["C_phi"])
-        if abs(C_phi - C_M / dt) > 1e-12 * abs(C_phi):
-            raise NotImplementedError("C_phi must equal C_M / dt (run_3D.py:189)")
+        # its own entry of the parameter dictionary in the reference (run_2D.py:187,208): the EMI forms read C_phi, the KNP
+        # forms C_M / dt (emiWeakForm.py:164,231-236; knpWeakForm.py:181-182)
+        C_phi = as_float(physical_params["C_phi"]) if "C_phi" in physical_params else C_M / dt
+        if not C_phi > 0.0:
+            raise ValueError("C_phi must be positive")
         rho = physical_params.get("rho", {})
-        key = (dt, F, psi, C_M, tuple(ion["z"] for ion in ion_list),
+        key = (dt, F, psi, C_M, C_phi, tuple(ion["z"] for ion in ion_list),
                tuple(as_float(ion["D"][t]) for ion in ion_list for t in self.tags),
                as_float(rho.get("z", 0.0)), tuple(as_float(rho.get(t, 0.0)) for t in self.tags))
         if key == self._params_key:
             return
         p = L.Params()
-        p.dt, p.F, p.psi, p.C_M = dt, F, psi, C_M
+        p.dt, p.F, p.psi, p.C_M, p.C_phi = dt, F, psi, C_M, C_phi
         for k, ion in enumerate(ion_list):
             p.z[k] = float(ion["z"])
             for s, t in enumerate(self.tags):

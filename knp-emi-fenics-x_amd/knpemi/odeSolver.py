@@ -15,7 +15,9 @@ cannot call -- a plug-in here either names one of the right-hand sides compiled
 into the library (`MODEL_ID` = "hh_si", "hh_mv" or "glial") or brings its own
 as HIP source in `RHS_HIP`: a `__device__ void rhs(double t, const double*
 states, double* values, double* parameters)` with the cfunc's semantics, compiled
-for gfx950 with hipRTC when the model is bound (csrc/kernels_rtc.hip).
+for gfx950 with hipRTC when the model is bound (csrc/kernels_rtc.hip) -- or has
+only what the reference's modules have, a Python `rhs_numba` / `rhs` made of
+assignments: `knpemi.rhs_codegen` translates its source text into that function.
 """
 from __future__ import annotations
 
@@ -62,6 +64,11 @@ class MembraneModel:
             return
         model_id = getattr(self.ode, "MODEL_ID", None)
         source = getattr(self.ode, "RHS_HIP", None)
+        if model_id not in _MODEL_IDS and source is None:
+            # a module written for the reference: its Python right-hand side (rhs_numba / rhs, odeSolver.py:96 takes the
+            # cfunc's address) is plain arithmetic -- translate the source text into the device function
+            from .rhs_codegen import hip_source_from_module
+            source = hip_source_from_module(self.ode)
         if model_id in _MODEL_IDS:
             L.check(dp.lib.knpemi_ode_bind(dp.h, sub, model, _MODEL_IDS[model_id],
                                            self.states.shape[1], self.parameters.shape[1]))
@@ -72,8 +79,8 @@ class MembraneModel:
         else:
             raise NotImplementedError(
                 f"membrane model module '{self.prefix}' has neither a MODEL_ID naming a shipped device RHS "
-                f"(one of {sorted(_MODEL_IDS)}) nor its own RHS_HIP source; a numba / Python RHS is host code and "
-                f"cannot run on the GPU (see examples/benchmark/mm_glial.py for a plug-in with RHS_HIP)")
+                f"(one of {sorted(_MODEL_IDS)}), nor its own RHS_HIP source, nor a Python right-hand side (rhs_numba / "
+                f"rhs) whose source knpemi.rhs_codegen could translate (see examples/benchmark/mm_glial.py)")
         self._dp, self._sub, self._model = dp, sub, model
         idx = []
         for name in ion_names:

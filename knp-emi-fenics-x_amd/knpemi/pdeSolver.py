@@ -239,7 +239,11 @@ def create_solver_emi(a, L, phi, entity_maps, subdomain_list, comm,
 
 def create_solver_knp(a, L, c, entity_maps, subdomain_list, comm,
                       direct=True, p=None, bcs=None, atol=1E-40, rtol=1E-5, threshold=None):
-    """ KNP solver: direct (LU) or GMRES preconditioned with p = a (pdeSolver.py:83-141) """
+    """ KNP solver: direct (LU) or GMRES preconditioned with p = a (pdeSolver.py:83-141).
+
+    `bcs` is accepted and dropped, exactly as in the reference: its `create_solver_knp` takes the argument (:84) and passes
+    it to neither `LinearProblem` call (:119-139) -- the concentration systems are pure Neumann problems made regular by
+    the mass term.  (`create_solver_emi` does honour `bcs`, :56,66, and so does this module.) """
     u = [val for tag in subdomain_list for val in c[tag]]       # [c[0][0], c[0][1], c[1][0], ...] (:117)
     prefix = "knp_direct_" if direct else "knp_iterative_"
     return LinearProblem("knp", a, L, u, subdomain_list, direct, p, None, atol, rtol, threshold, prefix)

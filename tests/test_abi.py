@@ -30,7 +30,7 @@ def test_constants_match_header():
                  "TRIANGLE", "TETRAHEDRON", "HEXAHEDRON", "MODEL_HH_SI", "MODEL_HH_MV", "MODEL_GLIAL",
                  "EINVAL", "EHIP", "EODE", "MAX_IONS", "MAX_SUB", "K_ODE", "K_EMI_ROWS", "K_UPDATE"):
         assert int(consts[name]) == getattr(L, name), name
-    assert C.sizeof(L.Params) == 8 * (4 + L.MAX_IONS + 8 * L.MAX_IONS + 1 + 8)
+    assert C.sizeof(L.Params) == 8 * (4 + L.MAX_IONS + 8 * L.MAX_IONS + 1 + 8 + 1)      # ... + C_phi
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")

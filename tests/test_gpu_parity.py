@@ -38,6 +38,25 @@ def test_assembly_matches_oracle(hip_lib, kind, r, splitting):
     assert max(errs.values()) < TOL, errs
 
 
+@pytest.mark.parametrize("kind,r", [("2d", 1), ("tet", 0), ("hex", 0)])
+@pytest.mark.parametrize("splitting", [True, False])
+def test_c_phi_is_its_own_parameter(hip_lib, kind, r, splitting):
+    """`physical_parameters['C_phi']` is an entry of its own in the reference (run_2D.py:187,208) and only the EMI forms read
+    it (emiWeakForm.py:164,231-236): with C_phi != C_M / dt the EMI coupling and Robin datum follow C_phi, the KNP
+    membrane terms keep C_M / dt."""
+    from setup_problem import C_M, DT
+    from knpemi.fem import Constant
+    s = Setup(kind, r)
+    s.physical_parameters['C_phi'] = Constant(s.mesh, 2.5 * C_M / DT)
+    s.perturb()
+    errs, (A, _, b, _, _) = _assemble_both(s, splitting)
+    assert max(errs.values()) < TOL, errs
+    s0 = Setup(kind, r)
+    s0.perturb()
+    _, (A0, _, b0, _, _) = _assemble_both(s0, splitting)
+    assert abs(A - A0).max() > 0 and np.abs(b - b0).max() > 0      # it does change the system
+
+
 def _distorted_hex_mesh(seed=3):
     """The r = 0 hexahedral box with every vertex moved by up to 15 % of the smallest spacing: trilinear cells
     with a non-constant Jacobian and non-planar membrane quadrilaterals."""
