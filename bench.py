@@ -77,9 +77,12 @@ class Case:
                 # (cm), on from the first step for 1 ms
                 cfg.update(delay=0.0, pulse_width=1.0, period=10.0, end_time=100.0, x_L=15e-4, x_U=17e-4, y_L=-1.0,
                            y_U=0.2e-4, z_L=-1.0, z_U=0.2e-4)
-                if world > 1:
-                    raise SystemExit("config5s runs on one GPU (the slab partitioner builds the idealized set-up)")
-                s = rsd.Problem(cfg)
+                if world > 1:      # weak scaling: a box `world` times as long, cut into x-slabs of whole cell layers
+                    from knpemi.fem.distributed import make_partitioned_astro
+                    cfg["mesh"]["length"] = 2 * world if scaling == "weak" else 2
+                    s = make_partitioned_astro(cfg, rank, world, method="slab")
+                else:
+                    s = rsd.Problem(cfg)
                 s.set_source(0.0)
                 self.models = [(mm["ode"], s.stim_params["stimulus"], s.stim_params["stimulus_locator"])
                                for tag in (1, 2) for mm in s.subdomain_list[tag]["mem_models"]]

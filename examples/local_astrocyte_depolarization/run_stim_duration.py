@@ -97,9 +97,11 @@ def source_region(x, cfg):
 class Problem:
     """Everything `solve_system` builds before the time loop (run_stim_duration.py:150-440)."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, mesh_data=None):
+        """mesh_data: (mesh, ct, ft) of one rank of a cell partition (knpemi.fem.distributed.make_partitioned_astro), as
+        DOLFINx hands every MPI rank its part of the mesh the reference reads (run_stim_duration.py:127-134)."""
         self.cfg = cfg
-        self.mesh, self.ct, self.ft = mesh, ct, ft = read_mesh(cfg)
+        self.mesh, self.ct, self.ft = mesh, ct, ft = mesh_data if mesh_data is not None else read_mesh(cfg)
         ECS = {"name": "ECS", "tag": 0}
         neuron = {"name": "neuron", "tag": 1, "membrane_tags": [1], "ode_models": {1: load_model("hh_mv")}}
         glial = {"name": "glial", "tag": 2, "membrane_tags": [2], "ode_models": {2: load_model("glial")}}

@@ -309,7 +309,7 @@ class DGSlab:
             h.mode = "gloo host-staged"
         else:
             # first choice: the library's own RCCL communicator on the DG handle's stream (knpemi_dg_comm_*), voted on
-            native = os.environ.get("KNPEMI_HALO_TORCH") is None
+            native = os.environ.get("KNPEMI_HALO_TORCH") is None and os.environ.get("KNPEMI_HALO_SYNC") is None
             if native:
                 buf = C.create_string_buffer(128)
                 ok = dp.lib.knpemi_comm_unique_id(buf, 128) == 0 if dist.get_rank() == 0 else True

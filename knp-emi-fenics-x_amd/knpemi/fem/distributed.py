@@ -152,7 +152,8 @@ class Halo:
             # first choice: RCCL called by the library itself (knpemi_comm_*: pack -> ncclSend/ncclRecv group -> unpack
             # on the library's stream, a few microseconds of host time per exchange instead of ~50 through
             # torch.distributed's Python layer).  All ranks must agree, so every step of the set-up is voted on.
-            native = os.environ.get("KNPEMI_HALO_TORCH") is None and stream_ordered is not None
+            # KNPEMI_HALO_SYNC=1 asks for the host-synchronised exchange, which only the torch transport has
+            native = os.environ.get("KNPEMI_HALO_TORCH") is None and os.environ.get("KNPEMI_HALO_SYNC") is None
             if native:
                 native = self._native_comm_init(dp, dev)
             if native:
@@ -449,5 +450,33 @@ def make_partitioned_problem(kind, r, rank, world, g_syn=10.0, length=None, meth
     s.owned_dofs = s.halo.owned_dofs
     s.local = local
     s.global_length = l * 16e-6
+    s.global_mesh = (mesh, ct, ft)
+    return s
+
+
+def make_partitioned_astro(cfg, rank, world, method="rcb", gather=None):
+    """The rank-local set-up of the three-sub-domain driver (ECS + neuron with the HH model + glia with the Kir4.1 / pump
+    model, pulsed ECS source: `examples/local_astrocyte_depolarization/run_stim_duration.Problem`) on a cell partition
+    of its mesh -- what DOLFINx's MPI partition gives the reference when that driver runs under `mpirun`
+    (run_stim_duration.py:127-134,168-211).  Three sub-domain halos, two membrane models (their ghost dofs integrated
+    redundantly), the source term evaluated on the local ECS vertices."""
+    import run_stim_duration as rsd
+    mesh, ct, ft = rsd.read_mesh(cfg)
+    cent = mesh.x[mesh.cells].mean(axis=1)
+    part = rcb_partition(cent, world) if method == "rcb" else slab_partition(cent, world)
+    local = LocalPart(mesh, ct, ft, part, rank, world)
+    s = rsd.Problem(cfg, mesh_data=(local.mesh, local.ct, local.ft))
+    if gather is None:
+        import torch.distributed as dist
+
+        def gather(obj):
+            out = [None] * world
+            dist.all_gather_object(out, obj)
+            return out
+    s.halo = VertexHalo(local, s.subdomain_list)
+    s.halo.build(gather)
+    s.owned_dofs = s.halo.owned_dofs
+    s.local = local
+    s.global_length = float(mesh.x[:, 0].max())
     s.global_mesh = (mesh, ct, ft)
     return s

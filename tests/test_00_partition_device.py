@@ -72,6 +72,29 @@ def test_two_rank_time_steps_with_distributed_solves(kind, method):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("method,world,solves", [("rcb", 2, False), ("slab", 3, False), ("rcb", 2, True)])
+def test_three_subdomain_driver_on_a_cell_partition(method, world, solves):
+    """BASELINE configs[4]'s set-up on a partition: ECS + neuron (HH, mV / ms) + glia (Kir4.1 / pump), two membrane
+    models, the pulsed ECS source on -- the reference runs this driver under MPI on DOLFINx's cell partition
+    (/root/reference/examples/local_astrocyte_depolarization/run_stim_duration.py:127-134,168-211).  Without solves the
+    partitioned run reproduces the single-rank run bit for bit (three sub-domain halos, ghost membrane dofs of both
+    models integrated redundantly); with the distributed solves to solver tolerance."""
+    args = ["--family", "astro", "--kind", "tet", "--steps", "4", "--method", method] + (["--solves"] if solves else [])
+    rcs, outs = _run_ranks(args, world=world)
+    assert rcs == [0] * world, "\n".join(outs)
+    assert "PARTITION STEPS OK" in outs[0], outs[0]
+
+
+@pytest.mark.gpu
+def test_two_rank_solves_with_jacobi_preconditioning_match_single_rank():
+    """KNPEMI_PC_JACOBI on a partitioned problem: the scaled SpMV A (D^-1 p) needs the owners' 1 / a_ii on the ghost
+    columns (round-2 advisor finding: ghost rows are identity rows, their local inverse diagonal is 1)."""
+    rcs, outs = _run_ranks(["--kind", "tet", "--steps", "3", "--method", "rcb", "--solves", "--jacobi"])
+    assert rcs == [0, 0], "\n".join(outs)
+    assert "PARTITION STEPS OK" in outs[0], outs[0]
+
+
+@pytest.mark.gpu
 def test_coarse_space_of_the_distributed_emi_solve_lowers_the_iteration_count(monkeypatch):
     """knpemi_set_distributed_coarse (piecewise constants over slices of every rank's sub-domains) on a cable cut in
     three (BASELINE configs[1] per rank; the global modes along the cable only matter once the cable is long in cells:

@@ -15,25 +15,41 @@ sys.path.insert(0, os.path.join(ROOT, "knp-emi-fenics-x_amd"))
 sys.path.insert(0, os.path.join(ROOT, "examples", "idealized_geometries"))
 
 
-def init_fields(s, L_x):
-    """Deterministic functions of the coordinates, so every rank and the global run start from the same state."""
+def init_fields(s, L_x, scale=1.0, v_rest=-0.0744):
+    """Deterministic functions of the coordinates, so every rank and the global run start from the same state.
+    scale: coordinate unit (1: metres, 100: the centimetres of the astrocyte driver); v_rest in the driver's unit."""
     for tag in s.subdomain_list:
         x = s.subdomain_list[tag]['mesh_sub'].x
-        w = np.sin(2 * np.pi * x[:, 0] / L_x) * np.cos(3e6 * x[:, 1]) * np.cos(2e6 * x[:, 2])
+        w = np.sin(2 * np.pi * x[:, 0] / L_x) * np.cos(3e6 / scale * x[:, 1]) * np.cos(2e6 / scale * x[:, 2])
         for k in range(2):
             s.c_prev[tag][k].x.array[:] *= 1.0 + 1e-3 * w * (1 + k)
             s.c[tag][k].x.array[:] = s.c_prev[tag][k].x._a
-        s.ion_list[-1][f'c_{tag}'].x.array[:] = -(1.0 / s.ion_list[-1]['z']) * sum(
-            ion['z'] * f.x._a for ion, f in zip(s.ion_list[:-1], s.c_prev[tag]))
-        s.phi[tag].x.array[:] = (-0.0744 if tag > 0 else 0.0) + 1e-3 * w
+        rho = s.physical_parameters.get('rho', {})
+        rho_term = float(getattr(rho.get(tag, 0.0), 'value', rho.get(tag, 0.0))) * float(rho.get('z', 0.0)) if rho else 0.0
+        s.ion_list[-1][f'c_{tag}'].x.array[:] = -(1.0 / s.ion_list[-1]['z']) * (rho_term + sum(
+            ion['z'] * f.x._a for ion, f in zip(s.ion_list[:-1], s.c_prev[tag])))
+        s.phi[tag].x.array[:] = (v_rest if tag > 0 else 0.0) * (1.0 + 1e-2 * w)
 
 
-def run(s, K, halo, mem_halo, solves=None):
+def membrane_models(s):
+    """[(tag, model dict)] in the stepper's registration order"""
+    return [(tag, mm) for tag, sd in s.subdomain_list.items() if tag > 0 for mm in sd.get('mem_models', [])]
+
+
+def run(s, K, halo, mem_halo, solves=None, jacobi=False):
     from knpemi.stepper import DeviceStepper
+    from knpemi import _lib as L
     st = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp), s.c, s.c_prev, s.phi, s.phi_M_prev,
                        device_solves=solves)
-    for mm in s.mem_models:
+    if jacobi:
+        st.dp.solver_setup(L.B_EMI, L.PC_JACOBI)
+        st.dp.solver_setup(L.B_KNP, L.PC_JACOBI)
+    for _, mm in membrane_models(s):
         st.add_membrane_model(mm['ode'], s.stim_params['stimulus'], s.stim_params['stimulus_locator'])
+    src = getattr(s, "f_source_K", None)
+    if src is not None:          # pulsed ECS source of the astrocyte driver: on from the first step
+        s.set_source(s.cfg["delay"])
+        st.set_source(0, s.f_source_K.x._a)
     if halo is not None:
         halo.attach(st.dp)
         halo.exchange_bulk()
@@ -47,11 +63,20 @@ def run(s, K, halo, mem_halo, solves=None):
     st.download()
     if halo is not None and getattr(halo, "_hook_error", None) is not None:
         raise halo._hook_error
-    ode = s.mem_models[0]['ode']
-    out = dict(x=ode.dof_locations.copy(), phiM=s.phi_M_prev[1].x._a.copy(), states=ode.states.copy())
+    # membrane fields of every cellular sub-domain, concatenated in sub-domain order (the order of the halo's keys)
+    xs, phiM, states, cur = [], [], [], {}
+    for tag, mm in membrane_models(s):
+        ode = mm['ode']
+        xs.append(np.hstack([ode.dof_locations, np.full((ode.nodes, 1), float(tag))]))
+        phiM.append(s.phi_M_prev[tag].x._a.copy())
+        st_pad = np.zeros((ode.nodes, 4))
+        st_pad[:, :ode.states.shape[1]] = ode.states
+        states.append(st_pad)
+        for n, f in mm['I_ch_k'].items():
+            cur.setdefault("I_" + n, []).append(f.x._a.copy())
+    out = dict(x=np.concatenate(xs), phiM=np.concatenate(phiM), states=np.concatenate(states))
+    out.update({k: np.concatenate(v) for k, v in cur.items()})
     out["iterations"] = list(getattr(st, "iterations", []))
-    for n, f in s.mem_models[0]['I_ch_k'].items():
-        out["I_" + n] = f.x._a.copy()
     # right-hand sides of the last step (they see the ghost membrane dofs through the facets of ghost cells)
     from knpemi import _lib as L
     dp = st.dp
@@ -86,6 +111,10 @@ def main():
     ap.add_argument("--rtol", type=float, nargs=2, default=(1e-8, 1e-10), metavar=("EMI", "KNP"),
                     help="relative tolerances of the two solves (the reference's are 1e-5 1e-7)")
     ap.add_argument("--tol", type=float, default=1e-5, help="bound on the relative field differences with --solves")
+    ap.add_argument("--jacobi", action="store_true", help="with --solves: Jacobi instead of AMG preconditioning for both systems")
+    ap.add_argument("--family", default="idealized", choices=["idealized", "astro"],
+                    help="astro: the three-sub-domain driver (ECS + neuron HH + glia Kir4.1/pump, pulsed ECS source) of "
+                         "examples/local_astrocyte_depolarization on a general cell partition (rcb / slab)")
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
@@ -95,15 +124,30 @@ def main():
     from knpemi.fem import make_mesh_3D
     from setup_problem import Setup
     solves = tuple(a.rtol) if a.solves else None
-    with contextlib.redirect_stdout(io.StringIO()):
+    astro = a.family == "astro"
+    scale, v_rest = (100.0, -70.0) if astro else (1.0, -0.0744)
+    if astro:
+        sys.path.insert(0, os.path.join(ROOT, "examples", "local_astrocyte_depolarization"))
+        import run_stim_duration as rsd
+        cfg = dict(rsd.DEFAULTS)
+        cfg["mesh"] = dict(kind="box3d", resolution_factor=a.resolution, cell_type="tetrahedron" if a.kind == "tet" else "hexahedron",
+                           length=2 * world)
+        cfg.update(delay=0.0, pulse_width=1.0, period=10.0, end_time=100.0, x_L=15e-4, x_U=17e-4, y_L=-1.0, y_U=0.2e-4,
+                   z_L=-1.0, z_U=0.2e-4)
         if a.method == "slabgen":
+            a.method = "slab"
+    with contextlib.redirect_stdout(io.StringIO()):
+        if astro:
+            from knpemi.fem.distributed import make_partitioned_astro
+            s = make_partitioned_astro(cfg, rank, world, method=a.method)
+        elif a.method == "slabgen":
             s = make_slab_problem(a.kind, a.resolution, rank, world, g_syn=10.0)
         else:
             from knpemi.fem.distributed import make_partitioned_problem
             s = make_partitioned_problem(a.kind, a.resolution, rank, world, g_syn=10.0, method=a.method)
     L_x = s.global_length
-    init_fields(s, L_x)
-    loc = run(s, a.steps, s.halo, not a.no_mem_halo, solves)
+    init_fields(s, L_x, scale, v_rest)
+    loc = run(s, a.steps, s.halo, not a.no_mem_halo, solves, a.jacobi)
     its_local = loc.pop("iterations")
     rows = loc.pop("rows")
     hx = L_x / (2 * world * 16 * 2 ** a.resolution)
@@ -122,9 +166,12 @@ def main():
     if rank == 0:
         with contextlib.redirect_stdout(io.StringIO()):
             ctype = {"tet": "tetrahedron", "hex": "hexahedron"}[a.kind]
-            g = Setup(a.kind, a.resolution, g_syn=10.0, mesh_data=make_mesh_3D(a.resolution, ctype, l=2 * world))
-        init_fields(g, L_x)
-        ref = run(g, a.steps, None, True, solves)
+            if astro:
+                g = rsd.Problem(cfg)
+            else:
+                g = Setup(a.kind, a.resolution, g_syn=10.0, mesh_data=make_mesh_3D(a.resolution, ctype, l=2 * world))
+        init_fields(g, L_x, scale, v_rest)
+        ref = run(g, a.steps, None, True, solves, a.jacobi)
         its_ref = ref.pop("iterations")
         ref_rows = ref.pop("rows")
         key = lambda x: tuple(np.rint(x / (hx / 64)).astype(np.int64))
