@@ -173,7 +173,8 @@ int knpemi_device_csr(knpemi_handle* h, int which, const int32_t** rowptr, const
 int knpemi_device_rhs(knpemi_handle* h, int which, const double** b);
 /* Write a solver result back into the bulk fields: x has the unknown order of the system
  * (`which` = KNPEMI_B_EMI -> phi, KNPEMI_B_KNP -> c).  on_device != 0: x is a device pointer (one launch, nothing
- * synchronised). */
+ * synchronised).  With KNPEMI_OPT_FUSE_UPDATE the KNP write-back is followed by (device: fused with) the end-of-step
+ * update knpemi_update_pde, on both paths. */
 int knpemi_set_solution(knpemi_handle* h, int which, const double* x, int on_device);
 int knpemi_get_solution(knpemi_handle* h, int which, double* x);
 

@@ -404,9 +404,9 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
           int n = 0;
           for (int p = rowptrL[chunks[c].start]; p < rowptrL[chunks[c].start + chunks[c].len]; ++p) {
             const int v = colindL[p];
-            if (seen[v] == id) continue;
+            if (seen[v] == id || (!mark && seen[v] == -2 - id)) continue;     // in the block already / counted in this probe
             if (mark) seen[v] = id;
-            else { seen[v] = -2 - id; }         // counted once within this probe, undone below
+            else seen[v] = -2 - id;             // undone below
             ++n;
           }
           if (!mark)
@@ -1239,6 +1239,14 @@ extern "C" int knpemi_set_solution(knpemi_handle* h, int which, const double* x,
                               x + (size_t)KS * h->voff[s] + (size_t)k * nv, nv * sizeof(double), kind, h->stream));
       }
   } else return fail(KNPEMI_EINVAL, "knpemi_set_solution: unknown system");
+  // KNPEMI_OPT_FUSE_UPDATE: whoever writes the KNP solution also performs the end-of-step update (the device write-back
+  // above does it in the same launch); the host path launches it after its copies, so that a caller's own solver whose
+  // result arrives through this entry point leaves c_prev, the eliminated ion and phi_M updated as well
+  if (!on_device && which == KNPEMI_B_KNP && h->fuse_update) {
+    if (!h->have_params) return fail(KNPEMI_EINVAL, "knpemi_set_solution: knpemi_set_params not called");
+    int rc = kn_launch_update_pde(h);
+    if (rc) return rc;
+  }
   if (!on_device) KN_HIP(hipStreamSynchronize(h->stream));
   return KNPEMI_OK;
 }

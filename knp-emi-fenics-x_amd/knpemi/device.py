@@ -16,6 +16,18 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import _lib as L
+
+try:                                    # content fingerprint of a host array (DeviceProblem._stamp)
+    import xxhash
+
+    def _digest(a):
+        return xxhash.xxh3_64_intdigest(memoryview(np.ascontiguousarray(a)).cast("B"))
+except ImportError:                     # pragma: no cover -- zlib is always there
+    import zlib
+
+    def _digest(a):
+        m = memoryview(np.ascontiguousarray(a)).cast("B")
+        return (zlib.crc32(m) << 32) | zlib.adler32(m)
 from .fem.function import as_float
 
 _CELL_KIND = {"triangle": L.TRIANGLE, "tetrahedron": L.TETRAHEDRON, "hexahedron": L.HEXAHEDRON}
@@ -203,11 +215,12 @@ class DeviceProblem:
     @staticmethod
     def _stamp(vec):
         """What "unchanged since the last upload" means: same vector object, no `.array` access since (`version`),
-        and the same content fingerprint -- a caller may keep a view (`a = f.x.array; ...; a[:] = v`, common in DOLFINx
-        driver code) and write through it without touching `.array` again; summing the array (one pass over host
-        memory, far cheaper than the upload it may save) catches that."""
+        and the same bytes -- a caller may keep a view (`a = f.x.array; ...; a[:] = v`, common in DOLFINx driver code)
+        and write through it without touching `.array` again.  The content is fingerprinted with a 64-bit hash of the
+        whole buffer (xxh3: ~10 GB/s, one pass over host memory, far cheaper than the upload it may save); a sum or a
+        sampled dot product would miss permuted or compensating edits."""
         a = vec._a
-        return (id(vec), vec.version, float(a.sum()), float(a[:: max(1, a.shape[0] // 64)].dot(a[:: max(1, a.shape[0] // 64)])))
+        return (id(vec), vec.version, a.shape[0], _digest(a))
 
     def push_array(self, field, sub, idx, a):
         a = np.ascontiguousarray(a, np.float64)
