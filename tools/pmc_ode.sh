@@ -10,7 +10,7 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES S
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM"; do
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/$OUT/p$i -- \
-      python3 $R/bench.py --workload $W --steps 5 --warmup 2 --cpu-steps 0 --solve-steps 0 > $R/gpurun_out/$OUT.p$i.log 2>&1
+      python3 $R/bench.py --workload $W --steps 5 --warmup 2 --repeats 1 --cpu-steps 0 --solve-steps 0 --no-dg --no-config3 > $R/gpurun_out/$OUT.p$i.log 2>&1
   echo "pass $i ($grp) done"
 done
 python3 $R/tools/pmc_summary.py $R/gpurun_out/$OUT

@@ -11,7 +11,7 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES S
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   timeout -k 10 500 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/$OUT/p$i -- \
-      python3 $R/bench.py --workload $W --steps 3 --warmup 1 --cpu-steps 0 --solve-steps 0 --no-overlap --no-dg > $R/gpurun_out/$OUT.p$i.log 2>&1
+      python3 $R/bench.py --workload $W --steps 3 --warmup 1 --repeats 1 --cpu-steps 0 --solve-steps 0 --no-overlap --no-dg --no-config3 > $R/gpurun_out/$OUT.p$i.log 2>&1
   echo "pass $i ($grp) done"
 done
 python3 $R/tools/pmc_summary.py $R/gpurun_out/$OUT

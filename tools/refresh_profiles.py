@@ -1,36 +1,143 @@
-"""Copy the artefacts written by tools/collect_profiles.sh / collect_traffic.sh (gpurun_out/) into profiles/ under their
-round-2 names and print the headline numbers."""
-import csv, glob, json, os, shutil
+"""Copy the artefacts written by tools/collect_profiles.sh / collect_traffic.sh / pmc_*.sh (gpurun_out/) into profiles/
+under their round-3 names and REGENERATE the numbers quoted in profiles/README.md from those files (the section between
+the `<!-- r03:begin -->` / `<!-- r03:end -->` markers is written by this script, never by hand: text and data cannot drift
+apart)."""
+import csv
+import glob
+import json
+import os
+import shutil
+
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
-last = lambda pattern: sorted(glob.glob(pattern), key=os.path.getmtime)[-1]
-cp = lambda a, b: shutil.copy(a, os.path.join(P, b))
-cp(last(G + "/r02/stats_config2/runc/*_kernel_stats.csv"), "r02_config2_kernel_stats.csv")
-cp(last(G + "/r02/stats_config3/runc/*_kernel_stats.csv"), "r02_config3_kernel_stats.csv")
-cp(last(G + "/r02/stats_dg/runc/*_kernel_stats.csv"), "r02_dg_config2_kernel_stats.csv")
-cp(last(G + "/r02/stats_config2h/runc/*_kernel_stats.csv"), "r02_config2h_kernel_stats.csv")
-for a, b in (("r02/bench_config2.json", "r02_bench_config2.json"), ("r02/bench_config3.json", "r02_bench_config3.json"),
-             ("r02/bench_config5s.json", "r02_bench_config5s.json"), ("r02/bench_config2h.json", "r02_bench_config2h.json"), ("r02/stats_dg.json", "r02_bench_dg_config2.json"),
-             ("r02/bench_dg_config3.json", "r02_bench_dg_config3.json")):
-    cp(os.path.join(G, a), b)
-name = {"emi_rows_v2": "emi_rows_kernel", "knp_rows_v2": "knp_rows_kernel"}
-out = {}
-for wl, f in (("config2", "traffic_config2_cg.json"), ("config3", "traffic_config3_cg.json")):
-    out[wl] = {name.get(k, k): v for k, v in json.load(open(os.path.join(G, f)))[wl].items()}
-for wl, f, key in (("config2", "traffic_r1_dg.json", "r1"), ("config3", "traffic_r2_dg.json", "r2")):
-    for k, v in json.load(open(os.path.join(G, f)))[key].items():
-        if k.startswith("dg_"):
-            out[wl][k] = v
-json.dump(out, open(os.path.join(P, "r02_traffic.json"), "w"), indent=1, sort_keys=True)
-for f in ("r02_bench_config2", "r02_bench_config3", "r02_bench_config5s", "r02_bench_config2h", "r02_bench_dg_config2", "r02_bench_dg_config3"):
-    d = json.loads(open(os.path.join(P, f + ".json")).read().strip().splitlines()[-1])
-    print(f, round(d["ms_per_step"], 4), "%.3e" % d["value"], round(d["roofline"]["frac"], 3), d["roofline"]["kernel"],
-          round(d["roofline"]["avg_launch_us"], 1), (d.get("with_solves") or {}).get("ms_per_step"),
-          (d.get("cpu_baseline") or {}).get("value"), {k: round(v, 1) for k, v in d.get("kernels_us_per_step", {}).items()})
-for f in ("r02_config2_kernel_stats.csv", "r02_dg_config2_kernel_stats.csv", "r02_config3_kernel_stats.csv", "r02_config2h_kernel_stats.csv"):
-    print(f)
-    for r in csv.DictReader(open(os.path.join(P, f))):
+
+
+def last(pattern):
+    hits = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return hits[-1] if hits else None
+
+
+def cp(a, b):
+    if a and os.path.exists(a):
+        shutil.copy(a, os.path.join(P, b))
+        return True
+    return False
+
+
+def line(path):
+    return json.loads(open(path).read().strip().splitlines()[-1])
+
+
+rows = []
+# ---- kernel statistics ------------------------------------------------------------------------------------------
+for wl, cmd in (("config2", "python3 bench.py --steps 20 --warmup 5` (the driver's command)"),
+                ("config3", "python3 bench.py --workload config3 --steps 20 --warmup 5 --cpu-steps 0 --solve-steps 0 --no-dg`"),
+                ("config2h", "python3 bench.py --workload config2h --steps 20 --warmup 5 --cpu-steps 0 --solve-steps 0 --no-dg --no-overlap`"),
+                ("dg", "python3 bench.py --variant dg --steps 50 --warmup 5`")):
+    name = f"r03_{wl}_kernel_stats.csv"
+    if not cp(last(f"{G}/r03/stats_{wl}/*/*_kernel_stats.csv"), name):
+        continue
+    picks = []
+    for r in csv.DictReader(open(os.path.join(P, name))):
         n = r["Name"]
-        if any(t in n for t in ("emi_rows", "knp_rows", "knp_membrane", "ode_step", "emi_membrane", "writeback", "dg_")):
+        if any(t in n for t in ("emi_rows", "knp_rows", "knp_membrane", "ode_step", "emi_membrane", "writeback", "dg_",
+                                "cg_dir", "down_kernel", "up_kernel", "bi_spmv", "bi_update", "dense_kernel")):
             short = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
-            print("   %-44s calls %5s avg %8.1f us" % (short[:44], r["Calls"], float(r["AverageNs"]) / 1e3))
+            picks.append(f"`{short}` {float(r['AverageNs']) / 1e3:.1f} us x {r['Calls']}")
+    rows.append((f"`{name}`", f"`rocprofv3 --kernel-trace --stats --output-format csv -- {cmd}", "; ".join(picks[:14])))
+
+# ---- bench lines ------------------------------------------------------------------------------------------------
+for f, cmd in (("bench_config2", "python bench.py --steps 20 --warmup 5"),
+               ("bench_config3", "python bench.py --workload config3 --steps 20 --warmup 5 --cpu-steps 0 --no-dg"),
+               ("bench_config2h", "python bench.py --workload config2h --steps 20 --warmup 5 --cpu-steps 0 --no-dg"),
+               ("bench_config5s", "python bench.py --workload config5s --steps 20 --warmup 5 --cpu-steps 0 --no-dg"),
+               ("bench_r3", "python bench.py --workload r3 --steps 10 --warmup 5 --repeats 3 --cpu-steps 0 --solve-steps 0 --no-dg"),
+               ("bench_dg_config3", "python bench.py --variant dg --workload config3 --steps 20 --warmup 3"),
+               ("bench_config2_plain_solver_loops", "KNPEMI_NO_FUSED=1 python bench.py --steps 20 --warmup 5 --cpu-steps 0 --no-dg --no-config3")):
+    if not cp(os.path.join(G, "r03", f + ".json"), f"r03_{f}.json"):
+        continue
+    d = line(os.path.join(P, f"r03_{f}.json"))
+    bits = [f"{d['ms_per_step']:.4f} ms/step, {d['value']:.3e} {d['unit']}"]
+    t = d.get("timing")
+    if t:
+        bits.append(f"median of {len(t['repeats_ms_per_step'])} windows ({t['min_ms_per_step']:.4f}..{t['max_ms_per_step']:.4f})")
+    ro = d.get("roofline") or {}
+    if ro:
+        bits.append(f"`roofline` {ro['kernel']} {ro['avg_launch_us']:.1f} us = {ro['frac']:.3f} of 8 TB/s"
+                    + (f" ({ro['frac_by_counters']:.3f} by counters)" if ro.get("frac_by_counters") else ""))
+    for k, v in (d.get("roofline_row_kernels_alone") or {}).items():
+        bits.append(f"{k} alone {v['avg_launch_us']:.1f} us = {v['frac']:.3f}"
+                    + (f" ({v['frac_by_counters']:.3f} by counters)" if v.get("frac_by_counters") else ""))
+    if d.get("spike_window"):
+        sw = d["spike_window"]
+        bits.append(f"spike window {sw['ms_per_step']:.4f} ms/step (ODE sweep {sw['ode_kernel_us_per_step']:.0f} us avg, {sw['ode_kernel_us_max']:.0f} max)")
+    ws = d.get("with_solves")
+    if ws:
+        bits.append(f"with_solves {ws['ms_per_step']:.3f} ms/step ({ws['emi']['iterations_avg']:.2f} CG + {ws['knp']['iterations_avg']:.2f} BiCGStab)")
+    cb = d.get("cpu_baseline")
+    if cb:
+        bits.append(f"CPU port {cb['value']:.2e} dofs/s on {cb['cores']} threads")
+    leg = d.get("config3_leg")
+    if leg:
+        al = leg.get("roofline_row_kernels_alone") or {}
+        bits.append("config3_leg " + f"{leg['ms_per_step']:.4f} ms/step; "
+                    + ", ".join(f"{k} alone {v['avg_launch_us']:.1f} us = {v['frac']:.3f}" for k, v in al.items()))
+    ku = d.get("kernels_us_per_step") or {}
+    if ku:
+        bits.append("kernels " + ", ".join(f"{k.replace('_kernel', '')} {v:.1f}" for k, v in ku.items()))
+    rows.append((f"`r03_{f}.json`", f"`{cmd}`", "; ".join(bits)))
+
+# ---- HBM traffic ------------------------------------------------------------------------------------------------
+traffic = {}
+name = {"emi_rows_v2": "emi_rows_kernel", "knp_rows_v2": "knp_rows_kernel"}
+for wl in ("config2", "config3"):
+    f = os.path.join(G, f"traffic_{wl}_cg.json")
+    if os.path.exists(f):
+        traffic[wl] = {name.get(k, k): v for k, v in json.load(open(f))[wl].items()}
+if traffic:
+    json.dump(traffic, open(os.path.join(P, "r03_traffic.json"), "w"), indent=1, sort_keys=True)
+    bits = []
+    for wl, ks in traffic.items():
+        for k, v in ks.items():
+            if "rows" in k or "membrane_kernel" in k:
+                hbm = (2 * v.get("FETCH_SIZE_KiB", 0) + v.get("WRITE_SIZE_KiB", 0)) / 1024
+                bits.append(f"{wl} {k}: 2 x {v.get('FETCH_SIZE_KiB', 0) / 1024:.1f} + {v.get('WRITE_SIZE_KiB', 0) / 1024:.1f} = {hbm:.1f} MiB")
+    rows.append(("`r03_traffic.json`", "`tools/collect_traffic.sh config2`, `... config3` (FETCH_SIZE, WRITE_SIZE, TCC_HIT_sum, "
+                 "TCC_MISS_sum each in its own `rocprofv3 --kernel-trace --pmc` pass of `bench.py --steps 5 --warmup 2 --repeats 1`)",
+                 "HBM-side bytes per launch, `(2 FETCH_SIZE + WRITE_SIZE) KiB` (gfx950 correction of the guide): " + "; ".join(bits)))
+
+# ---- PMC summaries ----------------------------------------------------------------------------------------------
+for src, dst, what in (("r03_pmc_ode/summary.json", "r03_pmc_ode_config2.json",
+                        "`tools/pmc_ode.sh config2 r03_pmc_ode`: three counter passes of the bench trajectory, all three clean"),
+                       ("r03_pmc_rows/summary.json", "r03_pmc_rows_config3.json", "`tools/pmc_rows.sh config3 r03_pmc_rows`")):
+    if cp(os.path.join(G, src), dst):
+        d = json.load(open(os.path.join(P, dst)))
+        bits = []
+        for k, v in d.items():
+            if "SQ_WAVES" in v and "SQ_INSTS_VALU" in v:
+                w = v["SQ_WAVES"]
+                msg = f"{k}: {v['SQ_INSTS_VALU'] / w:.0f} VALU + {v.get('SQ_INSTS_SALU', 0) / w:.0f} SALU + {v.get('SQ_INSTS_LDS', 0) / w:.0f} LDS instructions per wave"
+                if "SQ_WAVE_CYCLES" in v and "SQ_WAIT_ANY" in v:
+                    msg += f", waiting {100 * v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES']:.0f} % of the wave cycles"
+                bits.append(msg)
+        rows.append((f"`{dst}`", what, "; ".join(bits)))
+
+# ---- README section ---------------------------------------------------------------------------------------------
+readme = os.path.join(P, "README.md")
+text = open(readme).read()
+begin, end = "<!-- r03:begin -->", "<!-- r03:end -->"
+sec = [begin, "", "## Round 3", "",
+       "Written by `tools/refresh_profiles.py` from the files beside it (collected with `tools/collect_profiles.sh`, "
+       "`tools/collect_traffic.sh`, `tools/pmc_ode.sh`, `tools/pmc_rows.sh` on the MI355X box): every number below is read from "
+       "the file it stands next to.", "",
+       "| file | command | what it shows |", "|---|---|---|"]
+sec += [f"| {a} | {b} | {c} |" for a, b, c in rows]
+sec += ["", end]
+block = "\n".join(sec)
+if begin in text:
+    text = text[:text.index(begin)] + block + text[text.index(end) + len(end):]
+else:
+    text = text.rstrip("\n") + "\n\n" + block + "\n"
+open(readme, "w").write(text)
+for a, b, c in rows:
+    print(a, "--", c[:300])

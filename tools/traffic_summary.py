@@ -1,5 +1,5 @@
 """Per-kernel averages of the PMC passes written by tools/collect_traffic.sh -> gpurun_out/traffic_<workload>_<mode>.json
-(copy into profiles/r02_traffic.json under the workload's key)."""
+(copy into profiles/r03_traffic.json under the workload's key)."""
 import collections, csv, glob, json, re, sys
 root, workload, mode = sys.argv[1:4]
 out = collections.defaultdict(dict)
