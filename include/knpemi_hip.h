@@ -248,6 +248,11 @@ int knpemi_ode_stats(knpemi_handle* h, int sub, int model, int64_t* n_rhs, int64
  * the number of workgroups copied (<= max_blocks). */
 int knpemi_debug_ode_stamps(knpemi_handle* h, int sub, int model, uint64_t* out, int max_blocks);
 
+/* Diagnostics (no reference counterpart): evaluates one of the ODE sweep's device math helpers (csrc/lsoda_core.h) over
+ * host arrays on the current device, so that tests can bound their error against the C library: op 0: kn_div(a, b),
+ * 1: kn_exp(a), 2: kn_powr(a, b), 3: kn_log(a).  a, b, out: n doubles each (b is ignored by ops 1 and 3). */
+int knpemi_debug_math(int op, int n, const double* a, const double* b, double* out);
+
 /* End-of-step update: update_pde_variables (utils.py:238-295): c_prev <- c, eliminated ion from
  * electroneutrality, phi_M_prev <- tr(phi_i) - tr(phi_e). */
 int knpemi_update_pde(knpemi_handle* h);

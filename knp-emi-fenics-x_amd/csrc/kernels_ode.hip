@@ -120,3 +120,32 @@ int kn_lsoda_coef_upload(void** out) {
   *out = d;
   return KNPEMI_OK;
 }
+
+// ---- diagnostics: the sweep's math helpers over an array (knpemi_debug_math) ------------------------------------
+__global__ void debug_math_kernel(int op, int n, const double* __restrict__ a, const double* __restrict__ b,
+                                  double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = op == 0 ? kn_div(a[i], b[i]) : (op == 1 ? kn_exp(a[i]) : (op == 2 ? kn_powr(a[i], b[i]) : kn_log(a[i])));
+}
+
+extern "C" int knpemi_debug_math(int op, int n, const double* a, const double* b, double* out) {
+  if (op < 0 || op > 3 || n < 0 || !a || !out || ((op == 0 || op == 2) && !b)) {
+    kn_set_error("knpemi_debug_math: bad arguments");
+    return KNPEMI_EINVAL;
+  }
+  if (n == 0) return KNPEMI_OK;
+  double* d = nullptr;
+  KN_HIP(hipMalloc(reinterpret_cast<void**>(&d), 3 * sizeof(double) * (size_t)n));
+  int rc = KNPEMI_OK;
+  auto check = [&](hipError_t e) { if (e != hipSuccess && rc == KNPEMI_OK) { kn_set_error(hipGetErrorString(e)); rc = KNPEMI_EHIP; } };
+  check(hipMemcpy(d, a, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+  check(hipMemcpy(d + n, (op == 1 || op == 3) ? a : b, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+  if (rc == KNPEMI_OK) {
+    hipLaunchKernelGGL(debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op, n, d, d + n, d + 2 * (size_t)n);
+    check(hipGetLastError());
+    check(hipMemcpy(out, d + 2 * (size_t)n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(d);
+  return rc;
+}

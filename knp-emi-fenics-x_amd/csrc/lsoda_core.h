@@ -62,6 +62,8 @@ struct LsodaCoef {
   double cm1[13];
   double cm2[6];
   double sm1[13];
+  double rtesco[2][13][4];   // 1 / tesco and 1 / i (i = 1..15), correctly rounded on the host: the device multiplies
+  double rint_[16];          // where DSTODA divides by these constants (the reciprocals themselves are bit-identical)
 };
 
 #if !defined(__HIPCC_RTC__)
@@ -128,6 +130,11 @@ inline void lsoda_fill_coef(LsodaCoef* c) {
   for (int i = 1; i <= 5; ++i) c->cm2[i] = c->tesco[1][i][2] * c->elco[1][i][i + 1];
   static const double sm1[13] = {0.0, 0.5, 0.575, 0.55, 0.45, 0.35, 0.25, 0.2, 0.15, 0.1, 0.075, 0.05, 0.025};
   for (int i = 0; i < 13; ++i) c->sm1[i] = sm1[i];
+  for (int m = 0; m < 2; ++m)
+    for (int q = 0; q < 13; ++q)
+      for (int k = 0; k < 4; ++k) c->rtesco[m][q][k] = c->tesco[m][q][k] != 0.0 ? 1.0 / c->tesco[m][q][k] : 0.0;
+  c->rint_[0] = 0.0;
+  for (int i = 1; i < 16; ++i) c->rint_[i] = 1.0 / (double)i;
 }
 #endif
 
@@ -151,12 +158,23 @@ __device__ __forceinline__ double kn_dpp_quad(double v) {
 }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// max(a, b) as the one instruction it is.  fmax() on a value that arrived through a DPP move of its two halves is
+// preceded by a canonicalising v_max_f64 x, x, x (the compiler cannot know that the bits are a quiet number): one more
+// instruction per exchange, and every norm of the integrator is two exchanges deep.
+__device__ __forceinline__ double kn_max_raw(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+#endif
+
 template <int L>
 KN_HD double kn_group_max(double v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (L == 2 || L == 4) {
-    v = fmax(v, kn_dpp_quad<0xB1>(v));                      // lanes 1 0 3 2
-    if constexpr (L == 4) v = fmax(v, kn_dpp_quad<0x4E>(v));   // lanes 2 3 0 1
+    v = kn_max_raw(v, kn_dpp_quad<0xB1>(v));                      // lanes 1 0 3 2
+    if constexpr (L == 4) v = kn_max_raw(v, kn_dpp_quad<0x4E>(v));   // lanes 2 3 0 1
   } else {
 #pragma unroll
     for (int m = 1; m < L; m <<= 1) v = fmax(v, __shfl_xor(v, m));
@@ -184,24 +202,93 @@ KN_HD double kn_group_get(double v, int k) {   // value held by lane k of this l
   return v;
 }
 
-// a / b.  On the device: a times the hardware reciprocal estimate refined by two Newton steps (6 instructions, relative
-// error of a few 1e-16) instead of the IEEE division sequence (11 dependent instructions); the integrator is a
-// single dependent chain and divides four to eight times per trip.  The host build (the bit-for-bit comparison with the
-// sequential restatement and the nst / nfe comparison with ODEPACK) keeps the exact quotient.
+// a / b.  On the device: a times the hardware reciprocal estimate r0, corrected by the product form of the Newton
+// series, a r0 (1 + e)(1 + e^2) with e = 1 - b r0 (exact quotient: a r0 (1 + e + e^2 + e^3 + e^4 + ...), so the
+// relative error is e^4 plus rounding, a few 1e-16).  The integrator is ONE dependent chain -- a sweep is as long as the
+// longest path through its fp64 instructions (18 ns per dependent instruction on gfx950, 3.5 ns per independent one,
+// tools/probes/exec_skip.hip) -- and divides four to eight times per trip: the two legs {e, a r0} and {e^2, q (1 + e)}
+// run side by side, so a quotient is 4 instructions deep where two Newton steps on r0 followed by the product are 6
+// and the IEEE sequence 11.  The host build (the bit-for-bit comparison with the sequential restatement and the
+// nst / nfe comparison with ODEPACK) keeps the exact quotient.
 KN_HD double kn_div(double a, double b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  double r = __builtin_amdgcn_rcp(b);
-  r = fma(fma(-b, r, 1.0), r, r);
-  r = fma(fma(-b, r, 1.0), r, r);
-  return a * r;
+  const double r = __builtin_amdgcn_rcp(b);
+  const double e = fma(-b, r, 1.0);
+  double q = a * r;
+  const double e2 = e * e;
+  q = fma(q, e, q);
+  return fma(q, e2, q);
 #else
   return a / b;
 #endif
 }
 
-// x^e for x >= 0, e > 0 (the step-ratio formulas of DSTODA): exp(e log x), under half the instructions of
+// exp(x).  On the device: x = k ln 2 + r with |r| <= ln 2 / 2 (two-constant reduction), exp(r) from the degree-13
+// Taylor polynomial (remainder r^14 / 14! < 5e-18) in Estrin's arrangement -- pairs, quads, octets side by side: 4
+// dependent instructions after r where Horner's rule (the library's exp) is 12 -- then scaled by 2^k; rounding error
+// below 2 ulp (tests/test_gpu_parity.py::test_device_math_helpers).  The host build calls the C library.
+KN_HD double kn_exp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double k = __builtin_rint(x * 1.4426950408889634);
+  double r = fma(k, -0x1.62e42fefa39efp-1, x);
+  r = fma(k, -0x1.abc9e3b39803fp-56, r);
+  const double r2 = r * r;
+  const double p01 = 1.0 + r;
+  const double p23 = fma(r, 1.0 / 6.0, 0.5);
+  const double p45 = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  const double p67 = fma(r, 1.0 / 5040.0, 1.0 / 720.0);
+  const double p89 = fma(r, 1.0 / 362880.0, 1.0 / 40320.0);
+  const double pab = fma(r, 1.0 / 39916800.0, 1.0 / 3628800.0);
+  const double pcd = fma(r, 1.0 / 6227020800.0, 1.0 / 479001600.0);
+  const double r4 = r2 * r2;
+  const double q0 = fma(p23, r2, p01);
+  const double q1 = fma(p67, r2, p45);
+  const double q2 = fma(pab, r2, p89);
+  const double r8 = r4 * r4;
+  const double o0 = fma(q1, r4, q0);
+  const double o1 = fma(pcd, r4, q2);
+  double v = __builtin_amdgcn_ldexp(fma(o1, r8, o0), (int)k);
+  v = x > 709.782712893384 ? __builtin_inf() : v;     // also +inf (the reduction of an infinity is a NaN)
+  v = x < -745.1332191019412 ? 0.0 : v;               // also -inf
+  return v;
+#else
+  return exp(x);
+#endif
+}
+
+// log(x), x >= 0.  On the device: x = 2^k m with m in [sqrt(1/2), sqrt(2)), s = f / (2 + f), f = m - 1, and
+// log m = f - f^2/2 + s (f^2/2 + R(s^2)) with the degree-7 polynomial of the classical argument reduction (fdlibm's
+// published coefficients) split into its even and odd halves: 19 dependent instructions where the library's log
+// (double-double arithmetic, needed for pow, not here) is about 50; a few ulp.  Used by the step-ratio powers only.
+KN_HD double kn_log(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double m = __builtin_amdgcn_frexp_mant(x);   // [1/2, 1)
+  int k = __builtin_amdgcn_frexp_exp(x);
+  const bool lo = m < 0.7071067811865476;
+  m = lo ? m + m : m;
+  k = lo ? k - 1 : k;
+  const double f = m - 1.0;
+  const double s = kn_div(f, 2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                   2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)k;
+  double v = dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+  v = x == 0.0 ? -__builtin_inf() : v;
+  v = x == __builtin_inf() ? x : v;
+  v = x < 0.0 ? __builtin_nan("") : v;
+  return v;
+#else
+  return log(x);
+#endif
+}
+
+// x^e for x >= 0, e > 0 (the step-ratio formulas of DSTODA): exp(e log x), a third of the dependent instructions of
 // the general pow() on gfx950 and accurate to a few ulp, far inside what these heuristics resolve.
-KN_HD double kn_powr(double x, double e) { return exp(log(x) * e); }
+KN_HD double kn_powr(double x, double e) { return kn_exp(kn_log(x) * e); }
 
 // N = number of states (1..8); F is a model functor (membrane_models.h): `rhs(t, y, dy)` evaluates all
 // components, `rhs_lane(c, t, y)` component c.
@@ -226,6 +313,7 @@ struct Lsoda {
   double ysave[NI];          // ODEPACK's YH(lmax) slot: the correction saved for the order-increase test
   double el[ROWS + 1];       // method coefficients of the current (meth, nq); entries above l are 0
   double tq1, tq2, tq3;      // tesco(nq, 1..3) of the current (meth, nq)
+  double rtq1, rtq2, rtq3;   // their reciprocals (device: from the table; see over_tq)
   double ewt[NI], savf[NI], acor[NI], y[NI];
   double* work;
   KN_HD double& WM(int i, int j) const { return work[(i * N + j) * STRIDE]; }   // iteration matrix / its LU factors
@@ -233,10 +321,12 @@ struct Lsoda {
   int comp = 0;                                         // LANES = N: the component this lane owns
   double h, hu, tn, hold, rcr, crate, conit, el0, rmax, pdest, pdlast, pdnorm, ratio, tsw;
   double told, delp, pdh, rh, del, pnorm, rate;         // DSTODA / corrector locals that live across phases
+  double anorm;   // vmnorm(acor) of the corrector iteration just made (m > 0): the error test reads it
   int nq, l, meth, mused, miter, ialth, ipup, jcur, jstart, kflag, icount, irflag, nslp, nst, nfe,
       nje, lmax, maxord, nqu, ierpj;
   int m, ncf, ph, ret;
   int lhi;    // wave-uniform bound: l <= lhi on every running lane when a trip starts
+  int lseen;  // the order + 1 this lane had when lhi was last brought up to date
   unsigned long long st_last = 0, st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned st_cnt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -258,7 +348,32 @@ struct Lsoda {
 
   KN_HD double sm1(int i) const { return cf->sm1[i]; }
 
+  // x / tesco(nq, k) and x / i: on the device products with the tabulated reciprocals (a quotient costs 4 dependent
+  // instructions, lsoda_core.h kn_div; DSTODA divides by these constants in every step), true quotients on the host
+  KN_HD double over_tq(double x, double tq, double rtq) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)tq;
+    return x * rtq;
+#else
+    (void)rtq;
+    return x / tq;
+#endif
+  }
+  KN_HD double over_int(double x, int i) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return x * cf->rint_[i];
+#else
+    return x / (double)i;
+#endif
+  }
+
   KN_HD double vmnorm(const double* v) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // one component per lane: the group maximum of the weighted magnitudes is the norm (the maximum with 0 that
+    // opens the host loop only matters for a NaN, which here stays a NaN unless another component is a number --
+    // the corrector then fails and the sweep reports the dof, instead of accepting a step on a vanished norm)
+    if constexpr (NI == 1 && LANES > 1) return kn_group_max<LANES>(fabs(v[0]) * ewt[0]);
+#endif
     double vm = 0.0;
     _Pragma("unroll") for (int i = 0; i < NI; ++i) vm = fmax(vm, fabs(v[i]) * ewt[i]);
     return kn_group_max<LANES>(vm);
@@ -267,27 +382,35 @@ struct Lsoda {
   // ---- loops over the rows of the Nordsieck array ---------------------------------------------------------
   // fn(j) for j = FIRST .. cap, cap = the class (4, 6, 8 or 13) of the wave-uniform bound lb >= l.  Every body is
   // harmless on the rows between a lane's own l and the cap (zero rows, masked selects), so no row costs a branch.
-  template <int FIRST, int CAP, class Fn>
-  KN_HD void rows_to(Fn&& fn) {
-    _Pragma("unroll") for (int j = FIRST; j <= CAP; ++j) fn(j);
+  // The classes are nested, not alternatives: rows up to 4 unconditionally, then 5-6, 7-8, 9-13 behind wave-uniform
+  // tests, so the statement that updates a row exists once and updates its registers in place -- as four alternative
+  // unrolled copies every row had four definitions and the merge points were register-to-register copies of the whole
+  // array (a fifth of the instructions of a trip).
+  template <int FIRST, int LAST, class Fn>
+  KN_HD void rows_range(Fn&& fn) {
+    _Pragma("unroll") for (int j = FIRST; j <= LAST; ++j) fn(j);
   }
   template <int FIRST, class Fn>
   KN_HD void for_rows(int lb, Fn&& fn) {
-    if (lb <= 4) rows_to<FIRST, 4>(fn);
-    else if (lb <= 6) rows_to<FIRST, 6>(fn);
-    else if (lb <= 8) rows_to<FIRST, 8>(fn);
-    else rows_to<FIRST, ROWS>(fn);
+    rows_range<FIRST, 4>(fn);
+    if (lb > 4) {
+      rows_range<5, 6>(fn);
+      if (lb > 6) {
+        rows_range<7, 8>(fn);
+        if (lb > 8) rows_range<9, ROWS>(fn);
+      }
+    }
   }
-  template <int CAP, class Fn>
-  KN_HD void rows_down(Fn&& fn) {
-    _Pragma("unroll") for (int j = CAP; j >= 1; --j) fn(j);
+  template <int FIRST, int LAST, class Fn>
+  KN_HD void rows_range_down(Fn&& fn) {
+    _Pragma("unroll") for (int j = FIRST; j >= LAST; --j) fn(j);
   }
   template <class Fn>
   KN_HD void for_rows_down(int lb, Fn&& fn) {
-    if (lb <= 4) rows_down<4>(fn);
-    else if (lb <= 6) rows_down<6>(fn);
-    else if (lb <= 8) rows_down<8>(fn);
-    else rows_down<ROWS>(fn);
+    if (lb > 8) rows_range_down<ROWS, 9>(fn);
+    if (lb > 6) rows_range_down<8, 7>(fn);
+    if (lb > 4) rows_range_down<6, 5>(fn);
+    rows_range_down<4, 1>(fn);
   }
 
   // row j of the Nordsieck array, j <= jb (jb wave-uniform)
@@ -350,9 +473,12 @@ struct Lsoda {
     tq1 = cf->tesco[meth - 1][nq][1];
     tq2 = cf->tesco[meth - 1][nq][2];
     tq3 = cf->tesco[meth - 1][nq][3];
-    rcr = rcr * el[1] / el0;
+    rtq1 = cf->rtesco[meth - 1][nq][1];
+    rtq2 = cf->rtesco[meth - 1][nq][2];
+    rtq3 = cf->rtesco[meth - 1][nq][3];
+    rcr = kn_div(rcr * el[1], el0);
     el0 = el[1];
-    conit = 0.5 / (double)(nq + 2);
+    conit = over_int(0.5, nq + 2);
   }
 
   // new order: rows above the new l are dead in ODEPACK; here they return to zero
@@ -372,7 +498,7 @@ struct Lsoda {
       pdh = fmax(fabs(h) * pdlast, 0.000001);
       const double s = sm1(nq);
       if ((rh * pdh * 1.00001) >= s) {
-        rh = s / pdh;
+        rh = kn_div(s, pdh);
         irflag = 1;
       }
     }
@@ -615,7 +741,7 @@ struct Lsoda {
         rh2 = 2.0;
         nqm2 = nq < MXORDS ? nq : MXORDS;
       } else {
-        exsm = 1.0 / (double)l;
+        exsm = over_int(1.0, l);
         rh1 = kn_div(1.0, 1.2 * kn_powr(dsm, exsm) + 0.0000012);
         rh1it = 2.0 * rh1;
         pdh = pdlast * fabs(h);
@@ -624,12 +750,12 @@ struct Lsoda {
         if (nq > MXORDS) {   // (unreachable behind `nq > 5` above; kept as in DSTODA)
           nqm2 = MXORDS;
           const int lm2 = MXORDS + 1;
-          exm2 = 1.0 / (double)lm2;
+          exm2 = over_int(1.0, lm2);
           get_row(lm2 + 1, ROWS, row);
-          dm2 = vmnorm(row) / cf->cm2[MXORDS];
-          rh2 = 1.0 / (1.2 * kn_powr(dm2, exm2) + 0.0000012);
+          dm2 = kn_div(vmnorm(row), cf->cm2[MXORDS]);
+          rh2 = kn_div(1.0, 1.2 * kn_powr(dm2, exm2) + 0.0000012);
         } else {
-          dm2 = dsm * (cf->cm1[nq] / cf->cm2[nq]);
+          dm2 = dsm * kn_div(cf->cm1[nq], cf->cm2[nq]);
           rh2 = kn_div(1.0, 1.2 * kn_powr(dm2, exsm) + 0.0000012);
           nqm2 = nq;
         }
@@ -643,25 +769,25 @@ struct Lsoda {
       set_order(nqm2, ROWS);
       return;
     }
-    exsm = 1.0 / (double)l;
+    exsm = over_int(1.0, l);
     if (MXORDN < nq) {
       nqm1 = MXORDN;
       const int lm1 = MXORDN + 1;
-      exm1 = 1.0 / (double)lm1;
+      exm1 = over_int(1.0, lm1);
       get_row(lm1 + 1 > ROWS ? ROWS : lm1 + 1, ROWS, row);
-      dm1 = vmnorm(row) / cf->cm1[MXORDN];
-      rh1 = 1.0 / (1.2 * kn_powr(dm1, exm1) + 0.0000012);
+      dm1 = kn_div(vmnorm(row), cf->cm1[MXORDN]);
+      rh1 = kn_div(1.0, 1.2 * kn_powr(dm1, exm1) + 0.0000012);
     } else {
-      dm1 = dsm * (cf->cm2[nq] / cf->cm1[nq]);
-      rh1 = 1.0 / (1.2 * kn_powr(dm1, exsm) + 0.0000012);
+      dm1 = dsm * kn_div(cf->cm2[nq], cf->cm1[nq]);
+      rh1 = kn_div(1.0, 1.2 * kn_powr(dm1, exsm) + 0.0000012);
       nqm1 = nq;
       exm1 = exsm;
     }
     rh1it = 2.0 * rh1;
     pdh = pdnorm * fabs(h);
-    if ((pdh * rh1) > 0.00001) rh1it = sm1(nqm1) / pdh;
+    if ((pdh * rh1) > 0.00001) rh1it = kn_div(sm1(nqm1), pdh);
     rh1 = fmin(rh1, rh1it);
-    rh2 = 1.0 / (1.2 * kn_powr(dsm, exsm) + 0.0000012);
+    rh2 = kn_div(1.0, 1.2 * kn_powr(dsm, exsm) + 0.0000012);
     if ((rh1 * ratio) < (5.0 * rh2)) return;
     alpha = fmax(0.001, rh1);
     dm1 *= kn_powr(alpha, exm1);
@@ -678,21 +804,21 @@ struct Lsoda {
   // saved correction); after a failed error test rhup = 0.  Returns ODEPACK's orderflag.
   KN_HDN int orderswitch(bool want_up, double dsm, int lb) {
     int newq;
-    const double exsm = 1.0 / (double)l;
+    const double exsm = over_int(1.0, l);
     // the three candidates' error norms, then their roots in one go
     const bool up = want_up && l != lmax, dn = nq != 1;
     double dup = 1.0, ddn = 1.0;
     if (up) {
       _Pragma("unroll") for (int i = 0; i < NI; ++i) savf[i] = acor[i] - ysave[i];
-      dup = kn_div(vmnorm(savf), tq3);
+      dup = over_tq(vmnorm(savf), tq3, rtq3);
     }
     if (dn) {
       double row[NI];
       get_row(l, lb, row);
-      ddn = kn_div(vmnorm(row), tq1);
+      ddn = over_tq(vmnorm(row), tq1, rtq1);
     }
     double psm, pdn, pup;
-    pow3(dsm, exsm, ddn, 1.0 / (double)nq, dup, 1.0 / (double)(l + 1), psm, pdn, pup);
+    pow3(dsm, exsm, ddn, over_int(1.0, nq), dup, over_int(1.0, l + 1), psm, pdn, pup);
     double rhup = up ? kn_div(1.0, 1.4 * pup + 0.0000014) : 0.0;
     double rhsm = kn_div(1.0, 1.2 * psm + 0.0000012);
     double rhdn = dn ? kn_div(1.0, 1.3 * pdn + 0.0000013) : 0.0;
@@ -720,7 +846,7 @@ struct Lsoda {
       } else {
         rh = rhup;
         if (rh >= 1.1) {
-          const double r = el[0] / (double)l;   // el[0] holds el(l), refreshed below before every call
+          const double r = over_int(el[0], l);   // el[0] holds el(l), refreshed below before every call
           nq = l;
           l = nq + 1;
           double row[NI];
@@ -797,13 +923,13 @@ struct Lsoda {
         resetcoeff(lhi);
       }
       if (h != hold) {
-        rh = h / hold;
+        rh = kn_div(h, hold);
         h = hold;
         scaleh(lhi);
       }
     }
     if (jstart > 0 && h != hold) {
-      rh = h / hold;
+      rh = kn_div(h, hold);
       h = hold;
       scaleh(lhi);
     }
@@ -843,6 +969,9 @@ struct Lsoda {
         y[i] = savf[i] - acor[i];
       }
       del = vmnorm(y);
+      // the norm of the accumulated correction (what the error test looks at when m > 0) does not depend on del:
+      // evaluated here its exchanges overlap those of del instead of following the convergence test
+      if (m != 0) anorm = vmnorm(savf);
       _Pragma("unroll") for (int i = 0; i < NI; ++i) {
         y[i] = yh[1][i] + el[1] * savf[i];
         acor[i] = savf[i];
@@ -855,6 +984,7 @@ struct Lsoda {
         acor[i] += y[i];
         y[i] = yh[1][i] + el[1] * acor[i];
       }
+      if (m != 0) anorm = vmnorm(acor);
     }
     if (del <= 100.0 * pnorm * KN_ETA) { ph = PH_ERR; return; }
     if (m != 0 || meth != 1) {
@@ -864,7 +994,11 @@ struct Lsoda {
         rate = fmax(rate, rm);
         crate = fmax(0.2 * crate, rm);
       }
-      const double dcon = kn_div(del * fmin(1.0, 1.5 * crate), tq2 * conit);
+#if defined(__HIP_DEVICE_COMPILE__)
+      const double dcon = del * fmin(1.0, 1.5 * crate) * (rtq2 * (double)(2 * (nq + 2)));   // 1 / conit = 2 (nq + 2)
+#else
+      const double dcon = del * fmin(1.0, 1.5 * crate) / (tq2 * conit);
+#endif
       if (dcon <= 1.0) {
         pdest = fmax(pdest, kn_div(rate, fabs(h * el[1])));
         if (pdest != 0.0) pdlast = pdest;
@@ -904,8 +1038,8 @@ struct Lsoda {
     const int lb = lhi + 1 > ROWS ? ROWS : lhi + 1;   // an order increase in this phase can reach lhi + 1
     jcur = 0;
     double dsm;
-    if (m == 0) dsm = kn_div(del, tq2);
-    else dsm = kn_div(vmnorm(acor), tq2);
+    if (m == 0) dsm = over_tq(del, tq2, rtq2);
+    else dsm = over_tq(anorm, tq2, rtq2);
     if (dsm <= 1.0) {
       kflag = 0;
       nst++;
@@ -915,7 +1049,7 @@ struct Lsoda {
       for_rows<1>(lb, [&](int j) {
         _Pragma("unroll") for (int i = 0; i < NI; ++i) yh[j][i] += el[j] * acor[i];
       });
-      const double tq2u = tq2;   // tesco(nqu, 2) of the method that took the step (used by "endstoda")
+      const double tq2u = tq2, rtq2u = rtq2;   // tesco(nqu, 2) of the method that took the step (used by "endstoda")
       icount--;
       bool ended = false;
       if (icount < 0) {
@@ -946,7 +1080,7 @@ struct Lsoda {
         }
       }
       {   // "endstoda"
-        const double r = 1.0 / tq2u;
+        const double r = over_tq(1.0, tq2u, rtq2u);
         _Pragma("unroll") for (int i = 0; i < NI; ++i) acor[i] *= r;
         hold = h;
         jstart = 1;
@@ -959,7 +1093,7 @@ struct Lsoda {
       }
       if ((tn - tout) * h < 0.0) { ph = PH_TOP; return; }
       // intdy, k = 0: Horner from row l down
-      const double s = (tout - tn) / h;
+      const double s = kn_div(tout - tn, h);
       _Pragma("unroll") for (int i = 0; i < NI; ++i) y0[i] = 0.0;
       for_rows_down(lb, [&](int j) {
         _Pragma("unroll") for (int i = 0; i < NI; ++i)
@@ -1026,13 +1160,14 @@ struct Lsoda {
     }
     _Pragma("unroll") for (int i = 0; i < NI; ++i) ysave[i] = 0.0;
     tq1 = tq2 = tq3 = 0.0;
+    rtq1 = rtq2 = rtq3 = 0.0;
     tn = t0;
     tsw = t0;
     maxord = MXORDN;
     jstart = 0;
     nst = 0; nje = 0; nslp = 0;
     hu = 0.0; nqu = 0; mused = 0; miter = 0; meth = 1;
-    nq = 1; l = 2; lhi = 2;
+    nq = 1; l = 2; lhi = 2; lseen = 2;
     ret = 0;
     ph = PH_TOP;
     _Pragma("unroll") for (int i = 0; i < NI; ++i) y[i] = y0[i];
@@ -1048,15 +1183,15 @@ struct Lsoda {
     if (tol <= 0.0) {
       _Pragma("unroll") for (int i = 0; i < NI; ++i) {
         const double ayi = fabs(y[i]);
-        if (ayi != 0.0) tol = fmax(tol, atol / ayi);
+        if (ayi != 0.0) tol = fmax(tol, kn_div(atol, ayi));
       }
       tol = kn_group_max<LANES>(tol);
     }
     tol = fmax(tol, 100.0 * KN_ETA);
     tol = fmin(tol, 0.001);
     double sum = vmnorm(yh[2]);
-    sum = 1.0 / (tol * w0 * w0) + tol * sum * sum;
-    double h0 = 1.0 / sqrt(sum);
+    sum = kn_div(1.0, tol * w0 * w0) + tol * sum * sum;
+    double h0 = kn_div(1.0, sqrt(sum));
     h0 = fmin(h0, tdist);
     h0 = (tout - t0) >= 0.0 ? h0 : -h0;
     h = h0;
@@ -1070,9 +1205,14 @@ struct Lsoda {
         if (ph != PH_DONE) { ret = -7; ph = PH_DONE; }
         break;
       }
-      // keep l <= lhi on every running lane (an order rises by one per trip at most), let lhi fall when it can
-      if (KN_ANY(ph != PH_DONE && l > lhi)) ++lhi;
-      else if (lhi > 2 && !KN_ANY(ph != PH_DONE && l >= lhi)) --lhi;
+      // keep l <= lhi on every running lane (an order rises by one per trip at most) and let lhi fall when it can;
+      // orders change a few times per sweep, so the common trip pays for one wave-wide test only
+      if (KN_ANY(ph != PH_DONE && l != lseen)) {
+        lseen = l;
+        if (KN_ANY(ph != PH_DONE && l > lhi)) ++lhi;
+        else
+          while (lhi > 2 && !KN_ANY(ph != PH_DONE && l >= lhi)) --lhi;
+      }
       bool ran = false;
       if constexpr (STAMPS) { stamp(0, true); ran = KN_ANY(ph == PH_TOP); }
       if (ph == PH_TOP) phase_top(mxstep);

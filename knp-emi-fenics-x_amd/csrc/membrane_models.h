@@ -62,23 +62,39 @@ struct ModelHHSI {
     dy[3] = (-i_K - i_Na) / Cm;
   }
   // Component-wise evaluation for the one-lane-per-component integrator: lane c computes dy[c].  The
-  // four lanes of a system run the same instruction stream; what differs per lane (exponent
-  // arguments, rate-law variant) is chosen with selects, so there is no divergence.  Every expression
-  // is the one `rhs` evaluates, hence bit-identical results.  The side-effect currents are those of
-  // the lane that owns V (CURRENT_LANE).
+  // four lanes of a system run the same straight-line instruction stream; what differs per lane (offsets and scales
+  // of the two exponent arguments, rate-law variant) is a handful of per-lane constants fixed by `set_lane` before the
+  // sweep and selects on c -- no divergence, no branch.  Every lane needs two exponentials and ONE quotient (lanes m
+  // and n: alpha = k n1 / (e1 - 1); lane h: beta = 1 / (e2 + 1); lane V divides by the constant C_m, i.e. multiplies by
+  // its reciprocal), and the exponent arguments (off - u) / d and the numerator k (off - u), u = s (V + 65 mV), are
+  // each ONE fused multiply-add on V with per-lane coefficients: the right-hand side is the longest stretch of
+  // every trip of the integrator and its depth in dependent fp64 instructions is what a sweep costs (lsoda_core.h,
+  // kn_div).  The expressions are those of `rhs` up to these roundings.  The side-effect currents are those of the
+  // lane that owns V (CURRENT_LANE).
   static constexpr int CURRENT_LANE = 3;
+  double l_a1, l_b1, l_a2, l_b2, l_ka, l_kb, l_k2, l_rCm;
+  KN_HD void set_lane(int c) {
+    // exponent arguments and the numerator of alpha as linear functions of V: (off - u) / d with u = s (V + 65 mV)
+    const double sv = 1.0e3, off1 = c == 0 ? 25. : (c == 2 ? 10. : 0.), off2 = c == 1 ? 30. : 0.;
+    const double rd1 = c == 1 ? 1.0 / 20. : (c == 3 ? 1.0 / 0.002 : 1.0 / 10.);
+    const double rd2 = c == 0 ? 1.0 / 18. : (c == 1 ? 1.0 / 10. : 1.0 / 80.);
+    const double k1 = c == 0 ? 0.1e3 : 0.01e3;
+    l_a1 = c == 3 ? 0.0 : (off1 - 65.) * rd1;
+    l_b1 = c == 3 ? -rd1 : -sv * rd1;          // lane V: the argument is -fmod(t, period) / tau
+    l_a2 = (off2 - 65.) * rd2;
+    l_b2 = -sv * rd2;
+    l_ka = k1 * (off1 - 65.);
+    l_kb = -k1 * sv;
+    l_k2 = c == 0 ? 4.e3 : 0.125e3;
+    l_rCm = kn_div(1.0, Cm);
+  }
   KN_HD double rhs_lane(int c, double t, const double* y) const {
     const double m = y[0], h = y[1], n = y[2], V = y[3];
-    const double u = 1.0e3 * (V + 65.0e-3);
-    const double n1 = c == 0 ? (25. - u) : (c == 1 ? -u : (c == 2 ? (10. - u) : -kn_fmod_period(t, 0.03)));
-    const double d1 = c == 1 ? 20. : (c == 3 ? 0.002 : 10.);
-    const double n2 = c == 1 ? (30. - u) : -u;
-    const double d2 = c == 0 ? 18. : (c == 1 ? 10. : 80.);
-    const double e1 = exp(kn_div(n1, d1)), e2 = exp(kn_div(n2, d2));
-    const double k1 = c == 0 ? 0.1e3 : 0.01e3;
-    const double alpha = c == 1 ? 0.07e3 * e1 : kn_div(k1 * n1, e1 - 1);
-    const double k2 = c == 0 ? 4.e3 : 0.125e3;
-    const double beta = c == 1 ? kn_div(1.e3, e2 + 1) : k2 * e2;
+    const double tp = kn_fmod_period(t, 0.03);
+    const double e1 = kn_exp(fma(c == 3 ? tp : V, l_b1, l_a1)), e2 = kn_exp(fma(V, l_b2, l_a2));
+    const double q = kn_div(c == 1 ? 1.e3 : fma(V, l_kb, l_ka), c == 1 ? e2 + 1 : e1 - 1);
+    const double alpha = c == 1 ? 0.07e3 * e1 : q;
+    const double beta = c == 1 ? q : l_k2 * e2;
     const double gate = c == 0 ? m : (c == 1 ? h : n);
     const double dgate = (1 - gate) * alpha - gate * beta;
     const double i_stim = stim * e1 * (t < 125e-3 ? 1.0 : 0.0);
@@ -87,7 +103,7 @@ struct ModelHHSI {
     const double i_K = (glK + gK * (n2q * n2q)) * (V - E_K) - 2 * i_pump;
     I_Na = i_Na;
     I_K = i_K;
-    return c == 3 ? kn_div(-i_K - i_Na, Cm) : dgate;
+    return c == 3 ? (-i_K - i_Na) * l_rCm : dgate;
   }
   template <class Row>
   KN_HD void finish(const Row& p) const { p[15] = I_Na; p[16] = I_K; p[17] = 0.0; }
@@ -128,18 +144,29 @@ struct ModelHHMV {
   }
   // component-wise evaluation, see ModelHHSI::rhs_lane
   static constexpr int CURRENT_LANE = 3;
+  double l_a1, l_b1, l_a2, l_b2, l_ka, l_kb, l_k2, l_rCm;
+  KN_HD void set_lane(int c) {
+    // exponent arguments and the numerator of alpha as linear functions of V: (off - u) / d with u = s (V + 65 mV)
+    const double sv = 1.0, off1 = c == 0 ? 25. : (c == 2 ? 10. : 0.), off2 = c == 1 ? 30. : 0.;
+    const double rd1 = c == 1 ? 1.0 / 20. : (c == 3 ? 1.0 / 2.0 : 1.0 / 10.);
+    const double rd2 = c == 0 ? 1.0 / 18. : (c == 1 ? 1.0 / 10. : 1.0 / 80.);
+    const double k1 = c == 0 ? 0.1 : 0.01;
+    l_a1 = c == 3 ? 0.0 : (off1 - 65.) * rd1;
+    l_b1 = c == 3 ? -rd1 : -sv * rd1;          // lane V: the argument is -fmod(t, period) / tau
+    l_a2 = (off2 - 65.) * rd2;
+    l_b2 = -sv * rd2;
+    l_ka = k1 * (off1 - 65.);
+    l_kb = -k1 * sv;
+    l_k2 = c == 0 ? 4. : 0.125;
+    l_rCm = kn_div(1.0, Cm);
+  }
   KN_HD double rhs_lane(int c, double t, const double* y) const {
     const double m = y[0], h = y[1], n = y[2], V = y[3];
-    const double u = V + 65.0;
-    const double n1 = c == 0 ? (25. - u) : (c == 1 ? -u : (c == 2 ? (10. - u) : -kn_fmod_period(t, 30.0)));
-    const double d1 = c == 1 ? 20. : (c == 3 ? 2.0 : 10.);
-    const double n2 = c == 1 ? (30. - u) : -u;
-    const double d2 = c == 0 ? 18. : (c == 1 ? 10. : 80.);
-    const double e1 = exp(kn_div(n1, d1)), e2 = exp(kn_div(n2, d2));
-    const double k1 = c == 0 ? 0.1 : 0.01;
-    const double alpha = c == 1 ? 0.07 * e1 : kn_div(k1 * n1, e1 - 1);
-    const double k2 = c == 0 ? 4. : 0.125;
-    const double beta = c == 1 ? kn_div(1., e2 + 1) : k2 * e2;
+    const double tp = kn_fmod_period(t, 30.0);
+    const double e1 = kn_exp(fma(c == 3 ? tp : V, l_b1, l_a1)), e2 = kn_exp(fma(V, l_b2, l_a2));
+    const double q = kn_div(c == 1 ? 1. : fma(V, l_kb, l_ka), c == 1 ? e2 + 1 : e1 - 1);
+    const double alpha = c == 1 ? 0.07 * e1 : q;
+    const double beta = c == 1 ? q : l_k2 * e2;
     const double gate = c == 0 ? m : (c == 1 ? h : n);
     const double dgate = (1 - gate) * alpha - gate * beta;
     const double i_stim = stim * e1 * (t < 125 ? 1.0 : 0.0);
@@ -148,7 +175,7 @@ struct ModelHHMV {
     const double i_K = (glK + gK * (n2q * n2q)) * (V - E_K) - 2 * i_pump;
     I_Na = i_Na;
     I_K = i_K;
-    return c == 3 ? kn_div(-i_K - i_Na, Cm) : dgate;
+    return c == 3 ? (-i_K - i_Na) * l_rCm : dgate;
   }
   template <class Row>
   KN_HD void finish(const Row& p) const { p[15] = I_Na; p[16] = I_K; p[17] = 0.0; }
@@ -177,8 +204,8 @@ struct ModelGlial {
     (void)t;
     const double V = y[0];
     const double dphi = V - E_K;
-    const double C = 1 + exp(kn_div(dphi + 18.5, 42.4));
-    const double D = 1 + exp(kn_div(-(118.6 + V), 44.1));
+    const double C = 1 + kn_exp(kn_div(dphi + 18.5, 42.4));
+    const double D = 1 + kn_exp(kn_div(-(118.6 + V), 44.1));
     const double g_Kir = kn_div(gfac, C * D);
     const double i_Kir = glK * g_Kir * (V - E_K);
     const double i_Na = glNa * (V - E_Na) + 3 * i_pump;

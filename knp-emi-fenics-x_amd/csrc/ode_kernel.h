@@ -37,6 +37,12 @@ struct OdeArgs {
 
 constexpr int ODE_BLOCK = 64;
 
+// a model may fix per-lane constants of its component-wise right-hand side once per sweep (membrane_models.h)
+template <class M>
+KN_HD auto kn_model_set_lane(M& m, int c, int) -> decltype(m.set_lane(c), void()) { m.set_lane(c); }
+template <class M>
+KN_HD void kn_model_set_lane(M&, int, long) {}
+
 template <int S>
 struct StridedRow {   // p[j] of dof q in a [column][dof] table: base + j * S
   double* b;
@@ -95,6 +101,7 @@ __device__ __forceinline__ void ode_step_body(const OdeDev& D, const OdeArgs& a,
   Integrator s;
   if constexpr (STAMPS) s.st_last = __builtin_amdgcn_s_memtime();
   s.f.prepare(p);
+  if constexpr (LANES > 1) kn_model_set_lane(s.f, comp, 0);
   const int rc = s.integrate(&scf, work + threadIdx.x, y, a.t0, a.t0 + a.dt, a.rtol, a.atol, 10000, comp);
   // 3. write back: state row, phi_M_prev <- V; the lane that owns V stores the currents (the reference's
   //    RHS side effect) into the parameter row and the I_ch_k fields

@@ -131,6 +131,7 @@ SIGNATURES = {
     "knpemi_ode_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64),
                                    C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "knpemi_debug_ode_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_int]),
+    "knpemi_debug_math": (C.c_int, [C.c_int, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p]),
     "knpemi_update_pde": (C.c_int, [C.c_void_p]),
     "knpemi_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "knpemi_trace": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p]),

@@ -236,6 +236,52 @@ def test_ode_sweep_matches_scipy_lsoda(hip_lib, g_syn):
     assert abs(ode.time - 3 * s.dt) < 1e-15
 
 
+def test_device_math_helpers(hip_lib):
+    """The quotient, exponential and power the ODE sweep evaluates on the device (csrc/lsoda_core.h: kn_div = reciprocal
+    estimate times the product form of the Newton series, kn_exp = two-constant reduction + degree-13 polynomial in
+    Estrin's arrangement, kn_log = the classical f / (2 + f) reduction, kn_powr = exp(e log x)) against the C library:
+    within 4 ulp (kn_div, kn_exp, kn_log), 16 ulp (kn_powr: the rounding of log x is amplified by e |log x|), exact
+    limits at the ends of the range."""
+    rng = np.random.default_rng(11)
+    n = 200000
+
+    def run(op, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        out = np.empty_like(a)
+        L.check(hip_lib.knpemi_debug_math(op, a.size, L.dptr(a), L.dptr(b), L.dptr(out)))
+        return out
+
+    def ulps(x, ref):
+        return np.abs(x - ref) / np.spacing(np.abs(ref))
+
+    a = rng.standard_normal(n) * 10.0 ** rng.uniform(-30, 30, n)
+    b = rng.standard_normal(n) * 10.0 ** rng.uniform(-30, 30, n)
+    assert ulps(run(0, a, b), a / b).max() <= 4.0
+    assert ulps(run(0, np.ones(n), b), 1.0 / b).max() <= 4.0
+    x = np.concatenate([rng.uniform(-700.0, 700.0, n // 2), rng.uniform(-5.0, 5.0, n // 2)])
+    assert ulps(run(1, x, x), np.exp(x)).max() <= 4.0
+    ends = np.array([0.0, -0.0, 710.0, 1e300, np.inf, -746.0, -1e300, -np.inf, 709.0, -744.0, -708.0])
+    got = run(1, ends, ends)
+    with np.errstate(over="ignore"):
+        want = np.exp(ends)
+    assert np.array_equal(got[:8], want[:8])
+    assert ulps(got[8:], want[8:]).max() <= 4.0
+    assert np.isnan(run(1, np.array([np.nan]), np.array([np.nan]))[0])
+    pos = 10.0 ** rng.uniform(-300, 300, n)
+    pos[: n // 4] = rng.uniform(0.5, 2.0, n // 4)
+    assert ulps(run(3, pos, pos), np.log(pos)).max() <= 4.0
+    ends = np.array([0.0, np.inf, 1.0, 5e-324, 1e-310])
+    with np.errstate(divide="ignore"):
+        assert np.array_equal(run(3, ends, ends)[:3], np.log(ends[:3]))
+        assert ulps(run(3, ends, ends)[3:], np.log(ends[3:])).max() <= 4.0
+    assert np.isnan(run(3, np.array([-1.0, np.nan]), np.array([1.0, 1.0]))).all()
+    base = 10.0 ** rng.uniform(-12, 3, n)
+    ex = 1.0 / rng.integers(2, 14, n)
+    assert ulps(run(2, base, ex), base ** ex).max() <= 16.0
+    assert run(2, np.array([0.0]), np.array([0.5]))[0] == 0.0
+
+
 def test_lsoda_failure_is_reported(hip_lib):
     """`assert success` after every LSODA call (odeSolver.py:121): a dof whose state is NaN cannot be integrated; the
     sweep must say so (KNPEMI_EODE -> AssertionError, failure count) instead of returning silently, and the healthy
