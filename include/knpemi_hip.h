@@ -369,13 +369,17 @@ void* knpemi_stream(knpemi_handle* h);
  * emiWeakForm.py:138-241 / knpWeakForm.py:123-166 cell by cell, interior-penalty and upwind terms on the interior
  * facets of every sub-domain, and the reference's membrane terms (emiWeakForm.py:160-165,228-239,
  * knpWeakForm.py:168-214) on the tagged facets, with phi_M and I_ch living at the vertices of each membrane facet.
- * Simplices only (triangles, tetrahedra).  Dof (cell c, local vertex j) = c * nv + j; membrane node (facet f,
- * vertex a) = f * nf + a; CSR rows hold one nv-wide block per cell (the cell itself and its facet neighbours, in
- * increasing cell order).  The K - 1 concentration systems share the pattern of the potential system. */
+ * Triangles and tetrahedra (broken P1) and hexahedra (broken Q1: the cell type of the reference's own 3-D idealized
+ * mesh, make_mesh_3D.py:100-102; volume terms by the 2 x 2 x 2 Gauss rule, facet terms by the 2 x 2 rule with every
+ * quantity taken at the point, membrane terms by the reference's quadrilateral rules).  Dof (cell c, local vertex j)
+ * = c * nv + j; membrane node (facet f, vertex a) = f * nf + a; CSR rows hold one nv-wide block per cell (the cell
+ * itself and its facet neighbours, in increasing cell order).  The K - 1 concentration systems share the pattern of
+ * the potential system. */
 typedef struct knpemi_dg knpemi_dg;
 
 typedef struct {
-  int32_t cell_kind;            /* KNPEMI_TRIANGLE | KNPEMI_TETRAHEDRON */
+  int32_t cell_kind;            /* KNPEMI_TRIANGLE | KNPEMI_TETRAHEDRON | KNPEMI_HEXAHEDRON (broken Q1; local vertex j at the
+                                   reference point whose coordinate along axis a is bit a of j) */
   int32_t n_sub;                /* sub-domains, ECS = 0 */
   int32_t n_ions;               /* K = 2..4, the last one eliminated */
   int64_t n_cells, n_vertices, n_mem_facets;

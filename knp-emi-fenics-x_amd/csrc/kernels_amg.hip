@@ -186,7 +186,7 @@ double estimate_rho_block(const HostCsr& A, int bs) {
   const int nb = A.n / bs;
   std::vector<double> binv((size_t)nb * bs * bs);
   for (int c = 0; c < nb; ++c) {
-    double m[16] = {0};
+    double m[64] = {0};
     for (int a = 0; a < bs; ++a)
       for (int j = A.rp[c * bs + a]; j < A.rp[c * bs + a + 1]; ++j) {
         const int b = A.ci[j] - c * bs;
@@ -412,7 +412,8 @@ void launch_spmv(hipStream_t st, int n, int avg_row, const int* rp, const int* c
 void block_apply(hipStream_t st, const KnAmg& G, int n, const double* v, const double* x, double* y) {
   dim3 g((n + 255) / 256);
   if (G.block == 3) hipLaunchKernelGGL(amg_block_apply_kernel<3>, g, dim3(256), 0, st, n, G.binv, v, x, G.omega_block, y);
-  else hipLaunchKernelGGL(amg_block_apply_kernel<4>, g, dim3(256), 0, st, n, G.binv, v, x, G.omega_block, y);
+  else if (G.block == 4) hipLaunchKernelGGL(amg_block_apply_kernel<4>, g, dim3(256), 0, st, n, G.binv, v, x, G.omega_block, y);
+  else hipLaunchKernelGGL(amg_block_apply_kernel<8>, g, dim3(256), 0, st, n, G.binv, v, x, G.omega_block, y);
 }
 
 template <class T>
@@ -508,7 +509,10 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
     L.omega = 4.0 / (3.0 * rho);
     L.avg_row = cur.n ? (int)(cur.ci.size() / (size_t)cur.n) : 0;
     if (l == 0 && G.block > 0) {
-      if (cur.n % G.block || G.block > 4) { kn_set_error("AMG set-up: bad smoother block size"); return KNPEMI_EINVAL; }
+      if (cur.n % G.block || (G.block != 3 && G.block != 4 && G.block != 8)) {
+        kn_set_error("AMG set-up: bad smoother block size");
+        return KNPEMI_EINVAL;
+      }
       const double rb = estimate_rho_block(cur, G.block);
       if (!(rb > 0)) { kn_set_error("AMG set-up: singular diagonal block"); return KNPEMI_ESOLVE; }
       G.omega_block = 4.0 / (3.0 * rb);
@@ -647,7 +651,8 @@ int kn_amg_refresh(knpemi_handle* h, KnAmg& G, const double* vals) {
   dim3 g((nb + 255) / 256);
   if (G.block == 3) hipLaunchKernelGGL(amg_block_inv_kernel<3>, g, dim3(256), 0, h->stream, nb, L.A.rp, L.A.ci, vals, G.binv);
   else if (G.block == 4) hipLaunchKernelGGL(amg_block_inv_kernel<4>, g, dim3(256), 0, h->stream, nb, L.A.rp, L.A.ci, vals, G.binv);
-  else { kn_set_error("AMG: smoother blocks of 3 or 4 unknowns only"); return KNPEMI_EINVAL; }
+  else if (G.block == 8) hipLaunchKernelGGL(amg_block_inv_kernel<8>, dim3((nb + 63) / 64), dim3(64), 0, h->stream, nb, L.A.rp, L.A.ci, vals, G.binv);
+  else { kn_set_error("AMG: smoother blocks of 3, 4 or 8 unknowns only"); return KNPEMI_EINVAL; }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { kn_set_error(std::string("amg_block_inv_kernel: ") + hipGetErrorString(e)); return KNPEMI_EHIP; }
   return KNPEMI_OK;

@@ -31,105 +31,18 @@
 #include <cmath>
 #include <cstring>
 
-#include "knpemi_internal.h"
+#include "dg_internal.h"
 #include "ode_kernel.h"
 
 namespace {
 
-#ifndef KN_DG_BLOCK
-#define KN_DG_BLOCK 64
-#endif
-#ifndef KN_DG_ROUND
-#define KN_DG_ROUND KN_DG_BLOCK
-#endif
-constexpr int DG_BLOCK = KN_DG_BLOCK;   // threads (= rows) per workgroup
-constexpr int DG_RPITCH = 10;           // doubles per staged record in LDS
-constexpr int DG_ROUND = KN_DG_ROUND;   // rows whose image is in LDS at a time
-
-struct DgConsts {
-  int n_sub, K;
-  double F, psi, C_M, dt, inv_dt, C_phi, gamma;
-  double z[KN_MAXK];
-  double elim[KN_MAXK];              // -(z_k / z_K)
-  double D[KN_MAXSUB][KN_MAXK];
-  double kap[KN_MAXSUB][KN_MAXK];    // F psi z_k^2 D_k
-  double sig[KN_MAXSUB][KN_MAXK];    // F z_k D_k
-  double az2D[KN_MAXSUB][KN_MAXK];   // D_k z_k^2
-  double rho_term[KN_MAXSUB];        // -(1 / z_K) rho_z rho^s
-};
-
-struct DgDev {
-  int n_cell, n_dof, nq;             // nq: membrane nodes
-  int nquad;                         // points of the degree-6 membrane rule
-  long long nnz;
-  double* rec;
-  const int* nbr;
-  const unsigned* finfo;
-  const int* mfid;                   // [n_cell][nv] membrane facet of local facet f (-1)
-  const unsigned char* cell_sub;
-  const int* rowptr;
-  double* A_emi;
-  double* b_emi;
-  double* A_knp;                     // [K-1][nnz]
-  double* b_knp;                     // [K-1][n_dof]
-  double* phiM;                      // [nq]
-  double* Ich;                       // [KN_MAXK][nq]
-  const double* fsrc;                // [K-1][n_dof] or NULL
-  const double* qtab;                // weights, then shape values [nquad][nf]
-  const int* q2e;
-  const int* q2i;
-};
-
-struct DofRec {
-  double x[3], c[KN_MAXK], phi;
-};
-
-__device__ __forceinline__ DofRec load_rec(const double* rec, int dof) {
-  const double2* p = reinterpret_cast<const double2*>(rec + (size_t)dof * KN_REC);
-  const double2 a = p[0], b = p[1], c = p[2], d = p[3];
-  DofRec r;
-  r.x[0] = a.x; r.x[1] = a.y; r.x[2] = b.x;
-  r.c[3] = b.y; r.c[0] = c.x; r.c[1] = c.y; r.c[2] = d.x; r.phi = d.y;
-  return r;
-}
-
-// The workgroup's own records are staged in LDS by one coalesced pass (lane t loads record row0 + t) and read from there
-// by the NV lanes of each cell; 10-double pitch keeps the 16-byte reads of a wave on distinct banks.
-
-__device__ __forceinline__ void stage_rec(double* lrec, const double* rec, int dof, int t) {
-  const double2* p = reinterpret_cast<const double2*>(rec + (size_t)dof * KN_REC);
-  double2* q = reinterpret_cast<double2*>(lrec + t * DG_RPITCH);
-  const double2 a = p[0], b = p[1], c = p[2], d = p[3];
-  q[0] = a; q[1] = b; q[2] = c; q[3] = d;
-}
-
-__device__ __forceinline__ DofRec lds_rec(const double* lrec, int t) {
-  const double2* p = reinterpret_cast<const double2*>(lrec + t * DG_RPITCH);
-  const double2 a = p[0], b = p[1], c = p[2], d = p[3];
-  DofRec r;
-  r.x[0] = a.x; r.x[1] = a.y; r.x[2] = b.x;
-  r.c[3] = b.y; r.c[0] = c.x; r.c[1] = c.y; r.c[2] = d.x; r.phi = d.y;
-  return r;
-}
+using namespace kn_dg;
 
 template <int NV>
 struct Geo {
   double g[NV][NV - 1];   // gradients of the barycentric coordinates
   double vol;
 };
-
-// 1 / a and 1 / sqrt(a) from the hardware estimates plus two Newton steps (relative error ~1e-16): a fraction of the
-// instruction count of the IEEE division / square-root sequences, and the results are only compared at 1e-10.
-__device__ __forceinline__ double fast_rcp(double a) {
-  double r = __builtin_amdgcn_rcp(a);
-  r = fma(fma(-a, r, 1.0), r, r);
-  return fma(fma(-a, r, 1.0), r, r);
-}
-__device__ __forceinline__ double fast_rsqrt(double a) {
-  double y = __builtin_amdgcn_rsq(a);
-  y = y * fma(-0.5 * a * y, y, 1.5);
-  return y * fma(-0.5 * a * y, y, 1.5);
-}
 
 template <int GD>
 __device__ __forceinline__ double dot(const double (&a)[GD], const double (&b)[GD]) {
@@ -172,10 +85,6 @@ __device__ __forceinline__ void geometry(const double (&X)[NV][NV - 1], Geo<NV>&
     G.vol = fabs(det) * (1.0 / 6.0);
   }
 }
-
-// Workgroups are dealt to the 8 XCDs round robin; give every XCD a contiguous run of cells so that the neighbour
-// records a workgroup reads are mostly the ones its XCD's L2 already holds.  Bijection on [0, 8 * chunk).
-__device__ __forceinline__ int dg_block_index(int b, int chunk) { return (b & 7) * chunk + (b >> 3); }
 
 // position of every block of the row: the cell itself and the neighbours in increasing cell order
 template <int NV>
@@ -763,6 +672,7 @@ __global__ void dg_slot_kernel(double* rec, int slot, double* buf, int n, int to
 // ---------------------------------------------------------------------------------------------------------------------
 struct knpemi_dg {
   int device = 0, NV = 0, K = 0, n_sub = 0;
+  int NFC = 0, NFV = 0;            // facets per cell, vertices per facet (hexahedra: 6 and 4)
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DgDev dev{};
@@ -856,6 +766,7 @@ struct DgProf {   // brackets one launch with an event pair on the handle's stre
 
 int launch_emi(knpemi_dg* h, int flags) {
   DgProf prof(h, 0);
+  if (h->NV == 8) return kn_dg_hex_launch_emi(h->stream, h->dev, h->d_consts, !(flags & KNPEMI_NO_SPLITTING));
   const int NV = h->NV, rpb = (DG_BLOCK / NV) * NV;
   const int nblocks = (h->dev.n_dof + rpb - 1) / rpb, chunk = (nblocks + 7) / 8;
   const size_t lds = ((size_t)rpb * (NV == 3 ? dg_fs_emi<3>() : dg_fs_emi<4>()) +
@@ -880,6 +791,7 @@ int launch_knp_nv(knpemi_dg* h, int chunk, int split) {
 
 int launch_knp(knpemi_dg* h, int flags) {
   DgProf prof(h, 1);
+  if (h->NV == 8) return kn_dg_hex_launch_knp(h->stream, h->dev, h->d_consts, h->K - 1, !(flags & KNPEMI_NO_SPLITTING));
   const int NV = h->NV, rpb = (DG_BLOCK / NV) * NV;
   const int nblocks = (h->dev.n_dof + rpb - 1) / rpb, chunk = (nblocks + 7) / 8;
   const int split = !(flags & KNPEMI_NO_SPLITTING);
@@ -914,11 +826,20 @@ extern "C" void knpemi_dg_destroy(knpemi_dg* h) {
 extern "C" int knpemi_dg_create(const knpemi_dg_desc* d, int device, knpemi_dg** out) {
   if (!d || !out) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: null argument");
   *out = nullptr;
-  int NV;
-  if (d->cell_kind == KNPEMI_TRIANGLE) NV = 3;
-  else if (d->cell_kind == KNPEMI_TETRAHEDRON) NV = 4;
-  else return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: the DG variant is built for simplices (triangles, tetrahedra)");
-  const int GD = NV - 1, NF = NV - 1;
+  int NV, NFC, NF, GD;   // vertices and facets per cell, vertices per facet, dimension
+  if (d->cell_kind == KNPEMI_TRIANGLE) { NV = 3; NFC = 3; NF = 2; GD = 2; }
+  else if (d->cell_kind == KNPEMI_TETRAHEDRON) { NV = 4; NFC = 4; NF = 3; GD = 3; }
+  else if (d->cell_kind == KNPEMI_HEXAHEDRON) { NV = 8; NFC = 6; NF = 4; GD = 3; }
+  else return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: unknown cell kind");
+  const bool hex = NV == 8;
+  // local vertex of local facet f at facet position m.  Simplices: facet f is opposite vertex f, its vertices in
+  // increasing local order.  Hexahedra (tensor numbering: bit a of a local vertex is its coordinate along axis a):
+  // facet f = 2 a + b is xi_a = b, position m has bit 0 along the lower and bit 1 along the higher remaining axis.
+  auto facet_vertex = [&](int f, int m) {
+    if (!hex) return m < f ? m : m + 1;
+    const int a = f >> 1, b = f & 1, a1 = a == 0 ? 1 : 0, a2 = a == 2 ? 1 : 2;
+    return (b << a) | ((m & 1) << a1) | ((m >> 1) << a2);
+  };
   if (d->n_ions < 2 || d->n_ions > KN_MAXK) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: 2 to 4 ionic species are supported");
   if (d->n_sub < 1 || d->n_sub > KN_MAXSUB) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: bad n_sub");
   if (d->n_cells < 1 || d->n_cells * NV >= (int64_t)1 << 31) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: bad n_cells");
@@ -930,6 +851,7 @@ extern "C" int knpemi_dg_create(const knpemi_dg_desc* d, int device, knpemi_dg**
   auto* h = new knpemi_dg();
   std::unique_ptr<knpemi_dg, void (*)(knpemi_dg*)> guard(h, knpemi_dg_destroy);
   h->device = device; h->NV = NV; h->K = d->n_ions; h->n_sub = d->n_sub;
+  h->NFC = NFC; h->NFV = NF;
   KN_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   KN_HIP(hipEventCreate(&h->ev0));
   KN_HIP(hipEventCreate(&h->ev1));
@@ -938,28 +860,33 @@ extern "C" int knpemi_dg_create(const knpemi_dg_desc* d, int device, knpemi_dg**
   for (int c = 0; c < nc; ++c)
     if (d->cell_sub[c] < 0 || d->cell_sub[c] >= d->n_sub) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: cell_sub out of range");
   // facet -> (cell, local facet) by sorting the facets' sorted vertex tuples; membrane facets ride along with id < 0
-  struct Ent { std::array<int, 3> key; int id; };
+  struct Ent { std::array<int, 4> key; int id; };
   std::vector<Ent> ents;
-  ents.reserve((size_t)n + nmf);
-  auto make_key = [&](const int32_t* v, int skip, int cnt) {
-    std::array<int, 3> k = {-1, -1, -1};
-    int m = 0;
-    for (int a = 0; a < cnt; ++a) if (a != skip) k[m++] = v[a];
-    std::sort(k.begin(), k.begin() + m);
+  const int nfac = nc * NFC;
+  ents.reserve((size_t)nfac + nmf);
+  auto sorted_key = [&](std::array<int, 4> k) {
+    std::sort(k.begin(), k.begin() + NF);
     return k;
   };
-  for (int c = 0; c < nc; ++c)
-    for (int f = 0; f < NV; ++f) {
-      for (int a = 0; a < NV; ++a)
-        if (d->cells[(size_t)c * NV + a] < 0 || d->cells[(size_t)c * NV + a] >= d->n_vertices)
-          return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: vertex id out of range");
-      ents.push_back({make_key(d->cells + (size_t)c * NV, f, NV), c * NV + f});
+  for (int c = 0; c < nc; ++c) {
+    for (int a = 0; a < NV; ++a)
+      if (d->cells[(size_t)c * NV + a] < 0 || d->cells[(size_t)c * NV + a] >= d->n_vertices)
+        return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: vertex id out of range");
+    for (int f = 0; f < NFC; ++f) {
+      std::array<int, 4> k = {-1, -1, -1, -1};
+      for (int m = 0; m < NF; ++m) k[m] = d->cells[(size_t)c * NV + facet_vertex(f, m)];
+      ents.push_back({sorted_key(k), c * NFC + f});
     }
-  for (int m = 0; m < nmf; ++m) ents.push_back({make_key(d->mem_facets + (size_t)m * NF, -1, NF), -1 - m});
+  }
+  for (int m = 0; m < nmf; ++m) {
+    std::array<int, 4> k = {-1, -1, -1, -1};
+    for (int a = 0; a < NF; ++a) k[a] = d->mem_facets[(size_t)m * NF + a];
+    ents.push_back({sorted_key(k), -1 - m});
+  }
   std::sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key != b.key ? a.key < b.key : a.id < b.id; });
 
-  std::vector<int> nbr((size_t)n, -1), mfid((size_t)n, -1);
-  std::vector<unsigned> finfo((size_t)n, 0u);
+  std::vector<int> nbr((size_t)nfac, -1), mfid((size_t)nfac, -1);
+  std::vector<unsigned> finfo((size_t)nfac, 0u);
   std::vector<unsigned char> csub((size_t)nc);
   for (int c = 0; c < nc; ++c) csub[c] = (unsigned char)d->cell_sub[c];
   h->h_q2e.assign((size_t)nmf * NF, -1);
@@ -997,7 +924,7 @@ extern "C" int knpemi_dg_create(const knpemi_dg_desc* d, int device, knpemi_dg**
       if (mem >= 0) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: membrane facet is not shared by two cells");
       continue;
     }
-    const int c0 = cf[0] / NV, f0 = cf[0] % NV, c1 = cf[1] / NV, f1 = cf[1] % NV;
+    const int c0 = cf[0] / NFC, f0 = cf[0] % NFC, c1 = cf[1] / NFC, f1 = cf[1] % NFC;
     const int s0 = d->cell_sub[c0], s1 = d->cell_sub[c1];
     int kind0 = 1, kind1 = 1;
     if (mem >= 0) {
@@ -1011,23 +938,30 @@ extern "C" int knpemi_dg_create(const knpemi_dg_desc* d, int device, knpemi_dg**
     for (int side = 0; side < 2; ++side) {
       const int c = side ? c1 : c0, f = side ? f1 : f0, o = side ? c0 : c1, fo = side ? f0 : f1;
       unsigned w = (unsigned)(side ? kind1 : kind0) | (unsigned)fo << 2;
-      for (int a = 0; a < NV; ++a) {
-        if (a == f) continue;
+      for (int m = 0; m < NF; ++m) {
+        const int a = facet_vertex(f, m);
         const int v = d->cells[(size_t)c * NV + a];
         const int lo_ = local_of(o, v);
         if (lo_ < 0) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: two cells share a facet key but not its vertices");
-        w |= (unsigned)lo_ << (4 + 2 * a);
+        // simplices: 2-bit fields indexed by the cell's local vertex; hexahedra: 3-bit / 2-bit fields by facet position
+        w |= hex ? (unsigned)lo_ << (5 + 3 * m) : (unsigned)lo_ << (4 + 2 * a);
         if (mem >= 0) {
           int node = -1;
           for (int t = 0; t < NF; ++t) if (d->mem_facets[(size_t)mem * NF + t] == v) node = t;
           if (node < 0) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: membrane facet vertices do not match the cells'");
-          w |= (unsigned)node << (12 + 2 * a);
+          w |= hex ? (unsigned)node << (17 + 2 * m) : (unsigned)node << (12 + 2 * a);
           (d->cell_sub[c] == 0 ? h->h_q2e : h->h_q2i)[(size_t)mem * NF + node] = c * NV + a;
         }
       }
-      nbr[(size_t)c * NV + f] = o;
-      finfo[(size_t)c * NV + f] = w;
-      mfid[(size_t)c * NV + f] = mem;
+      if (hex) {   // the facet of the neighbour must be one of ITS facets with the four vertices at matching positions
+        const int ao = fo >> 1;
+        for (int m = 0; m < NF; ++m)
+          if ((int)((((w >> (5 + 3 * m)) & 7) >> ao) & 1) != (fo & 1))
+            return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: hexahedra are not in tensor-product vertex order");
+      }
+      nbr[(size_t)c * NFC + f] = o;
+      finfo[(size_t)c * NFC + f] = w;
+      mfid[(size_t)c * NFC + f] = mem;
     }
   }
   // CSR pattern: per row one nv-wide block per cell of {self} + neighbours, increasing cell order
@@ -1035,15 +969,15 @@ extern "C" int knpemi_dg_create(const knpemi_dg_desc* d, int device, knpemi_dg**
   int64_t nnz = 0;
   for (int c = 0; c < nc; ++c) {
     int cnt = 1;
-    for (int f = 0; f < NV; ++f) cnt += nbr[(size_t)c * NV + f] >= 0;
+    for (int f = 0; f < NFC; ++f) cnt += nbr[(size_t)c * NFC + f] >= 0;
     for (int i = 0; i < NV; ++i) { nnz += (int64_t)cnt * NV; h->h_rowptr[(size_t)c * NV + i + 1] = (int)nnz; }
     if (nnz >= ((int64_t)1 << 31) - 64) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: more than 2^31 matrix entries");
   }
   h->h_colind.resize((size_t)nnz);
   for (int c = 0; c < nc; ++c) {
-    int blk[5], cnt = 0;
+    int blk[7], cnt = 0;
     blk[cnt++] = c;
-    for (int f = 0; f < NV; ++f) if (nbr[(size_t)c * NV + f] >= 0) blk[cnt++] = nbr[(size_t)c * NV + f];
+    for (int f = 0; f < NFC; ++f) if (nbr[(size_t)c * NFC + f] >= 0) blk[cnt++] = nbr[(size_t)c * NFC + f];
     std::sort(blk, blk + cnt);
     for (int i = 0; i < NV; ++i) {
       int* ci = h->h_colind.data() + h->h_rowptr[(size_t)c * NV + i];

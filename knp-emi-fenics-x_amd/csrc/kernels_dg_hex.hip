@@ -1,0 +1,724 @@
+// DG(Q1) + symmetric interior penalty on hexahedra for gfx950: the broken-space variant on
+// the reference's own 3-D idealized mesh (examples/idealized_geometries/make_mesh_3D.py:100-102 builds Q1 hexahedra).
+//
+// As for the simplicial kernels (kernels_dg.hip) no reference file is restated: the discrete problem is the one
+// oracle/knpemi_dg_oracle.py (DGOracleQ1) spells out -- the reference's volume terms cell by cell with the 2 x 2 x 2 Gauss
+// rule, SIP + upwind terms with the 2 x 2 rule on interior facets (everything taken at the point), the reference's
+// membrane terms (emiWeakForm.py:160-165,228-239, knpWeakForm.py:168-214) with its quadrilateral rules on tagged facets.
+//
+// Layout.  Local vertex j of a cell sits at the reference point whose coordinate along axis a is bit a of j, dof
+// (cell c, vertex j) = 8 c + j in the 64-byte record layout of the other paths; local facet f = 2 a + b is xi_a = b, its
+// vertex at facet position m (bit 0 along the lower remaining axis, bit 1 along the higher) is facet_vertex(a, b, m).
+// nbr / finfo / mfid are [n_cell][6]; finfo = kind | neighbour's local facet << 2 | the neighbour's local vertex of my
+// facet vertex m << (5 + 3 m) | membrane node of facet vertex m << (17 + 2 m).  A row holds one 8-wide block per cell of
+// {the cell} + its facet neighbours in increasing cell order: every block of a row is one 64-byte line.
+//
+// One lane per row, one wave (8 cells) per workgroup, three phases:
+//   1. lane (cell, facet) -- 48 of the 64 lanes -- prepares its facet IN A FRAME ALIGNED WITH THE FACET: both adjacent
+//      cells are trilinear over (s, t) on the facet and a depth coordinate w, x = sum_m N_m(s, t) (x_m + w d_m) with d_m the
+//      edge from facet vertex m to the vertex behind it, so at a facet point the Jacobian of either cell is
+//      [t_s t_t d(s, t)] with the SHARED tangents t_s, t_t and the cell's own depth vector d.  The normal derivative of
+//      every basis function of either cell then needs three numbers per cell and point:
+//        grad phi_(m, w=0) . n = d_s N_m a_s + d_t N_m a_t - N_m c,   grad phi_(m, w=1) . n = N_m c,
+//        c = 1 / (d . n),  a_s = ((t_t x d) . n) / det,  a_t = ((d x t_s) . n) / det,  det = d . (t_s x t_t)
+//      -- no 3 x 3 inverse of the neighbour, no reference coordinates of the neighbour.  The lane leaves per point the
+//      surface weight, 1 / h_F = (|c_T| + |c_N|) / 2, (a_s, a_t, c) of both cells and the traces the rows need;
+//   1b. lane (cell, i) inverts the Jacobian at volume Gauss point i of its cell and leaves it in LDS;
+//   2. every lane builds its row: volume terms from the eight shared inverses, facet terms from the six facet summaries.
+//      Loops over facets, points and columns are unrolled, so every index into a register array is a compile-time
+//      constant; what depends on the lane's own vertex i are a few scalars per point (its trace and normal derivative).
+//      The neighbour blocks are put into the neighbour's local column order through a small LDS scratch and leave as
+//      four 16-byte stores per lane: whole 64-byte lines.
+#include <string>
+#include <type_traits>
+
+#include "dg_internal.h"
+
+namespace {
+
+using namespace kn_dg;
+
+constexpr int HX_NV = 8, HX_NFC = 6;
+constexpr int HX_CELLS = DG_BLOCK / HX_NV;          // cells per workgroup
+constexpr int HX_TASKS = HX_CELLS * HX_NFC;         // (cell, facet) pairs per workgroup
+constexpr int HX_FS_EMI = 49;                       // doubles per facet summary (12 per point, odd pitch)
+constexpr int HX_VG = 10;                           // inverse Jacobian (9) + weight * |det|
+constexpr int HX_SCR = 9;                           // scratch pitch of the column permutation
+constexpr double HX_G0 = 0.21132486540518711775, HX_G1 = 0.78867513459481288225;   // 2-point Gauss on [0, 1]
+
+__host__ __device__ constexpr int hx_ax1(int a) { return a == 0 ? 1 : 0; }
+__host__ __device__ constexpr int hx_ax2(int a) { return a == 2 ? 1 : 2; }
+__host__ __device__ constexpr int hx_facet_vertex(int a, int b, int m) {
+  return (b << a) | ((m & 1) << hx_ax1(a)) | ((m >> 1) << hx_ax2(a));
+}
+// value at a Gauss point of the 1-D shape function of a vertex: the far one (G0) when the bits differ
+__host__ __device__ constexpr double hx_w(int bit) { return bit ? HX_G0 : HX_G1; }
+
+struct Vec3 {
+  double x, y, z;
+};
+__device__ __forceinline__ Vec3 cross(const Vec3& a, const Vec3& b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ double dot3(const Vec3& a, const Vec3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// position of the row's blocks: the cell itself and its neighbours in increasing cell order
+__device__ __forceinline__ void hx_slots(int T, const int (&nb)[HX_NFC], int& slot_self, int (&slot)[HX_NFC]) {
+  slot_self = 0;
+#pragma unroll
+  for (int f = 0; f < HX_NFC; ++f) {
+    slot_self += nb[f] >= 0 && nb[f] < T;
+    int s = T < nb[f];
+#pragma unroll
+    for (int g = 0; g < HX_NFC; ++g) s += nb[g] >= 0 && nb[g] < nb[f];
+    slot[f] = s;
+  }
+}
+
+// tangents, surface element, outward unit normal of T and the depth-frame numbers of T and N at facet point p
+struct FacetFrame {
+  double A, aTs, aTt, cT, aNs, aNt, cN, N[4], ds[4], dt[4];
+};
+__device__ __forceinline__ void hx_shapes(int p, double (&N)[4], double (&ds)[4], double (&dt)[4]) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const double ws = ((m ^ p) & 1) ? HX_G0 : HX_G1, wt = (((m ^ p) >> 1) & 1) ? HX_G0 : HX_G1;
+    N[m] = ws * wt;
+    ds[m] = (m & 1) ? wt : -wt;
+    dt[m] = (m >> 1) ? ws : -ws;
+  }
+}
+__device__ __forceinline__ void hx_frame(int p, const double (&xm)[4][3], const double (&dT)[4][3], const double (&dN)[4][3],
+                                         bool have_n, FacetFrame& F) {
+  hx_shapes(p, F.N, F.ds, F.dt);
+  Vec3 ts{0, 0, 0}, tt{0, 0, 0}, eT{0, 0, 0}, eN{0, 0, 0};
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    ts.x += F.ds[m] * xm[m][0]; ts.y += F.ds[m] * xm[m][1]; ts.z += F.ds[m] * xm[m][2];
+    tt.x += F.dt[m] * xm[m][0]; tt.y += F.dt[m] * xm[m][1]; tt.z += F.dt[m] * xm[m][2];
+    eT.x += F.N[m] * dT[m][0]; eT.y += F.N[m] * dT[m][1]; eT.z += F.N[m] * dT[m][2];
+    eN.x += F.N[m] * dN[m][0]; eN.y += F.N[m] * dN[m][1]; eN.z += F.N[m] * dN[m][2];
+  }
+  const Vec3 cr = cross(ts, tt);
+  const double a2 = dot3(cr, cr), ra = fast_rsqrt(a2);
+  F.A = a2 * ra;
+  const double detT = dot3(cr, eT);
+  const double nu = detT > 0.0 ? -ra : ra;            // n = nu cr points away from T
+  const Vec3 n{nu * cr.x, nu * cr.y, nu * cr.z};
+  const double riT = fast_rcp(detT);
+  F.cT = dot3(cr, n) * riT;
+  F.aTs = dot3(cross(tt, eT), n) * riT;
+  F.aTt = dot3(cross(eT, ts), n) * riT;
+  F.cN = F.aNs = F.aNt = 0.0;
+  if (have_n) {
+    const double riN = fast_rcp(dot3(cr, eN));
+    F.cN = dot3(cr, n) * riN;
+    F.aNs = dot3(cross(tt, eN), n) * riN;
+    F.aNt = dot3(cross(eN, ts), n) * riN;
+  }
+}
+
+// inverse Jacobian (row t = grad xi_t) and weight * |det| of the cell at volume Gauss point p (runtime)
+__device__ __forceinline__ void hx_volume_point(const double (&X)[8][3], int p, double* out) {
+  double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};   // J[d][t] = d x_d / d xi_t
+  const double w0[2] = {(p & 1) ? HX_G0 : HX_G1, (p & 1) ? HX_G1 : HX_G0};          // shape of bit 0 = 0 / 1 along axis 0
+  const double w1[2] = {(p & 2) ? HX_G0 : HX_G1, (p & 2) ? HX_G1 : HX_G0};
+  const double w2[2] = {(p & 4) ? HX_G0 : HX_G1, (p & 4) ? HX_G1 : HX_G0};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const double a = w0[j & 1], b = w1[(j >> 1) & 1], c = w2[(j >> 2) & 1];
+    const double d0 = ((j & 1) ? 1.0 : -1.0) * b * c, d1 = ((j & 2) ? 1.0 : -1.0) * a * c, d2 = ((j & 4) ? 1.0 : -1.0) * a * b;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { J[d][0] += X[j][d] * d0; J[d][1] += X[j][d] * d1; J[d][2] += X[j][d] * d2; }
+  }
+  const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1], c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2],
+               c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+  const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02, ri = fast_rcp(det);
+  // inverse: Jinv[t][d] = cofactor(J)[d][t] / det
+  out[0] = c00 * ri; out[1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * ri; out[2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * ri;
+  out[3] = c01 * ri; out[4] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * ri; out[5] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * ri;
+  out[6] = c02 * ri; out[7] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * ri; out[8] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * ri;
+  out[9] = 0.125 * fabs(det);
+}
+
+// physical gradient and value of basis function J_ (compile time) at volume point p (runtime: the points are walked by a
+// real loop -- eight unrolled copies of the point's gradient table at once do not fit the register file)
+template <int J_>
+__device__ __forceinline__ double hx_grad(const double* Ji, int p, double (&g)[3]) {
+  const int x = J_ ^ p;
+  const double a = (x & 1) ? HX_G0 : HX_G1, b = (x & 2) ? HX_G0 : HX_G1, c = (x & 4) ? HX_G0 : HX_G1;
+  const double d0 = (J_ & 1) ? b * c : -(b * c), d1 = (J_ & 2) ? a * c : -(a * c), d2 = (J_ & 4) ? a * b : -(a * b);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) g[d] = d0 * Ji[d] + d1 * Ji[3 + d] + d2 * Ji[6 + d];
+  return a * b * c;
+}
+
+// the neighbour block of a row: values in facet order (on-facet vertices m, then the vertices behind them) -> the
+// neighbour's local column order through the lane's scratch line -> four 16-byte stores
+__device__ __forceinline__ void hx_store_nbr(double* scr, unsigned fi, const double (&B0)[4], const double (&B1)[4], double* dst) {
+  const int ao = ((fi >> 2) & 7) >> 1;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int jn = (fi >> (5 + 3 * m)) & 7;
+    scr[jn] = B0[m];
+    scr[jn ^ (1 << ao)] = B1[m];
+  }
+  double2* d2 = reinterpret_cast<double2*>(dst);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) d2[e] = make_double2(scr[2 * e], scr[2 * e + 1]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// potential system
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DG_BLOCK) void dg_emi_hex_kernel(DgDev D, const DgConsts* __restrict__ Cp, int chunk, int splitting) {
+  __shared__ double lrec[DG_BLOCK * DG_RPITCH];
+  __shared__ double fsum[HX_TASKS * HX_FS_EMI];
+  __shared__ double vgeo[DG_BLOCK * HX_VG];       // later the scratch of the column permutation (HX_SCR <= HX_VG)
+  const DgConsts& C = *Cp;
+  const int cell0 = dg_block_index(blockIdx.x, chunk) * HX_CELLS;
+  if (cell0 >= D.n_cell) return;
+  const int ncell = min(HX_CELLS, D.n_cell - cell0);
+  const int tid = threadIdx.x;
+  const int lc = tid >> 3, i = tid & 7, T = cell0 + lc, row = T * HX_NV + i;
+  const bool valid = lc < ncell;
+  // phase 0: records of the workgroup's cells; facet tables of this lane's (cell, facet) task
+  const int tc = tid / HX_NFC, tf = tid - tc * HX_NFC;
+  const bool task = tid < HX_TASKS && tc < ncell;
+  int tnb = -1, tmf = -1;
+  unsigned tfi = 0;
+  if (valid) {
+    const double2* p = reinterpret_cast<const double2*>(D.rec + (size_t)row * KN_REC);
+    double2* q = reinterpret_cast<double2*>(lrec + tid * DG_RPITCH);
+    const double2 a = p[0], b = p[1], c = p[2], d = p[3];
+    q[0] = a; q[1] = b; q[2] = c; q[3] = d;
+  }
+  if (task) {
+    tnb = D.nbr[(cell0 + tc) * HX_NFC + tf];
+    tfi = D.finfo[(cell0 + tc) * HX_NFC + tf];
+    tmf = D.mfid[(cell0 + tc) * HX_NFC + tf];
+  }
+  int nb[HX_NFC];
+  unsigned fi[HX_NFC];
+  int s = 0, rp = 0;
+  if (valid) {
+    s = D.cell_sub[T];
+    rp = D.rowptr[row];
+#pragma unroll
+    for (int f = 0; f < HX_NFC; ++f) { nb[f] = D.nbr[T * HX_NFC + f]; fi[f] = D.finfo[T * HX_NFC + f]; }
+  }
+  __syncthreads();
+  // phase 1: facet summaries
+  if (task && tnb >= 0) {
+    const int a = tf >> 1, b = tf & 1, kind = tfi & 3, ts_ = D.cell_sub[cell0 + tc];
+    double xm[4][3], dT[4][3], dN[4][3], kT[4], kN[4], sT0[4], sT1[4], sN0[4], sN1[4];
+    const int ao = ((tfi >> 2) & 7) >> 1;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int jv = hx_facet_vertex(a, b, m), jo = jv ^ (1 << a);
+      const double* r0 = lrec + (tc * HX_NV + jv) * DG_RPITCH;
+      const double* r1 = lrec + (tc * HX_NV + jo) * DG_RPITCH;
+      double k0 = 0.0, g0 = 0.0, g1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < KN_MAXK; ++q) {
+        k0 += C.kap[ts_][q] * r0[KN_CSLOT(q)]; g0 += C.sig[ts_][q] * r0[KN_CSLOT(q)]; g1 += C.sig[ts_][q] * r1[KN_CSLOT(q)];
+      }
+      kT[m] = k0; sT0[m] = g0; sT1[m] = g1;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { xm[m][d] = r0[d]; dT[m][d] = r1[d] - r0[d]; dN[m][d] = 0.0; }
+      kN[m] = sN0[m] = sN1[m] = 0.0;
+    }
+    double* my = fsum + tid * HX_FS_EMI;
+    if (kind == 1) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int jn = (tfi >> (5 + 3 * m)) & 7, jt = jn ^ (1 << ao);
+        const double* r0 = D.rec + ((size_t)tnb * HX_NV + jn) * KN_REC;
+        const double* r1 = D.rec + ((size_t)tnb * HX_NV + jt) * KN_REC;
+        double k0 = 0.0, g0 = 0.0, g1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < KN_MAXK; ++q) {
+          k0 += C.kap[ts_][q] * r0[KN_CSLOT(q)]; g0 += C.sig[ts_][q] * r0[KN_CSLOT(q)]; g1 += C.sig[ts_][q] * r1[KN_CSLOT(q)];
+        }
+        kN[m] = k0; sN0[m] = g0; sN1[m] = g1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) dN[m][d] = r1[d] - xm[m][d];
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        FacetFrame F;
+        hx_frame(p, xm, dT, dN, true, F);
+        double kTq = 0.0, kNq = 0.0, JT = 0.0, JN = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          kTq += F.N[m] * kT[m]; kNq += F.N[m] * kN[m];
+          JT += sT0[m] * (F.ds[m] * F.aTs + F.dt[m] * F.aTt - F.N[m] * F.cT) + sT1[m] * F.N[m] * F.cT;
+          JN += sN0[m] * (F.ds[m] * F.aNs + F.dt[m] * F.aNt - F.N[m] * F.cN) + sN1[m] * F.N[m] * F.cN;
+        }
+        double* o = my + 12 * p;
+        o[0] = 0.25 * F.A; o[1] = 0.5 * (fabs(F.cT) + fabs(F.cN));
+        o[2] = F.aTs; o[3] = F.aTt; o[4] = F.cT; o[5] = kTq; o[6] = JT;
+        o[7] = F.aNs; o[8] = F.aNt; o[9] = F.cN; o[10] = kNq; o[11] = JN;
+      }
+    } else {
+      // membrane facet: C_phi [u][v] and C_phi g [v] with the 2 x 2 rule; g = phi_M (- I_ch / C_phi without the
+      // splitting scheme) at the facet's own nodes (emiWeakForm.py:160-165, 228-239)
+      double g[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int q = tmf * 4 + ((tfi >> (17 + 2 * m)) & 3);
+        double v = D.phiM[q];
+        if (!splitting) {
+          double it = 0.0;
+          for (int k = 0; k < C.K; ++k) it += D.Ich[(size_t)k * D.nq + q];
+          v -= it / C.C_phi;
+        }
+        g[m] = v;
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        FacetFrame F;
+        hx_frame(p, xm, dT, dN, false, F);
+        double gq = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) gq += F.N[m] * g[m];
+        my[12 * p] = 0.25 * F.A * C.C_phi;
+        my[12 * p + 1] = gq;
+      }
+    }
+  }
+  // phase 1b: the cell's Jacobian at volume point i
+  double X[8][3], kap[8], sg[8];
+  if (valid) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double* r = lrec + (lc * HX_NV + j) * DG_RPITCH;
+      double k0 = 0.0, g0 = 0.0;
+#pragma unroll
+      for (int q = 0; q < KN_MAXK; ++q) { k0 += C.kap[s][q] * r[KN_CSLOT(q)]; g0 += C.sig[s][q] * r[KN_CSLOT(q)]; }
+      kap[j] = k0; sg[j] = g0;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) X[j][d] = r[d];
+    }
+    hx_volume_point(X, i, vgeo + tid * HX_VG);
+  }
+  __syncthreads();
+  if (!valid) return;   // (no barrier below: what follows only touches this lane's own scratch line)
+  // phase 2: the row
+  double A[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double rhs = 0.0;
+  {
+    const double* vg = vgeo + lc * HX_NV * HX_VG;
+    const int x = i;
+#pragma unroll 1
+    for (int P = 0; P < 8; ++P) {
+      const double* Ji = vg + P * HX_VG;
+      const double wd = Ji[9];
+      // the row's own gradient: runtime vertex i
+      const int xi = x ^ P;
+      const double a = (xi & 1) ? HX_G0 : HX_G1, b = (xi & 2) ? HX_G0 : HX_G1, c = (xi & 4) ? HX_G0 : HX_G1;
+      const double d0 = ((x & 1) ? b : -b) * c, d1 = ((x & 2) ? a : -a) * c, d2 = ((x & 4) ? a : -a) * b;
+      double gi[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) gi[d] = d0 * Ji[d] + d1 * Ji[3 + d] + d2 * Ji[6 + d];
+      double g[8][3], ph[8];
+      ph[0] = hx_grad<0>(Ji, P, g[0]); ph[1] = hx_grad<1>(Ji, P, g[1]); ph[2] = hx_grad<2>(Ji, P, g[2]);
+      ph[3] = hx_grad<3>(Ji, P, g[3]); ph[4] = hx_grad<4>(Ji, P, g[4]); ph[5] = hx_grad<5>(Ji, P, g[5]);
+      ph[6] = hx_grad<6>(Ji, P, g[6]); ph[7] = hx_grad<7>(Ji, P, g[7]);
+      double kq = 0.0, js[3] = {0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        kq += kap[j] * ph[j];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) js[d] += sg[j] * g[j][d];
+      }
+      const double wk = wd * kq;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) A[j] += wk * (gi[0] * g[j][0] + gi[1] * g[j][1] + gi[2] * g[j][2]);
+      rhs -= wd * (gi[0] * js[0] + gi[1] * js[1] + gi[2] * js[2]);
+    }
+  }
+  int slot_self, slot[HX_NFC];
+  hx_slots(T, nb, slot_self, slot);
+  __syncthreads();   // every lane of the wave is done with the shared Jacobians: their space becomes the scratch lines
+  double* scr = vgeo + tid * HX_SCR;
+  double* Arow = D.A_emi + rp;
+  auto facet = [&](auto F_) {
+    constexpr int f = decltype(F_)::value, a = f >> 1, b = f & 1;
+    if (nb[f] < 0) return;
+    const int kind = fi[f] & 3;
+    const bool on = ((i >> a) & 1) == b;
+    const int mi = ((i >> hx_ax1(a)) & 1) | (((i >> hx_ax2(a)) & 1) << 1);
+    const double* fd = fsum + (lc * HX_NFC + f) * HX_FS_EMI;
+    double B0[4] = {0, 0, 0, 0}, B1[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      double N[4], ds[4], dt[4];
+      hx_shapes(p, N, ds, dt);
+      const int xm_ = mi ^ p;
+      const double wa = (xm_ & 1) ? HX_G0 : HX_G1, wb = (xm_ & 2) ? HX_G0 : HX_G1;
+      const double Ni = wa * wb, dsi = (mi & 1) ? wb : -wb, dti = (mi & 2) ? wa : -wa;
+      const double* o = fd + 12 * p;
+      if (kind == 1) {
+        const double W = o[0], ih = o[1], aTs = o[2], aTt = o[3], cT = o[4], kT = o[5], JT = o[6];
+        const double aNs = o[7], aNt = o[8], cN = o[9], kN = o[10], JN = o[11];
+        const double phi_i = on ? Ni : 0.0;
+        const double gni = on ? dsi * aTs + dti * aTt - Ni * cT : Ni * cT;
+        const double pen = C.gamma * ih * (0.5 * (kT + kN)) * W * phi_i;
+        const double c1 = -0.5 * W * kT * phi_i, c2 = -0.5 * W * kT * gni, c1n = -0.5 * W * kN * phi_i;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const double gT = ds[m] * aTs + dt[m] * aTt - N[m] * cT;
+          const double gN = ds[m] * aNs + dt[m] * aNt - N[m] * cN;
+          A[hx_facet_vertex(a, b, m)] += c1 * gT + (c2 + pen) * N[m];
+          A[hx_facet_vertex(a, b, m) ^ (1 << a)] += c1 * (N[m] * cT);
+          B0[m] += c1n * gN - (c2 + pen) * N[m];
+          B1[m] += c1n * (N[m] * cN);
+        }
+        rhs += W * 0.5 * (JT + JN) * phi_i;
+      } else if (on) {
+        const double W = o[0] * Ni;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          A[hx_facet_vertex(a, b, m)] += W * N[m];
+          B0[m] -= W * N[m];
+        }
+        rhs += (kind == 3 ? W : -W) * o[1];
+      }
+    }
+    hx_store_nbr(scr, fi[f], B0, B1, Arow + slot[f] * HX_NV);
+    __builtin_amdgcn_sched_barrier(0);   // keep the six facets apart: hoisted summary reads of later facets cost registers
+  };
+  facet(std::integral_constant<int, 0>{}); facet(std::integral_constant<int, 1>{});
+  facet(std::integral_constant<int, 2>{}); facet(std::integral_constant<int, 3>{});
+  facet(std::integral_constant<int, 4>{}); facet(std::integral_constant<int, 5>{});
+  double2* d2 = reinterpret_cast<double2*>(Arow + slot_self * HX_NV);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) d2[e] = make_double2(A[2 * e], A[2 * e + 1]);
+  D.b_emi[row] = rhs;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// concentration systems: A_knp[k], b_knp[k], k < K - 1.  The unit-diffusivity SIP entries and the mass matrix are the
+// same for every ion (D_k is constant inside a sub-domain); the upwinded drift differs by the sign of z_k only, so the
+// row keeps the positive and the negative part of the facet's drift term apart and every ion picks its side.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KS> constexpr int hx_fs_knp() { return 41; }   // 10 per point | membrane: 4 x KS integrals
+
+template <int KS>
+__global__ __launch_bounds__(DG_BLOCK) void dg_knp_hex_kernel(DgDev D, const DgConsts* __restrict__ Cp, int chunk, int splitting) {
+  constexpr int FS = hx_fs_knp<KS>();
+  __shared__ double lrec[DG_BLOCK * DG_RPITCH];
+  __shared__ double fsum[HX_TASKS * FS];
+  __shared__ double vgeo[DG_BLOCK * HX_VG];
+  const DgConsts& C = *Cp;
+  const int cell0 = dg_block_index(blockIdx.x, chunk) * HX_CELLS;
+  if (cell0 >= D.n_cell) return;
+  const int ncell = min(HX_CELLS, D.n_cell - cell0);
+  const int tid = threadIdx.x;
+  const int lc = tid >> 3, i = tid & 7, T = cell0 + lc, row = T * HX_NV + i;
+  const bool valid = lc < ncell;
+  const int tc = tid / HX_NFC, tf = tid - tc * HX_NFC;
+  const bool task = tid < HX_TASKS && tc < ncell;
+  int tnb = -1, tmf = -1;
+  unsigned tfi = 0;
+  if (valid) {
+    const double2* p = reinterpret_cast<const double2*>(D.rec + (size_t)row * KN_REC);
+    double2* q = reinterpret_cast<double2*>(lrec + tid * DG_RPITCH);
+    const double2 a = p[0], b = p[1], c = p[2], d = p[3];
+    q[0] = a; q[1] = b; q[2] = c; q[3] = d;
+  }
+  if (task) {
+    tnb = D.nbr[(cell0 + tc) * HX_NFC + tf];
+    tfi = D.finfo[(cell0 + tc) * HX_NFC + tf];
+    tmf = D.mfid[(cell0 + tc) * HX_NFC + tf];
+  }
+  int nb[HX_NFC];
+  unsigned fi[HX_NFC];
+  int s = 0, rp = 0;
+  if (valid) {
+    s = D.cell_sub[T];
+    rp = D.rowptr[row];
+#pragma unroll
+    for (int f = 0; f < HX_NFC; ++f) { nb[f] = D.nbr[T * HX_NFC + f]; fi[f] = D.finfo[T * HX_NFC + f]; }
+  }
+  __syncthreads();
+  if (task && tnb >= 0) {
+    const int a = tf >> 1, b = tf & 1, kind = tfi & 3, ts_ = D.cell_sub[cell0 + tc];
+    const int ao = ((tfi >> 2) & 7) >> 1;
+    double xm[4][3], dT[4][3], dN[4][3], pT0[4], pT1[4], pN0[4], pN1[4];
+    const double* rT[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int jv = hx_facet_vertex(a, b, m), jo = jv ^ (1 << a);
+      const double* r0 = lrec + (tc * HX_NV + jv) * DG_RPITCH;
+      const double* r1 = lrec + (tc * HX_NV + jo) * DG_RPITCH;
+      rT[m] = r0;
+      pT0[m] = r0[7]; pT1[m] = r1[7];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { xm[m][d] = r0[d]; dT[m][d] = r1[d] - r0[d]; dN[m][d] = 0.0; }
+      const int jn = (tfi >> (5 + 3 * m)) & 7, jt = jn ^ (1 << ao);
+      const double* n0 = D.rec + ((size_t)tnb * HX_NV + jn) * KN_REC;
+      pN0[m] = n0[7];
+      pN1[m] = 0.0;
+      if (kind == 1) {
+        const double* n1 = D.rec + ((size_t)tnb * HX_NV + jt) * KN_REC;
+        pN1[m] = n1[7];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) dN[m][d] = n1[d] - xm[m][d];
+      }
+    }
+    double* my = fsum + tid * FS;
+    if (kind == 1) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        FacetFrame F;
+        hx_frame(p, xm, dT, dN, true, F);
+        double gT = 0.0, gN = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          gT += pT0[m] * (F.ds[m] * F.aTs + F.dt[m] * F.aTt - F.N[m] * F.cT) + pT1[m] * F.N[m] * F.cT;
+          gN += pN0[m] * (F.ds[m] * F.aNs + F.dt[m] * F.aNt - F.N[m] * F.cN) + pN1[m] * F.N[m] * F.cN;
+        }
+        double* o = my + 10 * p;
+        o[0] = 0.25 * F.A; o[1] = 0.5 * (fabs(F.cT) + fabs(F.cN));
+        o[2] = F.aTs; o[3] = F.aTt; o[4] = F.cT; o[5] = F.aNs; o[6] = F.aNt; o[7] = F.cN; o[8] = gT; o[9] = gN;
+      }
+    } else {
+      // membrane facet (knpWeakForm.py:168-214), 4 x 4 rule, once per (cell, facet).  With alpha_k = D_k z_k^2 c_k /
+      // sum_j D_j z_j^2 c_j of this side the integrand is
+      //   sgn [ alpha_k C_M / (F z_k dt) ([phi] - phi_M - (dt / C_M) I_ch) + I_ch_k / (F z_k) ],  sgn = +1 on the ECS side
+      double jm[4], pm[4], It[4], Ik[4][KN_MAXK], Gk[4][KS];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        jm[m] = kind == 2 ? pN0[m] - pT0[m] : pT0[m] - pN0[m];
+        const int q = tmf * 4 + ((tfi >> (17 + 2 * m)) & 3);
+        pm[m] = D.phiM[q];
+        double it = 0.0;
+#pragma unroll
+        for (int k = 0; k < KN_MAXK; ++k) {
+          Ik[m][k] = k < C.K ? D.Ich[(size_t)k * D.nq + q] : 0.0;
+          it += Ik[m][k];
+        }
+        It[m] = it;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) Gk[m][k] = 0.0;
+      }
+      const double sgn = kind == 2 ? 1.0 : -1.0;
+      const double* qw = D.qtab;
+      const double* qN = D.qtab + D.nquad;
+      const double* qd = D.qtab + D.nquad * 5;
+      for (int q = 0; q < D.nquad; ++q) {
+        double cq[KN_MAXK], iq[KN_MAXK], jq = 0.0, pq = 0.0, itq = 0.0, Nq[4];
+        Vec3 ts{0, 0, 0}, tt{0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < KN_MAXK; ++k) { cq[k] = 0.0; iq[k] = 0.0; }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          Nq[m] = qN[q * 4 + m];
+          const double d0 = qd[(q * 4 + m) * 2], d1 = qd[(q * 4 + m) * 2 + 1];
+          ts.x += d0 * xm[m][0]; ts.y += d0 * xm[m][1]; ts.z += d0 * xm[m][2];
+          tt.x += d1 * xm[m][0]; tt.y += d1 * xm[m][1]; tt.z += d1 * xm[m][2];
+          // ion k of the record sits in slot KN_CSLOT(k) = 4 + k (k < 3), 3 (k = 3)
+#pragma unroll
+          for (int k = 0; k < KN_MAXK; ++k) { cq[k] += Nq[m] * rT[m][KN_CSLOT(k)]; iq[k] += Nq[m] * Ik[m][k]; }
+          jq += Nq[m] * jm[m]; pq += Nq[m] * pm[m]; itq += Nq[m] * It[m];
+        }
+        const Vec3 cr = cross(ts, tt);
+        const double a2 = dot3(cr, cr), area = a2 * fast_rsqrt(a2);
+        double asum = 0.0;
+#pragma unroll
+        for (int k = 0; k < KN_MAXK; ++k) asum += C.az2D[ts_][k] * cq[k];
+        const double w = sgn * qw[q] * area;
+        double drive = jq - pq;
+        if (splitting) drive -= (C.dt / C.C_M) * itq;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const double al = C.az2D[ts_][k] * cq[k] / asum;
+          const double fz = 1.0 / (C.F * C.z[k]);
+          const double fq = w * (al * C.C_M * fz * C.inv_dt * drive + iq[k] * fz);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) Gk[m][k] += Nq[m] * fq;
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int k = 0; k < KS; ++k) my[m * KS + k] = Gk[m][k];
+    }
+  }
+  double X[8][3], ph[8];
+  if (valid) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double* r = lrec + (lc * HX_NV + j) * DG_RPITCH;
+      ph[j] = r[7];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) X[j][d] = r[d];
+    }
+    hx_volume_point(X, i, vgeo + tid * HX_VG);
+  }
+  __syncthreads();
+  if (!valid) return;
+  // volume: mass, unit stiffness, unit drift (grad phi_i . grad phi) phi_j
+  double M[8] = {0, 0, 0, 0, 0, 0, 0, 0}, S[8] = {0, 0, 0, 0, 0, 0, 0, 0}, Dr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  {
+    const double* vg = vgeo + lc * HX_NV * HX_VG;
+    const int x = i;
+#pragma unroll 1
+    for (int P = 0; P < 8; ++P) {
+      const double* Ji = vg + P * HX_VG;
+      const double wd = Ji[9];
+      const int xi = x ^ P;
+      const double a = (xi & 1) ? HX_G0 : HX_G1, b = (xi & 2) ? HX_G0 : HX_G1, c = (xi & 4) ? HX_G0 : HX_G1;
+      const double d0 = ((x & 1) ? b : -b) * c, d1 = ((x & 2) ? a : -a) * c, d2 = ((x & 4) ? a : -a) * b;
+      const double phi_i = a * b * c;
+      double gi[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) gi[d] = d0 * Ji[d] + d1 * Ji[3 + d] + d2 * Ji[6 + d];
+      double g[8][3], pj[8];
+      pj[0] = hx_grad<0>(Ji, P, g[0]); pj[1] = hx_grad<1>(Ji, P, g[1]); pj[2] = hx_grad<2>(Ji, P, g[2]);
+      pj[3] = hx_grad<3>(Ji, P, g[3]); pj[4] = hx_grad<4>(Ji, P, g[4]); pj[5] = hx_grad<5>(Ji, P, g[5]);
+      pj[6] = hx_grad<6>(Ji, P, g[6]); pj[7] = hx_grad<7>(Ji, P, g[7]);
+      double gp[3] = {0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) gp[d] += ph[j] * g[j][d];
+      const double dr = wd * (gi[0] * gp[0] + gi[1] * gp[1] + gi[2] * gp[2]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        M[j] += wd * phi_i * pj[j];
+        S[j] += wd * (gi[0] * g[j][0] + gi[1] * g[j][1] + gi[2] * g[j][2]);
+        Dr[j] += dr * pj[j];
+      }
+    }
+  }
+  int slot_self, slot[HX_NFC];
+  hx_slots(T, nb, slot_self, slot);
+  __syncthreads();
+  double* scr = vgeo + tid * HX_SCR;
+  // right-hand sides: mass times (c_k / dt + f_k), then the membrane integrals of the row's function
+  double rhs[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      double v = lrec[(lc * HX_NV + j) * DG_RPITCH + KN_CSLOT(k)] * C.inv_dt;
+      if (D.fsrc && s == 0) v += D.fsrc[(size_t)k * D.n_dof + T * HX_NV + j];
+      acc += M[j] * v;
+    }
+    rhs[k] = acc;
+  }
+  double UP[8] = {0, 0, 0, 0, 0, 0, 0, 0}, UM[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // own block: drift leaving / entering
+  auto facet = [&](auto F_) {
+    constexpr int f = decltype(F_)::value, a = f >> 1, b = f & 1;
+    if (nb[f] < 0) return;
+    const int kind = fi[f] & 3;
+    const bool on = ((i >> a) & 1) == b;
+    const int mi = ((i >> hx_ax1(a)) & 1) | (((i >> hx_ax2(a)) & 1) << 1);
+    const double* fd = fsum + (lc * HX_NFC + f) * FS;
+    if (kind != 1) {
+      if (on) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) rhs[k] += fd[mi * KS + k];
+      }
+      // the membrane couples the two sides through the right-hand side only: the neighbour block is zero
+      const double z4[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < KS; ++k) hx_store_nbr(scr, fi[f], z4, z4, D.A_knp + (size_t)k * D.nnz + rp + slot[f] * HX_NV);
+      return;
+    }
+    double B0[4] = {0, 0, 0, 0}, B1[4] = {0, 0, 0, 0}, VP[4] = {0, 0, 0, 0}, VM[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      double N[4], ds[4], dt[4];
+      hx_shapes(p, N, ds, dt);
+      const int xm_ = mi ^ p;
+      const double wa = (xm_ & 1) ? HX_G0 : HX_G1, wb = (xm_ & 2) ? HX_G0 : HX_G1;
+      const double Ni = wa * wb, dsi = (mi & 1) ? wb : -wb, dti = (mi & 2) ? wa : -wa;
+      const double* o = fd + 10 * p;
+      const double W = o[0], ih = o[1], aTs = o[2], aTt = o[3], cT = o[4], aNs = o[5], aNt = o[6], cN = o[7];
+      const double phi_i = on ? Ni : 0.0;
+      const double gni = on ? dsi * aTs + dti * aTt - Ni * cT : Ni * cT;
+      const double pen = C.gamma * ih * W * phi_i;
+      const double c1 = -0.5 * W * phi_i, c2 = -0.5 * W * gni;
+      const double b0 = -C.psi * 0.5 * (o[8] + o[9]) * W * phi_i;   // beta_k W phi_i = z_k D_k b0
+      const double bp = fmax(b0, 0.0), bm = fmin(b0, 0.0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const double gT = ds[m] * aTs + dt[m] * aTt - N[m] * cT;
+        const double gN = ds[m] * aNs + dt[m] * aNt - N[m] * cN;
+        S[hx_facet_vertex(a, b, m)] += c1 * gT + (c2 + pen) * N[m];
+        S[hx_facet_vertex(a, b, m) ^ (1 << a)] += c1 * (N[m] * cT);
+        B0[m] += c1 * gN - (c2 + pen) * N[m];
+        B1[m] += c1 * (N[m] * cN);
+        UP[hx_facet_vertex(a, b, m)] += bp * N[m];
+        UM[hx_facet_vertex(a, b, m)] += bm * N[m];
+        VP[m] += bp * N[m];
+        VM[m] += bm * N[m];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const double Dk = C.D[s][k], zD = C.z[k] * Dk;
+      double b0k[4], b1k[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        // upwind: the neighbour's trace carries the flux where the drift enters T (beta < 0)
+        b0k[m] = Dk * B0[m] + zD * (C.z[k] > 0.0 ? VM[m] : VP[m]);
+        b1k[m] = Dk * B1[m];
+      }
+      hx_store_nbr(scr, fi[f], b0k, b1k, D.A_knp + (size_t)k * D.nnz + rp + slot[f] * HX_NV);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the six facets apart: hoisted summary reads of later facets cost registers
+  };
+  facet(std::integral_constant<int, 0>{}); facet(std::integral_constant<int, 1>{});
+  facet(std::integral_constant<int, 2>{}); facet(std::integral_constant<int, 3>{});
+  facet(std::integral_constant<int, 4>{}); facet(std::integral_constant<int, 5>{});
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    const double Dk = C.D[s][k], zD = C.z[k] * Dk, zpD = zD * C.psi;
+    double2* d2 = reinterpret_cast<double2*>(D.A_knp + (size_t)k * D.nnz + rp + slot_self * HX_NV);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      double v[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int j = 2 * e + t;
+        v[t] = M[j] * C.inv_dt + Dk * S[j] + zpD * Dr[j] + zD * (C.z[k] > 0.0 ? UP[j] : UM[j]);
+      }
+      d2[e] = make_double2(v[0], v[1]);
+    }
+    D.b_knp[(size_t)k * D.n_dof + row] = rhs[k];
+  }
+}
+
+int hx_check(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    kn_set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return KNPEMI_EHIP;
+  }
+  return KNPEMI_OK;
+}
+
+}  // namespace
+
+int kn_dg_hex_launch_emi(hipStream_t st, const kn_dg::DgDev& D, const kn_dg::DgConsts* d_consts, int splitting) {
+  const int nblocks = (D.n_cell + HX_CELLS - 1) / HX_CELLS, chunk = (nblocks + 7) / 8;
+  hipLaunchKernelGGL(dg_emi_hex_kernel, dim3(8 * chunk), dim3(DG_BLOCK), 0, st, D, d_consts, chunk, splitting);
+  return hx_check("dg_emi_hex_kernel");
+}
+
+int kn_dg_hex_launch_knp(hipStream_t st, const kn_dg::DgDev& D, const kn_dg::DgConsts* d_consts, int KS, int splitting) {
+  const int nblocks = (D.n_cell + HX_CELLS - 1) / HX_CELLS, chunk = (nblocks + 7) / 8;
+  const dim3 grid(8 * chunk), block(DG_BLOCK);
+  switch (KS) {
+    case 1: hipLaunchKernelGGL(dg_knp_hex_kernel<1>, grid, block, 0, st, D, d_consts, chunk, splitting); break;
+    case 2: hipLaunchKernelGGL(dg_knp_hex_kernel<2>, grid, block, 0, st, D, d_consts, chunk, splitting); break;
+    default: hipLaunchKernelGGL(dg_knp_hex_kernel<3>, grid, block, 0, st, D, d_consts, chunk, splitting); break;
+  }
+  return hx_check("dg_knp_hex_kernel");
+}

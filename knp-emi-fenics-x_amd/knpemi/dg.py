@@ -1,5 +1,6 @@
-"""Host side of the DG(P1) + symmetric-interior-penalty variant (include/knpemi_hip.h,
-`knpemi_dg_*`).
+"""Host side of the DG + symmetric-interior-penalty variant (include/knpemi_hip.h, `knpemi_dg_*`):
+broken P1 on triangles and tetrahedra, broken Q1 on hexahedra (the cell type of the reference's own 3-D idealized mesh,
+`examples/idealized_geometries/make_mesh_3D.py:100-102`; tensor-product vertex order, as `create_box` produces).
 
 The reference has no such class -- its code is continuous Galerkin on sub-meshes; only `README.md:5-7` and the marker
 convention of `examples/idealized_geometries/make_mesh_2D.py:88-90` ("interior facets tagged 0") refer to the DG method
@@ -21,7 +22,7 @@ import scipy.sparse as sp
 
 from . import _lib as L
 
-_KIND = {"triangle": L.TRIANGLE, "tetrahedron": L.TETRAHEDRON}
+_KIND = {"triangle": L.TRIANGLE, "tetrahedron": L.TETRAHEDRON, "hexahedron": L.HEXAHEDRON}
 
 
 class DGProblem:
@@ -29,11 +30,11 @@ class DGProblem:
         """`ct`, `ft`: cell and facet MeshTags of `mesh` (or dense arrays); `subdomain_tags`: cell tags in sub-domain
         order, ECS first (`run_2D.py:145-169`); `membrane_tags`: facet tags that mark membranes."""
         if mesh.cell_type not in _KIND:
-            raise ValueError("the DG variant is built for triangles and tetrahedra")
+            raise ValueError("the DG variant is built for triangles, tetrahedra and hexahedra")
         self.lib = L.load()
         self.mesh = mesh
         self.nv = mesh.cells.shape[1]
-        self.nf = self.nv - 1
+        self.nf = mesh.facets.shape[1]                      # vertices per facet
         self.K = int(n_ions)
         cell_tags = np.asarray(ct.dense() if hasattr(ct, "dense") else ct)
         tag_to_sub = {int(t): i for i, t in enumerate(subdomain_tags)}

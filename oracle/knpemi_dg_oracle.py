@@ -293,3 +293,275 @@ class DGOracle:
         ce, ci = self.mem_cells()
         le, li = self.mem_local()
         return field[ce[:, None], le], field[ci[:, None], li]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Broken Q1 on hexahedra (the reference's own 3-D idealized mesh is hexahedral, make_mesh_3D.py:100-102)
+# ----------------------------------------------------------------------------------------------------------------------
+def _hex_ref(j):
+    """Reference coordinates of local vertex j of a hexahedron (tensor ordering: bit a of j is the coordinate along axis a)."""
+    return np.array([(j >> a) & 1 for a in range(3)], float)
+
+
+_HEX_FACETS = [[j for j in range(8) if ((j >> a) & 1) == b] for a in range(3) for b in range(2)]   # facet f = 2 a + b
+
+
+class DGOracleQ1(DGOracle):
+    """The same discrete problem on broken Q1 over hexahedra.  Local vertex j of a cell sits at the reference point whose
+    coordinate along axis a is bit a of j; dof (cell c, local vertex j) = 8 c + j; local facet f = 2 a + b is xi_a = b.
+
+    What differs from the simplicial statement above is only what a non-constant Jacobian forces:
+      * volume terms: the 2 x 2 x 2 Gauss rule, Jacobian inverted at every point (as the CG forms on hexahedra,
+        oracle/knpemi_oracle.py) -- exact on parallelepipeds;
+      * interior facets: the 2 x 2 Gauss rule on the facet's bilinear parametrisation, every quantity (normal, the two
+        cells' gradients, kappa, the drift velocity and with it the upwind side, and 1 / h_F = mean of the two cells'
+        |grad xi_normal|) taken at the point;
+      * membrane facets: the rules of the CG forms on quadrilaterals (degree 2 -> 2 x 2 for the potential coupling,
+        degree 6 -> 4 x 4 for the rational concentration terms).
+    Every point is mapped into each adjacent cell's own reference coordinates and the basis is evaluated through that
+    cell's own Jacobian -- the kernels instead work in a frame aligned with the facet."""
+
+    def __init__(self, x, cells, cell_type, cell_sub, mem_facets, mem_tags):
+        assert cell_type == "hexahedron"
+        self.x = np.asarray(x, float)
+        self.cells = np.asarray(cells, np.int64)
+        self.cell_type, self.facet_type = cell_type, "quadrilateral"
+        self.cell_sub = np.asarray(cell_sub, np.int64)
+        self.nc, self.nv = self.cells.shape
+        self.d = 3
+        self.n = self.nc * self.nv
+        pts, wts = quadrature("hexahedron", 2)
+        det, _ = self._geom(np.arange(self.nc), np.broadcast_to(pts, (self.nc,) + pts.shape))
+        self.vol = det @ wts
+        owners = {}
+        for c in range(self.nc):
+            for f, lv in enumerate(_HEX_FACETS):
+                owners.setdefault(tuple(sorted(self.cells[c, lv])), []).append((c, f))
+        self.mem_facets = np.asarray(mem_facets, np.int64).reshape(-1, 4)
+        self.mem_tags = np.asarray(mem_tags)
+        self.nmf, self.nf = self.mem_facets.shape
+        mem = {tuple(sorted(v)): i for i, v in enumerate(self.mem_facets)}
+        self.interior, self.membrane, self._memf = [], [None] * len(mem), [None] * len(mem)
+        for key, own in owners.items():
+            if len(own) == 1:
+                continue
+            (c0, f0), (c1, f1) = own
+            if key in mem:
+                s0, s1 = self.cell_sub[c0], self.cell_sub[c1]
+                assert min(s0, s1) == 0 and max(s0, s1) > 0, "a membrane separates the ECS from one cell"
+                e, i = ((c0, f0), (c1, f1)) if s0 == 0 else ((c1, f1), (c0, f0))
+                self.membrane[mem[key]] = (e[0], i[0], self.mem_tags[mem[key]])
+                self._memf[mem[key]] = (e[1], i[1])
+            else:
+                assert self.cell_sub[c0] == self.cell_sub[c1], "untagged facet between two sub-domains"
+                self.interior.append((c0, c1, f0, f1))
+
+    # -- geometry ----------------------------------------------------------------------------------------------
+    def _geom(self, c, xi):
+        """Cells c (m,), reference points xi (m, q, 3) -> |det J| (m, q), physical gradients (m, q, 8, 3), basis (m, q, 8)."""
+        m, q = xi.shape[:2]
+        phi = np.ones((m, q, 8))
+        dphi = np.ones((m, q, 8, 3))
+        for v in range(8):
+            for a in range(3):
+                bit = (v >> a) & 1
+                f = xi[:, :, a] if bit else 1.0 - xi[:, :, a]
+                phi[:, :, v] *= f
+                for t in range(3):
+                    dphi[:, :, v, t] *= (1.0 if bit else -1.0) if t == a else f
+        J = np.einsum("mag,mqat->mqgt", self.x[self.cells[c]], dphi)
+        G = np.einsum("mqat,mqtg->mqag", dphi, np.linalg.inv(J))
+        self._last_phi, self._last_J = phi, J
+        return np.abs(np.linalg.det(J)), G
+
+    def _on_facet(self, c, f, verts, st):
+        """Reference coordinates in cells c (m,) of the points st (q, 2) of the facets whose vertices (global ids, in the
+        order that defines the parametrisation) are verts (m, 4): bilinear interpolation of the vertices' own reference
+        coordinates (the two parametrisations of a shared facet differ by a symmetry of the square)."""
+        N = np.stack([(1 - st[:, 0]) * (1 - st[:, 1]), st[:, 0] * (1 - st[:, 1]), (1 - st[:, 0]) * st[:, 1],
+                      st[:, 0] * st[:, 1]], axis=1)                       # (q, 4)
+        ref = np.zeros((len(c), 4, 3))
+        for k in range(len(c)):
+            for a in range(4):
+                j = int(np.nonzero(self.cells[c[k]] == verts[k, a])[0][0])
+                ref[k, a] = _hex_ref(j)
+        return np.einsum("qa,mad->mqd", N, ref), N
+
+    def _facet_points(self, cT, fT, degree):
+        """Gauss points of the facets fT of cells cT in T's parametrisation: vertices (m, 4), points st, weights,
+        reference points in T, surface measure * weight (m, q) and the outward unit normal of T (m, q, 3)."""
+        st, w = quadrature("quadrilateral", degree)
+        verts = np.array([self.cells[c, _HEX_FACETS[f]] for c, f in zip(cT, fT)], np.int64).reshape(-1, 4)
+        xiT, N = self._on_facet(cT, fT, verts, st)
+        _, GT = self._geom(cT, xiT)
+        JT = self._last_J
+        ax = np.array([f // 2 for f in fT])
+        sd = np.array([1.0 if f % 2 else -1.0 for f in fT])
+        m = len(cT)
+        t1 = np.stack([JT[k, :, :, [a for a in range(3) if a != ax[k]][0]] for k in range(m)])
+        t2 = np.stack([JT[k, :, :, [a for a in range(3) if a != ax[k]][1]] for k in range(m)])
+        cr = np.cross(t1, t2)
+        area = np.linalg.norm(cr, axis=2)
+        # outward normal: sign * grad xi_axis / |grad xi_axis|; grad xi_a = sum_j ref_a(j) grad phi_j
+        refa = np.array([[(j >> a) & 1 for j in range(8)] for a in range(3)], float)
+        gxi = np.einsum("mj,mqjd->mqd", refa[ax], GT)
+        n = sd[:, None, None] * gxi / np.linalg.norm(gxi, axis=2)[:, :, None]
+        return verts, st, w[None, :] * area, xiT, n, np.linalg.norm(gxi, axis=2)
+
+    def _interior_q1(self, degree=3):
+        I = np.array(self.interior, np.int64).reshape(-1, 4)
+        cT, cN, fT, fN = I.T
+        verts, st, wA, xiT, n, ghT = self._facet_points(cT, fT, degree)
+        _, GT = self._geom(cT, xiT)
+        lamT = self._last_phi
+        xiN, _ = self._on_facet(cN, fN, verts, st)
+        _, GN = self._geom(cN, xiN)
+        lamN = self._last_phi
+        refa = np.array([[(j >> a) & 1 for j in range(8)] for a in range(3)], float)
+        gxiN = np.einsum("mj,mqjd->mqd", refa[fN // 2], GN)
+        inv_h = 0.5 * (ghT + np.linalg.norm(gxiN, axis=2))
+        return cT, cN, wA, n, inv_h, (lamT, lamN), (GT, GN)
+
+    def mem_local(self):
+        le = np.zeros((self.nmf, 4), np.int64)
+        li = np.zeros_like(le)
+        for f, (ce, ci, _) in enumerate(self.membrane):
+            for a, v in enumerate(self.mem_facets[f]):
+                le[f, a] = np.nonzero(self.cells[ce] == v)[0][0]
+                li[f, a] = np.nonzero(self.cells[ci] == v)[0][0]
+        return le, li
+
+    def _membrane_q1(self, degree):
+        """Quadrature on the membrane facets in their own vertex order: weights * measure (m, q), facet basis (q, 4),
+        basis of the ECS cell and of the intracellular cell at the points (m, q, 8)."""
+        ce, ci = self.mem_cells()
+        st, w = quadrature("quadrilateral", degree)
+        fe = np.array([f[0] for f in self._memf])
+        fi = np.array([f[1] for f in self._memf])
+        xiE, N = self._on_facet(ce, fe, self.mem_facets, st)
+        xiI, _ = self._on_facet(ci, fi, self.mem_facets, st)
+        XF = self.x[self.mem_facets]
+        dN = np.stack([np.stack([-(1 - st[:, 1]), (1 - st[:, 1]), -st[:, 1], st[:, 1]], 1),
+                       np.stack([-(1 - st[:, 0]), -st[:, 0], (1 - st[:, 0]), st[:, 0]], 1)], 2)   # (q, 4, 2)
+        T = np.einsum("mad,qat->mqdt", XF, dN)
+        area = np.linalg.norm(np.cross(T[..., 0], T[..., 1]), axis=2)
+        self._geom(ce, xiE)
+        lam_e = self._last_phi
+        self._geom(ci, xiI)
+        lam_i = self._last_phi
+        return ce, ci, w[None, :] * area, N, lam_e, lam_i
+
+    # -- potential equation -------------------------------------------------------------------------------------
+    def assemble_emi(self, params, ions, c_all, phi_M, I_ch, mem_tags_used=None, splitting_scheme=True, gamma=10.0):
+        F, C_phi = params["F"], params["C_M"] / params["dt"]
+        kap = self.kappa(params, ions, c_all)
+        acc = []
+        b = np.zeros((self.nc, 8))
+        allc = np.arange(self.nc)
+        pts, wts = quadrature("hexahedron", 2)
+        det, G = self._geom(allc, np.broadcast_to(pts, (self.nc,) + pts.shape))
+        lam = self._last_phi
+        wq = det * wts[None, :]
+        kq = np.einsum("cqj,cj->cq", lam, kap)
+        self._add_blocks(acc, allc, allc, np.einsum("cq,cq,cqid,cqjd->cij", wq, kq, G, G))
+        for ion, c in zip(ions, c_all):
+            Dc = np.asarray(ion["D"])[self.cell_sub]
+            gc = np.einsum("cj,cqjd->cqd", c, G)
+            b -= F * ion["z"] * Dc[:, None] * np.einsum("cq,cqid,cqd->ci", wq, G, gc)
+        if self.interior:
+            cT, cN, wA, n, inv_h, lams, Gs = self._interior_q1()
+            side = ((cT, 1.0), (cN, -1.0))
+            kqf = [np.einsum("mqj,mj->mq", lams[s], kap[c]) for s, (c, _) in enumerate(side)]
+            gn = [np.einsum("mqjd,mqd->mqj", Gs[s], n) for s in range(2)]
+            kavg = 0.5 * (kqf[0] + kqf[1])
+            for s, (cs, sg_s) in enumerate(side):
+                for t, (ct_, sg_t) in enumerate(side):
+                    blk = (-0.5 * sg_s * np.einsum("mq,mqi,mq,mqj->mij", wA, lams[s], kqf[t], gn[t])
+                           - 0.5 * sg_t * np.einsum("mq,mqj,mq,mqi->mij", wA, lams[t], kqf[s], gn[s])
+                           + gamma * sg_s * sg_t * np.einsum("mq,mq,mq,mqi,mqj->mij", inv_h, wA, kavg, lams[s], lams[t]))
+                    self._add_blocks(acc, cs, ct_, blk)
+            for ion, c in zip(ions, c_all):
+                Dsub = np.asarray(ion["D"])
+                fl = 0.5 * sum(Dsub[self.cell_sub[cc]][:, None] * np.einsum("mj,mqj->mq", c[cc], gn[s])
+                               for s, cc in enumerate((cT, cN)))
+                for s, (cs, sg_s) in enumerate(side):
+                    np.add.at(b, cs, sg_s * F * ion["z"] * np.einsum("mq,mq,mqi->mi", wA, fl, lams[s]))
+        if self.nmf:
+            ce, ci, wA, N, lam_e, lam_i = self._membrane_q1(2)
+            for (cr, lr, sr), (cc, lc, sc) in itertools.product(((ci, lam_i, 1.0), (ce, lam_e, -1.0)), repeat=2):
+                self._add_blocks(acc, cr, cc, C_phi * sr * sc * np.einsum("mq,mqi,mqj->mij", wA, lr, lc))
+            g = np.array(phi_M, float)
+            if not splitting_scheme:
+                g = g - sum(I_ch) / C_phi
+            gq = np.einsum("qa,ma->mq", N, g)
+            np.add.at(b, ci, C_phi * np.einsum("mq,mq,mqi->mi", wA, gq, lam_i))
+            np.add.at(b, ce, -C_phi * np.einsum("mq,mq,mqi->mi", wA, gq, lam_e))
+        return self._csr(acc), b.ravel()
+
+    # -- concentration equations --------------------------------------------------------------------------------
+    def assemble_knp(self, params, ions, c_all, phi, phi_M, I_ch, splitting_scheme=True, gamma=10.0, f_source=None):
+        K = len(ions)
+        ns = K - 1
+        psi, C_M, F, dt = params["psi"], params["C_M"], params["F"], params["dt"]
+        allc = np.arange(self.nc)
+        pts, wts = quadrature("hexahedron", 2)
+        det, G = self._geom(allc, np.broadcast_to(pts, (self.nc,) + pts.shape))
+        lam = self._last_phi
+        wq = det * wts[None, :]
+        mass = np.einsum("cq,cqi,cqj->cij", wq, lam, lam)
+        stiff = np.einsum("cq,cqid,cqjd->cij", wq, G, G)
+        gphi = np.einsum("cj,cqjd->cqd", phi, G)
+        drift = np.einsum("cq,cqid,cqd,cqj->cij", wq, G, gphi, lam)
+        accs = [[] for _ in range(ns)]
+        b = np.zeros((ns, self.nc, 8))
+        for k in range(ns):
+            Dc = np.asarray(ions[k]["D"])[self.cell_sub][:, None, None]
+            self._add_blocks(accs[k], allc, allc, mass / dt + Dc * stiff + ions[k]["z"] * psi * Dc * drift)
+            rhs = c_all[k] / dt
+            if f_source is not None and k in f_source:
+                rhs = rhs + np.where(self.cell_sub[:, None] == 0, f_source[k], 0.0)
+            b[k] += np.einsum("cij,cj->ci", mass, rhs)
+        if self.interior:
+            cT, cN, wA, n, inv_h, lams, Gs = self._interior_q1()
+            side = ((cT, 1.0), (cN, -1.0))
+            gn = [np.einsum("mqjd,mqd->mqj", Gs[s], n) for s in range(2)]
+            gpn = [np.einsum("mj,mqj->mq", phi[c], gn[s]) for s, (c, _) in enumerate(side)]
+            for k in range(ns):
+                Dsub, z = np.asarray(ions[k]["D"]), ions[k]["z"]
+                Ds = [Dsub[self.cell_sub[cT]], Dsub[self.cell_sub[cN]]]
+                Davg = 0.5 * (Ds[0] + Ds[1])
+                beta = -z * psi * 0.5 * (Ds[0][:, None] * gpn[0] + Ds[1][:, None] * gpn[1])     # (m, q)
+                up = np.where(beta > 0, 0, 1)
+                for s, (cs, sg_s) in enumerate(side):
+                    for t, (ct_, sg_t) in enumerate(side):
+                        blk = (-0.5 * sg_s * np.einsum("mq,mqi,m,mqj->mij", wA, lams[s], Ds[t], gn[t])
+                               - 0.5 * sg_t * np.einsum("mq,mqj,m,mqi->mij", wA, lams[t], Ds[s], gn[s])
+                               + gamma * sg_s * sg_t * np.einsum("mq,m,mq,mqi,mqj->mij", inv_h, Davg, wA, lams[s], lams[t])
+                               + sg_s * np.einsum("mq,mq,mqi,mqj->mij", np.where(up == t, beta, 0.0), wA, lams[s], lams[t]))
+                        self._add_blocks(accs[k], cs, ct_, blk)
+        if self.nmf:
+            ce, ci, wA, N, lam_e, lam_i = self._membrane_q1(6)
+            at = lambda field, c, lam_: np.einsum("mqj,mj->mq", lam_, field[c])
+            asum = sum(np.asarray(ion["D"])[self.cell_sub][:, None] * ion["z"] ** 2 * c for ion, c in zip(ions, c_all))
+            pm = np.einsum("qa,ma->mq", N, np.asarray(phi_M, float))
+            It = np.einsum("qa,ma->mq", N, sum(I_ch))
+            jump = at(phi, ci, lam_i) - at(phi, ce, lam_e)
+            for k in range(ns):
+                Dsub, z = np.asarray(ions[k]["D"]), ions[k]["z"]
+                a_e = Dsub[self.cell_sub[ce]][:, None] * z * z * at(c_all[k], ce, lam_e) / at(asum, ce, lam_e)
+                a_i = Dsub[self.cell_sub[ci]][:, None] * z * z * at(c_all[k], ci, lam_i) / at(asum, ci, lam_i)
+                C_e, C_i = a_e * C_M / (F * z * dt), a_i * C_M / (F * z * dt)
+                Ik = np.einsum("qa,ma->mq", N, I_ch[k])
+                g_e = pm - dt / (C_M * a_e) * Ik
+                g_i = pm - dt / (C_M * a_i) * Ik
+                if splitting_scheme:
+                    g_e, g_i = g_e + (dt / C_M) * It, g_i + (dt / C_M) * It
+                np.add.at(b[k], ce, np.einsum("mq,mq,mqi->mi", wA, -C_e * g_e + C_e * jump, lam_e))
+                np.add.at(b[k], ci, np.einsum("mq,mq,mqi->mi", wA, C_i * g_i - C_i * jump, lam_i))
+        return [self._csr(a) for a in accs], b.reshape(ns, self.n)
+
+
+def make_dg_oracle(x, cells, cell_type, cell_sub, mem_facets, mem_tags):
+    """The restatement for the mesh's cell type."""
+    cls = DGOracleQ1 if cell_type == "hexahedron" else DGOracle
+    return cls(x, cells, cell_type, cell_sub, mem_facets, mem_tags)

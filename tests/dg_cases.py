@@ -15,21 +15,36 @@ import scipy.sparse.linalg as spla
 import mms_knp_problem as K
 
 
-def make_mesh(dim, M, membrane):
+def make_mesh(dim, M, membrane, cell="simplex"):
+    """Unit square / cube with M cells per edge; cell = "hexahedron": Q1 hexahedra (dim 3)."""
     from knpemi.fem import create_box, create_unit_square
     from knpemi.fem.idealized import _tag
-    mesh = create_unit_square(None, M, M) if dim == 2 else create_box(None, [np.zeros(3), np.ones(3)], (M, M, M),
-                                                                       "tetrahedron")
+    mesh = create_unit_square(None, M, M) if dim == 2 else create_box(
+        None, [np.zeros(3), np.ones(3)], (M, M, M), "hexahedron" if cell == "hexahedron" else "tetrahedron")
+    nfv = mesh.facets.shape[1]
     if membrane:
         ct, ft = _tag(mesh, [([0.25] * dim, [0.75] * dim)], [1], full_facet_tags=False)
         sel = ft.values == 1
         return mesh, ct.dense(), mesh.facets[ft.indices[sel]], ft.values[sel]
-    return mesh, np.zeros(mesh.num_cells, np.int32), np.zeros((0, dim), np.int32), np.zeros(0, np.int32)
+    return mesh, np.zeros(mesh.num_cells, np.int32), np.zeros((0, nfv), np.int32), np.zeros(0, np.int32)
 
 
 def l2_error(be, uh, exact):
-    """L2 norm of (broken P1 field uh (nc, nv) - exact) with the vertex + centroid rule (degree 2 / 3)."""
+    """L2 norm of (broken P1 field uh (nc, nv) - exact) with the vertex + centroid rule (degree 2 / 3); broken Q1 on
+    hexahedra: the 3 x 3 x 3 Gauss rule through the trilinear map."""
     nv = uh.shape[1]
+    if nv == 8:
+        g, w = np.polynomial.legendre.leggauss(3)
+        g, w = 0.5 * (g + 1.0), 0.5 * w
+        tot = 0.0
+        for a, wa in zip(g, w):
+            for b_, wb in zip(g, w):
+                for c_, wc in zip(g, w):
+                    N = np.array([(a if j & 1 else 1 - a) * (b_ if j & 2 else 1 - b_) * (c_ if j & 4 else 1 - c_)
+                                  for j in range(8)])
+                    Xq = np.einsum("j,cjd->cd", N, be.X)
+                    tot = tot + wa * wb * wc * be.vol * (uh @ N - exact(Xq.T)) ** 2
+        return float(np.sqrt(np.sum(tot)))
     d = nv - 1
     Xc = be.X.mean(axis=1)
     ev = (uh - exact(be.X.reshape(-1, d).T).reshape(uh.shape)) ** 2
@@ -167,12 +182,12 @@ def pm_on_facets(be, pm, splitting, I, dt):
 
 
 class OracleBackend:
-    def __init__(self, dim, M, membrane, gamma=10.0):
+    def __init__(self, dim, M, membrane, gamma=10.0, cell="simplex"):
         import knpemi_dg_oracle as dg
-        mesh, cell_sub, mfac, mtag = make_mesh(dim, M, membrane)
-        self.o = dg.DGOracle(mesh.x, mesh.cells, mesh.cell_type, cell_sub, mfac, mtag)
+        mesh, cell_sub, mfac, mtag = make_mesh(dim, M, membrane, cell)
+        self.o = dg.make_dg_oracle(mesh.x, mesh.cells, mesh.cell_type, cell_sub, mfac, mtag)
         self.X = mesh.x[mesh.cells]
-        self.XM = mesh.x[mfac].reshape(len(mfac), dim, dim)
+        self.XM = mesh.x[mfac].reshape(len(mfac), mfac.shape[1] if len(mfac) else dim, dim)
         self.cell_sub = np.asarray(cell_sub)
         self.vol = self.o.vol
         self.gamma = gamma

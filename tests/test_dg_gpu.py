@@ -80,6 +80,59 @@ def test_dg_assembly_matches_oracle(hip_lib, dim, M, K, splitting):
         assert np.all(np.diff(cols) > 0) and r in cols
 
 
+def _hex_problem(M, membrane, n_ions=3, gamma=10.0, distort=None, seed=5):
+    """Unit cube of M^3 hexahedra, a cube of cells in the middle as the intracellular sub-domain; distort: None (boxes),
+    "shear" (parallelepipeds with a full metric tensor), "random" (general trilinear cells: interior vertices moved)."""
+    from knpemi.dg import DGProblem
+    from knpemi.fem import create_box
+    from knpemi.fem.idealized import _tag
+    import knpemi_dg_oracle as dg
+    mesh = create_box(None, [np.zeros(3), np.ones(3)], (M, M, M), "hexahedron")
+    if membrane:
+        ct, ft = _tag(mesh, [([0.25] * 3, [0.75] * 3)], [1], full_facet_tags=False)
+    else:
+        ct, ft = _tag(mesh, [], [], full_facet_tags=False)
+    x = mesh.x
+    if distort == "shear":
+        S = np.array([[1.0, 0.25, -0.15], [0.1, 0.9, 0.2], [-0.2, 0.05, 1.1]])
+        x[:] = x @ S.T
+    elif distort == "random":
+        rng = np.random.default_rng(seed)
+        inner = np.all((x > 1e-9) & (x < 1 - 1e-9), axis=1)
+        x[inner] += (0.18 / M) * (rng.random((inner.sum(), 3)) - 0.5)
+    dp = DGProblem(mesh, ct, ft, [0, 1], [1], n_ions=n_ions)
+    dp.gamma = gamma
+    o = dg.make_dg_oracle(mesh.x, mesh.cells, mesh.cell_type, dp.cell_sub, dp.mem_facets, dp.mem_tags)
+    return dp, o
+
+
+@pytest.mark.parametrize("splitting", [True, False])
+@pytest.mark.parametrize("M,K,distort", [(4, 3, None), (4, 3, "shear"), (4, 3, "random"), (6, 2, "random"), (4, 4, "shear")])
+def test_dg_q1_assembly_on_hexahedra_matches_oracle(hip_lib, M, K, distort, splitting):
+    """Broken Q1 on hexahedra (csrc/kernels_dg_hex.hip: facet-aligned frames, shared Jacobian inverses) against the
+    restatement that maps every point into each cell's own reference coordinates (DGOracleQ1): boxes, parallelepipeds
+    with a full metric tensor and general trilinear cells, membrane terms and source included, different diffusivities
+    on the two sides, 1e-10 of the largest entry."""
+    dp, o = _hex_problem(M, True, n_ions=K, gamma=7.5, distort=distort)
+    zs = [1.0, -1.0, 2.0, -1.0][:K]
+    ions = [dict(name=f"i{k}", z=zs[k], D=[1.0 + 0.3 * k, 0.6 + 0.2 * k]) for k in range(K)]
+    params = dict(dt=0.05, F=1.3, psi=0.8, C_M=0.7)
+    c_all, phi, phi_M, I_ch, src = _random_state(dp, K, 1)
+    _push(dp, params, ions, c_all, phi, phi_M, I_ch, src)
+    dp.assemble_emi(splitting)
+    dp.assemble_knp(splitting)
+    A, b = o.assemble_emi(params, ions, c_all, phi_M, I_ch, splitting_scheme=splitting, gamma=7.5)
+    assert csr_rel_err(dp.matrix(0), A) < TOL and rel_err(dp.rhs(0), b) < TOL
+    As, bs = o.assemble_knp(params, ions, c_all, phi, phi_M, I_ch, splitting_scheme=splitting, gamma=7.5, f_source=src)
+    for k in range(K - 1):
+        assert csr_rel_err(dp.matrix(1 + k), As[k]) < TOL, k
+        assert rel_err(dp.rhs(1 + k), bs[k]) < TOL, k
+    assert dp.nv == 8 and dp.nf == 4 and np.all(np.diff(dp.indptr) % 8 == 0)
+    for r in (0, dp.n // 2, dp.n - 1):
+        cols = dp.indices[dp.indptr[r]:dp.indptr[r + 1]]
+        assert np.all(np.diff(cols) > 0) and r in cols
+
+
 @pytest.mark.parametrize("dim", [2, 3])
 def test_dg_assembly_matches_oracle_at_physical_scales(hip_lib, dim):
     """The reference's idealized geometries and SI parameters (micrometre cells, D ~ 1e-9 m^2/s, dt = 0.1 ms,
