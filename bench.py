@@ -385,12 +385,15 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, wo
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     family, kind, r = WORKLOADS[args.workload]
-    if family != "idealized" or kind != "tet":
-        raise SystemExit("--variant dg runs on the idealized tetrahedral workloads (config2, config3, r3)")
+    if family != "idealized" or kind not in ("tet", "hex"):
+        raise SystemExit("--variant dg runs on the idealized 3-D workloads (config2, config3, r3; config2h: broken Q1 on hexahedra)")
+    if kind == "hex" and world > 1:
+        raise SystemExit("--variant dg on hexahedra runs on one GPU (the slab partition of knpemi.dg.DGSlab cuts tetrahedral meshes)")
+    cell_name = "tetrahedra" if kind == "tet" else "hexahedra"
     slab = None
     with contextlib.redirect_stdout(io.StringIO()):
         if world == 1:
-            dp = dg_time.build(r)
+            dp = dg_time.build(r, cell="tetrahedron" if kind == "tet" else "hexahedron")
         else:
             from knpemi.dg import DGSlab
             slab = DGSlab(r, 2 * world, rank, world, device=torch.cuda.current_device())
@@ -464,20 +467,23 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, wo
         "value": dofs / (elapsed / steps), "unit": "dofs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"{args.workload}: make_mesh_3D geometry r={r}, {dp.n_cells} tetrahedra, broken P1: {dp.n} dofs "
+        "config": {"workload": f"{args.workload}: make_mesh_3D geometry r={r}, {dp.n_cells} {cell_name}, broken "
+                               f"{'P1' if kind == 'tet' else 'Q1'}: {dp.n} dofs "
                                f"per field, {dp.nnz} CSR entries per system, {dp.nmf * dp.nf} membrane facet nodes (HH), 3 ions",
-                   "variant": "DG(P1) + symmetric interior penalty (gamma = 10), upwinded drift", "dofs_per_step": dofs,
+                   "variant": f"DG({'P1' if kind == 'tet' else 'Q1'}) + symmetric interior penalty (gamma = 10), upwinded drift",
+                   "dofs_per_step": dofs,
                    "partition": ("none" if slab is None else
                                  f"x-slabs of a {32 * world} um box (config 2 per GPU), one ghost-cell layer per cut, "
                                  f"ghost dofs refreshed once per step: {slab.mode}"),
                    "state": "fields held at the initial state in the timed steps; whole steps with the device solves in with_solves"},
-        "roofline": roof(1, "dg_knp_kernel", knp_us),
-        "roofline_potential_kernel": roof(0, "dg_emi_kernel", emi_us),
-        "kernels_us_per_step": {"dg_emi_kernel": emi_us, "dg_knp_kernel": knp_us},
+        "roofline": roof(1, "dg_knp_kernel" if kind == "tet" else "dg_knp_hex_kernel", knp_us),
+        "roofline_potential_kernel": roof(0, "dg_emi_kernel" if kind == "tet" else "dg_emi_hex_kernel", emi_us),
+        "kernels_us_per_step": {("dg_emi_kernel" if kind == "tet" else "dg_emi_hex_kernel"): emi_us,
+                                ("dg_knp_kernel" if kind == "tet" else "dg_knp_hex_kernel"): knp_us},
         "ode": {"rhs_evals_per_dof_per_step": n_rhs / max(1, dp.nmf * dp.nf) / steps},
     }
     n_solve = getattr(args, "solve_steps", 0)
-    if world == 1 and cpu and n_solve > 0 and dp.n <= 1_000_000:
+    if world == 1 and cpu and n_solve > 0 and dp.n <= 1_400_000:
         # whole DG time steps: the two systems solved on the device (CG / BiCGStab + auxiliary-space AMG at the reference's
         # rtol 1e-5 / 1e-7, knpemi_dg_solve_emi/knp), the update taken from the solution without leaving the device
         def solved_step(k):
@@ -505,9 +511,9 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, wo
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import knpemi_dg_oracle as dgo
         from knpemi.fem.idealized import make_mesh_3D
-        mesh, ct, ft = make_mesh_3D(0, "tetrahedron")
+        mesh, ct, ft = make_mesh_3D(0, "tetrahedron" if kind == "tet" else "hexahedron")
         sel = ft.values == 1
-        o = dgo.DGOracle(mesh.x, mesh.cells, mesh.cell_type, ct.dense(), mesh.facets[ft.indices[sel]], ft.values[sel])
+        o = dgo.make_dg_oracle(mesh.x, mesh.cells, mesh.cell_type, ct.dense(), mesh.facets[ft.indices[sel]], ft.values[sel])
         shape, ms_ = (o.nc, o.nv), (o.nmf, o.nf)
         ions = [dict(z=1.0, D=[1.33e-9] * 2), dict(z=1.0, D=[1.96e-9] * 2), dict(z=-1.0, D=[2.03e-9] * 2)]
         pr = dict(dt=dt, F=96485.0, psi=96485.0 / (8.314 * 300.0), C_M=0.02)
@@ -521,7 +527,7 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, wo
         tc = (time.perf_counter() - t0) / reps
         out["cpu_baseline"] = {"value": o.n * 3 / tc, "unit": "dofs/s", "cores": 1, "kind": "port",
                                "sample": f"{reps} assemblies (potential + 2 concentration systems, no ODE sweep) of the numpy "
-                                         f"restatement oracle/knpemi_dg_oracle.py on the r=0 mesh ({o.nc} tetrahedra, "
+                                         f"restatement oracle/knpemi_dg_oracle.py on the r=0 mesh ({o.nc} {cell_name}, "
                                          f"{o.n} dofs per field), {tc * 1e3:.0f} ms each; there is no reference DG code"}
     return out
 

@@ -859,6 +859,31 @@ extern "C" int knpemi_dg_create(const knpemi_dg_desc* d, int device, knpemi_dg**
   const int nc = (int)d->n_cells, nmf = (int)d->n_mem_facets, n = nc * NV;
   for (int c = 0; c < nc; ++c)
     if (d->cell_sub[c] < 0 || d->cell_sub[c] >= d->n_sub) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: cell_sub out of range");
+  if (hex) {
+    // tensor-product vertex order (bit a of a local vertex = its coordinate along axis a): the trilinear map of a cell
+    // given in another order (e.g. the counter-clockwise order of other formats) folds over, i.e. its Jacobian
+    // determinant changes sign between the corners
+    for (int c = 0; c < nc; ++c) {
+      int pos = 0, neg = 0;
+      for (int j = 0; j < 8; ++j) {
+        double e[3][3];
+        for (int a = 0; a < 3; ++a) {
+          const int v0 = d->cells[(size_t)c * 8 + j], v1 = d->cells[(size_t)c * 8 + (j ^ (1 << a))];
+          if (v0 < 0 || v0 >= d->n_vertices || v1 < 0 || v1 >= d->n_vertices)
+            return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: vertex id out of range");
+          const double sgn = ((j >> a) & 1) ? -1.0 : 1.0;
+          for (int k = 0; k < 3; ++k) e[a][k] = sgn * (d->x[(size_t)v1 * 3 + k] - d->x[(size_t)v0 * 3 + k]);
+        }
+        const double det = e[0][0] * (e[1][1] * e[2][2] - e[1][2] * e[2][1]) - e[0][1] * (e[1][0] * e[2][2] - e[1][2] * e[2][0]) +
+                           e[0][2] * (e[1][0] * e[2][1] - e[1][1] * e[2][0]);
+        pos += det > 0.0;
+        neg += det < 0.0;
+      }
+      if (pos != 8 && neg != 8)
+        return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: hexahedron " + std::to_string(c) +
+                                          " is degenerate or not in tensor-product vertex order");
+    }
+  }
   // facet -> (cell, local facet) by sorting the facets' sorted vertex tuples; membrane facets ride along with id < 0
   struct Ent { std::array<int, 4> key; int id; };
   std::vector<Ent> ents;

@@ -23,8 +23,9 @@
 //        c = 1 / (d . n),  a_s = ((t_t x d) . n) / det,  a_t = ((d x t_s) . n) / det,  det = d . (t_s x t_t)
 //      -- no 3 x 3 inverse of the neighbour, no reference coordinates of the neighbour.  The lane leaves per point the
 //      surface weight, 1 / h_F = (|c_T| + |c_N|) / 2, (a_s, a_t, c) of both cells and the traces the rows need;
-//   1b. lane (cell, i) inverts the Jacobian at volume Gauss point i of its cell and leaves it in LDS;
-//   2. every lane builds its row: volume terms from the eight shared inverses, facet terms from the six facet summaries.
+//   1b. lane (cell, i) inverts the Jacobian at volume Gauss point i of its cell and leaves the physical gradients of the
+//      cell's 8 basis functions at that point in LDS;
+//   2. every lane builds its row: volume terms from the eight shared gradient tables, facet terms from the six summaries.
 //      Loops over facets, points and columns are unrolled, so every index into a register array is a compile-time
 //      constant; what depends on the lane's own vertex i are a few scalars per point (its trace and normal derivative).
 //      The neighbour blocks are put into the neighbour's local column order through a small LDS scratch and leave as
@@ -42,7 +43,7 @@ constexpr int HX_NV = 8, HX_NFC = 6;
 constexpr int HX_CELLS = DG_BLOCK / HX_NV;          // cells per workgroup
 constexpr int HX_TASKS = HX_CELLS * HX_NFC;         // (cell, facet) pairs per workgroup
 constexpr int HX_FS_EMI = 49;                       // doubles per facet summary (12 per point, odd pitch)
-constexpr int HX_VG = 10;                           // inverse Jacobian (9) + weight * |det|
+constexpr int HX_VG = 25;                           // per volume point: the 8 physical gradients (24) + weight * |det|
 constexpr int HX_SCR = 9;                           // scratch pitch of the column permutation
 constexpr double HX_G0 = 0.21132486540518711775, HX_G1 = 0.78867513459481288225;   // 2-point Gauss on [0, 1]
 
@@ -118,39 +119,44 @@ __device__ __forceinline__ void hx_frame(int p, const double (&xm)[4][3], const 
   }
 }
 
-// inverse Jacobian (row t = grad xi_t) and weight * |det| of the cell at volume Gauss point p (runtime)
+// the physical gradients of the 8 basis functions and weight * |det J| of the cell at volume Gauss point p (runtime):
+// out[3 j + d] = d phi_j / d x_d, out[24] = |det| / 8.  Computed once per (cell, point) by the lane whose vertex has the
+// point's number and read by the 8 rows of the cell.
 __device__ __forceinline__ void hx_volume_point(const double (&X)[8][3], int p, double* out) {
   double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};   // J[d][t] = d x_d / d xi_t
   const double w0[2] = {(p & 1) ? HX_G0 : HX_G1, (p & 1) ? HX_G1 : HX_G0};          // shape of bit 0 = 0 / 1 along axis 0
   const double w1[2] = {(p & 2) ? HX_G0 : HX_G1, (p & 2) ? HX_G1 : HX_G0};
   const double w2[2] = {(p & 4) ? HX_G0 : HX_G1, (p & 4) ? HX_G1 : HX_G0};
+  double dr[8][3];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const double a = w0[j & 1], b = w1[(j >> 1) & 1], c = w2[(j >> 2) & 1];
-    const double d0 = ((j & 1) ? 1.0 : -1.0) * b * c, d1 = ((j & 2) ? 1.0 : -1.0) * a * c, d2 = ((j & 4) ? 1.0 : -1.0) * a * b;
+    dr[j][0] = ((j & 1) ? 1.0 : -1.0) * b * c; dr[j][1] = ((j & 2) ? 1.0 : -1.0) * a * c; dr[j][2] = ((j & 4) ? 1.0 : -1.0) * a * b;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { J[d][0] += X[j][d] * d0; J[d][1] += X[j][d] * d1; J[d][2] += X[j][d] * d2; }
+    for (int d = 0; d < 3; ++d) { J[d][0] += X[j][d] * dr[j][0]; J[d][1] += X[j][d] * dr[j][1]; J[d][2] += X[j][d] * dr[j][2]; }
   }
   const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1], c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2],
                c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
   const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02, ri = fast_rcp(det);
-  // inverse: Jinv[t][d] = cofactor(J)[d][t] / det
-  out[0] = c00 * ri; out[1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * ri; out[2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * ri;
-  out[3] = c01 * ri; out[4] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * ri; out[5] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * ri;
-  out[6] = c02 * ri; out[7] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * ri; out[8] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * ri;
-  out[9] = 0.125 * fabs(det);
+  // inverse: Ji[t][d] = cofactor(J)[d][t] / det  (row t = grad xi_t)
+  double Ji[9];
+  Ji[0] = c00 * ri; Ji[1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * ri; Ji[2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * ri;
+  Ji[3] = c01 * ri; Ji[4] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * ri; Ji[5] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * ri;
+  Ji[6] = c02 * ri; Ji[7] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * ri; Ji[8] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * ri;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) out[3 * j + d] = dr[j][0] * Ji[d] + dr[j][1] * Ji[3 + d] + dr[j][2] * Ji[6 + d];
+  out[24] = 0.125 * fabs(det);
 }
 
-// physical gradient and value of basis function J_ (compile time) at volume point p (runtime: the points are walked by a
-// real loop -- eight unrolled copies of the point's gradient table at once do not fit the register file)
-template <int J_>
-__device__ __forceinline__ double hx_grad(const double* Ji, int p, double (&g)[3]) {
-  const int x = J_ ^ p;
-  const double a = (x & 1) ? HX_G0 : HX_G1, b = (x & 2) ? HX_G0 : HX_G1, c = (x & 4) ? HX_G0 : HX_G1;
-  const double d0 = (J_ & 1) ? b * c : -(b * c), d1 = (J_ & 2) ? a * c : -(a * c), d2 = (J_ & 4) ? a * b : -(a * b);
+// values of the 8 basis functions at volume point p (runtime)
+__device__ __forceinline__ void hx_values(int p, double (&ph)[8]) {
+  const double w0[2] = {(p & 1) ? HX_G0 : HX_G1, (p & 1) ? HX_G1 : HX_G0};
+  const double w1[2] = {(p & 2) ? HX_G0 : HX_G1, (p & 2) ? HX_G1 : HX_G0};
+  const double w2[2] = {(p & 4) ? HX_G0 : HX_G1, (p & 4) ? HX_G1 : HX_G0};
 #pragma unroll
-  for (int d = 0; d < 3; ++d) g[d] = d0 * Ji[d] + d1 * Ji[3 + d] + d2 * Ji[6 + d];
-  return a * b * c;
+  for (int j = 0; j < 8; ++j) ph[j] = w0[j & 1] * w1[(j >> 1) & 1] * w2[(j >> 2) & 1];
 }
 
 // the neighbour block of a row: values in facet order (on-facet vertices m, then the vertices behind them) -> the
@@ -312,19 +318,15 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_emi_hex_kernel(DgDev D, const DgC
     const int x = i;
 #pragma unroll 1
     for (int P = 0; P < 8; ++P) {
-      const double* Ji = vg + P * HX_VG;
-      const double wd = Ji[9];
-      // the row's own gradient: runtime vertex i
-      const int xi = x ^ P;
-      const double a = (xi & 1) ? HX_G0 : HX_G1, b = (xi & 2) ? HX_G0 : HX_G1, c = (xi & 4) ? HX_G0 : HX_G1;
-      const double d0 = ((x & 1) ? b : -b) * c, d1 = ((x & 2) ? a : -a) * c, d2 = ((x & 4) ? a : -a) * b;
-      double gi[3];
-#pragma unroll
-      for (int d = 0; d < 3; ++d) gi[d] = d0 * Ji[d] + d1 * Ji[3 + d] + d2 * Ji[6 + d];
+      const double* gt = vg + P * HX_VG;
+      const double wd = gt[24];
+      const double gi[3] = {gt[3 * x], gt[3 * x + 1], gt[3 * x + 2]};   // the row's own gradient: runtime vertex
       double g[8][3], ph[8];
-      ph[0] = hx_grad<0>(Ji, P, g[0]); ph[1] = hx_grad<1>(Ji, P, g[1]); ph[2] = hx_grad<2>(Ji, P, g[2]);
-      ph[3] = hx_grad<3>(Ji, P, g[3]); ph[4] = hx_grad<4>(Ji, P, g[4]); ph[5] = hx_grad<5>(Ji, P, g[5]);
-      ph[6] = hx_grad<6>(Ji, P, g[6]); ph[7] = hx_grad<7>(Ji, P, g[7]);
+      hx_values(P, ph);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) g[j][d] = gt[3 * j + d];
       double kq = 0.0, js[3] = {0, 0, 0};
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -567,19 +569,17 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_knp_hex_kernel(DgDev D, const DgC
     const int x = i;
 #pragma unroll 1
     for (int P = 0; P < 8; ++P) {
-      const double* Ji = vg + P * HX_VG;
-      const double wd = Ji[9];
+      const double* gt = vg + P * HX_VG;
+      const double wd = gt[24];
+      const double gi[3] = {gt[3 * x], gt[3 * x + 1], gt[3 * x + 2]};
       const int xi = x ^ P;
-      const double a = (xi & 1) ? HX_G0 : HX_G1, b = (xi & 2) ? HX_G0 : HX_G1, c = (xi & 4) ? HX_G0 : HX_G1;
-      const double d0 = ((x & 1) ? b : -b) * c, d1 = ((x & 2) ? a : -a) * c, d2 = ((x & 4) ? a : -a) * b;
-      const double phi_i = a * b * c;
-      double gi[3];
-#pragma unroll
-      for (int d = 0; d < 3; ++d) gi[d] = d0 * Ji[d] + d1 * Ji[3 + d] + d2 * Ji[6 + d];
+      const double phi_i = ((xi & 1) ? HX_G0 : HX_G1) * ((xi & 2) ? HX_G0 : HX_G1) * ((xi & 4) ? HX_G0 : HX_G1);
       double g[8][3], pj[8];
-      pj[0] = hx_grad<0>(Ji, P, g[0]); pj[1] = hx_grad<1>(Ji, P, g[1]); pj[2] = hx_grad<2>(Ji, P, g[2]);
-      pj[3] = hx_grad<3>(Ji, P, g[3]); pj[4] = hx_grad<4>(Ji, P, g[4]); pj[5] = hx_grad<5>(Ji, P, g[5]);
-      pj[6] = hx_grad<6>(Ji, P, g[6]); pj[7] = hx_grad<7>(Ji, P, g[7]);
+      hx_values(P, pj);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) g[j][d] = gt[3 * j + d];
       double gp[3] = {0, 0, 0};
 #pragma unroll
       for (int j = 0; j < 8; ++j)

@@ -84,7 +84,8 @@ def emi_boltzmann(be):
     ph, cs = K.emi_exact(be.X.reshape(-1, d).T)
     shape = be.X.shape[:2]
     params = dict(dt=1.0, F=1.0, psi=K.PSI, C_M=1.0)
-    A, b = be.emi(params, ions_unit(), [c.reshape(shape) for c in cs], np.zeros((0, d)), [np.zeros((0, d))] * 3, True)
+    nf = be.XM.shape[1]
+    A, b = be.emi(params, ions_unit(), [c.reshape(shape) for c in cs], np.zeros((0, nf)), [np.zeros((0, nf))] * 3, True)
     x = solve_pinned(A, b).reshape(shape)
     exact = lambda X: K.emi_exact(X)[0]
     w = np.repeat(be.vol / shape[1], shape[1])
@@ -128,7 +129,8 @@ def knp_volume(be):
     c_all = [ce[0](Xf).reshape(shape), ce[1](Xf).reshape(shape), cel(Xf).reshape(shape)]
     params = dict(dt=K.DT, F=1.0, psi=K.PSI, C_M=1.0)
     f = {k: src[k](Xf).reshape(shape) for k in range(2)}
-    As, b = be.knp(params, ions_unit(), c_all, ph(Xf).reshape(shape), np.zeros((0, d)), [np.zeros((0, d))] * 3, True, f)
+    nf = be.XM.shape[1]
+    As, b = be.knp(params, ions_unit(), c_all, ph(Xf).reshape(shape), np.zeros((0, nf)), [np.zeros((0, nf))] * 3, True, f)
     errs = []
     for k in range(2):
         x = solve(As[k], b[k]).reshape(shape)
@@ -187,7 +189,7 @@ class OracleBackend:
         mesh, cell_sub, mfac, mtag = make_mesh(dim, M, membrane, cell)
         self.o = dg.make_dg_oracle(mesh.x, mesh.cells, mesh.cell_type, cell_sub, mfac, mtag)
         self.X = mesh.x[mesh.cells]
-        self.XM = mesh.x[mfac].reshape(len(mfac), mfac.shape[1] if len(mfac) else dim, dim)
+        self.XM = mesh.x[mfac].reshape(len(mfac), mfac.shape[1], dim)
         self.cell_sub = np.asarray(cell_sub)
         self.vol = self.o.vol
         self.gamma = gamma

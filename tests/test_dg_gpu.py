@@ -133,7 +133,7 @@ def test_dg_q1_assembly_on_hexahedra_matches_oracle(hip_lib, M, K, distort, spli
         assert np.all(np.diff(cols) > 0) and r in cols
 
 
-@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("dim", [2, 3, "hex"])
 def test_dg_assembly_matches_oracle_at_physical_scales(hip_lib, dim):
     """The reference's idealized geometries and SI parameters (micrometre cells, D ~ 1e-9 m^2/s, dt = 0.1 ms,
     run_2D.py:174-251): determinants of 1e-14 .. 1e-21 and matrix entries spread over many decades must not cost the
@@ -141,9 +141,9 @@ def test_dg_assembly_matches_oracle_at_physical_scales(hip_lib, dim):
     from knpemi.dg import DGProblem
     from knpemi.fem.idealized import make_mesh_2D, make_mesh_3D
     import knpemi_dg_oracle as dg
-    mesh, ct, ft = make_mesh_2D(1) if dim == 2 else make_mesh_3D(0, "tetrahedron")
+    mesh, ct, ft = make_mesh_2D(1) if dim == 2 else make_mesh_3D(0, "tetrahedron" if dim == 3 else "hexahedron")
     dp = DGProblem(mesh, ct, ft, [0, 1], [1])
-    o = dg.DGOracle(mesh.x, mesh.cells, mesh.cell_type, dp.cell_sub, dp.mem_facets, dp.mem_tags)
+    o = dg.make_dg_oracle(mesh.x, mesh.cells, mesh.cell_type, dp.cell_sub, dp.mem_facets, dp.mem_tags)
     ions = [dict(name="Na", z=1.0, D=[1.33e-9] * 2), dict(name="K", z=1.0, D=[1.96e-9] * 2), dict(name="Cl", z=-1.0, D=[2.03e-9] * 2)]
     params = dict(dt=1e-4, F=96485.0, psi=96485.0 / (8.314 * 300.0), C_M=0.02)
     ins = (dp.cell_sub > 0)[:, None] * np.ones((1, dp.nv), bool)
@@ -181,8 +181,10 @@ def test_dg_assembly_without_membrane_and_bit_reproducible(hip_lib):
     assert np.array_equal(dp.matrix(0).data, A0.data) and np.array_equal(dp.matrix(1).data, A1.data)
 
 
-def test_dg_update_matches_oracle(hip_lib):
-    dp, o = _problem(2, 8, True)
+@pytest.mark.parametrize("cell", ["triangle", "hexahedron"])
+def test_dg_update_matches_oracle(hip_lib, cell):
+    dp, o = _problem(2, 8, True) if cell == "triangle" else _hex_problem(4, True, distort="random")
+    d = dp.X.shape[2]
     ions = C.ions_unit()
     params = dict(dt=0.1, F=1.0, psi=1.0, C_M=1.0)
     c_all, phi, phi_M, I_ch, _ = _random_state(dp, 3, 3)
@@ -197,14 +199,15 @@ def test_dg_update_matches_oracle(hip_lib):
     assert rel_err(dp.get_membrane_potential(), pm) < 1e-14
     e, i = dp.membrane_dofs()
     assert np.all(dp.cell_sub[e // dp.nv] == 0) and np.all(dp.cell_sub[i // dp.nv] == 1)
-    assert np.array_equal(dp.X.reshape(-1, 2)[e.ravel()], dp.XM.reshape(-1, 2))
+    assert np.array_equal(dp.X.reshape(-1, d)[e.ravel()], dp.XM.reshape(-1, d))
 
 
 class DeviceBackend:
     """tests/dg_cases.py backend on the HIP kernels."""
 
-    def __init__(self, dim, M, membrane, gamma=10.0):
-        self.dp, self.o = _problem(dim, M, membrane, gamma=gamma)
+    def __init__(self, dim, M, membrane, gamma=10.0, cell="simplex"):
+        self.dp, self.o = (_hex_problem(M, membrane, gamma=gamma) if cell == "hexahedron"
+                           else _problem(dim, M, membrane, gamma=gamma))
         self.X, self.XM, self.cell_sub, self.vol = self.dp.X, self.dp.XM, self.dp.cell_sub, self.o.vol
 
     def emi(self, params, ions, c_all, phi_M, I_ch, splitting):
@@ -238,20 +241,37 @@ def test_dg_mms_rates_through_the_device_assembly(hip_lib, dim, sizes):
     assert r_emi > 1.7 and np.all(r_knp > 1.6), (e_emi, e_knp)
 
 
+def test_dg_q1_mms_rates_through_the_device_assembly(hip_lib):
+    """Broken Q1 on hexahedra: second order in L2 for the potential with a membrane jump and for the concentrations
+    (volume problem with source; membrane flux problem) with the matrices the HIP kernels produce."""
+    e_emi, e_vol, e_mem = [], [], []
+    for M in (4, 8):
+        e_emi.append(C.emi_membrane(DeviceBackend(3, M, True, cell="hexahedron"), True)[0])
+        e_vol.append(C.knp_volume(DeviceBackend(3, M, False, cell="hexahedron"))[0])
+    for M in (8, 12):
+        e_mem.append(C.knp_membrane(DeviceBackend(3, M, True, cell="hexahedron"), True)[0])
+    r_emi = np.log2(e_emi[0] / e_emi[1])
+    r_vol = np.log2(np.array(e_vol[0]) / np.array(e_vol[1]))
+    r_mem = np.log2(np.array(e_mem[0]) / np.array(e_mem[1])) / np.log2(1.5)
+    print("DG(Q1) MMS on the device: EMI", e_emi, r_emi, "KNP volume", e_vol, r_vol, "KNP membrane", e_mem, r_mem)
+    assert r_emi > 1.7 and np.all(r_vol > 1.6) and np.all(r_mem > 1.6), (e_emi, e_vol, e_mem)
+
+
 def test_dg_volume_mms_with_source_on_device(hip_lib):
     errs = [C.knp_volume(DeviceBackend(2, M, False))[0] for M in (8, 16, 32)]
     rates = np.log2(np.array(errs[:-1]) / np.array(errs[1:]))
     assert np.all(rates[-1] > 1.8), (errs, rates)
 
 
-def test_dg_membrane_ode_sweep_matches_scipy_lsoda(hip_lib):
+@pytest.mark.parametrize("cell", ["triangle", "hexahedron"])
+def test_dg_membrane_ode_sweep_matches_scipy_lsoda(hip_lib, cell):
     """Hodgkin-Huxley sweep over the membrane nodes of the broken space: traces of the concentrations taken from the
     two cells of every membrane facet, V <- phi_M, LSODA, phi_M <- V, I_ch_k <- parameter columns -- against ODEPACK
     (scipy) on the same tables, tolerances of the CG-path test (tests/test_gpu_parity.py)."""
     import knpemi_oracle as ko
     from knpemi import _lib as L
     from setup_problem import C_M, PSI
-    dp, o = _problem(2, 8, True)
+    dp, o = _problem(2, 8, True) if cell == "triangle" else _hex_problem(4, True)
     m = ko.MODELS["hh_si"]
     ix = m["pidx"]
     names = ["Na", "K", "Cl"]
@@ -302,8 +322,10 @@ def test_dg_error_paths(hip_lib):
     ct, ft = _tag(mesh, [([0.25] * 2, [0.75] * 2)], [1], full_facet_tags=False)
     with pytest.raises(KnpemiError, match="not in mem_facets"):
         DGProblem(mesh, ct, ft, [0, 1], [7])                # the interface is not declared a membrane
-    with pytest.raises(ValueError, match="triangles and tetrahedra"):
-        DGProblem(create_box(None, [np.zeros(3), np.ones(3)], (2, 2, 2), "hexahedron"), ct, ft, [0, 1], [1])
+    hexm = create_box(None, [np.zeros(3), np.ones(3)], (2, 2, 2), "hexahedron")
+    hexm.cells[:] = hexm.cells[:, [0, 1, 3, 2, 4, 5, 7, 6]]      # counter-clockwise faces instead of the tensor order
+    with pytest.raises(KnpemiError, match="tensor-product vertex order"):
+        DGProblem(hexm, np.zeros(hexm.num_cells, np.int32), np.zeros(len(hexm.facets), np.int32), [0], [1])
     dp = DGProblem(mesh, ct, ft, [0, 1], [1])
     with pytest.raises(KnpemiError, match="set_params"):
         dp.assemble_emi()
@@ -355,7 +377,7 @@ def test_dg_time_loop_on_the_device_matches_the_restatement(hip_lib):
     assert v.mean() > -0.0744 + 0.010
 
 
-@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("dim", [2, 3, "hex"])
 def test_dg_device_solves_match_direct_solves(hip_lib, dim):
     """knpemi_dg_solve_emi / knpemi_dg_solve_knp (CG with the constants projected out / BiCGStab, AMG over the continuous
     P1 auxiliary space; pdeSolver.py:24-35,74-78,99-110) on the systems of the idealized geometries at SI scales against
@@ -366,7 +388,7 @@ def test_dg_device_solves_match_direct_solves(hip_lib, dim):
     from run_2D_dg import solve_singular
     from knpemi.dg import DGProblem
     from knpemi.fem.idealized import make_mesh_2D, make_mesh_3D
-    mesh, ct, ft = make_mesh_2D(2) if dim == 2 else make_mesh_3D(0, "tetrahedron")
+    mesh, ct, ft = make_mesh_2D(2) if dim == 2 else make_mesh_3D(0, "tetrahedron" if dim == 3 else "hexahedron")
     dp = DGProblem(mesh, ct, ft, [0, 1], [1])
     assert dp.n > 640                                               # beyond the size the AMG inverts directly
     ions = [dict(name="Na", z=1.0, D=[1.33e-9] * 2), dict(name="K", z=1.0, D=[1.96e-9] * 2), dict(name="Cl", z=-1.0, D=[2.03e-9] * 2)]

@@ -68,6 +68,31 @@ def test_dg_knp_membrane_terms(dim, sizes, splitting):
     assert np.all(rates[-1] > (1.7 if dim == 2 else 1.6)) and np.all(errs[-1] < (2e-2 if dim == 2 else 8e-2)), (errs, rates)
 
 
+def test_dg_q1_restatement_on_hexahedra_is_second_order_and_keeps_the_invariants():
+    """Broken Q1 on hexahedra (DGOracleQ1; the reference's own 3-D cell type, make_mesh_3D.py:100-102): the manufactured
+    problems at second order, symmetry of the SIP potential matrix with the constants in its kernel, a compatible
+    right-hand side, and mass conservation of the concentration matrices."""
+    out = [C.emi_boltzmann(C.OracleBackend(3, M, False, cell="hexahedron")) for M in (4, 8)]
+    assert np.log2(out[0][0] / out[1][0]) > 1.8 and out[1][0] < 2e-2, [o[0] for o in out]
+    A, b = out[0][1], out[0][2]
+    assert abs(A - A.T).max() < 1e-12 * abs(A).max()
+    assert np.abs(A @ np.ones(A.shape[0])).max() < 1e-10 * abs(A).max()
+    assert abs(b.sum()) < 1e-10 * np.abs(b).sum()
+    vol = [C.knp_volume(C.OracleBackend(3, M, False, cell="hexahedron")) for M in (4, 8)]
+    assert np.all(np.log2(np.array(vol[0][0]) / np.array(vol[1][0])) > 1.7), [v[0] for v in vol]
+    be = C.OracleBackend(3, 4, False, cell="hexahedron")
+    mass_col = np.repeat(be.vol / 8, 8) / C.K.DT
+    for Ak in vol[0][1]:
+        assert np.abs(np.asarray(Ak.sum(axis=0)).ravel() - mass_col).max() < 1e-10 * abs(Ak).max()
+    mem = [C.emi_membrane(C.OracleBackend(3, M, True, cell="hexahedron"), True) for M in (4, 8)]
+    assert np.log2(mem[0][0] / mem[1][0]) > 1.7 and mem[1][1] < 5e-3, [m[:2] for m in mem]
+    _, _, A, _ = mem[0]
+    w = np.linalg.eigvalsh(A.toarray())
+    assert w[0] > -1e-10 * w[-1] and w[1] > 1e-8 * w[-1], w[:3]      # one zero eigenvalue (the constant), no more
+    km = [C.knp_membrane(C.OracleBackend(3, M, True, cell="hexahedron"), True)[0] for M in (8, 12)]
+    assert np.all(np.log2(np.array(km[0]) / np.array(km[1])) / np.log2(1.5) > 1.6), km
+
+
 def test_dg_penalty_parameter_only_changes_the_error_constant():
     e10 = C.emi_boltzmann(C.OracleBackend(2, 16, False, gamma=10.0))[0]
     e40 = C.emi_boltzmann(C.OracleBackend(2, 16, False, gamma=40.0))[0]

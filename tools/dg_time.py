@@ -23,10 +23,10 @@ def init_fields(dp):
     return dp
 
 
-def build(r, l=2):
+def build(r, l=2, cell="tetrahedron"):
     from knpemi.dg import DGProblem
     from knpemi.fem.idealized import make_mesh_3D
-    mesh, ct, ft = make_mesh_3D(r, "tetrahedron", l=l)
+    mesh, ct, ft = make_mesh_3D(r, cell, l=l)
     return init_fields(DGProblem(mesh, ct, ft, [0, 1], [1]))
 
 
@@ -34,7 +34,8 @@ def algorithmic_bytes(dp, which):
     """HBM bytes one launch must move: the CSR values and right-hand sides it writes, the dof records, connectivity and
     row pointers it reads once (neighbour records are re-reads of the same array: cache traffic, not counted)."""
     n, nnz, KS = dp.n, dp.nnz, dp.K - 1
-    reads = n * 64 + n * (4 + 4 + 4 + 4) + dp.n_cells
+    nfc = 6 if dp.nv == 8 else dp.nv                    # facets per cell: nbr, finfo, mfid entries
+    reads = n * 64 + dp.n_cells * nfc * 12 + n * 4 + dp.n_cells
     if which == 0:
         return reads + nnz * 8 + n * 8
     return reads + KS * (nnz * 8 + n * 8)
@@ -45,8 +46,9 @@ if __name__ == "__main__":
     ap.add_argument("-r", type=int, default=1)
     ap.add_argument("-l", type=int, default=2)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--cell", default="tetrahedron", choices=["tetrahedron", "hexahedron"])
     a = ap.parse_args()
-    dp = build(a.r, a.l)
+    dp = build(a.r, a.l, a.cell)
     print(f"cells {dp.n_cells} dofs {dp.n} nnz {dp.nnz} membrane nodes {dp.nmf * dp.nf}")
     for which, name in ((0, "dg_emi_kernel"), (1, "dg_knp_kernel")):
         ms = dp.time_kernel(which, a.reps)
