@@ -44,6 +44,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level 
 LAUNCH_FLOOR_US = 5.0      # duration of a trivial streaming kernel in the same event brackets on this stack
 PROFILE_STEPS = 5
 SPIKE_SEARCH = 72        # trajectory steps recorded at least: contains the action potential of the stimulated cell end
+if os.environ.get("KNPEMI_BENCH_TRAJ_MIN"):     # rehearsals of the N > 1 code path on one GPU (gloo, ranks sharing the card)
+    SPIKE_SEARCH = max(8, int(os.environ["KNPEMI_BENCH_TRAJ_MIN"]))
 WITH_SOLVES_START = 10   # trajectory step the with_solves pass starts from, whatever --steps / --warmup are
 
 WORKLOADS = {
@@ -406,7 +408,11 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, wo
     prow[pi("Cm")] = 0.02
     prow[pi("z_Na")], prow[pi("z_K")], prow[pi("z_Cl")], prow[pi("psi")] = 1.0, 1.0, -1.0, 96485.0 / (8.314 * 300.0)
     names = ("Na", "K", "Cl")
-    dp.ode_bind(L.MODEL_HH_SI, np.asarray(mm_hh.init_state_values(), float), prow,
+    # the stimulus of the idealized drivers (setup_problem.py:83-84, run_3D.py): g_syn = 10 on the membrane nodes with
+    # x < 20 um, written into those nodes' parameter rows -- the stimulated end of the cell fires during the run
+    ptab = np.tile(prow, (dp.nmf * dp.nf, 1))
+    ptab[dp.XM.reshape(-1, dp.XM.shape[2])[:, 0] < 20e-6, pi("stim_amplitude")] = 10.0
+    dp.ode_bind(L.MODEL_HH_SI, np.asarray(mm_hh.init_state_values(), float), ptab,
                 sum(([pi(f"{n}_e"), pi(f"{n}_i"), pi(f"I_ch_{n}")] for n in names), []), mm_hh.state_indices("V"))
     c_new = torch.tensor(np.stack([dp.get_concentration(k).ravel() for k in range(2)]), device="cuda")
     torch.cuda.synchronize()
@@ -475,7 +481,8 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, wo
                    "partition": ("none" if slab is None else
                                  f"x-slabs of a {32 * world} um box (config 2 per GPU), one ghost-cell layer per cut, "
                                  f"ghost dofs refreshed once per step: {slab.mode}"),
-                   "state": "fields held at the initial state in the timed steps; whole steps with the device solves in with_solves"},
+                   "state": "concentrations and potential held at the initial state in the timed steps, the membrane ODEs "
+                            "stimulated (g_syn = 10 for x < 20 um); whole steps with the device solves in with_solves"},
         "roofline": roof(1, "dg_knp_kernel" if kind == "tet" else "dg_knp_hex_kernel", knp_us),
         "roofline_potential_kernel": roof(0, "dg_emi_kernel" if kind == "tet" else "dg_emi_hex_kernel", emi_us),
         "kernels_us_per_step": {("dg_emi_kernel" if kind == "tet" else "dg_emi_hex_kernel"): emi_us,
@@ -506,7 +513,11 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, wo
         out["with_solves"] = {"ms_per_step": ts * 1e3, "steps": n_solve, "first_step_with_amg_setup_s": t_first,
                               "cg_iterations_per_step": sum(a for a, _ in its) / n_solve,
                               "bicgstab_iterations_per_step": sum(b for _, b in its) / n_solve,
-                              "rtol": [1e-5, 1e-7], "state": "membrane at rest (no stimulus), fields evolving"}
+                              "rtol": [1e-5, 1e-7],
+                              "state": "stimulated membrane (g_syn = 10 for x < 20 um), fields evolving: the steps follow the "
+                                       "timed ones, i.e. while the stimulated end of the cell depolarises",
+                              "phi_M_range_at_the_end": [float(dp.get_membrane_potential().min()),
+                                                         float(dp.get_membrane_potential().max())]}
     if cpu and rank == 0 and world == 1:      # the only use of oracle/ in this function: the timed CPU restatement
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import knpemi_dg_oracle as dgo
@@ -698,6 +709,13 @@ def measure(workload, args, torch, dist, rank, world, steps, warmup, repeats, sp
             L.check(lib.knpemi_profile_read(dp.h, kid, C.byref(n), C.byref(ms)))      # synchronises, clears the brackets
             ode_us_per_step.append(ms.value * 1e3)
         L.check(lib.knpemi_profile(dp.h, 0))
+        if dist is not None:
+            # every rank must pick the SAME window (the replay exchanges halos step by step: ranks that replayed
+            # different numbers of steps wait for each other forever): the slowest rank's sweep decides, step by step
+            red_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            tt = torch.tensor(ode_us_per_step, dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ode_us_per_step = [float(v) for v in tt.cpu()]
         peak = int(np.argmax(ode_us_per_step))
         spike_first = int(min(max(0, peak - steps // 2), len(rhs_per_step) - steps))
         spike_w = timed_windows(spike_first, max(3, repeats // 2))
@@ -846,6 +864,9 @@ def main():
                     help="assemble A_knp twice per step as the reference does (p = a, knpWeakForm.py:319)")
     args = ap.parse_args()
 
+    if os.environ.get("KNPEMI_BENCH_WATCHDOG"):   # diagnosis of a stuck rank: Python stacks of every thread after so many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["KNPEMI_BENCH_WATCHDOG"]), repeat=True, file=sys.stderr)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

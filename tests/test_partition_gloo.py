@@ -120,6 +120,16 @@ def test_slab_partition_world2_gloo(tmp_path, kind):
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
 
 
+def test_slab_partition_world8_gloo(tmp_path):
+    """The driver's 8-GPU run cuts a box eight times as long into eight slabs (bench.py --gpus 8, weak scaling): the same
+    checks -- ownership partitions the dofs, the forward halo delivers the owners' values, owned rows equal the rows of the
+    global assembly -- with eight ranks, interior ranks having two neighbours."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(8, port, "tet", str(tmp_path)), nprocs=8, join=True)
+    assert all((tmp_path / f"ok_{r}").exists() for r in range(8))
+
+
 def _general_worker(rank, world, port, method, out_dir):
     """General cell partitioner on a vertex- and cell-shuffled tetrahedral mesh (no structure left for the partition
     or the halo to lean on): ownership partitions the dofs, the id-keyed halo delivers owner values, and the owned rows
