@@ -389,8 +389,6 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, wo
     family, kind, r = WORKLOADS[args.workload]
     if family != "idealized" or kind not in ("tet", "hex"):
         raise SystemExit("--variant dg runs on the idealized 3-D workloads (config2, config3, r3; config2h: broken Q1 on hexahedra)")
-    if kind == "hex" and world > 1:
-        raise SystemExit("--variant dg on hexahedra runs on one GPU (the slab partition of knpemi.dg.DGSlab cuts tetrahedral meshes)")
     cell_name = "tetrahedra" if kind == "tet" else "hexahedra"
     slab = None
     with contextlib.redirect_stdout(io.StringIO()):
@@ -398,7 +396,8 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, wo
             dp = dg_time.build(r, cell="tetrahedron" if kind == "tet" else "hexahedron")
         else:
             from knpemi.dg import DGSlab
-            slab = DGSlab(r, 2 * world, rank, world, device=torch.cuda.current_device())
+            slab = DGSlab(r, 2 * world, rank, world, device=torch.cuda.current_device(),
+                          cell="tetrahedron" if kind == "tet" else "hexahedron")
             dp = dg_time.init_fields(slab.dp)
             slab.attach()
             slab.exchange()

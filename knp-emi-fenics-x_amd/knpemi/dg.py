@@ -253,8 +253,8 @@ class DGProblem:
 
 
 class DGSlab:
-    """One rank's part of the DG problem on `make_mesh_3D(r, tetrahedron, l)` cut into x-slabs of whole hexahedron
-    layers: its own layers plus ONE ghost layer on each interior side (the cells across the cut facets), generated
+    """One rank's part of the DG problem on `make_mesh_3D(r, cell, l)` (cell = "tetrahedron": broken P1 on the 6-tet split,
+    "hexahedron": broken Q1) cut into x-slabs of whole hexahedron layers: its own layers plus ONE ghost layer on each interior side (the cells across the cut facets), generated
     locally with the global coordinates (`make_mesh_3D_slab`) -- nothing global is ever built.
 
     Rows of owned cells are complete: their facet neighbours are all local.  Once per step the ghost cells' dofs (K
@@ -264,7 +264,7 @@ class DGSlab:
     need no exchange -- the same arrangement as the CG path (knpemi/fem/distributed.py).
     """
 
-    def __init__(self, r, l, rank, world, n_ions=3, device=0):
+    def __init__(self, r, l, rank, world, n_ions=3, device=0, cell="tetrahedron"):
         from .fem.idealized import make_mesh_3D_slab
         from .fem.distributed import Halo
         nx = l * 16 * 2 ** r
@@ -273,11 +273,12 @@ class DGSlab:
         if self.b - self.a < 1:
             raise ValueError("fewer hexahedron layers than ranks")
         lo, hi = max(self.a - 1, 0), min(self.b + 1, nx)
-        mesh, ct, ft = make_mesh_3D_slab(r, "tetrahedron", l, (lo, hi))
+        mesh, ct, ft = make_mesh_3D_slab(r, cell, l, (lo, hi))
         self.dp = DGProblem(mesh, ct, ft, [0, 1], [1], n_ions=n_ions, device=device)
         dp = self.dp
         nxl = hi - lo
-        self.layer = lo + (np.arange(dp.n_cells) // 6) % nxl        # global layer of every local cell (x fastest)
+        self.cells_per_hex = 6 if cell == "tetrahedron" else 1
+        self.layer = lo + (np.arange(dp.n_cells) // self.cells_per_hex) % nxl   # global layer of every local cell (x fastest)
         self.owned_cells = (self.layer >= self.a) & (self.layer < self.b)
         self.rank, self.world, self.nx = rank, world, nx
 

@@ -119,13 +119,13 @@ def test_coarse_space_of_the_distributed_emi_solve_lowers_the_iteration_count(mo
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_dg_variant_cell_partition_equals_single_rank_bit_for_bit(world):
-    """The DG(P1)+SIP variant on x-slabs with one ghost-cell layer (knpemi.dg.DGSlab): after three steps (facet-node ODE
+@pytest.mark.parametrize("world,cell", [(2, "tetrahedron"), (3, "tetrahedron"), (2, "hexahedron")])
+def test_dg_variant_cell_partition_equals_single_rank_bit_for_bit(world, cell):
+    """The DG + SIP variant (broken P1 on tetrahedra, broken Q1 on hexahedra) on x-slabs with one ghost-cell layer (knpemi.dg.DGSlab): after three steps (facet-node ODE
     sweep, both assemblies, update, ghost refresh through knpemi_dg_halo_pack/unpack with the ghosts poisoned before
     every exchange) the matrix rows, right-hand sides and fields of the owned cells and the potentials, currents and
     ODE states of the owned membrane nodes equal those of the whole box on one rank, bit for bit."""
-    rcs, outs = _run_ranks(["--steps", "3"], world=world, tool="check_dg_partition.py")
+    rcs, outs = _run_ranks(["--steps", "3", "--cell", cell], world=world, tool="check_dg_partition.py")
     assert rcs == [0] * world, "\n".join(outs)
     assert "DG PARTITION OK" in outs[0], outs[0]
 

@@ -67,6 +67,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("-r", type=int, default=0)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--cell", default="tetrahedron", choices=["tetrahedron", "hexahedron"])
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     backend = os.environ.get("KNPEMI_BENCH_BACKEND", "gloo")
@@ -75,7 +76,7 @@ def main():
     from knpemi.dg import DGProblem, DGSlab
     from knpemi.fem.idealized import make_mesh_3D
     dev = torch.cuda.current_device()
-    slab = DGSlab(a.r, 2, rank, world, device=dev)
+    slab = DGSlab(a.r, 2, rank, world, device=dev, cell=a.cell)
     setup(slab.dp)
     slab.attach()
     slab.exchange()
@@ -83,7 +84,7 @@ def main():
     ok = True
     if True:   # every rank checks its own part against the whole box (each builds it: small mesh)
         with contextlib.redirect_stdout(io.StringIO()):
-            mesh, ct, ft = make_mesh_3D(a.r, "tetrahedron", l=2)
+            mesh, ct, ft = make_mesh_3D(a.r, a.cell, l=2)
         g = DGProblem(mesh, ct, ft, [0, 1], [1], device=dev)
         setup(g)
         ref = run(g, a.steps)
@@ -91,10 +92,11 @@ def main():
         nxg = slab.nx
         lo = max(slab.a - 1, 0)
         nxl = min(slab.b + 1, nxg) - lo
-        # local cell -> global cell (x fastest, 6 tetrahedra per hexahedron)
+        # local cell -> global cell (x fastest; 6 tetrahedra per hexahedron on the simplicial mesh)
         lc = np.arange(dp.n_cells)
-        hx, t = lc // 6, lc % 6
-        gcell = ((hx // nxl) * nxg + lo + hx % nxl) * 6 + t
+        cph = slab.cells_per_hex
+        hx, t = lc // cph, lc % cph
+        gcell = ((hx // nxl) * nxg + lo + hx % nxl) * cph + t
         own = np.flatnonzero(slab.owned_cells)
         for w in range(3):
             for c in own[:: max(1, len(own) // 4000)]:
