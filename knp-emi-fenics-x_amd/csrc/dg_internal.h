@@ -102,6 +102,7 @@ __device__ __forceinline__ int dg_block_index(int b, int chunk) { return (b & 7)
 
 }  // namespace kn_dg
 
-// Q1 hexahedra (kernels_dg_hex.hip): one launch each, on `st`; KS = K - 1 solved ions
-int kn_dg_hex_launch_emi(hipStream_t st, const kn_dg::DgDev& D, const kn_dg::DgConsts* d_consts, int splitting);
-int kn_dg_hex_launch_knp(hipStream_t st, const kn_dg::DgDev& D, const kn_dg::DgConsts* d_consts, int KS, int splitting);
+// Q1 hexahedra (kernels_dg_hex.hip): one launch each, on `st`; KS = K - 1 solved ions; box != 0: every cell is an
+// orthogonal parallelepiped (the closed-frame kernels), 0: general trilinear cells
+int kn_dg_hex_launch_emi(hipStream_t st, const kn_dg::DgDev& D, const kn_dg::DgConsts* d_consts, int splitting, int box);
+int kn_dg_hex_launch_knp(hipStream_t st, const kn_dg::DgDev& D, const kn_dg::DgConsts* d_consts, int KS, int splitting, int box);

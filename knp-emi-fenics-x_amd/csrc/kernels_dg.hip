@@ -673,6 +673,7 @@ __global__ void dg_slot_kernel(double* rec, int slot, double* buf, int n, int to
 struct knpemi_dg {
   int device = 0, NV = 0, K = 0, n_sub = 0;
   int NFC = 0, NFV = 0;            // facets per cell, vertices per facet (hexahedra: 6 and 4)
+  int hex_box = 0;                 // hexahedra: every cell is an orthogonal parallelepiped (box-mesh kernels)
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DgDev dev{};
@@ -766,7 +767,7 @@ struct DgProf {   // brackets one launch with an event pair on the handle's stre
 
 int launch_emi(knpemi_dg* h, int flags) {
   DgProf prof(h, 0);
-  if (h->NV == 8) return kn_dg_hex_launch_emi(h->stream, h->dev, h->d_consts, !(flags & KNPEMI_NO_SPLITTING));
+  if (h->NV == 8) return kn_dg_hex_launch_emi(h->stream, h->dev, h->d_consts, !(flags & KNPEMI_NO_SPLITTING), h->hex_box);
   const int NV = h->NV, rpb = (DG_BLOCK / NV) * NV;
   const int nblocks = (h->dev.n_dof + rpb - 1) / rpb, chunk = (nblocks + 7) / 8;
   const size_t lds = ((size_t)rpb * (NV == 3 ? dg_fs_emi<3>() : dg_fs_emi<4>()) +
@@ -791,7 +792,7 @@ int launch_knp_nv(knpemi_dg* h, int chunk, int split) {
 
 int launch_knp(knpemi_dg* h, int flags) {
   DgProf prof(h, 1);
-  if (h->NV == 8) return kn_dg_hex_launch_knp(h->stream, h->dev, h->d_consts, h->K - 1, !(flags & KNPEMI_NO_SPLITTING));
+  if (h->NV == 8) return kn_dg_hex_launch_knp(h->stream, h->dev, h->d_consts, h->K - 1, !(flags & KNPEMI_NO_SPLITTING), h->hex_box);
   const int NV = h->NV, rpb = (DG_BLOCK / NV) * NV;
   const int nblocks = (h->dev.n_dof + rpb - 1) / rpb, chunk = (nblocks + 7) / 8;
   const int split = !(flags & KNPEMI_NO_SPLITTING);
@@ -883,6 +884,32 @@ extern "C" int knpemi_dg_create(const knpemi_dg_desc* d, int device, knpemi_dg**
         return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: hexahedron " + std::to_string(c) +
                                           " is degenerate or not in tensor-product vertex order");
     }
+    // box mesh (every mesh of the reference's 3-D driver, make_mesh_3D.py:100-102): all cells orthogonal parallelepipeds to
+    // 1e-12 of their size -- the kernels then use constant facet frames (kernels_dg_hex.hip); KNPEMI_DG_HEX_GENERAL=1
+    // keeps the general kernels (tests run both on the same mesh)
+    bool box = getenv("KNPEMI_DG_HEX_GENERAL") == nullptr;
+    for (int c = 0; c < nc && box; ++c) {
+      const int32_t* cv = d->cells + (size_t)c * 8;
+      const double* x0 = d->x + (size_t)cv[0] * 3;
+      double e[3][3], len[3];
+      for (int t = 0; t < 3; ++t) {
+        const double* xt = d->x + (size_t)cv[1 << t] * 3;
+        for (int k = 0; k < 3; ++k) e[t][k] = xt[k] - x0[k];
+        len[t] = std::sqrt(e[t][0] * e[t][0] + e[t][1] * e[t][1] + e[t][2] * e[t][2]);
+      }
+      const double size = std::max(len[0], std::max(len[1], len[2]));
+      for (int a = 0; a < 3 && box; ++a)
+        for (int b = a + 1; b < 3; ++b)
+          if (std::fabs(e[a][0] * e[b][0] + e[a][1] * e[b][1] + e[a][2] * e[b][2]) > 1e-12 * len[a] * len[b]) box = false;
+      for (int j = 0; j < 8 && box; ++j) {
+        const double* xj = d->x + (size_t)cv[j] * 3;
+        for (int k = 0; k < 3; ++k) {
+          const double want = x0[k] + ((j & 1) ? e[0][k] : 0.0) + ((j & 2) ? e[1][k] : 0.0) + ((j & 4) ? e[2][k] : 0.0);
+          if (std::fabs(xj[k] - want) > 1e-12 * size) box = false;
+        }
+      }
+    }
+    h->hex_box = box ? 1 : 0;
   }
   // facet -> (cell, local facet) by sorting the facets' sorted vertex tuples; membrane facets ride along with id < 0
   struct Ent { std::array<int, 4> key; int id; };

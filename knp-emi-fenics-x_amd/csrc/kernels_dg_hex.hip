@@ -44,7 +44,7 @@ constexpr int HX_CELLS = DG_BLOCK / HX_NV;          // cells per workgroup
 constexpr int HX_TASKS = HX_CELLS * HX_NFC;         // (cell, facet) pairs per workgroup
 constexpr int HX_FS_EMI = 49;                       // doubles per facet summary (12 per point, odd pitch)
 constexpr int HX_VG = 25;                           // per volume point: the 8 physical gradients (24) + weight * |det|
-constexpr int HX_SCR = 9;                           // scratch pitch of the column permutation
+constexpr int HX_SCR = 10;                          // scratch pitch of the block transposition (even: 16-byte reads)
 constexpr double HX_G0 = 0.21132486540518711775, HX_G1 = 0.78867513459481288225;   // 2-point Gauss on [0, 1]
 
 __host__ __device__ constexpr int hx_ax1(int a) { return a == 0 ? 1 : 0; }
@@ -159,9 +159,13 @@ __device__ __forceinline__ void hx_values(int p, double (&ph)[8]) {
   for (int j = 0; j < 8; ++j) ph[j] = w0[j & 1] * w1[(j >> 1) & 1] * w2[(j >> 2) & 1];
 }
 
-// the neighbour block of a row: values in facet order (on-facet vertices m, then the vertices behind them) -> the
-// neighbour's local column order through the lane's scratch line -> four 16-byte stores
-__device__ __forceinline__ void hx_store_nbr(double* scr, unsigned fi, const double (&B0)[4], const double (&B1)[4], double* dst) {
+// A block of a row (8 values = one 64-byte line of the CSR value array) leaves through LDS: every lane puts its block
+// into its scratch line -- a neighbour block in the NEIGHBOUR's local column order (values arrive in facet order: on-facet
+// vertices m, then the vertices behind them) -- and the offset of the line into dsts; then four lanes store one line
+// together (16 bytes each, 16 whole lines per store instruction) instead of every lane storing quarter lines of its own
+// (64 partial lines per instruction: the write path then runs at a quarter of its request rate).  Called by ALL lanes of
+// the workgroup: `have` = this lane's row has the block, at element offset `off` of `base`.
+__device__ __forceinline__ void hx_put_nbr(double* scr, unsigned fi, const double (&B0)[4], const double (&B1)[4]) {
   const int ao = ((fi >> 2) & 7) >> 1;
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
@@ -169,9 +173,32 @@ __device__ __forceinline__ void hx_store_nbr(double* scr, unsigned fi, const dou
     scr[jn] = B0[m];
     scr[jn ^ (1 << ao)] = B1[m];
   }
-  double2* d2 = reinterpret_cast<double2*>(dst);
+}
+__device__ __forceinline__ void hx_put_own(double* scr, const double (&A)[8]) {
+  double2* q = reinterpret_cast<double2*>(scr);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) d2[e] = make_double2(scr[2 * e], scr[2 * e + 1]);
+  for (int e = 0; e < 4; ++e) q[e] = make_double2(A[2 * e], A[2 * e + 1]);
+}
+// The workgroup is ONE wavefront: its LDS operations execute in program order, so the exchange between the lanes needs
+// no barrier -- only the compiler must keep the order (and the counter wait makes the written data visible to the
+// reads that follow).  __syncthreads() would also wait for every global store still in flight (its fence covers global
+// memory): seven to fourteen times per row, each time the full latency of the write path.
+static_assert(DG_BLOCK == 64, "the block stores of the hexahedral kernels assume single-wave workgroups");
+__device__ __forceinline__ void hx_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void hx_flush(const double* scrs, int* dsts, int tid, bool have, int off, double* base) {
+  dsts[tid] = have ? off : -1;
+  hx_lds_sync();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = 16 * k + (tid >> 2), part = tid & 3;
+    const int d = dsts[r];
+    if (d >= 0)
+      *reinterpret_cast<double2*>(base + d + 2 * part) = *reinterpret_cast<const double2*>(scrs + r * HX_SCR + 2 * part);
+  }
+  hx_lds_sync();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -180,7 +207,8 @@ __device__ __forceinline__ void hx_store_nbr(double* scr, unsigned fi, const dou
 __global__ __launch_bounds__(DG_BLOCK) void dg_emi_hex_kernel(DgDev D, const DgConsts* __restrict__ Cp, int chunk, int splitting) {
   __shared__ double lrec[DG_BLOCK * DG_RPITCH];
   __shared__ double fsum[HX_TASKS * HX_FS_EMI];
-  __shared__ double vgeo[DG_BLOCK * HX_VG];       // later the scratch of the column permutation (HX_SCR <= HX_VG)
+  __shared__ double vgeo[DG_BLOCK * HX_VG];       // later the scratch of the block transposition (HX_SCR <= HX_VG)
+  __shared__ int dsts[DG_BLOCK];
   const DgConsts& C = *Cp;
   const int cell0 = dg_block_index(blockIdx.x, chunk) * HX_CELLS;
   if (cell0 >= D.n_cell) return;
@@ -204,8 +232,8 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_emi_hex_kernel(DgDev D, const DgC
     tfi = D.finfo[(cell0 + tc) * HX_NFC + tf];
     tmf = D.mfid[(cell0 + tc) * HX_NFC + tf];
   }
-  int nb[HX_NFC];
-  unsigned fi[HX_NFC];
+  int nb[HX_NFC] = {-1, -1, -1, -1, -1, -1};
+  unsigned fi[HX_NFC] = {0, 0, 0, 0, 0, 0};
   int s = 0, rp = 0;
   if (valid) {
     s = D.cell_sub[T];
@@ -309,11 +337,10 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_emi_hex_kernel(DgDev D, const DgC
     hx_volume_point(X, i, vgeo + tid * HX_VG);
   }
   __syncthreads();
-  if (!valid) return;   // (no barrier below: what follows only touches this lane's own scratch line)
-  // phase 2: the row
+  // phase 2: the row (every lane stays for the block stores below)
   double A[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   double rhs = 0.0;
-  {
+  if (valid) {
     const double* vg = vgeo + lc * HX_NV * HX_VG;
     const int x = i;
 #pragma unroll 1
@@ -344,10 +371,10 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_emi_hex_kernel(DgDev D, const DgC
   hx_slots(T, nb, slot_self, slot);
   __syncthreads();   // every lane of the wave is done with the shared Jacobians: their space becomes the scratch lines
   double* scr = vgeo + tid * HX_SCR;
-  double* Arow = D.A_emi + rp;
   auto facet = [&](auto F_) {
     constexpr int f = decltype(F_)::value, a = f >> 1, b = f & 1;
-    if (nb[f] < 0) return;
+    const bool have = valid && nb[f] >= 0;
+    if (have) {
     const int kind = fi[f] & 3;
     const bool on = ((i >> a) & 1) == b;
     const int mi = ((i >> hx_ax1(a)) & 1) | (((i >> hx_ax2(a)) & 1) << 1);
@@ -388,16 +415,16 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_emi_hex_kernel(DgDev D, const DgC
         rhs += (kind == 3 ? W : -W) * o[1];
       }
     }
-    hx_store_nbr(scr, fi[f], B0, B1, Arow + slot[f] * HX_NV);
-    __builtin_amdgcn_sched_barrier(0);   // keep the six facets apart: hoisted summary reads of later facets cost registers
+    hx_put_nbr(scr, fi[f], B0, B1);
+    }
+    hx_flush(vgeo, dsts, tid, have, rp + slot[f] * HX_NV, D.A_emi);
   };
   facet(std::integral_constant<int, 0>{}); facet(std::integral_constant<int, 1>{});
   facet(std::integral_constant<int, 2>{}); facet(std::integral_constant<int, 3>{});
   facet(std::integral_constant<int, 4>{}); facet(std::integral_constant<int, 5>{});
-  double2* d2 = reinterpret_cast<double2*>(Arow + slot_self * HX_NV);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) d2[e] = make_double2(A[2 * e], A[2 * e + 1]);
-  D.b_emi[row] = rhs;
+  if (valid) hx_put_own(scr, A);
+  hx_flush(vgeo, dsts, tid, valid, rp + slot_self * HX_NV, D.A_emi);
+  if (valid) D.b_emi[row] = rhs;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -413,6 +440,7 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_knp_hex_kernel(DgDev D, const DgC
   __shared__ double lrec[DG_BLOCK * DG_RPITCH];
   __shared__ double fsum[HX_TASKS * FS];
   __shared__ double vgeo[DG_BLOCK * HX_VG];
+  __shared__ int dsts[DG_BLOCK];
   const DgConsts& C = *Cp;
   const int cell0 = dg_block_index(blockIdx.x, chunk) * HX_CELLS;
   if (cell0 >= D.n_cell) return;
@@ -435,8 +463,8 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_knp_hex_kernel(DgDev D, const DgC
     tfi = D.finfo[(cell0 + tc) * HX_NFC + tf];
     tmf = D.mfid[(cell0 + tc) * HX_NFC + tf];
   }
-  int nb[HX_NFC];
-  unsigned fi[HX_NFC];
+  int nb[HX_NFC] = {-1, -1, -1, -1, -1, -1};
+  unsigned fi[HX_NFC] = {0, 0, 0, 0, 0, 0};
   int s = 0, rp = 0;
   if (valid) {
     s = D.cell_sub[T];
@@ -561,10 +589,9 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_knp_hex_kernel(DgDev D, const DgC
     hx_volume_point(X, i, vgeo + tid * HX_VG);
   }
   __syncthreads();
-  if (!valid) return;
-  // volume: mass, unit stiffness, unit drift (grad phi_i . grad phi) phi_j
+  // volume: mass, unit stiffness, unit drift (grad phi_i . grad phi) phi_j   (every lane stays for the block stores)
   double M[8] = {0, 0, 0, 0, 0, 0, 0, 0}, S[8] = {0, 0, 0, 0, 0, 0, 0, 0}, Dr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  {
+  if (valid) {
     const double* vg = vgeo + lc * HX_NV * HX_VG;
     const int x = i;
 #pragma unroll 1
@@ -606,7 +633,7 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_knp_hex_kernel(DgDev D, const DgC
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       double v = lrec[(lc * HX_NV + j) * DG_RPITCH + KN_CSLOT(k)] * C.inv_dt;
-      if (D.fsrc && s == 0) v += D.fsrc[(size_t)k * D.n_dof + T * HX_NV + j];
+      if (D.fsrc && s == 0 && valid) v += D.fsrc[(size_t)k * D.n_dof + T * HX_NV + j];
       acc += M[j] * v;
     }
     rhs[k] = acc;
@@ -614,23 +641,17 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_knp_hex_kernel(DgDev D, const DgC
   double UP[8] = {0, 0, 0, 0, 0, 0, 0, 0}, UM[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // own block: drift leaving / entering
   auto facet = [&](auto F_) {
     constexpr int f = decltype(F_)::value, a = f >> 1, b = f & 1;
-    if (nb[f] < 0) return;
+    const bool have = valid && nb[f] >= 0;
     const int kind = fi[f] & 3;
     const bool on = ((i >> a) & 1) == b;
     const int mi = ((i >> hx_ax1(a)) & 1) | (((i >> hx_ax2(a)) & 1) << 1);
     const double* fd = fsum + (lc * HX_NFC + f) * FS;
-    if (kind != 1) {
-      if (on) {
-#pragma unroll
-        for (int k = 0; k < KS; ++k) rhs[k] += fd[mi * KS + k];
-      }
-      // the membrane couples the two sides through the right-hand side only: the neighbour block is zero
-      const double z4[4] = {0, 0, 0, 0};
-#pragma unroll
-      for (int k = 0; k < KS; ++k) hx_store_nbr(scr, fi[f], z4, z4, D.A_knp + (size_t)k * D.nnz + rp + slot[f] * HX_NV);
-      return;
-    }
     double B0[4] = {0, 0, 0, 0}, B1[4] = {0, 0, 0, 0}, VP[4] = {0, 0, 0, 0}, VM[4] = {0, 0, 0, 0};
+    if (have && kind != 1 && on) {   // the membrane couples the two sides through the right-hand side only (zero block)
+#pragma unroll
+      for (int k = 0; k < KS; ++k) rhs[k] += fd[mi * KS + k];
+    }
+    if (have && kind == 1) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       double N[4], ds[4], dt[4];
@@ -660,19 +681,22 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_knp_hex_kernel(DgDev D, const DgC
         VM[m] += bm * N[m];
       }
     }
+    }
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
-      const double Dk = C.D[s][k], zD = C.z[k] * Dk;
-      double b0k[4], b1k[4];
+      if (have) {
+        const double Dk = C.D[s][k], zD = C.z[k] * Dk;
+        double b0k[4], b1k[4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        // upwind: the neighbour's trace carries the flux where the drift enters T (beta < 0)
-        b0k[m] = Dk * B0[m] + zD * (C.z[k] > 0.0 ? VM[m] : VP[m]);
-        b1k[m] = Dk * B1[m];
+        for (int m = 0; m < 4; ++m) {
+          // upwind: the neighbour's trace carries the flux where the drift enters T (beta < 0)
+          b0k[m] = Dk * B0[m] + zD * (C.z[k] > 0.0 ? VM[m] : VP[m]);
+          b1k[m] = Dk * B1[m];
+        }
+        hx_put_nbr(scr, fi[f], b0k, b1k);
       }
-      hx_store_nbr(scr, fi[f], b0k, b1k, D.A_knp + (size_t)k * D.nnz + rp + slot[f] * HX_NV);
+      hx_flush(vgeo, dsts, tid, have, rp + slot[f] * HX_NV, D.A_knp + (size_t)k * D.nnz);
     }
-    __builtin_amdgcn_sched_barrier(0);   // keep the six facets apart: hoisted summary reads of later facets cost registers
   };
   facet(std::integral_constant<int, 0>{}); facet(std::integral_constant<int, 1>{});
   facet(std::integral_constant<int, 2>{}); facet(std::integral_constant<int, 3>{});
@@ -680,18 +704,540 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_knp_hex_kernel(DgDev D, const DgC
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
     const double Dk = C.D[s][k], zD = C.z[k] * Dk, zpD = zD * C.psi;
-    double2* d2 = reinterpret_cast<double2*>(D.A_knp + (size_t)k * D.nnz + rp + slot_self * HX_NV);
+    double v[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      double v[2];
+    for (int j = 0; j < 8; ++j) v[j] = M[j] * C.inv_dt + Dk * S[j] + zpD * Dr[j] + zD * (C.z[k] > 0.0 ? UP[j] : UM[j]);
+    if (valid) hx_put_own(scr, v);
+    hx_flush(vgeo, dsts, tid, valid, rp + slot_self * HX_NV, D.A_knp + (size_t)k * D.nnz);
+    if (valid) D.b_knp[(size_t)k * D.n_dof + row] = rhs[k];
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Box meshes: every cell an orthogonal parallelepiped (checked at knpemi_dg_create; every mesh of the reference's 3-D
+// driver is one, make_mesh_3D.py:100-102).  Then the Jacobian is constant and diagonal in the cell's own frame,
+//   grad phi_i . grad phi_j = sum_t dref_i[t] dref_j[t] / |e_t|^2        (e_t: the cell's edge along axis t),
+// the depth vector of either cell at a facet is parallel to the normal, so a_s = a_t = 0 and c = -/+ 1 / |e_a| is the
+// same at the four facet points: grad phi_(m, 0) . n = -N_m c, grad phi_(m, 1) . n = N_m c.  Every entry of a row that a
+// facet contributes to is then  sum_p e(p) N_m(p)  with FOUR row scalars e per point (own block on / behind the facet,
+// neighbour block on / behind the facet) -- a 4 x 4 product per kind instead of sixteen three-term entries per point --
+// the facet summary shrinks to 4 + 4 (2) numbers per point, the gradient tables disappear, and with 18 (15) kB of LDS
+// and half the registers two workgroups share a SIMD.  Same numbers as the general kernels up to rounding
+// (tests/test_dg_gpu.py runs both on the same box mesh).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int HX_FS_BOX_EMI = 21;    // W ih cT cN | (kT kN JT JN) x 4 points
+constexpr int HX_FS_BOX_KNP = 13;    // W ih cT cN | (gT gN) x 4 points     (membrane: 4 x KS integrals)
+
+struct BoxCell {
+  double h2inv[3];   // 1 / |e_t|^2
+  double wd;         // |det J| / 8
+};
+__device__ __forceinline__ BoxCell hx_box_cell(const double* r0, const double* r1, const double* r2, const double* r4) {
+  BoxCell B;
+  double vol = 1.0;
+  const double* rt[3] = {r1, r2, r4};
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int j = 2 * e + t;
-        v[t] = M[j] * C.inv_dt + Dk * S[j] + zpD * Dr[j] + zD * (C.z[k] > 0.0 ? UP[j] : UM[j]);
-      }
-      d2[e] = make_double2(v[0], v[1]);
+  for (int t = 0; t < 3; ++t) {
+    const double ex = rt[t][0] - r0[0], ey = rt[t][1] - r0[1], ez = rt[t][2] - r0[2];
+    const double l2 = ex * ex + ey * ey + ez * ez, ri = fast_rsqrt(l2);
+    B.h2inv[t] = ri * ri;
+    vol *= l2 * ri;
+  }
+  B.wd = 0.125 * vol;
+  return B;
+}
+
+// |edge| between two records
+__device__ __forceinline__ double hx_edge_len(const double* a, const double* b) {
+  const double ex = b[0] - a[0], ey = b[1] - a[1], ez = b[2] - a[2];
+  const double l2 = ex * ex + ey * ey + ez * ez;
+  return l2 * fast_rsqrt(l2);
+}
+
+// acc[m] += sum over the four facet points of e[p] N_m(p)
+__device__ __forceinline__ void hx_fold(const double (&e)[4], double (&acc)[4]) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const double N = (((m ^ p) & 1) ? HX_G0 : HX_G1) * ((((m ^ p) >> 1) & 1) ? HX_G0 : HX_G1);
+      acc[m] += e[p] * N;
     }
-    D.b_knp[(size_t)k * D.n_dof + row] = rhs[k];
+}
+
+__global__ __launch_bounds__(DG_BLOCK, 3) void dg_emi_hex_box_kernel(DgDev D, const DgConsts* __restrict__ Cp, int chunk, int splitting) {
+  __shared__ double lrec[DG_BLOCK * DG_RPITCH];   // the records; after the second barrier the scratch lines of the block stores
+  __shared__ double fsum[HX_TASKS * HX_FS_BOX_EMI];
+  __shared__ int dsts[DG_BLOCK];
+  double* const scrs = lrec;                      // (HX_SCR == DG_RPITCH; the rows are done with the records by then)
+  const DgConsts& C = *Cp;
+  const int cell0 = dg_block_index(blockIdx.x, chunk) * HX_CELLS;
+  if (cell0 >= D.n_cell) return;
+  const int ncell = min(HX_CELLS, D.n_cell - cell0);
+  const int tid = threadIdx.x;
+  const int lc = tid >> 3, i = tid & 7, T = cell0 + lc, row = T * HX_NV + i;
+  const bool valid = lc < ncell;
+  const int tc = tid / HX_NFC, tf = tid - tc * HX_NFC;
+  const bool task = tid < HX_TASKS && tc < ncell;
+  int tnb = -1, tmf = -1;
+  unsigned tfi = 0;
+  if (valid) {
+    const double2* p = reinterpret_cast<const double2*>(D.rec + (size_t)row * KN_REC);
+    double2* q = reinterpret_cast<double2*>(lrec + tid * DG_RPITCH);
+    const double2 a = p[0], b = p[1], c = p[2], d = p[3];
+    q[0] = a; q[1] = b; q[2] = c; q[3] = d;
+  }
+  if (task) {
+    tnb = D.nbr[(cell0 + tc) * HX_NFC + tf];
+    tfi = D.finfo[(cell0 + tc) * HX_NFC + tf];
+    tmf = D.mfid[(cell0 + tc) * HX_NFC + tf];
+  }
+  int nb[HX_NFC] = {-1, -1, -1, -1, -1, -1};
+  unsigned fi[HX_NFC] = {0, 0, 0, 0, 0, 0};
+  int s = 0, rp = 0;
+  if (valid) {
+    s = D.cell_sub[T];
+    rp = D.rowptr[row];
+#pragma unroll
+    for (int f = 0; f < HX_NFC; ++f) { nb[f] = D.nbr[T * HX_NFC + f]; fi[f] = D.finfo[T * HX_NFC + f]; }
+  }
+  __syncthreads();
+  if (task && tnb >= 0) {
+    const int a = tf >> 1, b = tf & 1, kind = tfi & 3, ts_ = D.cell_sub[cell0 + tc];
+    const int ao = ((tfi >> 2) & 7) >> 1;
+    const double* r0[4];
+    double kT[4], kN[4], dsT[4], dsN[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int jv = hx_facet_vertex(a, b, m), jo = jv ^ (1 << a);
+      r0[m] = lrec + (tc * HX_NV + jv) * DG_RPITCH;
+      const double* r1 = lrec + (tc * HX_NV + jo) * DG_RPITCH;
+      double k0 = 0.0, g0 = 0.0, g1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < KN_MAXK; ++q) {
+        k0 += C.kap[ts_][q] * r0[m][KN_CSLOT(q)]; g0 += C.sig[ts_][q] * r0[m][KN_CSLOT(q)]; g1 += C.sig[ts_][q] * r1[KN_CSLOT(q)];
+      }
+      kT[m] = k0; dsT[m] = g1 - g0; kN[m] = 0.0; dsN[m] = 0.0;
+    }
+    const double* cb = lrec + tc * HX_NV * DG_RPITCH;
+    const double hT = hx_edge_len(cb, cb + (1 << a) * DG_RPITCH);
+    const double A = hx_edge_len(cb, cb + (1 << hx_ax1(a)) * DG_RPITCH) * hx_edge_len(cb, cb + (1 << hx_ax2(a)) * DG_RPITCH);
+    double* my = fsum + tid * HX_FS_BOX_EMI;
+    if (kind == 1) {
+      double hN = 1.0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int jn = (tfi >> (5 + 3 * m)) & 7, jt = jn ^ (1 << ao);
+        const double* n0 = D.rec + ((size_t)tnb * HX_NV + jn) * KN_REC;
+        const double* n1 = D.rec + ((size_t)tnb * HX_NV + jt) * KN_REC;
+        double k0 = 0.0, g0 = 0.0, g1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < KN_MAXK; ++q) {
+          k0 += C.kap[ts_][q] * n0[KN_CSLOT(q)]; g0 += C.sig[ts_][q] * n0[KN_CSLOT(q)]; g1 += C.sig[ts_][q] * n1[KN_CSLOT(q)];
+        }
+        kN[m] = k0; dsN[m] = g1 - g0;
+        if (m == 0) hN = hx_edge_len(n0, n1);
+      }
+      const double cT = -fast_rcp(hT), cN = fast_rcp(hN);
+      my[0] = 0.25 * A; my[1] = 0.5 * (cN - cT); my[2] = cT; my[3] = cN;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        double N[4], ds[4], dt[4];
+        hx_shapes(p, N, ds, dt);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { a0 += N[m] * kT[m]; a1 += N[m] * kN[m]; a2 += N[m] * dsT[m]; a3 += N[m] * dsN[m]; }
+        my[4 + 4 * p] = a0; my[5 + 4 * p] = a1; my[6 + 4 * p] = a2 * cT; my[7 + 4 * p] = a3 * cN;
+      }
+    } else {
+      double g[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int q = tmf * 4 + ((tfi >> (17 + 2 * m)) & 3);
+        double v = D.phiM[q];
+        if (!splitting) {
+          double it = 0.0;
+          for (int k = 0; k < C.K; ++k) it += D.Ich[(size_t)k * D.nq + q];
+          v -= it / C.C_phi;
+        }
+        g[m] = v;
+      }
+      my[0] = 0.25 * A * C.C_phi;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        double N[4], ds[4], dt[4];
+        hx_shapes(p, N, ds, dt);
+        my[4 + 4 * p] = N[0] * g[0] + N[1] * g[1] + N[2] * g[2] + N[3] * g[3];
+      }
+    }
+  }
+  double kap[8], sg[8];
+  BoxCell Bc{};
+  if (valid) {
+    const double* cb = lrec + lc * HX_NV * DG_RPITCH;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double* r = cb + j * DG_RPITCH;
+      double k0 = 0.0, g0 = 0.0;
+#pragma unroll
+      for (int q = 0; q < KN_MAXK; ++q) { k0 += C.kap[s][q] * r[KN_CSLOT(q)]; g0 += C.sig[s][q] * r[KN_CSLOT(q)]; }
+      kap[j] = k0; sg[j] = g0;
+    }
+    Bc = hx_box_cell(cb, cb + DG_RPITCH, cb + 2 * DG_RPITCH, cb + 4 * DG_RPITCH);
+  }
+  __syncthreads();
+  double A[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double rhs = 0.0;
+  auto point = [&](auto P_) {
+    constexpr int P = decltype(P_)::value;
+    const int xi = i ^ P;
+    const double a = (xi & 1) ? HX_G0 : HX_G1, b = (xi & 2) ? HX_G0 : HX_G1, c = (xi & 4) ? HX_G0 : HX_G1;
+    // u[t] = dref_i[t] / |e_t|^2
+    const double u0 = ((i & 1) ? b : -b) * c * Bc.h2inv[0], u1 = ((i & 2) ? a : -a) * c * Bc.h2inv[1],
+                 u2 = ((i & 4) ? a : -a) * b * Bc.h2inv[2];
+    double kq = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0, dd[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      constexpr double G[2] = {HX_G1, HX_G0};
+      const int x = j ^ P;
+      const double wa = G[x & 1], wb = G[(x >> 1) & 1], wc = G[(x >> 2) & 1];
+      const double d0 = ((j & 1) ? 1.0 : -1.0) * wb * wc, d1 = ((j & 2) ? 1.0 : -1.0) * wa * wc, d2 = ((j & 4) ? 1.0 : -1.0) * wa * wb;
+      kq += kap[j] * (wa * wb * wc);
+      s0 += sg[j] * d0; s1 += sg[j] * d1; s2 += sg[j] * d2;
+      dd[j] = u0 * d0 + u1 * d1 + u2 * d2;
+    }
+    const double wk = Bc.wd * kq;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) A[j] += wk * dd[j];
+    rhs -= Bc.wd * (u0 * s0 + u1 * s1 + u2 * s2);
+  };
+  point(std::integral_constant<int, 0>{}); point(std::integral_constant<int, 1>{});
+  point(std::integral_constant<int, 2>{}); point(std::integral_constant<int, 3>{});
+  point(std::integral_constant<int, 4>{}); point(std::integral_constant<int, 5>{});
+  point(std::integral_constant<int, 6>{}); point(std::integral_constant<int, 7>{});
+  int slot_self, slot[HX_NFC];
+  hx_slots(T, nb, slot_self, slot);
+  double* scr = scrs + tid * HX_SCR;
+  auto facet = [&](auto F_) {
+    constexpr int f = decltype(F_)::value, a = f >> 1, b = f & 1;
+    const bool have = valid && nb[f] >= 0;
+    const int kind = fi[f] & 3;
+    const bool on = ((i >> a) & 1) == b;
+    const int mi = ((i >> hx_ax1(a)) & 1) | (((i >> hx_ax2(a)) & 1) << 1);
+    const double* fd = fsum + (lc * HX_NFC + f) * HX_FS_BOX_EMI;
+    double B0[4] = {0, 0, 0, 0}, B1[4] = {0, 0, 0, 0};
+    const double W = fd[0];
+    if (have && kind == 1) {
+      const double ih = fd[1], cT = fd[2], cN = fd[3];
+      const double sgi = on ? -cT : cT, onf = on ? 1.0 : 0.0;
+      double eo[4], et[4], e0[4], e1[4], Ao[4] = {0, 0, 0, 0}, At[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int xm_ = mi ^ p;
+        const double Ni = ((xm_ & 1) ? HX_G0 : HX_G1) * ((xm_ & 2) ? HX_G0 : HX_G1);
+        const double kT = fd[4 + 4 * p], kN = fd[5 + 4 * p];
+        const double phi_i = onf * Ni, gni = Ni * sgi;
+        const double pen = C.gamma * ih * (0.5 * (kT + kN)) * W * phi_i;
+        const double c1 = -0.5 * W * kT * phi_i, c2 = -0.5 * W * kT * gni, c1n = -0.5 * W * kN * phi_i;
+        eo[p] = c2 + pen - c1 * cT;
+        et[p] = c1 * cT;
+        e0[p] = -(c2 + pen) - c1n * cN;
+        e1[p] = c1n * cN;
+        rhs += W * 0.5 * (fd[6 + 4 * p] + fd[7 + 4 * p]) * phi_i;
+      }
+      hx_fold(eo, Ao); hx_fold(et, At); hx_fold(e0, B0); hx_fold(e1, B1);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        A[hx_facet_vertex(a, b, m)] += Ao[m];
+        A[hx_facet_vertex(a, b, m) ^ (1 << a)] += At[m];
+      }
+    } else if (have && on) {
+      double e[4], Am[4] = {0, 0, 0, 0}, g = 0.0;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int xm_ = mi ^ p;
+        e[p] = W * (((xm_ & 1) ? HX_G0 : HX_G1) * ((xm_ & 2) ? HX_G0 : HX_G1));
+        g += e[p] * fd[4 + 4 * p];
+      }
+      hx_fold(e, Am);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        A[hx_facet_vertex(a, b, m)] += Am[m];
+        B0[m] = -Am[m];
+      }
+      rhs += kind == 3 ? g : -g;
+    }
+    if (have) hx_put_nbr(scr, fi[f], B0, B1);
+    hx_flush(scrs, dsts, tid, have, rp + slot[f] * HX_NV, D.A_emi);
+  };
+  facet(std::integral_constant<int, 0>{}); facet(std::integral_constant<int, 1>{});
+  facet(std::integral_constant<int, 2>{}); facet(std::integral_constant<int, 3>{});
+  facet(std::integral_constant<int, 4>{}); facet(std::integral_constant<int, 5>{});
+  if (valid) hx_put_own(scr, A);
+  hx_flush(scrs, dsts, tid, valid, rp + slot_self * HX_NV, D.A_emi);
+  if (valid) D.b_emi[row] = rhs;
+}
+
+template <int KS>
+__global__ __launch_bounds__(DG_BLOCK, 2) void dg_knp_hex_box_kernel(DgDev D, const DgConsts* __restrict__ Cp, int chunk, int splitting) {
+  constexpr int FS = HX_FS_BOX_KNP;
+  __shared__ double lrec[DG_BLOCK * DG_RPITCH];
+  __shared__ double fsum[HX_TASKS * FS];
+  __shared__ double scrs[DG_BLOCK * HX_SCR];
+  __shared__ int dsts[DG_BLOCK];
+  const DgConsts& C = *Cp;
+  const int cell0 = dg_block_index(blockIdx.x, chunk) * HX_CELLS;
+  if (cell0 >= D.n_cell) return;
+  const int ncell = min(HX_CELLS, D.n_cell - cell0);
+  const int tid = threadIdx.x;
+  const int lc = tid >> 3, i = tid & 7, T = cell0 + lc, row = T * HX_NV + i;
+  const bool valid = lc < ncell;
+  const int tc = tid / HX_NFC, tf = tid - tc * HX_NFC;
+  const bool task = tid < HX_TASKS && tc < ncell;
+  int tnb = -1, tmf = -1;
+  unsigned tfi = 0;
+  if (valid) {
+    const double2* p = reinterpret_cast<const double2*>(D.rec + (size_t)row * KN_REC);
+    double2* q = reinterpret_cast<double2*>(lrec + tid * DG_RPITCH);
+    const double2 a = p[0], b = p[1], c = p[2], d = p[3];
+    q[0] = a; q[1] = b; q[2] = c; q[3] = d;
+  }
+  if (task) {
+    tnb = D.nbr[(cell0 + tc) * HX_NFC + tf];
+    tfi = D.finfo[(cell0 + tc) * HX_NFC + tf];
+    tmf = D.mfid[(cell0 + tc) * HX_NFC + tf];
+  }
+  int nb[HX_NFC] = {-1, -1, -1, -1, -1, -1};
+  unsigned fi[HX_NFC] = {0, 0, 0, 0, 0, 0};
+  int s = 0, rp = 0;
+  if (valid) {
+    s = D.cell_sub[T];
+    rp = D.rowptr[row];
+#pragma unroll
+    for (int f = 0; f < HX_NFC; ++f) { nb[f] = D.nbr[T * HX_NFC + f]; fi[f] = D.finfo[T * HX_NFC + f]; }
+  }
+  __syncthreads();
+  if (task && tnb >= 0) {
+    const int a = tf >> 1, b = tf & 1, kind = tfi & 3, ts_ = D.cell_sub[cell0 + tc];
+    const int ao = ((tfi >> 2) & 7) >> 1;
+    const double* rT[4];
+    double pT0[4], pN0[4], dpT[4], dpN[4];
+    double hN = 1.0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int jv = hx_facet_vertex(a, b, m), jo = jv ^ (1 << a);
+      rT[m] = lrec + (tc * HX_NV + jv) * DG_RPITCH;
+      const double* r1 = lrec + (tc * HX_NV + jo) * DG_RPITCH;
+      pT0[m] = rT[m][7];
+      dpT[m] = r1[7] - rT[m][7];
+      const int jn = (tfi >> (5 + 3 * m)) & 7, jt = jn ^ (1 << ao);
+      const double* n0 = D.rec + ((size_t)tnb * HX_NV + jn) * KN_REC;
+      pN0[m] = n0[7];
+      dpN[m] = 0.0;
+      if (kind == 1) {
+        const double* n1 = D.rec + ((size_t)tnb * HX_NV + jt) * KN_REC;
+        dpN[m] = n1[7] - n0[7];
+        if (m == 0) hN = hx_edge_len(n0, n1);
+      }
+    }
+    const double* cb = lrec + tc * HX_NV * DG_RPITCH;
+    const double hT = hx_edge_len(cb, cb + (1 << a) * DG_RPITCH);
+    const double A = hx_edge_len(cb, cb + (1 << hx_ax1(a)) * DG_RPITCH) * hx_edge_len(cb, cb + (1 << hx_ax2(a)) * DG_RPITCH);
+    double* my = fsum + tid * FS;
+    if (kind == 1) {
+      const double cT = -fast_rcp(hT), cN = fast_rcp(hN);
+      my[0] = 0.25 * A; my[1] = 0.5 * (cN - cT); my[2] = cT; my[3] = cN;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        double N[4], ds[4], dt[4];
+        hx_shapes(p, N, ds, dt);
+        double gT = 0.0, gN = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { gT += N[m] * dpT[m]; gN += N[m] * dpN[m]; }
+        my[4 + 2 * p] = gT * cT; my[5 + 2 * p] = gN * cN;
+      }
+    } else {
+      // membrane facet (knpWeakForm.py:168-214), 4 x 4 rule, once per (cell, facet); the surface element is constant
+      double jm[4], pm[4], It[4], Ik[4][KN_MAXK], Gk[4][KS];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        jm[m] = kind == 2 ? pN0[m] - pT0[m] : pT0[m] - pN0[m];
+        const int q = tmf * 4 + ((tfi >> (17 + 2 * m)) & 3);
+        pm[m] = D.phiM[q];
+        double it = 0.0;
+#pragma unroll
+        for (int k = 0; k < KN_MAXK; ++k) {
+          Ik[m][k] = k < C.K ? D.Ich[(size_t)k * D.nq + q] : 0.0;
+          it += Ik[m][k];
+        }
+        It[m] = it;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) Gk[m][k] = 0.0;
+      }
+      const double sgn = kind == 2 ? 1.0 : -1.0;
+      const double* qw = D.qtab;
+      const double* qN = D.qtab + D.nquad;
+      for (int q = 0; q < D.nquad; ++q) {
+        double cq[KN_MAXK], iq[KN_MAXK], jq = 0.0, pq = 0.0, itq = 0.0, Nq[4];
+#pragma unroll
+        for (int k = 0; k < KN_MAXK; ++k) { cq[k] = 0.0; iq[k] = 0.0; }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          Nq[m] = qN[q * 4 + m];
+#pragma unroll
+          for (int k = 0; k < KN_MAXK; ++k) { cq[k] += Nq[m] * rT[m][KN_CSLOT(k)]; iq[k] += Nq[m] * Ik[m][k]; }
+          jq += Nq[m] * jm[m]; pq += Nq[m] * pm[m]; itq += Nq[m] * It[m];
+        }
+        double asum = 0.0;
+#pragma unroll
+        for (int k = 0; k < KN_MAXK; ++k) asum += C.az2D[ts_][k] * cq[k];
+        const double w = sgn * qw[q] * A;
+        double drive = jq - pq;
+        if (splitting) drive -= (C.dt / C.C_M) * itq;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const double al = C.az2D[ts_][k] * cq[k] / asum;
+          const double fz = 1.0 / (C.F * C.z[k]);
+          const double fq = w * (al * C.C_M * fz * C.inv_dt * drive + iq[k] * fz);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) Gk[m][k] += Nq[m] * fq;
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int k = 0; k < KS; ++k) my[m * KS + k] = Gk[m][k];
+    }
+  }
+  double ph[8];
+  BoxCell Bc{};
+  if (valid) {
+    const double* cb = lrec + lc * HX_NV * DG_RPITCH;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ph[j] = cb[j * DG_RPITCH + 7];
+    Bc = hx_box_cell(cb, cb + DG_RPITCH, cb + 2 * DG_RPITCH, cb + 4 * DG_RPITCH);
+  }
+  __syncthreads();
+  double M[8] = {0, 0, 0, 0, 0, 0, 0, 0}, S[8] = {0, 0, 0, 0, 0, 0, 0, 0}, Dr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto point = [&](auto P_) {
+    constexpr int P = decltype(P_)::value;
+    const int xi = i ^ P;
+    const double a = (xi & 1) ? HX_G0 : HX_G1, b = (xi & 2) ? HX_G0 : HX_G1, c = (xi & 4) ? HX_G0 : HX_G1;
+    const double u0 = ((i & 1) ? b : -b) * c * Bc.h2inv[0], u1 = ((i & 2) ? a : -a) * c * Bc.h2inv[1],
+                 u2 = ((i & 4) ? a : -a) * b * Bc.h2inv[2];
+    const double phi_i = a * b * c;
+    double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      constexpr double G[2] = {HX_G1, HX_G0};
+      const int x = j ^ P;
+      const double wa = G[x & 1], wb = G[(x >> 1) & 1], wc = G[(x >> 2) & 1];
+      g0 += ph[j] * (((j & 1) ? 1.0 : -1.0) * wb * wc);
+      g1 += ph[j] * (((j & 2) ? 1.0 : -1.0) * wa * wc);
+      g2 += ph[j] * (((j & 4) ? 1.0 : -1.0) * wa * wb);
+    }
+    const double dr = Bc.wd * (u0 * g0 + u1 * g1 + u2 * g2), wm = Bc.wd * phi_i;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      constexpr double G[2] = {HX_G1, HX_G0};
+      const int x = j ^ P;
+      const double wa = G[x & 1], wb = G[(x >> 1) & 1], wc = G[(x >> 2) & 1];
+      const double d0 = ((j & 1) ? 1.0 : -1.0) * wb * wc, d1 = ((j & 2) ? 1.0 : -1.0) * wa * wc, d2 = ((j & 4) ? 1.0 : -1.0) * wa * wb;
+      const double pj = wa * wb * wc;
+      M[j] += wm * pj;
+      S[j] += Bc.wd * (u0 * d0 + u1 * d1 + u2 * d2);
+      Dr[j] += dr * pj;
+    }
+  };
+  point(std::integral_constant<int, 0>{}); point(std::integral_constant<int, 1>{});
+  point(std::integral_constant<int, 2>{}); point(std::integral_constant<int, 3>{});
+  point(std::integral_constant<int, 4>{}); point(std::integral_constant<int, 5>{});
+  point(std::integral_constant<int, 6>{}); point(std::integral_constant<int, 7>{});
+  int slot_self, slot[HX_NFC];
+  hx_slots(T, nb, slot_self, slot);
+  double* scr = scrs + tid * HX_SCR;
+  double rhs[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      double v = lrec[(lc * HX_NV + j) * DG_RPITCH + KN_CSLOT(k)] * C.inv_dt;
+      if (D.fsrc && s == 0 && valid) v += D.fsrc[(size_t)k * D.n_dof + T * HX_NV + j];
+      acc += M[j] * v;
+    }
+    rhs[k] = acc;
+  }
+  double UP[8] = {0, 0, 0, 0, 0, 0, 0, 0}, UM[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto facet = [&](auto F_) {
+    constexpr int f = decltype(F_)::value, a = f >> 1, b = f & 1;
+    const bool have = valid && nb[f] >= 0;
+    const int kind = fi[f] & 3;
+    const bool on = ((i >> a) & 1) == b;
+    const int mi = ((i >> hx_ax1(a)) & 1) | (((i >> hx_ax2(a)) & 1) << 1);
+    const double* fd = fsum + (lc * HX_NFC + f) * FS;
+    double B0[4] = {0, 0, 0, 0}, B1[4] = {0, 0, 0, 0}, VP[4] = {0, 0, 0, 0}, VM[4] = {0, 0, 0, 0};
+    if (have && kind != 1 && on) {   // the membrane couples the two sides through the right-hand side only (zero block)
+#pragma unroll
+      for (int k = 0; k < KS; ++k) rhs[k] += fd[mi * KS + k];
+    }
+    if (have && kind == 1) {
+    const double W = fd[0], ih = fd[1], cT = fd[2], cN = fd[3];
+    const double sgi = on ? -cT : cT, onf = on ? 1.0 : 0.0;
+    double eo[4], et[4], e0[4], e1[4], ep[4], em[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int xm_ = mi ^ p;
+      const double Ni = ((xm_ & 1) ? HX_G0 : HX_G1) * ((xm_ & 2) ? HX_G0 : HX_G1);
+      const double phi_i = onf * Ni, gni = Ni * sgi;
+      const double pen = C.gamma * ih * W * phi_i;
+      const double c1 = -0.5 * W * phi_i, c2 = -0.5 * W * gni;
+      eo[p] = c2 + pen - c1 * cT;
+      et[p] = c1 * cT;
+      e0[p] = -(c2 + pen) - c1 * cN;
+      e1[p] = c1 * cN;
+      const double b0 = -C.psi * 0.5 * (fd[4 + 2 * p] + fd[5 + 2 * p]) * W * phi_i;
+      ep[p] = fmax(b0, 0.0);
+      em[p] = fmin(b0, 0.0);
+    }
+    double So[4] = {0, 0, 0, 0}, St[4] = {0, 0, 0, 0};
+    hx_fold(eo, So); hx_fold(et, St); hx_fold(e0, B0); hx_fold(e1, B1); hx_fold(ep, VP); hx_fold(em, VM);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      S[hx_facet_vertex(a, b, m)] += So[m];
+      S[hx_facet_vertex(a, b, m) ^ (1 << a)] += St[m];
+      UP[hx_facet_vertex(a, b, m)] += VP[m];
+      UM[hx_facet_vertex(a, b, m)] += VM[m];
+    }
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      if (have) {
+        const double Dk = C.D[s][k], zD = C.z[k] * Dk;
+        double b0k[4], b1k[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          b0k[m] = Dk * B0[m] + zD * (C.z[k] > 0.0 ? VM[m] : VP[m]);
+          b1k[m] = Dk * B1[m];
+        }
+        hx_put_nbr(scr, fi[f], b0k, b1k);
+      }
+      hx_flush(scrs, dsts, tid, have, rp + slot[f] * HX_NV, D.A_knp + (size_t)k * D.nnz);
+    }
+  };
+  facet(std::integral_constant<int, 0>{}); facet(std::integral_constant<int, 1>{});
+  facet(std::integral_constant<int, 2>{}); facet(std::integral_constant<int, 3>{});
+  facet(std::integral_constant<int, 4>{}); facet(std::integral_constant<int, 5>{});
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    const double Dk = C.D[s][k], zD = C.z[k] * Dk, zpD = zD * C.psi;
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = M[j] * C.inv_dt + Dk * S[j] + zpD * Dr[j] + zD * (C.z[k] > 0.0 ? UP[j] : UM[j]);
+    if (valid) hx_put_own(scr, v);
+    hx_flush(scrs, dsts, tid, valid, rp + slot_self * HX_NV, D.A_knp + (size_t)k * D.nnz);
+    if (valid) D.b_knp[(size_t)k * D.n_dof + row] = rhs[k];
   }
 }
 
@@ -706,15 +1252,24 @@ int hx_check(const char* what) {
 
 }  // namespace
 
-int kn_dg_hex_launch_emi(hipStream_t st, const kn_dg::DgDev& D, const kn_dg::DgConsts* d_consts, int splitting) {
+int kn_dg_hex_launch_emi(hipStream_t st, const kn_dg::DgDev& D, const kn_dg::DgConsts* d_consts, int splitting, int box) {
   const int nblocks = (D.n_cell + HX_CELLS - 1) / HX_CELLS, chunk = (nblocks + 7) / 8;
-  hipLaunchKernelGGL(dg_emi_hex_kernel, dim3(8 * chunk), dim3(DG_BLOCK), 0, st, D, d_consts, chunk, splitting);
+  if (box) hipLaunchKernelGGL(dg_emi_hex_box_kernel, dim3(8 * chunk), dim3(DG_BLOCK), 0, st, D, d_consts, chunk, splitting);
+  else hipLaunchKernelGGL(dg_emi_hex_kernel, dim3(8 * chunk), dim3(DG_BLOCK), 0, st, D, d_consts, chunk, splitting);
   return hx_check("dg_emi_hex_kernel");
 }
 
-int kn_dg_hex_launch_knp(hipStream_t st, const kn_dg::DgDev& D, const kn_dg::DgConsts* d_consts, int KS, int splitting) {
+int kn_dg_hex_launch_knp(hipStream_t st, const kn_dg::DgDev& D, const kn_dg::DgConsts* d_consts, int KS, int splitting, int box) {
   const int nblocks = (D.n_cell + HX_CELLS - 1) / HX_CELLS, chunk = (nblocks + 7) / 8;
   const dim3 grid(8 * chunk), block(DG_BLOCK);
+  if (box) {
+    switch (KS) {
+      case 1: hipLaunchKernelGGL(dg_knp_hex_box_kernel<1>, grid, block, 0, st, D, d_consts, chunk, splitting); break;
+      case 2: hipLaunchKernelGGL(dg_knp_hex_box_kernel<2>, grid, block, 0, st, D, d_consts, chunk, splitting); break;
+      default: hipLaunchKernelGGL(dg_knp_hex_box_kernel<3>, grid, block, 0, st, D, d_consts, chunk, splitting); break;
+    }
+    return hx_check("dg_knp_hex_box_kernel");
+  }
   switch (KS) {
     case 1: hipLaunchKernelGGL(dg_knp_hex_kernel<1>, grid, block, 0, st, D, d_consts, chunk, splitting); break;
     case 2: hipLaunchKernelGGL(dg_knp_hex_kernel<2>, grid, block, 0, st, D, d_consts, chunk, splitting); break;

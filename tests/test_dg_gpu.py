@@ -96,6 +96,11 @@ def _hex_problem(M, membrane, n_ions=3, gamma=10.0, distort=None, seed=5):
     if distort == "shear":
         S = np.array([[1.0, 0.25, -0.15], [0.1, 0.9, 0.2], [-0.2, 0.05, 1.1]])
         x[:] = x @ S.T
+    elif distort == "rotate":
+        c, s_ = np.cos(0.7), np.sin(0.7)
+        R = np.array([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]]) @ np.array([[1.0, 0.0, 0.0], [0.0, np.cos(0.4), -np.sin(0.4)],
+                                                                              [0.0, np.sin(0.4), np.cos(0.4)]])
+        x[:] = (x * np.array([1.0, 0.6, 1.7])) @ R.T
     elif distort == "random":
         rng = np.random.default_rng(seed)
         inner = np.all((x > 1e-9) & (x < 1 - 1e-9), axis=1)
@@ -131,6 +136,38 @@ def test_dg_q1_assembly_on_hexahedra_matches_oracle(hip_lib, M, K, distort, spli
     for r in (0, dp.n // 2, dp.n - 1):
         cols = dp.indices[dp.indptr[r]:dp.indptr[r + 1]]
         assert np.all(np.diff(cols) > 0) and r in cols
+
+
+@pytest.mark.parametrize("splitting", [True, False])
+def test_dg_q1_box_mesh_kernels_agree_with_the_general_kernels(hip_lib, splitting, monkeypatch):
+    """On a mesh of orthogonal parallelepipeds (every mesh of the reference's 3-D driver) knpemi_dg_create selects the
+    box-mesh kernels (constant facet frames, no gradient tables, csrc/kernels_dg_hex.hip); KNPEMI_DG_HEX_GENERAL=1 keeps
+    the general ones.  Both against the restatement, and against each other to rounding; a rotated box mesh (orthogonal
+    cells that are not axis-aligned) takes the box kernels too."""
+    K = 3
+    ions = [dict(name=f"i{k}", z=z, D=[1.0 + 0.3 * k, 0.6 + 0.2 * k]) for k, z in enumerate((1.0, -1.0, 2.0))]
+    params = dict(dt=0.05, F=1.3, psi=0.8, C_M=0.7)
+    out = {}
+    for name in ("box", "general", "rotated"):
+        if name == "general":
+            monkeypatch.setenv("KNPEMI_DG_HEX_GENERAL", "1")
+        else:
+            monkeypatch.delenv("KNPEMI_DG_HEX_GENERAL", raising=False)
+        dp, o = _hex_problem(5, True, n_ions=K, gamma=7.5, distort="rotate" if name == "rotated" else None)
+        c_all, phi, phi_M, I_ch, src = _random_state(dp, K, 1)
+        _push(dp, params, ions, c_all, phi, phi_M, I_ch, src)
+        dp.assemble_emi(splitting)
+        dp.assemble_knp(splitting)
+        A, b = o.assemble_emi(params, ions, c_all, phi_M, I_ch, splitting_scheme=splitting, gamma=7.5)
+        assert csr_rel_err(dp.matrix(0), A) < TOL and rel_err(dp.rhs(0), b) < TOL, name
+        As, bs = o.assemble_knp(params, ions, c_all, phi, phi_M, I_ch, splitting_scheme=splitting, gamma=7.5, f_source=src)
+        for k in range(K - 1):
+            assert csr_rel_err(dp.matrix(1 + k), As[k]) < TOL and rel_err(dp.rhs(1 + k), bs[k]) < TOL, (name, k)
+        out[name] = [dp.matrix(w) for w in range(K)] + [dp.rhs(w) for w in range(K)]
+    for w in range(K):
+        assert csr_rel_err(out["box"][w], out["general"][w]) < 1e-13
+        assert rel_err(out["box"][K + w], out["general"][K + w]) < 1e-12
+    assert abs(out["box"][0] - out["general"][0]).max() > 0          # (two different kernels did run)
 
 
 @pytest.mark.parametrize("dim", [2, 3, "hex"])

@@ -11,7 +11,7 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES S
            "FETCH_SIZE WRITE_SIZE"; do
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/$OUT/p$i -- \
-      python3 $R/tools/dg_time.py -r $RR --reps 3 > $R/gpurun_out/$OUT.p$i.log 2>&1 || echo "pass $i failed"
+      python3 $R/tools/dg_time.py -r $RR --reps 3 $DG_TIME_ARGS > $R/gpurun_out/$OUT.p$i.log 2>&1 || echo "pass $i failed"
   echo "pass $i ($grp) done"
 done
 python3 $R/tools/pmc_summary.py $R/gpurun_out/$OUT
