@@ -311,9 +311,13 @@ struct Lsoda {
   double rtol, atol;
   double yh[ROWS + 1][NI];   // Nordsieck array, rows 1..13; rows above l are kept at +0
   double ysave[NI];          // ODEPACK's YH(lmax) slot: the correction saved for the order-increase test
-  double el[ROWS + 1];       // method coefficients of the current (meth, nq); entries above l are 0
-  double tq1, tq2, tq3;      // tesco(nq, 1..3) of the current (meth, nq)
-  double rtq1, rtq2, rtq3;   // their reciprocals (device: from the table; see over_tq)
+  // The method coefficients el(1..l) of the current (meth, nq) are the row elco[meth - 1][nq][.] of the table (entries
+  // above l = nq + 1 are zero there): read from the table where they are used (the workgroup's copy is in LDS on the
+  // device) instead of being held in 28 registers per lane -- the integrator state did not fit the 256 architected
+  // registers and lived partly in accumulator registers, every use a copy.  el(1) is used in every corrector pass.
+  double el1;
+  double tq2;                // tesco(nq, 2) of the current (meth, nq); tesco(nq, 1) and (nq, 3) are read where the order
+  double rtq2;               // is selected; rtq2: its reciprocal (device: from the table; see over_tq)
   double ewt[NI], savf[NI], acor[NI], y[NI];
   double* work;
   KN_HD double& WM(int i, int j) const { return work[(i * N + j) * STRIDE]; }   // iteration matrix / its LU factors
@@ -469,15 +473,12 @@ struct Lsoda {
 
   // coefficients of the current (meth, nq): el(1..l), tesco(nq, 1..3)   [DSTODA label 150]
   KN_HD void resetcoeff(int lb) {
-    for_rows<1>(lb, [&](int i) { el[i] = (i <= l) ? cf->elco[meth - 1][nq][i] : 0.0; });
-    tq1 = cf->tesco[meth - 1][nq][1];
+    (void)lb;
+    el1 = cf->elco[meth - 1][nq][1];
     tq2 = cf->tesco[meth - 1][nq][2];
-    tq3 = cf->tesco[meth - 1][nq][3];
-    rtq1 = cf->rtesco[meth - 1][nq][1];
     rtq2 = cf->rtesco[meth - 1][nq][2];
-    rtq3 = cf->rtesco[meth - 1][nq][3];
-    rcr = kn_div(rcr * el[1], el0);
-    el0 = el[1];
+    rcr = kn_div(rcr * el1, el0);
+    el0 = el1;
     conit = over_int(0.5, nq + 2);
   }
 
@@ -810,12 +811,12 @@ struct Lsoda {
     double dup = 1.0, ddn = 1.0;
     if (up) {
       _Pragma("unroll") for (int i = 0; i < NI; ++i) savf[i] = acor[i] - ysave[i];
-      dup = over_tq(vmnorm(savf), tq3, rtq3);
+      dup = over_tq(vmnorm(savf), cf->tesco[meth - 1][nq][3], cf->rtesco[meth - 1][nq][3]);   // (order selection only)
     }
     if (dn) {
       double row[NI];
       get_row(l, lb, row);
-      ddn = over_tq(vmnorm(row), tq1, rtq1);
+      ddn = over_tq(vmnorm(row), cf->tesco[meth - 1][nq][1], cf->rtesco[meth - 1][nq][1]);
     }
     double psm, pdn, pup;
     pow3(dsm, exsm, ddn, over_int(1.0, nq), dup, over_int(1.0, l + 1), psm, pdn, pup);
@@ -846,7 +847,7 @@ struct Lsoda {
       } else {
         rh = rhup;
         if (rh >= 1.1) {
-          const double r = over_int(el[0], l);   // el[0] holds el(l), refreshed below before every call
+          const double r = over_int(cf->elco[meth - 1][nq][l], l);   // el(l) of the order that took the step
           nq = l;
           l = nq + 1;
           double row[NI];
@@ -868,13 +869,6 @@ struct Lsoda {
     if (newq == nq) return 1;
     set_order(newq, lb);
     return 2;
-  }
-
-  // el(l) of the current coefficients (a per-lane row index: one select chain, only where it is needed)
-  KN_HD void load_el_l(int lb) {
-    double v = 0.0;
-    for_rows<1>(lb, [&](int j) { v = (j == l) ? el[j] : v; });
-    el[0] = v;
   }
 
   // ---- phases -----------------------------------------------------------------------------------
@@ -973,7 +967,7 @@ struct Lsoda {
       // evaluated here its exchanges overlap those of del instead of following the convergence test
       if (m != 0) anorm = vmnorm(savf);
       _Pragma("unroll") for (int i = 0; i < NI; ++i) {
-        y[i] = yh[1][i] + el[1] * savf[i];
+        y[i] = yh[1][i] + el1 * savf[i];
         acor[i] = savf[i];
       }
     } else {
@@ -982,7 +976,7 @@ struct Lsoda {
       del = vmnorm(y);
       _Pragma("unroll") for (int i = 0; i < NI; ++i) {
         acor[i] += y[i];
-        y[i] = yh[1][i] + el[1] * acor[i];
+        y[i] = yh[1][i] + el1 * acor[i];
       }
       if (m != 0) anorm = vmnorm(acor);
     }
@@ -1000,7 +994,7 @@ struct Lsoda {
       const double dcon = del * fmin(1.0, 1.5 * crate) / (tq2 * conit);
 #endif
       if (dcon <= 1.0) {
-        pdest = fmax(pdest, kn_div(rate, fabs(h * el[1])));
+        pdest = fmax(pdest, kn_div(rate, fabs(h * el1)));
         if (pdest != 0.0) pdlast = pdest;
         ph = PH_ERR;
         return;
@@ -1047,7 +1041,8 @@ struct Lsoda {
       nqu = nq;
       mused = meth;
       for_rows<1>(lb, [&](int j) {
-        _Pragma("unroll") for (int i = 0; i < NI; ++i) yh[j][i] += el[j] * acor[i];
+        const double elj = cf->elco[meth - 1][nq][j];
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) yh[j][i] += elj * acor[i];
       });
       const double tq2u = tq2, rtq2u = rtq2;   // tesco(nqu, 2) of the method that took the step (used by "endstoda")
       icount--;
@@ -1065,7 +1060,6 @@ struct Lsoda {
         ialth--;
         if (ialth == 0) {
           stamp(5, true);
-          load_el_l(lb);
           const int orderflag = orderswitch(true, dsm, lb);
           stamp(8, true);
           if (orderflag != 0) {
@@ -1113,7 +1107,6 @@ struct Lsoda {
       return;
     }
     if (kflag > -3) {
-      load_el_l(lb);
       const int orderflag = orderswitch(false, dsm, lb);
       if (orderflag == 2) resetcoeff(lb);
       if (orderflag == 0) rh = fmin(rh, 0.2);
@@ -1155,12 +1148,11 @@ struct Lsoda {
     rtol = rtol_;
     atol = atol_;
     _Pragma("unroll") for (int j = 0; j <= ROWS; ++j) {
-      el[j] = 0.0;
       _Pragma("unroll") for (int i = 0; i < NI; ++i) yh[j][i] = 0.0;
     }
     _Pragma("unroll") for (int i = 0; i < NI; ++i) ysave[i] = 0.0;
-    tq1 = tq2 = tq3 = 0.0;
-    rtq1 = rtq2 = rtq3 = 0.0;
+    tq2 = 0.0;
+    rtq2 = 0.0;
     tn = t0;
     tsw = t0;
     maxord = MXORDN;

@@ -31,6 +31,8 @@ if [ $part = bench ]; then
   python3 bench.py --workload config5s --steps 20 --warmup 5 --cpu-steps 0 --no-dg > $O/bench_config5s.json 2> $O/bench_config5s.err; echo "bench config5s done"
   python3 bench.py --workload r3 --steps 10 --warmup 5 --repeats 3 --cpu-steps 0 --solve-steps 0 --no-dg > $O/bench_r3.json 2> $O/bench_r3.err; echo "bench r3 done"
   python3 bench.py --variant dg --workload config3 --steps 20 --warmup 3 > $O/bench_dg_config3.json 2> $O/bench_dg_config3.err; echo "bench dg config3 done"
+  python3 bench.py --variant dg --workload config2h --steps 20 --warmup 3 --solve-steps 0 > $O/bench_dg_config2h.json 2> $O/bench_dg_config2h.err; echo "bench dg config2h (broken Q1, box-mesh kernels) done"
+  KNPEMI_DG_HEX_GENERAL=1 python3 bench.py --variant dg --workload config2h --steps 20 --warmup 3 --solve-steps 0 > $O/bench_dg_config2h_general_kernels.json 2> $O/bench_dg_config2h_general.err; echo "bench dg config2h (general kernels) done"
   KNPEMI_NO_FUSED=1 python3 bench.py --steps 20 --warmup 5 --cpu-steps 0 --no-dg --no-config3 > $O/bench_config2_plain_solver_loops.json 2> $O/bench_config2_plain.err; echo "bench config2 (plain solver loops) done"
 fi
 done

@@ -53,6 +53,8 @@ for f, cmd in (("bench_config2", "python bench.py --steps 20 --warmup 5"),
                ("bench_config5s", "python bench.py --workload config5s --steps 20 --warmup 5 --cpu-steps 0 --no-dg"),
                ("bench_r3", "python bench.py --workload r3 --steps 10 --warmup 5 --repeats 3 --cpu-steps 0 --solve-steps 0 --no-dg"),
                ("bench_dg_config3", "python bench.py --variant dg --workload config3 --steps 20 --warmup 3"),
+               ("bench_dg_config2h", "python bench.py --variant dg --workload config2h --steps 20 --warmup 3 --solve-steps 0"),
+               ("bench_dg_config2h_general_kernels", "KNPEMI_DG_HEX_GENERAL=1 python bench.py --variant dg --workload config2h --steps 20 --warmup 3 --solve-steps 0"),
                ("bench_config2_plain_solver_loops", "KNPEMI_NO_FUSED=1 python bench.py --steps 20 --warmup 5 --cpu-steps 0 --no-dg --no-config3")):
     if not cp(os.path.join(G, "r03", f + ".json"), f"r03_{f}.json"):
         continue
@@ -72,8 +74,13 @@ for f, cmd in (("bench_config2", "python bench.py --steps 20 --warmup 5"),
         sw = d["spike_window"]
         bits.append(f"spike window {sw['ms_per_step']:.4f} ms/step (ODE sweep {sw['ode_kernel_us_per_step']:.0f} us avg, {sw['ode_kernel_us_max']:.0f} max)")
     ws = d.get("with_solves")
-    if ws:
+    if ws and "emi" in ws:
         bits.append(f"with_solves {ws['ms_per_step']:.3f} ms/step ({ws['emi']['iterations_avg']:.2f} CG + {ws['knp']['iterations_avg']:.2f} BiCGStab)")
+    elif ws:
+        bits.append(f"with_solves {ws['ms_per_step']:.3f} ms/step ({ws['cg_iterations_per_step']:.1f} CG + {ws['bicgstab_iterations_per_step']:.1f} BiCGStab)")
+    rp = d.get("roofline_potential_kernel")
+    if rp:
+        bits.append(f"{rp['kernel']} {rp['avg_launch_us']:.1f} us = {rp['frac']:.3f}")
     cb = d.get("cpu_baseline")
     if cb:
         bits.append(f"CPU port {cb['value']:.2e} dofs/s on {cb['cores']} threads")
