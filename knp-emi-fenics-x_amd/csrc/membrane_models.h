@@ -22,6 +22,15 @@
 // fmod(t, period) for the periodic stimulus: inside the first period the remainder is t itself (fmod is exact, so
 // this returns the same bits) and the ~70-instruction reduction loop is skipped -- by the whole wavefront, since all
 // membrane dofs of a sweep integrate the same time interval.
+// Both exponentials of a lane are evaluated here, side by side: the second one is only used by the gate lanes, and left
+// alone the compiler sinks its whole evaluation into that divergent region -- after the first one, so the two dependent
+// chains no longer overlap and the polynomial's constants are materialised twice.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KN_KEEP_TOGETHER(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#else
+#define KN_KEEP_TOGETHER(a, b) ((void)0)
+#endif
+
 KN_HD double kn_fmod_period(double t, double period) {
   if (t >= 0.0 && t < period) return t;
   return fmod(t, period);
@@ -91,7 +100,8 @@ struct ModelHHSI {
   KN_HD double rhs_lane(int c, double t, const double* y) const {
     const double m = y[0], h = y[1], n = y[2], V = y[3];
     const double tp = kn_fmod_period(t, 0.03);
-    const double e1 = kn_exp(fma(c == 3 ? tp : V, l_b1, l_a1)), e2 = kn_exp(fma(V, l_b2, l_a2));
+    double e1 = kn_exp(fma(c == 3 ? tp : V, l_b1, l_a1)), e2 = kn_exp(fma(V, l_b2, l_a2));
+    KN_KEEP_TOGETHER(e1, e2);
     const double q = kn_div(c == 1 ? 1.e3 : fma(V, l_kb, l_ka), c == 1 ? e2 + 1 : e1 - 1);
     const double alpha = c == 1 ? 0.07e3 * e1 : q;
     const double beta = c == 1 ? q : l_k2 * e2;
@@ -163,7 +173,8 @@ struct ModelHHMV {
   KN_HD double rhs_lane(int c, double t, const double* y) const {
     const double m = y[0], h = y[1], n = y[2], V = y[3];
     const double tp = kn_fmod_period(t, 30.0);
-    const double e1 = kn_exp(fma(c == 3 ? tp : V, l_b1, l_a1)), e2 = kn_exp(fma(V, l_b2, l_a2));
+    double e1 = kn_exp(fma(c == 3 ? tp : V, l_b1, l_a1)), e2 = kn_exp(fma(V, l_b2, l_a2));
+    KN_KEEP_TOGETHER(e1, e2);
     const double q = kn_div(c == 1 ? 1. : fma(V, l_kb, l_ka), c == 1 ? e2 + 1 : e1 - 1);
     const double alpha = c == 1 ? 0.07 * e1 : q;
     const double beta = c == 1 ? q : l_k2 * e2;
