@@ -956,6 +956,11 @@ def main():
             dg = run_dg(args, torch, steps=10, warmup=2, cpu=False)
             out["dg_variant"] = {k: dg[k] for k in ("value", "unit", "ms_per_step", "config", "roofline",
                                                      "roofline_potential_kernel", "kernels_us_per_step")}
+            # the same variant on the reference's own 3-D cell type: broken Q1 on the hexahedral box (config2h, 165 888 cells)
+            hargs = argparse.Namespace(**{**vars(args), "workload": "config2h"})
+            dgh = run_dg(hargs, torch, steps=10, warmup=2, cpu=False)
+            out["dg_variant_hexahedra"] = {k: dgh[k] for k in ("value", "unit", "ms_per_step", "config", "roofline",
+                                                                "roofline_potential_kernel", "kernels_us_per_step")}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

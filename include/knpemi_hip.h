@@ -436,6 +436,15 @@ int knpemi_dg_update(knpemi_dg* h, const double* c_new, int on_device);
  * KNPEMI_ESOLVE at maxit.  solve_emi writes the potential field; solve_knp keeps the solution on the device and, with
  * update != 0, runs knpemi_dg_update on it; knpemi_dg_get_solution copies it out ([K-1][n_dofs]).  Single rank. */
 int knpemi_dg_solve_emi(knpemi_dg* h, double rtol, double atol, int maxit, int* iters, double* relres);
+/* On a cell partition (knpemi.dg.DGSlab; the reference's parallel KSP, SURVEY section 8 e + f1, for the f4 variant): the two
+ * solves become solves of the global systems exactly as knpemi_set_distributed arranges for the CG path -- owned rows
+ * only, halo of every SpMV argument, all-reduced dot products, per-rank auxiliary-space AMG.  `owned`: one byte per local
+ * broken dof, 1 = dof of an owned cell (NULL: back to single-rank solves); vector orders for `halo`: KNPEMI_B_EMI one value
+ * per dof, KNPEMI_B_KNP [solved ion][dof].  knpemi_dg_solver_handle returns the knpemi_handle the solves run on, for
+ * knpemi_vec_gather / knpemi_vec_scatter in the halo hook (NULL on error). */
+int knpemi_dg_set_distributed(knpemi_dg* h, const uint8_t* owned, void* reduce_buf_dev, knpemi_allreduce_fn allreduce,
+                              knpemi_halo_fn halo, void* ctx);
+void* knpemi_dg_solver_handle(knpemi_dg* h);
 int knpemi_dg_solve_knp(knpemi_dg* h, double rtol, double atol, int maxit, int* iters, double* relres, int update);
 int knpemi_dg_get_solution(knpemi_dg* h, double* c_host);
 /* on != 0: both solves start from 2 x_n - x_(n-1) (the last two solutions) instead of x_n, as knpemi_extrapolate_guess

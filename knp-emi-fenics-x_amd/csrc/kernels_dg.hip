@@ -1312,6 +1312,86 @@ int dg_solver(knpemi_dg* h, knpemi_handle** out) {
 
 }  // namespace
 
+// The solver handle of a DG problem (a knpemi_handle that carries the stream, the two CSR systems and the dof records):
+// knpemi_vec_gather / knpemi_vec_scatter take it for the ghost refresh of a solver vector on a cell partition.
+extern "C" void* knpemi_dg_solver_handle(knpemi_dg* h) {
+  if (!h) { kn_set_error("knpemi_dg_solver_handle: null handle"); return nullptr; }
+  if (hipSetDevice(h->device) != hipSuccess) return nullptr;
+  knpemi_handle* s = nullptr;
+  return dg_solver(h, &s) == KNPEMI_OK ? s : nullptr;
+}
+
+// Cell partition (knpemi.dg.DGSlab): knpemi_dg_solve_emi / knpemi_dg_solve_knp become solves of the GLOBAL systems, as
+// knpemi_set_distributed does for the CG path -- rows of owned cells only (ghost rows become identity rows), every SpMV
+// after a ghost refresh of its argument (`halo`), dot products over owned dofs summed with `allreduce`, each rank's
+// auxiliary-space AMG on its own diagonal block.  owned: one byte per local broken dof (1 = dof of an owned cell), NULL
+// switches back to single-rank solves.  Vector orders: KNPEMI_B_EMI one value per dof, KNPEMI_B_KNP [solved ion][dof].
+extern "C" int knpemi_dg_set_distributed(knpemi_dg* h, const uint8_t* owned, void* reduce_buf_dev, knpemi_allreduce_fn allreduce,
+                                         knpemi_halo_fn halo, void* ctx) {
+  if (!h) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_set_distributed: null handle");
+  KN_HIP(hipSetDevice(h->device));
+  knpemi_handle* s = nullptr;
+  int rc = dg_solver(h, &s);
+  if (rc) return rc;
+  KnDist& d = s->dist;
+  const int n = h->dev.n_dof, KS = h->K - 1;
+  s->amg_emi.built = false;      // the preconditioner changes with the ownership
+  s->amg_knp.built = false;
+  // first aggregates of the auxiliary space: all broken dofs at one (sub-domain, mesh vertex) -- on a partition the dofs of
+  // ghost cells (identity rows of the rank's diagonal block) get aggregates of their own
+  std::vector<int> agg((size_t)n);
+  int na = h->n_aux;
+  if (owned) {
+    std::vector<int> ghost_of((size_t)h->n_aux, -1);
+    for (int i = 0; i < n; ++i) {
+      if (owned[i]) { agg[i] = h->aux_of[i]; continue; }
+      int& g = ghost_of[h->aux_of[i]];
+      if (g < 0) g = na++;
+      agg[i] = g;
+    }
+    // an auxiliary vertex all of whose dofs are ghosts leaves an empty aggregate behind: renumber the used ones
+    std::vector<int> used((size_t)na, 0), renum((size_t)na, -1);
+    for (int i = 0; i < n; ++i) used[agg[i]] = 1;
+    int cnt = 0;
+    for (int a = 0; a < na; ++a) if (used[a]) renum[a] = cnt++;
+    for (int i = 0; i < n; ++i) agg[i] = renum[agg[i]];
+    na = cnt;
+  } else {
+    agg = h->aux_of;
+  }
+  if (!getenv("KNPEMI_DG_PLAIN_AMG")) {
+    s->amg_emi.first_agg = agg;
+    s->amg_emi.first_na = na;
+    s->amg_knp.first_agg.resize((size_t)KS * n);
+    for (int k = 0; k < KS; ++k)
+      for (int i = 0; i < n; ++i) s->amg_knp.first_agg[(size_t)k * n + i] = k * na + agg[i];
+    s->amg_knp.first_na = KS * na;
+  }
+  if (!owned) { d.on = false; return KNPEMI_OK; }
+  if (!reduce_buf_dev || !allreduce || !halo)
+    return dg_fail(KNPEMI_EINVAL, "knpemi_dg_set_distributed: reduction buffer and both communication hooks are required");
+  d.h_owned_emi.assign(owned, owned + n);
+  d.h_owned_knp.resize((size_t)KS * n);
+  for (int k = 0; k < KS; ++k) std::copy(owned, owned + n, d.h_owned_knp.begin() + (size_t)k * n);
+  const uint8_t* p = nullptr;
+  if ((rc = dg_upload(h, d.h_owned_emi, &p))) return rc;
+  d.d_owned_emi = const_cast<uint8_t*>(p);
+  if ((rc = dg_upload(h, d.h_owned_knp, &p))) return rc;
+  d.d_owned_knp = const_cast<uint8_t*>(p);
+  d.d_red = static_cast<double*>(reduce_buf_dev);
+  d.allreduce = allreduce; d.halo = halo; d.ctx = ctx;
+  double cnt = 0.0;   // owned dofs over all ranks (mean of the constant null space)
+  for (int i = 0; i < n; ++i) cnt += owned[i] ? 1.0 : 0.0;
+  KN_HIP(hipMemcpyAsync(d.d_red, &cnt, sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (allreduce(ctx, 1)) return dg_fail(KNPEMI_EHIP, "knpemi_dg_set_distributed: allreduce hook failed");
+  KN_HIP(hipMemcpyAsync(&cnt, d.d_red, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  KN_HIP(hipStreamSynchronize(h->stream));
+  d.n_owned_global = cnt;
+  d.nc = 0;            // (no cross-rank coarse space for the DG systems)
+  d.on = true;
+  return KNPEMI_OK;
+}
+
 // Device solves of the two DG systems (pdeSolver.py:24-35,74-78,99-110 with the iterative options): CG on the
 // symmetric interior-penalty potential system with the constants projected out, BiCGStab on the K - 1 concentration
 // systems taken as one block-diagonal system; preconditioner = the smoothed-aggregation AMG of the CG path whose first

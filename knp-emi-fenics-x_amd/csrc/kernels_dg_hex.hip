@@ -28,8 +28,9 @@
 //   2. every lane builds its row: volume terms from the eight shared gradient tables, facet terms from the six summaries.
 //      Loops over facets, points and columns are unrolled, so every index into a register array is a compile-time
 //      constant; what depends on the lane's own vertex i are a few scalars per point (its trace and normal derivative).
-//      The neighbour blocks are put into the neighbour's local column order through a small LDS scratch and leave as
-//      four 16-byte stores per lane: whole 64-byte lines.
+//      Every block of a row is one 64-byte line: the lanes put their blocks (a neighbour block in the neighbour's local
+//      column order) into LDS scratch lines and four lanes store one line together, 16 whole lines per instruction.
+// Box meshes (all cells orthogonal parallelepipeds) take the kernels at the end of this file.
 #include <string>
 #include <type_traits>
 

@@ -191,6 +191,8 @@ SIGNATURES = {
     "knpemi_dg_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "knpemi_dg_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), c_dbl_p]),
     "knpemi_dg_stream": (C.c_void_p, [C.c_void_p]),
+    "knpemi_dg_set_distributed": (C.c_int, [C.c_void_p, c_u8_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "knpemi_dg_solver_handle": (C.c_void_p, [C.c_void_p]),
 }
 
 

@@ -334,6 +334,55 @@ class DGSlab:
         self.mode = h.mode
         self._d = h._device_plan(self.plan, 5)
 
+    def enable_solves(self):
+        """`solve_emi` / `solve_knp` of this rank's DGProblem become solves of the GLOBAL systems
+        (knpemi_dg_set_distributed; the reference runs its KSP solves under MPI, SURVEY §8 e): owned rows only, ghost
+        refresh of every SpMV argument, all-reduced dot products, per-rank auxiliary-space AMG.  Transports: the
+        `torch.distributed` ones of the field halo (stream-ordered RCCL, host-synchronised RCCL, gloo host-staged)."""
+        if self._d is None and self.world > 1:
+            raise RuntimeError("DGSlab.enable_solves: call attach() first")
+        h, dp, torch = self._halo, self.dp, self._halo.torch
+        KS, n = dp.K - 1, dp.n
+        sh = dp.lib.knpemi_dg_solver_handle(dp.h)
+        if not sh:
+            L.check(-1)
+        self._solver_handle = C.c_void_p(sh)
+        knp = lambda g: np.concatenate([np.asarray(g, np.int64) + k * n for k in range(KS)])
+        mapped = {key: dict(nb=pl["nb"], send=knp(pl["send"]), recv=knp(pl["recv"])) for key, pl in self.plan.items()}
+        self._vec = {L.B_EMI: h._device_plan(self.plan, 1), L.B_KNP: h._device_plan(mapped, 1)}
+        h._red = torch.zeros(8 + 64, dtype=torch.float64, device=h._device)
+        self._hook_error = None
+
+        def allreduce(ctx, m):
+            try:
+                h._allreduce(m)
+                return 0
+            except Exception as exc:       # noqa: BLE001 -- must not propagate through the C frame
+                self._hook_error = exc
+                return -1
+
+        def halo(ctx, vec, which):
+            try:
+                d = self._vec[which]
+                if d is not None:
+                    L.check(dp.lib.knpemi_vec_gather(self._solver_handle, vec, d["send_idx"].data_ptr(), d["send_idx"].numel(),
+                                                     d["send_buf"].data_ptr()))
+                    native, self._halo._native = getattr(self._halo, "_native", False), False   # (field halo may be library RCCL)
+                    try:
+                        self._halo._transfer(d)
+                    finally:
+                        self._halo._native = native
+                    L.check(dp.lib.knpemi_vec_scatter(self._solver_handle, vec, d["recv_idx"].data_ptr(), d["recv_idx"].numel(),
+                                                      d["recv_buf"].data_ptr()))
+                return 0
+            except Exception as exc:       # noqa: BLE001
+                self._hook_error = exc
+                return -1
+        own = np.ascontiguousarray(np.repeat(self.owned_cells.astype(np.uint8), dp.nv))
+        self._cb = (L.ALLREDUCE_FN(allreduce), L.HALO_FN(halo))    # keep the callbacks alive
+        L.check(dp.lib.knpemi_dg_set_distributed(dp.h, own.ctypes.data_as(L.c_u8_p), h._red.data_ptr(),
+                                                 C.cast(self._cb[0], C.c_void_p), C.cast(self._cb[1], C.c_void_p), None))
+
     def exchange(self):
         """Refresh the ghost cells' concentrations and potential from their owners."""
         d, dp = self._d, self.dp

@@ -131,6 +131,18 @@ def test_dg_variant_cell_partition_equals_single_rank_bit_for_bit(world, cell):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cell", ["tetrahedron", "hexahedron"])
+def test_dg_variant_distributed_solves_match_single_rank(cell):
+    """knpemi_dg_set_distributed (knpemi.dg.DGSlab.enable_solves): CG on the potential system and BiCGStab on the
+    concentration systems of the DG variant solved GLOBALLY on two slabs -- owned rows, ghost refresh of every SpMV argument,
+    all-reduced dot products, per-rank auxiliary-space AMG -- agree with the single-rank solves of the whole box to solver
+    accuracy (the reference runs these KSP solves under MPI)."""
+    rcs, outs = _run_ranks(["--steps", "2", "--cell", cell, "--solves"], world=2, tool="check_dg_partition.py")
+    assert rcs == [0, 0], "\n".join(outs)
+    assert "DG PARTITION OK" in outs[0] and "distributed solves" in outs[0], outs[0]
+
+
+@pytest.mark.gpu
 def test_rccl_halo_transport_rehearsal_on_one_gpu():
     """Real RCCL on one GPU (a world-size-1 group sending the packed halo to itself, tools/check_async_halo.py): the
     stream-ordered exchange through torch.distributed and the library's own transport (knpemi_comm_init / _sendrecv /

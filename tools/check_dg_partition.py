@@ -68,6 +68,9 @@ def main():
     ap.add_argument("-r", type=int, default=0)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--cell", default="tetrahedron", choices=["tetrahedron", "hexahedron"])
+    ap.add_argument("--solves", action="store_true",
+                    help="after the steps: the two systems solved on the partition (knpemi_dg_set_distributed) against the "
+                         "single-rank solves of the whole box")
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     backend = os.environ.get("KNPEMI_BENCH_BACKEND", "gloo")
@@ -130,10 +133,47 @@ def main():
         st_g = ref["ode"].reshape(g.nmf, nfg, -1)[gi]
         if not np.array_equal(st_l, st_g):
             ok = False
+    sol_msg = ""
+    if a.solves:
+        # the systems of the state both runs have reached: solved GLOBALLY on the partition (every rank takes part); the
+        # owned cells' parts, put together, must satisfy the single-rank systems of the whole box to the solver's tolerance
+        rt_e, rt_k = 1e-8, 1e-11
+        slab.enable_solves()
+        dp = slab.dp
+        dp.assemble_emi()
+        it_e, _ = dp.solve_emi(rtol=rt_e)
+        phi_l = dp.get_potential()
+        dp.assemble_knp()
+        it_k, _ = dp.solve_knp(rtol=rt_k)
+        c_l = dp.solution().reshape(2, dp.n_cells, dp.nv)
+        if slab._hook_error is not None:
+            raise slab._hook_error
+        own = np.flatnonzero(slab.owned_cells)
+        parts = [None] * world
+        dist.all_gather_object(parts, (gcell[own], phi_l[own], c_l[:, own]))
+        phi_x = np.zeros((g.n_cells, g.nv))
+        c_x = np.zeros((2, g.n_cells, g.nv))
+        for gc, ph, cc in parts:
+            phi_x[gc] = ph
+            c_x[:, gc] = cc
+        g.assemble_emi()
+        A, bb = g.matrix(0), g.rhs(0)
+        bb = bb - bb.mean()
+        ge, _ = g.solve_emi(rtol=rt_e)              # (the single-rank iteration count, for the record)
+        r_e = np.linalg.norm(A @ phi_x.ravel() - bb) / np.linalg.norm(bb)
+        g.set_potential(phi_x)                      # the concentration systems are assembled with the potential just solved
+        g.assemble_knp()
+        r_k = max(np.linalg.norm(g.matrix(1 + k) @ c_x[k].ravel() - g.rhs(1 + k)) / np.linalg.norm(g.rhs(1 + k)) for k in range(2))
+        sol_msg = (f"distributed solves: residuals of the assembled solution in the single-rank systems {r_e:.2e} (potential), "
+                   f"{r_k:.2e} (concentrations); {it_e} CG / {it_k} BiCGStab iterations on the partition, {ge} CG on one rank")
+        if not (r_e < 20 * rt_e and r_k < 100 * rt_k and abs(phi_x.mean()) < 1e-10 * np.abs(phi_x).max()):
+            ok = False
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
         print(f"mode {slab.mode}; owned cells {int(slab.owned_cells.sum())} of {slab.dp.n_cells} local")
+        if sol_msg:
+            print(sol_msg)
         print("DG PARTITION OK" if int(flag.item()) else "DG PARTITION MISMATCH")
     dist.barrier()
     dist.destroy_process_group()

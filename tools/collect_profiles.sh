@@ -2,8 +2,8 @@
 # Round-end evidence on the GPU box: rocprofv3 kernel statistics of the bench command, bench lines of every workload.
 # Everything lands under gpurun_out/r03/ ; tools/refresh_profiles.py copies what is to be judged into profiles/ and
 # regenerates the numbers quoted in profiles/README.md from those files.  usage: tools/collect_profiles.sh [part ...]
-# parts: stats bench (default: both)
-PARTS=${@:-stats bench}
+# parts: stats bench bench2 (default: all; each part fits one 20-minute gpurun call)
+PARTS=${@:-stats bench bench2}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03
 mkdir -p $O
@@ -29,6 +29,9 @@ if [ $part = bench ]; then
   python3 bench.py --workload config3 --steps 20 --warmup 5 --cpu-steps 0 --no-dg > $O/bench_config3.json 2> $O/bench_config3.err; echo "bench config3 done"
   python3 bench.py --workload config2h --steps 20 --warmup 5 --cpu-steps 0 --no-dg > $O/bench_config2h.json 2> $O/bench_config2h.err; echo "bench config2h done"
   python3 bench.py --workload config5s --steps 20 --warmup 5 --cpu-steps 0 --no-dg > $O/bench_config5s.json 2> $O/bench_config5s.err; echo "bench config5s done"
+fi
+if [ $part = bench2 ]; then
+  cd $R
   python3 bench.py --workload r3 --steps 10 --warmup 5 --repeats 3 --cpu-steps 0 --solve-steps 0 --no-dg > $O/bench_r3.json 2> $O/bench_r3.err; echo "bench r3 done"
   python3 bench.py --variant dg --workload config3 --steps 20 --warmup 3 > $O/bench_dg_config3.json 2> $O/bench_dg_config3.err; echo "bench dg config3 done"
   python3 bench.py --variant dg --workload config2h --steps 20 --warmup 3 --solve-steps 0 > $O/bench_dg_config2h.json 2> $O/bench_dg_config2h.err; echo "bench dg config2h (broken Q1, box-mesh kernels) done"
