@@ -251,18 +251,20 @@ __global__ void extrapolate_kernel(int n, double* __restrict__ cur, int stride, 
 }
 
 // ---- coarse space of the distributed EMI preconditioner ---------------------------------------------------------
-// Aggregates (knpemi_set_distributed_coarse): the owned vertices of every sub-domain of this rank, binned into k slices
-// along the longest axis of their bounding box; agg_of[i] = local aggregate of unknown i (-1: ghost), and per aggregate
-// the list of its unknowns (agg_ptr / agg_idx).
-// restriction: one workgroup per local aggregate sums r over its list in a fixed order (reproducible) and writes its
-// entry of the coarse vector in the reduction buffer; the all-reduce fills in the other ranks' entries.
+// Coarse functions (knpemi_set_distributed_coarse): per rank and sub-domain the k + 1 hat functions over k slices of the
+// owned vertices' extent along its longest axis (piecewise linear along the axis, a partition of unity on the owned
+// vertices; the two half hats that meet at a cut between ranks are separate functions, so the space contains the
+// continuous piecewise-linear functions across the cuts).  agg_of[i] = the lower node of unknown i (-1: ghost), agg_w[i]
+// its weight in the upper node; per node the list of its unknowns and their weights (agg_ptr / agg_idx / agg_wt).
+// restriction: one workgroup per local node sums the weighted r over its list in a fixed order (reproducible) and writes
+// its entry of the coarse vector in the reduction buffer; the all-reduce fills in the other ranks' entries.
 __global__ __launch_bounds__(256) void coarse_restrict_kernel(const double* __restrict__ r, const int* __restrict__ agg_ptr,
-                                                              const int* __restrict__ agg_idx, int nl, int rank, int world,
-                                                              double* __restrict__ red) {
+                                                              const int* __restrict__ agg_idx, const double* __restrict__ agg_wt,
+                                                              int nl, int rank, int world, double* __restrict__ red) {
   __shared__ double sh[256];
   const int a = blockIdx.x;
   double acc = 0.0;
-  for (int t = agg_ptr[a] + threadIdx.x; t < agg_ptr[a + 1]; t += 256) acc += r[agg_idx[t]];
+  for (int t = agg_ptr[a] + threadIdx.x; t < agg_ptr[a + 1]; t += 256) acc += agg_wt[t] * r[agg_idx[t]];
   sh[threadIdx.x] = acc;
   __syncthreads();
   for (int m = 128; m > 0; m >>= 1) {
@@ -286,14 +288,15 @@ __global__ void coarse_solve_kernel(const double* __restrict__ inv, const double
   zc[a] = v;
 }
 
-// prolongation: z += z_c[aggregate] on the owned unknowns (mode 0); mode 1: z = indicator of aggregate `pick`
-__global__ void coarse_prolong_kernel(int n, const int* __restrict__ agg_of, const double* __restrict__ zc, double* __restrict__ z,
-                                      int mode, int pick) {
+// prolongation: z += (1 - w) z_c[node] + w z_c[node + 1] on the owned unknowns (mode 0); mode 1: z = coarse function `pick`
+__global__ void coarse_prolong_kernel(int n, const int* __restrict__ agg_of, const double* __restrict__ agg_w,
+                                      const double* __restrict__ zc, double* __restrict__ z, int mode, int pick) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int a = agg_of[i];
-  if (mode == 0) { if (a >= 0) z[i] += zc[a]; }
-  else z[i] = (a >= 0 && a == pick) ? 1.0 : 0.0;
+  const double w = a >= 0 ? agg_w[i] : 0.0;
+  if (mode == 0) { if (a >= 0) z[i] += (1.0 - w) * zc[a] + w * zc[a + 1]; }
+  else z[i] = a < 0 ? 0.0 : (a == pick ? 1.0 - w : (a + 1 == pick ? w : 0.0));
 }
 
 struct Ctx {
@@ -456,13 +459,13 @@ static int ensure_work(knpemi_handle* h, size_t n) {
 static void coarse_restrict(Ctx& c, const double* r) {
   knpemi_handle* h = c.h;
   KnDist& d = h->dist;
-  hipLaunchKernelGGL(coarse_restrict_kernel, dim3(d.nl), dim3(256), 0, h->stream, r, d.d_agg_ptr, d.d_agg_idx, d.nl, d.rank,
-                     d.world, d.d_red);
+  hipLaunchKernelGGL(coarse_restrict_kernel, dim3(d.nl), dim3(256), 0, h->stream, r, d.d_agg_ptr, d.d_agg_idx, d.d_agg_wt, d.nl,
+                     d.rank, d.world, d.d_red);
   if (int e = d.allreduce(d.ctx, KN_COARSE_OFF + d.nc)) c.comm_rc = c.comm_rc ? c.comm_rc : e;
 }
 
-// Coarse operator A_c = Phi^T A Phi of the partitioned EMI system (one column per (rank, sub-domain): an SpMV of its
-// indicator and a restriction), then on the host the inverse of A_c + alpha 1 1^T (A_c has the constants in its kernel;
+// Coarse operator A_c = Phi^T A Phi of the partitioned EMI system (one column per coarse function: an SpMV of it and a
+// restriction), then on the host the inverse of A_c + alpha 1 1^T (A_c has the constants in its kernel;
 // the residuals it is applied to have zero mean) with empty aggregates decoupled.
 static int coarse_setup(Ctx& c, double* work_phi, double* work_y) {
   knpemi_handle* h = c.h;
@@ -477,8 +480,8 @@ static int coarse_setup(Ctx& c, double* work_phi, double* work_y) {
   for (int j = 0; j < nc; ++j) {
     const int rj = j / nl, aj = j % nl;
     // phi_j: 1 on the owned unknowns of aggregate aj of rank rj (ghost copies are filled by the SpMV's halo), 0 elsewhere
-    hipLaunchKernelGGL(coarse_prolong_kernel, grid1(c.n), dim3(256), 0, h->stream, c.n, d.d_agg_of, (const double*)nullptr,
-                       work_phi, 1, rj == d.rank ? aj : -1);
+    hipLaunchKernelGGL(coarse_prolong_kernel, grid1(c.n), dim3(256), 0, h->stream, c.n, d.d_agg_of, d.d_agg_w,
+                       (const double*)nullptr, work_phi, 1, rj == d.rank ? aj : -2);
     spmv(c, work_phi, work_y, nullptr);
     coarse_restrict(c, work_y);
     KN_HIP(hipMemcpyAsync(col.data(), d.d_red + KN_COARSE_OFF, nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -530,7 +533,7 @@ static void coarse_correct(Ctx& c, const double* r, double* z) {
   coarse_restrict(c, r);
   hipLaunchKernelGGL(coarse_solve_kernel, dim3(1), dim3(KN_COARSE_MAX), 0, h->stream, d.d_coarse_inv, d.d_red, d.nl, d.rank, d.nc,
                      d.d_coarse_z);
-  hipLaunchKernelGGL(coarse_prolong_kernel, grid1(c.n), dim3(256), 0, h->stream, c.n, d.d_agg_of, d.d_coarse_z, z, 0, 0);
+  hipLaunchKernelGGL(coarse_prolong_kernel, grid1(c.n), dim3(256), 0, h->stream, c.n, d.d_agg_of, d.d_agg_w, d.d_coarse_z, z, 0, 0);
 }
 
 // Jacobi-PCG on A_emi x = b_emi, x = phi (record component 7, gathered into a contiguous vector first).

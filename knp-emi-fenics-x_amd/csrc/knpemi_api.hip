@@ -1526,15 +1526,19 @@ extern "C" int knpemi_set_distributed_coarse(knpemi_handle* h, int rank, int wor
   if (!d.on) return fail(KNPEMI_EINVAL, "knpemi_set_distributed_coarse: call knpemi_set_distributed first");
   KN_HIP(hipSetDevice(h->device));
   d.rank = rank; d.world = world;
-  d.k = std::max(1, KN_COARSE_MAX / (world * h->n_sub));      // as many slices per sub-domain as the coarse size allows
-  d.nl = h->n_sub * d.k;
+  // as many nodes per (rank, sub-domain) as the coarse size allows: k slices, k + 1 hat functions (k = 0: one constant)
+  const int nodes = std::max(1, KN_COARSE_MAX / (world * h->n_sub));
+  d.k = nodes - 1;
+  d.nl = h->n_sub * nodes;
   d.nc = world * d.nl;
   d.coarse_built = false;
-  // aggregates: the owned vertices of a sub-domain, binned along the longest axis of their bounding box
+  // the owned vertices of a sub-domain along the longest axis of their bounding box: slice b, position t in it ->
+  // weight 1 - t in node b, t in node b + 1
   const int Ntot = h->dev.Ntot;
   std::vector<double> rec((size_t)Ntot * KN_REC);
   KN_HIP(hipMemcpy(rec.data(), h->dev.VR, rec.size() * sizeof(double), hipMemcpyDeviceToHost));
   std::vector<int> agg_of(Ntot, -1);
+  std::vector<double> agg_w(Ntot, 0.0);
   for (int s = 0; s < h->n_sub; ++s) {
     const int v0 = h->voff[s], v1 = v0 + h->n_vert[s];
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
@@ -1547,26 +1551,49 @@ extern "C" int knpemi_set_distributed_coarse(knpemi_handle* h, int rank, int wor
     const double len = hi[ax] - lo[ax];
     for (int v = v0; v < v1; ++v) {
       if (!d.h_owned_emi[v]) continue;
-      int bin = len > 0 ? (int)((rec[(size_t)v * KN_REC + ax] - lo[ax]) / len * d.k) : 0;
-      agg_of[v] = s * d.k + std::min(d.k - 1, std::max(0, bin));
+      int bin = 0;
+      double t = 0.0;
+      if (d.k > 0 && len > 0) {
+        const double u = (rec[(size_t)v * KN_REC + ax] - lo[ax]) / len * d.k;
+        bin = std::min(d.k - 1, std::max(0, (int)u));
+        t = std::min(1.0, std::max(0.0, u - bin));
+      }
+      agg_of[v] = s * nodes + bin;
+      agg_w[v] = t;
     }
   }
   std::vector<int> ptr(d.nl + 1, 0), idx;
-  for (int v = 0; v < Ntot; ++v) if (agg_of[v] >= 0) ++ptr[agg_of[v] + 1];
+  std::vector<double> wts;
+  for (int v = 0; v < Ntot; ++v)
+    if (agg_of[v] >= 0) {
+      ++ptr[agg_of[v] + 1];
+      if (agg_w[v] > 0.0) ++ptr[agg_of[v] + 2];
+    }
   for (int a = 0; a < d.nl; ++a) ptr[a + 1] += ptr[a];
   idx.resize(ptr[d.nl]);
+  wts.resize(ptr[d.nl]);
   {
     std::vector<int> fill(ptr.begin(), ptr.end() - 1);
-    for (int v = 0; v < Ntot; ++v) if (agg_of[v] >= 0) idx[fill[agg_of[v]]++] = v;
+    for (int v = 0; v < Ntot; ++v)
+      if (agg_of[v] >= 0) {
+        const int a = agg_of[v];
+        idx[fill[a]] = v; wts[fill[a]++] = 1.0 - agg_w[v];
+        if (agg_w[v] > 0.0) { idx[fill[a + 1]] = v; wts[fill[a + 1]++] = agg_w[v]; }
+      }
   }
   int rc;
   const int* p = nullptr;
+  const double* pd = nullptr;
   if ((rc = dev_upload(h, agg_of, &p))) return rc;
   d.d_agg_of = const_cast<int*>(p);
+  if ((rc = dev_upload(h, agg_w, &pd))) return rc;
+  d.d_agg_w = const_cast<double*>(pd);
   if ((rc = dev_upload(h, ptr, &p))) return rc;
   d.d_agg_ptr = const_cast<int*>(p);
   if ((rc = dev_upload(h, idx, &p))) return rc;
   d.d_agg_idx = const_cast<int*>(p);
+  if ((rc = dev_upload(h, wts, &pd))) return rc;
+  d.d_agg_wt = const_cast<double*>(pd);
   return KNPEMI_OK;
 }
 

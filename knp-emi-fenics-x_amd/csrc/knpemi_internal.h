@@ -192,15 +192,17 @@ struct KnDist {
   knpemi_halo_fn halo = nullptr;
   void* ctx = nullptr;
   double n_owned_global = 0.0;                     // owned EMI unknowns summed over the ranks
-  // Coarse space of the distributed EMI preconditioner (knpemi_set_distributed_coarse): piecewise constants over k slices
-  // (along the longest axis) of every sub-domain of every rank.  nc = world * n_sub * k <= KN_COARSE_MAX.
-  int rank = -1, world = 0, nc = 0, nl = 0, k = 1;   // nl = n_sub * k local aggregates, nc = world * nl
+  // Coarse space of the distributed EMI preconditioner (knpemi_set_distributed_coarse): hat functions over k slices (along
+  // the longest axis) of every sub-domain of every rank.  nc = world * n_sub * (k + 1) <= KN_COARSE_MAX.
+  int rank = -1, world = 0, nc = 0, nl = 0, k = 1;   // nl = n_sub * (k + 1) local nodes, nc = world * nl
   bool coarse_built = false;
   double* d_coarse_inv = nullptr;                  // [nc][nc] (A_c + alpha 1 1^T)^-1, the same on every rank
   double* d_coarse_z = nullptr;                    // [nl] this rank's coarse corrections
-  int* d_agg_of = nullptr;                         // [Ntot] local aggregate of every unknown, -1 for ghosts
+  int* d_agg_of = nullptr;                         // [Ntot] lower local node of every unknown, -1 for ghosts
+  double* d_agg_w = nullptr;                       // [Ntot] its weight in the upper node
   int* d_agg_ptr = nullptr;                        // [nl + 1]
-  int* d_agg_idx = nullptr;                        // unknowns of every aggregate
+  int* d_agg_idx = nullptr;                        // unknowns of every node ...
+  double* d_agg_wt = nullptr;                      // ... and their weights
 };
 #define KN_COARSE_MAX 64
 #define KN_COARSE_OFF 8                            // coarse vector sits behind the 8 scalars of the reduction buffer

@@ -96,14 +96,15 @@ def test_two_rank_solves_with_jacobi_preconditioning_match_single_rank():
 
 @pytest.mark.gpu
 def test_coarse_space_of_the_distributed_emi_solve_lowers_the_iteration_count(monkeypatch):
-    """knpemi_set_distributed_coarse (piecewise constants over slices of every rank's sub-domains) on a cable cut in
+    """knpemi_set_distributed_coarse (hat functions over slices of every rank's sub-domains along the cable) on a cable cut in
     three (BASELINE configs[1] per rank; the global modes along the cable only matter once the cable is long in cells:
     at resolution 0 both counts are equal), solved to the reference's tolerances (pdeSolver.py:9,84: rtol 1e-5, the example drivers pass 1e-7 for KNP;
     the correction removes the smooth error the first iterations spend their time on, at 1e-8 the interface modes of
     the non-overlapping blocks set the count and the gain is 10 %): fewer CG iterations than the block-Jacobi AMG
     alone, fields within what those tolerances leave (I_K is a small remainder of channel and pump currents).  Six steps:
-    the first two solves start cold and need 52 against 57 iterations, from the third on 31, 29, 28, 19 against
-    51, 49, 49, 47."""
+    39, 40, 39, 23, 22, 21 iterations against 54, 55, 62, 49, 49, 42 without the coarse space (piecewise constants over
+    the same slices, the round-2 version: 52, 52, 31, 29, 28, 19); one rank needs 11, 11, 11, 9, 8, 7 -- what remains are
+    the interface modes of the non-overlapping blocks."""
     import re
     mean = {}
     for off in ("", "1"):
