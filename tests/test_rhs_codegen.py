@@ -73,7 +73,8 @@ def _host_build(hip_source):
     d = tempfile.mkdtemp()
     src = os.path.join(d, "rhs.cpp")
     with open(src, "w") as f:
-        f.write("#include <cmath>\nusing namespace std;\n#define __device__\n" + hip_source +
+        # (kn_exp / kn_log are the sweep's device versions of exp / log, csrc/lsoda_core.h: the C library's on the host)
+        f.write("#include <cmath>\nusing namespace std;\n#define __device__\n#define kn_exp exp\n#define kn_log log\n" + hip_source +
                 '\nextern "C" void call(double t, const double* s, double* v, double* p) { rhs(t, s, v, p); }\n')
     so = os.path.join(d, "rhs.so")
     subprocess.check_call(["g++", "-O0", "-shared", "-fPIC", "-o", so, src])
