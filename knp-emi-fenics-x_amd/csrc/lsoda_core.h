@@ -49,8 +49,12 @@
 // true when the predicate holds on any active lane of the wavefront (a scalar branch condition on the device)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define KN_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
+// a && b on any lane, as the AND of the two lane masks (the ballot of a conjunction is materialised as a 0 / 1 value per
+// lane and compared again)
+#define KN_ANY2(a, b) ((__builtin_amdgcn_ballot_w64(a) & __builtin_amdgcn_ballot_w64(b)) != 0ull)
 #else
 #define KN_ANY(c) (c)
+#define KN_ANY2(a, b) ((a) && (b))
 #endif
 
 // Method coefficients (ODEPACK CFODE), 1-based like the original: elco[meth-1][nq][i],
@@ -448,6 +452,11 @@ struct Lsoda {
       if (!(e > 0.0)) bad = 1.0;
       ewt[i] = kn_div(1.0, e);
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // a non-positive weight happens on no lane of a healthy sweep: one wave-wide test instead of the exchanges of a group
+    // maximum in every step
+    if (!KN_ANY(bad != 0.0)) return true;
+#endif
     return kn_group_max<LANES>(bad) == 0.0;
   }
 
@@ -1190,20 +1199,20 @@ struct Lsoda {
     _Pragma("unroll") for (int i = 0; i < NI; ++i) yh[2][i] *= h0;
 
     // one trip = one right-hand-side evaluation for every lane that is still integrating
-    const long trips_max = 16L * (long)mxstep + 64;
+    const int trips_max = 16 * mxstep + 64;
     stamp(6, true);
-    for (long trip = 0; KN_ANY(ph != PH_DONE); ++trip) {
+    for (int trip = 0; KN_ANY(ph != PH_DONE); ++trip) {
       if (trip >= trips_max) {   // cannot happen (mxstep bounds every path); never leave a wave spinning
         if (ph != PH_DONE) { ret = -7; ph = PH_DONE; }
         break;
       }
       // keep l <= lhi on every running lane (an order rises by one per trip at most) and let lhi fall when it can;
       // orders change a few times per sweep, so the common trip pays for one wave-wide test only
-      if (KN_ANY(ph != PH_DONE && l != lseen)) {
+      if (KN_ANY2(ph != PH_DONE, l != lseen)) {
         lseen = l;
-        if (KN_ANY(ph != PH_DONE && l > lhi)) ++lhi;
+        if (KN_ANY2(ph != PH_DONE, l > lhi)) ++lhi;
         else
-          while (lhi > 2 && !KN_ANY(ph != PH_DONE && l >= lhi)) --lhi;
+          while (lhi > 2 && !KN_ANY2(ph != PH_DONE, l >= lhi)) --lhi;
       }
       bool ran = false;
       if constexpr (STAMPS) { stamp(0, true); ran = KN_ANY(ph == PH_TOP); }
