@@ -82,6 +82,44 @@ int aggregate(const HostCsr& A, const std::vector<double>& d, double theta, bool
   return na;
 }
 
+// Splits given aggregates into the connected components of the strong couplings inside them (union-find; the numbering
+// of the components follows their lowest member, so the result does not depend on the order of the unions).  Unknowns
+// that are not owned (identity rows of a rank's diagonal block) have no couplings: those of one given aggregate stay together.
+int split_aggregates(const HostCsr& A, const std::vector<double>& d, double theta, const uint8_t* owned, std::vector<int>& agg, int na) {
+  const int n = A.n;
+  std::vector<int> parent(n);
+  for (int i = 0; i < n; ++i) parent[i] = i;
+  auto find = [&](int i) {
+    while (parent[i] != i) { parent[i] = parent[parent[i]]; i = parent[i]; }
+    return i;
+  };
+  auto unite = [&](int a, int b) {
+    a = find(a); b = find(b);
+    if (a != b) parent[std::max(a, b)] = std::min(a, b);
+  };
+  std::vector<int> first_ghost(na, -1);
+  for (int i = 0; i < n; ++i) {
+    if (owned && !owned[i]) {
+      int& g = first_ghost[agg[i]];
+      if (g < 0) g = i; else unite(g, i);
+      continue;
+    }
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+      const int c = A.ci[j];
+      if (c == i || agg[c] != agg[i] || (owned && !owned[c])) continue;
+      if (-A.v[j] >= theta * std::sqrt(std::fabs(d[i] * d[c]))) unite(i, c);
+    }
+  }
+  std::vector<int> id(n, -1);
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) {
+    const int r = find(i);
+    if (id[r] < 0) id[r] = cnt++;
+    agg[i] = id[r];
+  }
+  return cnt;
+}
+
 // C = A * B (Gustavson, columns of each row sorted)
 HostCsr spgemm(const HostCsr& A, const HostCsr& B) {
   HostCsr C;
@@ -533,6 +571,7 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
     if (l == 0 && G.first_na > 0 && (int)G.first_agg.size() == cur.n) {
       agg = G.first_agg;
       na = G.first_na;
+      if (G.split_first) na = split_aggregates(cur, d, G.split_theta, h_owned, agg, na);
     } else if (cur.n > n_dense) {
       // a threshold that leaves (almost) no strong connections stalls the coarsening: relax it for this level
       double th = theta;

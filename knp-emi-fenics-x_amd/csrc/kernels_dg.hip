@@ -1303,6 +1303,9 @@ int dg_solver(knpemi_dg* h, knpemi_handle** out) {
     for (int i = 0; i < n; ++i) s->amg_knp.first_agg[(size_t)k * n + i] = k * h->n_aux + h->aux_of[i];
   s->amg_knp.first_na = KS * h->n_aux;
   s->amg_emi.block = s->amg_knp.block = h->NV;       // block-Jacobi smoothing over the dofs of a cell
+  // the vertex aggregates are split along the weakly penalised facets (KnAmg::split_first; KNPEMI_DG_AUX_UNSPLIT=1 keeps
+  // the continuous P1 space as the first coarse level)
+  s->amg_emi.split_first = s->amg_knp.split_first = !getenv("KNPEMI_DG_AUX_UNSPLIT");
   if (getenv("KNPEMI_DG_PLAIN_AMG")) { s->amg_emi.first_na = s->amg_knp.first_na = 0; }
   if (getenv("KNPEMI_DG_POINT_JACOBI")) { s->amg_emi.block = s->amg_knp.block = 0; }
   h->sol = s;

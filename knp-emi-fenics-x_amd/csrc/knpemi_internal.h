@@ -157,6 +157,12 @@ struct KnAmg {
   // strength-based aggregation only starts there).  first_na == 0: aggregate every level by strength.
   std::vector<int> first_agg;
   int first_na = 0;
+  // split_first: the given aggregates are split into the connected components of their strong couplings (-a_ij >=
+  // split_theta sqrt(a_ii a_jj) between two dofs of ONE given aggregate): the interior penalty of a stretched cell
+  // ties coincident dofs together across the facets along the long direction a hundred times more strongly than across
+  // the others, and the low-energy error of the DG systems is continuous only across the former.
+  bool split_first = false;
+  double split_theta = 0.1;
   // Optional block-Jacobi smoother on the finest level: `block` consecutive unknowns (the dofs of a DG cell) form a
   // block whose inverse is refreshed from the current values before every solve (kn_amg_refresh).  0: point Jacobi.
   int block = 0;
