@@ -55,6 +55,8 @@ WORKLOADS = {
     "config3": ("idealized", "tet", 2),     # 995 328 tets on ONE GPU (the 8-GPU mesh of configs[2])
     "r3": ("idealized", "tet", 3),          # 7.96 M tets
     "2d": ("idealized", "2d", 3),
+    "tet_r0": ("idealized", "tet", 0),      # small meshes for solver diagnostics (tools/dg_solves.py)
+    "hex_r1": ("idealized", "hex", 1),
     # BASELINE.json configs[4] stand-in (the emimesh mesh needs a network fetch): three sub-domains -- ECS, neuron
     # (cells 1, 3: HH, mV / ms units), glia (cells 2, 4: Kir4.1 + pump) -- with the pulsed ECS K+ source of
     # examples/local_astrocyte_depolarization/run_stim_duration.py on the box mesh

@@ -16,6 +16,7 @@
 // only, so the solve still converges to the current system; the Krylov driver rebuilds when the iteration count
 // has doubled (the conductivities drift slowly with the concentrations).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <numeric>
 
@@ -118,6 +119,69 @@ int split_aggregates(const HostCsr& A, const std::vector<double>& d, double thet
     agg[i] = id[r];
   }
   return cnt;
+}
+
+// Aggregation that keeps strongly POSITIVELY coupled unknowns apart (KnAmg::positive_conflict).  On the first coarse level of
+// the DG systems on stretched hexahedra the two ends of a cell are coupled by +0.5 sqrt(a_ii a_jj) (the mass-like factor
+// of the long direction): the smooth error takes independent values there, but each end is negatively coupled to the
+// in-plane neighbours of the other one just above the strength threshold, and the plain greedy pass glues the two
+// cross-sections together -- every variation along the long direction is then lost to the coarse space (convergence
+// factor 0.97 of the two-level cycle on that operator).  Rule: an unknown does not join an aggregate that holds a
+// strongly positive partner of it; neighbours are taken in the order of their strength, so the in-plane ones come first.
+int aggregate_apart(const HostCsr& A, const std::vector<double>& d, double theta, double theta_pos, std::vector<int>& agg) {
+  const int n = A.n;
+  std::vector<int> srp(n + 1, 0), sci, prp(n + 1, 0), pci;
+  std::vector<std::pair<double, int>> row;
+  for (int i = 0; i < n; ++i) {
+    row.clear();
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+      const int c = A.ci[j];
+      if (c == i) continue;
+      const double s = std::sqrt(std::fabs(d[i] * d[c]));
+      if (-A.v[j] > 0.0 && -A.v[j] >= theta * s) row.emplace_back(A.v[j], c);
+      else if (A.v[j] >= theta_pos * s) pci.push_back(c);
+    }
+    std::sort(row.begin(), row.end());     // most negative first; ties by column: reproducible
+    for (auto& e : row) sci.push_back(e.second);
+    srp[i + 1] = (int)sci.size();
+    prp[i + 1] = (int)pci.size();
+  }
+  agg.assign(n, -1);
+  std::vector<std::vector<int>> members;
+  auto conflicts = [&](int k, const std::vector<int>& mem) {
+    for (int j = prp[k]; j < prp[k + 1]; ++j)
+      for (int m : mem) if (m == pci[j]) return true;
+    return false;
+  };
+  for (int i = 0; i < n; ++i) {
+    if (agg[i] >= 0 || srp[i] == srp[i + 1]) continue;
+    bool free_nb = true;
+    for (int j = srp[i]; j < srp[i + 1] && free_nb; ++j) free_nb = agg[sci[j]] < 0;
+    if (!free_nb) continue;
+    std::vector<int> mem{i};
+    for (int j = srp[i]; j < srp[i + 1]; ++j) if (!conflicts(sci[j], mem)) mem.push_back(sci[j]);
+    for (int k : mem) agg[k] = (int)members.size();
+    members.push_back(std::move(mem));
+  }
+  std::vector<int> pass1(agg);
+  for (int i = 0; i < n; ++i) {
+    if (pass1[i] >= 0) continue;
+    for (int j = srp[i]; j < srp[i + 1]; ++j) {
+      const int a = pass1[sci[j]];
+      if (a >= 0 && !conflicts(i, members[a])) { agg[i] = a; members[a].push_back(i); break; }
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    if (agg[i] >= 0) continue;
+    std::vector<int> mem{i};
+    agg[i] = (int)members.size();
+    for (int j = srp[i]; j < srp[i + 1]; ++j) {
+      const int c = sci[j];
+      if (agg[c] < 0 && !conflicts(c, mem)) { agg[c] = agg[i]; mem.push_back(c); }
+    }
+    members.push_back(std::move(mem));
+  }
+  return (int)members.size();
 }
 
 // C = A * B (Gustavson, columns of each row sorted)
@@ -277,7 +341,8 @@ HostCsr smoothed_prolongator(const HostCsr& A, const std::vector<double>& d, con
       acc[c] += v;
     };
     add(agg[i], 1.0);
-    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) add(agg[A.ci[j]], -w * A.v[j] / d[i]);
+    if (w != 0.0)
+      for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) add(agg[A.ci[j]], -w * A.v[j] / d[i]);
     std::sort(cols.begin(), cols.end());
     for (int c : cols) { P.ci.push_back(c); P.v.push_back(acc[c]); }
     P.rp[i + 1] = (int)P.ci.size();
@@ -522,6 +587,8 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
       }
 
   const double theta = G.theta;
+  const bool verbose = getenv("KNPEMI_AMG_VERBOSE") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
   // fused cycle: one level fewer is worth more than a cheaper coarsest solve (every level costs two launches per cycle)
   const bool fused = G.want_fused && G.block == 0 && !h_owned && G.first_na == 0;
   const int n_dense = fused ? 1024 : 640, max_levels = 12;
@@ -576,7 +643,7 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
       // a threshold that leaves (almost) no strong connections stalls the coarsening: relax it for this level
       double th = theta;
       for (int attempt = 0; attempt < 6; ++attempt, th = attempt == 5 ? 0.0 : 0.5 * th) {
-        na = aggregate(cur, d, th, G.negative_strength, agg);
+        na = G.positive_conflict ? aggregate_apart(cur, d, th, 0.2, agg) : aggregate(cur, d, th, G.negative_strength, agg);
         if (na < cur.n * 0.7) break;
       }
     }
@@ -591,9 +658,14 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
       L.nc = 0;
       G.lev.push_back(L);
       work += 3 * (size_t)cur.n;
+      if (verbose) fprintf(stderr, "[knpemi amg] level %d (last): n %d nnz %zu, %s (%.2f s)\n", l, cur.n, cur.ci.size(),
+                           L.dense_inv ? "dense inverse" : "Jacobi", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
       break;
     }
-    HostCsr P = smoothed_prolongator(cur, d, agg, na, L.omega);
+    // given aggregates (auxiliary space): the piecewise-constant prolongator IS the embedding of that space (every broken
+    // dof takes the value of its vertex); smoothing it would only widen the stencil of every coarser operator
+    const bool given = l == 0 && G.first_na > 0 && (int)G.first_agg.size() == cur.n;
+    HostCsr P = smoothed_prolongator(cur, d, agg, na, given && G.first_tentative ? 0.0 : L.omega);
     HostCsr R = transpose(P);
     L.nc = na;
     L.p_row = std::max(1, (int)(P.ci.size() / (size_t)P.n));
@@ -618,6 +690,8 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
     }
     G.lev.push_back(L);
     work += 3 * (size_t)cur.n;
+    if (verbose) fprintf(stderr, "[knpemi amg] level %d: n %d nnz %zu -> %d aggregates, P nnz %zu, omega %.3g (%.2f s)\n", l, cur.n,
+                         cur.ci.size(), na, P.ci.size(), L.omega, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
     cur = spgemm(R, spgemm(cur, P));
   }
   // per-level work vectors x, r, t (level 0 uses the caller's r and z for r and x)

@@ -1306,6 +1306,9 @@ int dg_solver(knpemi_dg* h, knpemi_handle** out) {
   // the vertex aggregates are split along the weakly penalised facets (KnAmg::split_first; KNPEMI_DG_AUX_UNSPLIT=1 keeps
   // the continuous P1 space as the first coarse level)
   s->amg_emi.split_first = s->amg_knp.split_first = !getenv("KNPEMI_DG_AUX_UNSPLIT");
+  s->amg_emi.first_tentative = s->amg_knp.first_tentative = !getenv("KNPEMI_DG_AUX_SMOOTHED");
+  s->amg_emi.positive_conflict = s->amg_knp.positive_conflict = !getenv("KNPEMI_DG_PLAIN_AGGREGATION");
+  if (const char* th = getenv("KNPEMI_DG_THETA")) s->amg_emi.theta = s->amg_knp.theta = atof(th);
   if (getenv("KNPEMI_DG_PLAIN_AMG")) { s->amg_emi.first_na = s->amg_knp.first_na = 0; }
   if (getenv("KNPEMI_DG_POINT_JACOBI")) { s->amg_emi.block = s->amg_knp.block = 0; }
   h->sol = s;

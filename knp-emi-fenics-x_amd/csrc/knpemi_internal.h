@@ -162,6 +162,8 @@ struct KnAmg {
   // ties coincident dofs together across the facets along the long direction a hundred times more strongly than across
   // the others, and the low-energy error of the DG systems is continuous only across the former.
   bool split_first = false;
+  bool positive_conflict = false;    // aggregation keeps strongly positively coupled unknowns apart (aggregate_apart)
+  bool first_tentative = false;      // the prolongator of the given aggregates is not smoothed
   double split_theta = 0.1;
   // Optional block-Jacobi smoother on the finest level: `block` consecutive unknowns (the dofs of a DG cell) form a
   // block whose inverse is refreshed from the current values before every solve (kn_amg_refresh).  0: point Jacobi.
