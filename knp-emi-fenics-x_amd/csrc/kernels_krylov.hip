@@ -25,8 +25,9 @@ enum { S_RHO = 0, S_RHO_OLD, S_PAP, S_ALPHA, S_BETA, S_OMEGA, S_RR, S_BB, S_TS, 
 // acts on (converged / restart / error with the scalars in the message), not as a NaN that has already overwritten x.
 enum { F_RHO_ZERO = 1, F_RV_ZERO = 2, F_OMEGA_ZERO = 4, F_PAP_ZERO = 8 };
 
-// y = A * (x .* dinv?), or (dinv == NULL, b != NULL) the residual y = b - A x : 16 lanes per row
-template <bool SCALED>
+// y = A * (x .* dinv?), or (dinv == NULL, b != NULL) the residual y = b - A x : LPR lanes per row, four independent
+// index -> value -> gather chains per lane and trip
+template <bool SCALED, int LPR>
 __global__ __launch_bounds__(256) void spmv_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ colind,
                                                    const double* __restrict__ vals, const double* __restrict__ x,
                                                    const double* __restrict__ dinv, double* __restrict__ y,
@@ -34,23 +35,37 @@ __global__ __launch_bounds__(256) void spmv_kernel(int n, const int* __restrict_
                                                    const uint8_t* __restrict__ owned = nullptr,
                                                    double* __restrict__ dinv_out = nullptr) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int row = t >> 4, l = t & 15;
+  const int row = t / LPR, l = t % LPR;
   double acc = 0.0, diag = 0.0;
   // partitioned problem: only the rows of owned unknowns are assembled completely; ghost rows give 0
   const bool live = row < n && (!owned || owned[row]);
   if (live) {
-    const int a = rowptr[row], b = rowptr[row + 1];
-    for (int j = a + l; j < b; j += 16) {
+    const int a = rowptr[row], e = rowptr[row + 1];
+    double acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    int j = a + l;
+    for (; j + 3 * LPR < e; j += 4 * LPR) {
+      const int c0 = colind[j], c1 = colind[j + LPR], c2 = colind[j + 2 * LPR], c3 = colind[j + 3 * LPR];
+      const double v0 = vals[j], v1 = vals[j + LPR], v2 = vals[j + 2 * LPR], v3 = vals[j + 3 * LPR];
+      if (SCALED) {
+        acc += v0 * (x[c0] * dinv[c0]); acc1 += v1 * (x[c1] * dinv[c1]);
+        acc2 += v2 * (x[c2] * dinv[c2]); acc3 += v3 * (x[c3] * dinv[c3]);
+      } else {
+        acc += v0 * x[c0]; acc1 += v1 * x[c1]; acc2 += v2 * x[c2]; acc3 += v3 * x[c3];
+        diag = c0 == row ? v0 : c1 == row ? v1 : c2 == row ? v2 : c3 == row ? v3 : diag;
+      }
+    }
+    for (; j < e; j += LPR) {
       const int c = colind[j];
       acc += vals[j] * (SCALED ? x[c] * dinv[c] : x[c]);
       if (!SCALED && c == row) diag = vals[j];
     }
+    acc = (acc + acc1) + (acc2 + acc3);
   }
 #pragma unroll
-  for (int m = 8; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+  for (int m = LPR / 2; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
   if (!SCALED && dinv_out) {   // the inverse diagonal as a by-product of the first residual (diag_inv_kernel's rule)
 #pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) diag += __shfl_xor(diag, m);
+    for (int m = LPR / 2; m >= 1; m >>= 1) diag += __shfl_xor(diag, m);
     if (row < n && l == 0) dinv_out[row] = diag != 0.0 ? 1.0 / diag : 1.0;
   }
   if (row < n && l == 0) y[row] = live ? ((!SCALED && b) ? b[row] - acc : acc) : 0.0;
@@ -134,7 +149,16 @@ __global__ __launch_bounds__(RED_THREADS) void dots_kernel(int n, int nd, const 
   __shared__ double sh[3][RED_THREADS];
   __shared__ bool last;
   double s0 = 0, s1 = 0, s2 = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  const int stride = gridDim.x * blockDim.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {     // four independent loads per vector in flight
+    const double x0 = a0[i], x1 = a0[i + stride], x2 = a0[i + 2 * stride], x3 = a0[i + 3 * stride];
+    const double y0 = b0[i], y1 = b0[i + stride], y2 = b0[i + 2 * stride], y3 = b0[i + 3 * stride];
+    s0 += x0 * y0; s0 += x1 * y1; s0 += x2 * y2; s0 += x3 * y3;
+    if (nd > 1) { s1 += a1[i] * b1[i]; s1 += a1[i + stride] * b1[i + stride]; s1 += a1[i + 2 * stride] * b1[i + 2 * stride]; s1 += a1[i + 3 * stride] * b1[i + 3 * stride]; }
+    if (nd > 2) { s2 += a2[i] * b2[i]; s2 += a2[i + stride] * b2[i + stride]; s2 += a2[i + 2 * stride] * b2[i + 2 * stride]; s2 += a2[i + 3 * stride] * b2[i + 3 * stride]; }
+  }
+  for (; i < n; i += stride) {
     s0 += a0[i] * b0[i];
     if (nd > 1) s1 += a1[i] * b1[i];
     if (nd > 2) s2 += a2[i] * b2[i];
@@ -308,25 +332,45 @@ struct Ctx {
   const uint8_t* owned = nullptr;
   int which = 0;
   int comm_rc = 0;     // first failure of a communication hook
+  int lpr = 16;        // lanes per row of the SpMV (spmv_lanes)
 };
+
+// lanes per row from the average row length (read once per system and handle)
+int spmv_lanes(knpemi_handle* h, int which, const int* rowptr, int n) {
+  int& l = h->spmv_lpr[which == KNPEMI_B_KNP ? 1 : 0];
+  if (l == 0) {
+    int nnz = 0;
+    if (hipMemcpy(&nnz, rowptr + n, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return 16;
+    l = n > 0 && nnz / n <= 24 ? 4 : 16;
+  }
+  return l;
+}
 
 inline dim3 grid1(int n) { return dim3((n + 255) / 256); }
 
 void spmv(Ctx& c, const double* x, double* y, const double* dinv, const double* b = nullptr, double* dinv_out = nullptr) {
-  dim3 g(((size_t)c.n * 16 + 255) / 256);
+  dim3 g(((size_t)c.n * c.lpr + 255) / 256);
   if (c.owned) {   // the argument's ghost entries take their owners' values first
     const KnDist& d = c.h->dist;
     if (int e = d.halo(d.ctx, const_cast<double*>(x), c.which)) c.comm_rc = c.comm_rc ? c.comm_rc : e;
   }
-  if (dinv) hipLaunchKernelGGL((spmv_kernel<true>), g, dim3(256), 0, c.h->stream, c.n, c.rowptr, c.colind, c.vals, x, dinv, y,
+  if (c.lpr == 4) {
+    if (dinv) hipLaunchKernelGGL((spmv_kernel<true, 4>), g, dim3(256), 0, c.h->stream, c.n, c.rowptr, c.colind, c.vals, x, dinv, y,
+                                 (const double*)nullptr, c.owned);
+    else hipLaunchKernelGGL((spmv_kernel<false, 4>), g, dim3(256), 0, c.h->stream, c.n, c.rowptr, c.colind, c.vals, x, dinv, y, b,
+                            c.owned, dinv_out);
+    return;
+  }
+  if (dinv) hipLaunchKernelGGL((spmv_kernel<true, 16>), g, dim3(256), 0, c.h->stream, c.n, c.rowptr, c.colind, c.vals, x, dinv, y,
                                (const double*)nullptr, c.owned);
-  else hipLaunchKernelGGL((spmv_kernel<false>), g, dim3(256), 0, c.h->stream, c.n, c.rowptr, c.colind, c.vals, x, dinv, y, b,
+  else hipLaunchKernelGGL((spmv_kernel<false, 16>), g, dim3(256), 0, c.h->stream, c.n, c.rowptr, c.colind, c.vals, x, dinv, y, b,
                           c.owned, dinv_out);
 }
 
 void dots(Ctx& c, int nd, const double* a0, const double* b0, const double* a1, const double* b1, const double* a2,
           const double* b2, int op, int d0 = 0, int d1 = 0, int d2 = 0, double scale = 1.0) {
-  const int nb = std::min(RED_BLOCKS, (c.n + RED_THREADS - 1) / RED_THREADS);
+  // 16 entries per thread: every block costs ~50 ns at the ticket counter, whatever it sums
+  const int nb = std::min(RED_BLOCKS, (c.n + 16 * RED_THREADS - 1) / (16 * RED_THREADS));
   double* red = c.owned ? c.h->dist.d_red : nullptr;
   hipLaunchKernelGGL(dots_kernel, dim3(nb), dim3(RED_THREADS), 0, c.h->stream, c.n, nd, a0, b0, a1, b1, a2, b2, c.partial,
                      reinterpret_cast<unsigned*>(c.partial + 3 * RED_BLOCKS), c.sc, op, d0, d1, d2, scale, red);
@@ -545,6 +589,7 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   const size_t N = h->kry_n;
   double *x = h->kry, *r = x + N, *z = r + N, *p = z + N, *q = p + N, *b = q + N, *dinv = b + N, *ones = h->kry + 10 * N;
   Ctx c{h, n, D.rowptr, D.colind, D.A_emi, h->kry + 11 * N, h->kry + 11 * N + 64};
+  c.lpr = spmv_lanes(h, KNPEMI_B_EMI, D.rowptr, n);
   const KnDist& dist = h->dist;
   bool has_ghosts = false;
   double n_mean = (double)n;
@@ -681,6 +726,7 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   double *x = h->kry, *r = x + N, *rhat = r + N, *p = rhat + N, *v = p + N, *s = v + N, *t = s + N, *dinv = t + N;
   double *phat = h->kry + 8 * N, *shat = h->kry + 9 * N;
   Ctx c{h, n, D.krowptr, D.kcolind, D.A_knp, h->kry + 11 * N, h->kry + 11 * N + 64};
+  c.lpr = spmv_lanes(h, KNPEMI_B_KNP, D.krowptr, n);
   const KnDist& dist = h->dist;
   if (dist.on) {
     c.owned = dist.d_owned_knp;

@@ -260,6 +260,7 @@ struct knpemi_handle {
   double* kry = nullptr; size_t kry_n = 0;           // Krylov workspace (kernels_krylov.hip)
   int kry_ones_masked = 0;                           // the workspace's `ones` vector currently holds the ownership mask
   void* kry_pinned = nullptr;                        // pinned host buffer the solvers' scalars are read through
+  int spmv_lpr[2] = {0, 0};          // lanes per row of the Krylov SpMV of the two systems (from the average row length)
   double* fused_part = nullptr; size_t fused_part_n = 0;   // block partials of the dot products fused into the solver kernels
   double* guess_old[2] = {nullptr, nullptr};         // previous solutions (EMI, KNP) for knpemi_extrapolate_guess
   int guess_have[2] = {0, 0};                        // previous solutions stored so far (0, 1, 2)

@@ -460,6 +460,42 @@ def test_dg_device_solves_match_direct_solves(hip_lib, dim):
             assert rel_err(c[k], spla.splu(Ak.tocsc()).solve(bk)) < 1e-9, k
 
 
+@pytest.mark.parametrize("cell", ["tetrahedron", "hexahedron"])
+def test_dg_split_auxiliary_space_lowers_the_iteration_count(hip_lib, cell, monkeypatch):
+    """The first coarse level of the DG hierarchies: the broken dofs at a (sub-domain, vertex) are split into the connected
+    components of their strong couplings (KnAmg::split_first) and strongly positively coupled unknowns stay in different
+    aggregates below (aggregate_apart).  On the 10:1 cells of the idealized geometries the continuous auxiliary space
+    (KNPEMI_DG_AUX_UNSPLIT=1) needs at least twice the iterations; both converge to the same solution."""
+    from knpemi.dg import DGProblem
+    from knpemi.fem.idealized import make_mesh_3D
+    mesh, ct, ft = make_mesh_3D(0, cell)
+    ions = [dict(name="Na", z=1.0, D=[1.33e-9] * 2), dict(name="K", z=1.0, D=[1.96e-9] * 2), dict(name="Cl", z=-1.0, D=[2.03e-9] * 2)]
+    params = dict(dt=1e-4, F=96485.0, psi=96485.0 / (8.314 * 300.0), C_M=0.02)
+    rng = np.random.default_rng(3)
+    out = {}
+    for mode in ("split", "unsplit"):
+        if mode == "unsplit":
+            monkeypatch.setenv("KNPEMI_DG_AUX_UNSPLIT", "1")
+            monkeypatch.setenv("KNPEMI_DG_PLAIN_AGGREGATION", "1")
+        dp = DGProblem(mesh, ct, ft, [0, 1], [1])
+        ins = (dp.cell_sub > 0)[:, None] * np.ones((1, dp.nv), bool)
+        if mode == "split":
+            w = rng.standard_normal((dp.n_cells, dp.nv))
+            phi_M = -0.0744 + 1e-3 * rng.standard_normal((dp.nmf, dp.nf))
+            I_ch = [1e-2 * rng.standard_normal((dp.nmf, dp.nf)) for _ in range(3)]
+        c_all = [np.where(ins, i, e) * (1.0 + 1e-3 * w) for (e, i) in ((100.0, 12.0), (4.0, 125.0), (104.0, 137.0))]
+        _push(dp, params, ions, c_all, np.where(ins, -0.0744, 0.0), phi_M, I_ch)
+        dp.assemble_emi()
+        its_e, rr = dp.solve_emi(rtol=1e-8)
+        phi = dp.get_potential().copy()
+        dp.assemble_knp()
+        its_k, rr = dp.solve_knp(rtol=1e-10)
+        out[mode] = (its_e, its_k, phi, dp.solution().copy())
+    (e1, k1, p1, c1), (e0, k0, p0, c0) = out["split"], out["unsplit"]
+    assert 2 * e1 <= e0 and 2 * k1 <= k0, (e1, e0, k1, k0)
+    assert rel_err(p1, p0) < 1e-5 and rel_err(c1, c0) < 1e-8
+
+
 def test_dg_time_loop_with_device_solves_follows_the_direct_solves(hip_lib):
     """The whole DG time step on the device (ODE sweep, assemblies, CG / BiCGStab + AMG at the reference's rtol
     1e-5 / 1e-7, update without leaving the device) against the same loop with SciPy's direct solves: ten steps of
