@@ -377,7 +377,7 @@ def with_solves(case, replay, start, n_steps, torch):
                     "iterations_max": max(its["knp"]), **info["knp"]}}
 
 
-def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, world=1):
+def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, world=1, solves=None):
     """The DG(P1) + interior-penalty variant (csrc/kernels_dg.hip) on the workload's mesh: one step =
     membrane ODE sweep over the facet nodes + potential-system assembly + concentration-systems assembly + end-of-step
     update (+ the ghost-cell refresh at N > 1: x-slabs of an N times longer box, knpemi.dg.DGSlab), device-resident.
@@ -491,7 +491,7 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, wo
         "ode": {"rhs_evals_per_dof_per_step": n_rhs / max(1, dp.nmf * dp.nf) / steps},
     }
     n_solve = getattr(args, "solve_steps", 0)
-    if world == 1 and cpu and n_solve > 0 and dp.n <= 1_400_000:
+    if world == 1 and (cpu if solves is None else solves) and n_solve > 0 and dp.n <= 1_400_000:
         # whole DG time steps: the two systems solved on the device (CG / BiCGStab + auxiliary-space AMG at the reference's
         # rtol 1e-5 / 1e-7, knpemi_dg_solve_emi/knp), the update taken from the solution without leaving the device
         def solved_step(k):
@@ -955,9 +955,9 @@ def main():
                                                    "kernels_us_per_step", "ode")}
     if rank == 0:
         if world == 1 and not args.no_dg and tet:
-            dg = run_dg(args, torch, steps=10, warmup=2, cpu=False)
+            dg = run_dg(args, torch, steps=10, warmup=2, cpu=False, solves=True)
             out["dg_variant"] = {k: dg[k] for k in ("value", "unit", "ms_per_step", "config", "roofline",
-                                                     "roofline_potential_kernel", "kernels_us_per_step")}
+                                                     "roofline_potential_kernel", "kernels_us_per_step", "with_solves")}
             # the same variant on the reference's own 3-D cell type: broken Q1 on the hexahedral box (config2h, 165 888 cells)
             hargs = argparse.Namespace(**{**vars(args), "workload": "config2h"})
             dgh = run_dg(hargs, torch, steps=10, warmup=2, cpu=False)
