@@ -60,44 +60,44 @@ __device__ __forceinline__ double row_sum(const int* __restrict__ rp, const int*
 // kernels_krylov.hip).  Instead the PRODUCER of a vector leaves one partial sum per block (plain stores; the kernel
 // boundary publishes them) and every block of the CONSUMER adds the <= 2048 partials up again, in the same fixed order:
 // one <= 16 KiB read from L2 and an LDS tree per block, identical bits in every block, bit-reproducible.
+// sum over the 256 threads of a block: butterflies inside the waves (no barrier), the four wave sums through LDS -- one
+// barrier instead of the eight of an LDS tree; the order is fixed, every thread returns the same bits
 template <int ND>
-__device__ __forceinline__ void block_partials(double (&v)[ND], double* const (&dst)[ND]) {
-  __shared__ double sh[ND][FT];
+__device__ __forceinline__ void block_sum(double (&v)[ND]) {
+  __shared__ double sh[ND][FT / 64];
   const int t = threadIdx.x;
 #pragma unroll
-  for (int k = 0; k < ND; ++k) sh[k][t] = v[k];
-  __syncthreads();
-  for (int w = FT / 2; w > 0; w >>= 1) {
-    if (t < w)
+  for (int k = 0; k < ND; ++k) {
 #pragma unroll
-      for (int k = 0; k < ND; ++k) sh[k][t] += sh[k][t + w];
-    __syncthreads();
+    for (int m = 32; m >= 1; m >>= 1) v[k] += __shfl_xor(v[k], m);
   }
-  if (t == 0)
+  if ((t & 63) == 0)
 #pragma unroll
-    for (int k = 0; k < ND; ++k) dst[k][blockIdx.x] = sh[k][0];
+    for (int k = 0; k < ND; ++k) sh[k][t >> 6] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < ND; ++k) v[k] = (sh[k][0] + sh[k][1]) + (sh[k][2] + sh[k][3]);
+  __syncthreads();      // the buffer is reused by the next call
+}
+
+template <int ND>
+__device__ __forceinline__ void block_partials(double (&v)[ND], double* const (&dst)[ND]) {
+  block_sum<ND>(v);
+  if (threadIdx.x == 0)
+#pragma unroll
+    for (int k = 0; k < ND; ++k) dst[k][blockIdx.x] = v[k];
 }
 
 template <int ND>
 __device__ __forceinline__ void totals(const double* const (&src)[ND], int np, double (&out)[ND]) {
-  __shared__ double sh[ND][FT];
   const int t = threadIdx.x;
 #pragma unroll
   for (int k = 0; k < ND; ++k) {
     double s = 0.0;
     for (int i = t; i < np; i += FT) s += src[k][i];
-    sh[k][t] = s;
+    out[k] = s;
   }
-  __syncthreads();
-  for (int w = FT / 2; w > 0; w >>= 1) {
-    if (t < w)
-#pragma unroll
-      for (int k = 0; k < ND; ++k) sh[k][t] += sh[k][t + w];
-    __syncthreads();
-  }
-#pragma unroll
-  for (int k = 0; k < ND; ++k) out[k] = sh[k][0];
-  __syncthreads();      // the buffers are reused by block_partials
+  block_sum<ND>(out);
 }
 
 __device__ __forceinline__ void raise_flag(double* sc, int bit) { sc[S_FLAG] = (double)((int)sc[S_FLAG] | bit); }
