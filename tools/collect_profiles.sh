@@ -36,6 +36,10 @@ if [ $part = bench2 ]; then
   python3 bench.py --variant dg --workload config3 --steps 20 --warmup 3 > $O/bench_dg_config3.json 2> $O/bench_dg_config3.err; echo "bench dg config3 done"
   python3 bench.py --variant dg --workload config2h --steps 20 --warmup 3 --solve-steps 0 > $O/bench_dg_config2h.json 2> $O/bench_dg_config2h.err; echo "bench dg config2h (broken Q1, box-mesh kernels) done"
   KNPEMI_DG_HEX_GENERAL=1 python3 bench.py --variant dg --workload config2h --steps 20 --warmup 3 --solve-steps 0 > $O/bench_dg_config2h_general_kernels.json 2> $O/bench_dg_config2h_general.err; echo "bench dg config2h (general kernels) done"
+  python3 tools/dg_solves.py --workload config2 --steps 10 --warmup 2 > $O/dg_solves_config2.json 2> $O/dg_solves_config2.err; echo "dg solves config2 done"
+  KNPEMI_DG_AUX_UNSPLIT=1 KNPEMI_DG_PLAIN_AGGREGATION=1 KNPEMI_DG_AUX_SMOOTHED=1 python3 tools/dg_solves.py --workload config2 --steps 10 --warmup 2 > $O/dg_solves_config2_continuous_aux_space.json 2> $O/dg_solves_config2_cont.err; echo "dg solves config2 (round-2 auxiliary space) done"
+  python3 tools/dg_solves.py --workload hex_r1 --steps 10 --warmup 2 > $O/dg_solves_hex_r1.json 2> $O/dg_solves_hex_r1.err; echo "dg solves hexahedra r=1 done"
+  python3 tools/dg_solves.py --workload config2h --steps 10 --warmup 2 --solve-steps 5 > $O/dg_solves_config2h.json 2> $O/dg_solves_config2h.err; echo "dg solves config2h done"
   KNPEMI_NO_FUSED=1 python3 bench.py --steps 20 --warmup 5 --cpu-steps 0 --no-dg --no-config3 > $O/bench_config2_plain_solver_loops.json 2> $O/bench_config2_plain.err; echo "bench config2 (plain solver loops) done"
 fi
 done

@@ -18,10 +18,12 @@ def last(pattern):
 
 
 def cp(a, b):
+    """Fresh artefact -> profiles/; without one the file already in profiles/ (an earlier collection of this round) stays
+    and keeps its row."""
     if a and os.path.exists(a):
         shutil.copy(a, os.path.join(P, b))
         return True
-    return False
+    return os.path.exists(os.path.join(P, b))
 
 
 def line(path):
@@ -94,6 +96,19 @@ for f, cmd in (("bench_config2", "python bench.py --steps 20 --warmup 5"),
         bits.append("kernels " + ", ".join(f"{k.replace('_kernel', '')} {v:.1f}" for k, v in ku.items()))
     rows.append((f"`r03_{f}.json`", f"`{cmd}`", "; ".join(bits)))
 
+# ---- whole DG steps with the device solves (tools/dg_solves.py) ---------------------------------------------------
+for f, cmd in (("dg_solves_config2", "python tools/dg_solves.py --workload config2 --steps 10 --warmup 2"),
+               ("dg_solves_config2_continuous_aux_space", "KNPEMI_DG_AUX_UNSPLIT=1 KNPEMI_DG_PLAIN_AGGREGATION=1 KNPEMI_DG_AUX_SMOOTHED=1 python tools/dg_solves.py --workload config2 --steps 10 --warmup 2` (the round-2 auxiliary space)"),
+               ("dg_solves_hex_r1", "python tools/dg_solves.py --workload hex_r1 --steps 10 --warmup 2"),
+               ("dg_solves_config2h", "python tools/dg_solves.py --workload config2h --steps 10 --warmup 2 --solve-steps 5")):
+    if not cp(os.path.join(G, "r03", f + ".json"), f"r03_{f}.json"):
+        continue
+    ws = line(os.path.join(P, f"r03_{f}.json"))["with_solves"]
+    rows.append((f"`r03_{f}.json`", f"`{cmd}" + ("" if cmd.endswith(")") else "`"),
+                 f"whole DG steps with the device solves: {ws['ms_per_step']:.2f} ms/step, {ws['cg_iterations_per_step']:.1f} CG + "
+                 f"{ws['bicgstab_iterations_per_step']:.1f} BiCGStab iterations per step, first step with the hierarchy set-up "
+                 f"{ws['first_step_with_amg_setup_s']:.1f} s"))
+
 # ---- HBM traffic ------------------------------------------------------------------------------------------------
 traffic = {}
 name = {"emi_rows_v2": "emi_rows_kernel", "knp_rows_v2": "knp_rows_kernel"}
@@ -101,6 +116,8 @@ for wl in ("config2", "config3"):
     f = os.path.join(G, f"traffic_{wl}_cg.json")
     if os.path.exists(f):
         traffic[wl] = {name.get(k, k): v for k, v in json.load(open(f))[wl].items()}
+if not traffic and os.path.exists(os.path.join(P, "r03_traffic.json")):
+    traffic = json.load(open(os.path.join(P, "r03_traffic.json")))
 if traffic:
     json.dump(traffic, open(os.path.join(P, "r03_traffic.json"), "w"), indent=1, sort_keys=True)
     bits = []
