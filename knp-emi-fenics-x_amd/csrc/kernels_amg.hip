@@ -327,8 +327,13 @@ double estimate_rho_block(const HostCsr& A, int bs) {
   return 1.1 * lam;     // the iteration approaches rho from below
 }
 
-// P = (I - w D^-1 A) T for the piecewise-constant T of `agg`
-HostCsr smoothed_prolongator(const HostCsr& A, const std::vector<double>& d, const std::vector<int>& agg, int na, double w) {
+// P = (I - w D^-1 A) T for the piecewise-constant T of `agg`.  filter_theta > 0: the smoothing uses the FILTERED operator
+// -- off-diagonal entries that are not strong (-a_ij >= filter_theta sqrt(a_ii a_jj)) are dropped and added to the
+// diagonal, so the basis functions spread along the strong couplings only and the coarse stencils stay narrow (on the
+// stretched cells the weak entries are the majority: 977 entries per row on the third level of the hexahedral DG
+// hierarchy without it).
+HostCsr smoothed_prolongator(const HostCsr& A, const std::vector<double>& d, const std::vector<int>& agg, int na, double w,
+                             double filter_theta = 0.0) {
   HostCsr P;
   P.n = A.n; P.m = na;
   P.rp.assign(A.n + 1, 0);
@@ -341,8 +346,21 @@ HostCsr smoothed_prolongator(const HostCsr& A, const std::vector<double>& d, con
       acc[c] += v;
     };
     add(agg[i], 1.0);
-    if (w != 0.0)
+    if (w != 0.0 && filter_theta > 0.0) {
+      double dF = d[i];
+      for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+        const int c = A.ci[j];
+        if (c != i && !(-A.v[j] >= filter_theta * std::sqrt(std::fabs(d[i] * d[c])))) dF += A.v[j];
+      }
+      if (!(dF >= 0.25 * d[i])) dF = d[i];        // (lumping must not empty the diagonal)
+      add(agg[i], -w);                             // the diagonal of the filtered row: -w dF / dF
+      for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+        const int c = A.ci[j];
+        if (c != i && -A.v[j] >= filter_theta * std::sqrt(std::fabs(d[i] * d[c]))) add(agg[c], -w * A.v[j] / dF);
+      }
+    } else if (w != 0.0) {
       for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) add(agg[A.ci[j]], -w * A.v[j] / d[i]);
+    }
     std::sort(cols.begin(), cols.end());
     for (int c : cols) { P.ci.push_back(c); P.v.push_back(acc[c]); }
     P.rp[i + 1] = (int)P.ci.size();
@@ -697,7 +715,7 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
     // given aggregates (auxiliary space): the piecewise-constant prolongator IS the embedding of that space (every broken
     // dof takes the value of its vertex); smoothing it would only widen the stencil of every coarser operator
     const bool given = l == 0 && G.first_na > 0 && (int)G.first_agg.size() == cur.n;
-    HostCsr P = smoothed_prolongator(cur, d, agg, na, given && G.first_tentative ? 0.0 : L.omega);
+    HostCsr P = smoothed_prolongator(cur, d, agg, na, given && G.first_tentative ? 0.0 : L.omega, G.filter_theta);
     HostCsr R = transpose(P);
     L.nc = na;
     L.p_row = std::max(1, (int)(P.ci.size() / (size_t)P.n));

@@ -629,8 +629,16 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     // stretched Q1 cells couple the two ends of an edge along the long direction positively: aggregate_apart keeps them
     // in different aggregates (config 2h: 9.35 / 3.95 -> 7.4 / 2.9 iterations per solve; on simplices the plain greedy
     // pass is the better one, 5.3 / 2.35 against 5.75 / 2.6 at config 2).  The DG solver handle sets the flag itself.
-    if (h->NV == 8) G.positive_conflict = true;
+    // (plain_knp marks the solver handle of a DG problem, which has made its own choices: kernels_dg.hip)
+    if (h->plain_knp) {}
+    else if (h->NV == 8) G.positive_conflict = true;
+    // simplices: prolongator smoothing along the strong couplings only (KnAmg::filter_theta): the operator complexity
+    // falls from 2.5-2.8 to 1.5, the iteration counts stay (995 k tets: 6.65 / 2.8 -> 6.75 / 2.85, 3.34 -> 2.37 ms per
+    // step with solves).  On stretched Q1 cells the weak entries are large positive ones and lumping them spoils the
+    // smoothing (config 2h: 7.4 -> 12.6 iterations): no filter there.
+    else G.filter_theta = 0.02;
     if (getenv("KNPEMI_AMG_APART")) G.positive_conflict = atoi(getenv("KNPEMI_AMG_APART")) != 0;
+    if (const char* ft = getenv("KNPEMI_AMG_FILTER")) G.filter_theta = atof(ft);
     G.want_fused = !dist.on && use_fused();
     // the diagonal block of a rank that has ghosts has lost couplings: it is non-singular
     if ((rc = kn_amg_setup(h, G, n, D.rowptr, D.colind, D.A_emi, !has_ghosts,
@@ -755,8 +763,16 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     // stretched Q1 cells couple the two ends of an edge along the long direction positively: aggregate_apart keeps them
     // in different aggregates (config 2h: 9.35 / 3.95 -> 7.4 / 2.9 iterations per solve; on simplices the plain greedy
     // pass is the better one, 5.3 / 2.35 against 5.75 / 2.6 at config 2).  The DG solver handle sets the flag itself.
-    if (h->NV == 8) G.positive_conflict = true;
+    // (plain_knp marks the solver handle of a DG problem, which has made its own choices: kernels_dg.hip)
+    if (h->plain_knp) {}
+    else if (h->NV == 8) G.positive_conflict = true;
+    // simplices: prolongator smoothing along the strong couplings only (KnAmg::filter_theta): the operator complexity
+    // falls from 2.5-2.8 to 1.5, the iteration counts stay (995 k tets: 6.65 / 2.8 -> 6.75 / 2.85, 3.34 -> 2.37 ms per
+    // step with solves).  On stretched Q1 cells the weak entries are large positive ones and lumping them spoils the
+    // smoothing (config 2h: 7.4 -> 12.6 iterations): no filter there.
+    else G.filter_theta = 0.02;
     if (getenv("KNPEMI_AMG_APART")) G.positive_conflict = atoi(getenv("KNPEMI_AMG_APART")) != 0;
+    if (const char* ft = getenv("KNPEMI_AMG_FILTER")) G.filter_theta = atof(ft);
     G.want_fused = !dist.on && use_fused();
     if ((rc = kn_amg_setup(h, G, n, D.krowptr, D.kcolind, D.A_knp, false,
                            dist.on ? dist.h_owned_knp.data() : nullptr))) return rc;

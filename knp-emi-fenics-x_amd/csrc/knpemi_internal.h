@@ -163,6 +163,7 @@ struct KnAmg {
   // the others, and the low-energy error of the DG systems is continuous only across the former.
   bool split_first = false;
   bool positive_conflict = false;    // aggregation keeps strongly positively coupled unknowns apart (aggregate_apart)
+  double filter_theta = 0.0;         // > 0: prolongator smoothing with the filtered operator (weak entries lumped)
   bool first_tentative = false;      // the prolongator of the given aggregates is not smoothed
   double split_theta = 0.1;
   // Optional block-Jacobi smoother on the finest level: `block` consecutive unknowns (the dofs of a DG cell) form a
