@@ -328,10 +328,11 @@ double estimate_rho_block(const HostCsr& A, int bs) {
 }
 
 // P = (I - w D^-1 A) T for the piecewise-constant T of `agg`.  filter_theta > 0: the smoothing uses the FILTERED operator
-// -- off-diagonal entries that are not strong (-a_ij >= filter_theta sqrt(a_ii a_jj)) are dropped and added to the
-// diagonal, so the basis functions spread along the strong couplings only and the coarse stencils stay narrow (on the
-// stretched cells the weak entries are the majority: 977 entries per row on the third level of the hexahedral DG
-// hierarchy without it).
+// -- off-diagonal entries that are not large (|a_ij| >= filter_theta sqrt(a_ii a_jj)) are dropped and added to the
+// diagonal, so the basis functions spread along the large couplings only and the coarse stencils stay narrow (on the
+// stretched cells the small entries are the majority: 977 entries per row on the third level of the hexahedral DG
+// hierarchy without it).  By magnitude, not by sign: the big positive entries of stretched Q1 cells must stay in the
+// smoothing (lumped into the diagonal they inflate it and the smoothing is lost).
 HostCsr smoothed_prolongator(const HostCsr& A, const std::vector<double>& d, const std::vector<int>& agg, int na, double w,
                              double filter_theta = 0.0) {
   HostCsr P;
@@ -350,13 +351,13 @@ HostCsr smoothed_prolongator(const HostCsr& A, const std::vector<double>& d, con
       double dF = d[i];
       for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
         const int c = A.ci[j];
-        if (c != i && !(-A.v[j] >= filter_theta * std::sqrt(std::fabs(d[i] * d[c])))) dF += A.v[j];
+        if (c != i && !(std::fabs(A.v[j]) >= filter_theta * std::sqrt(std::fabs(d[i] * d[c])))) dF += A.v[j];
       }
       if (!(dF >= 0.25 * d[i])) dF = d[i];        // (lumping must not empty the diagonal)
       add(agg[i], -w);                             // the diagonal of the filtered row: -w dF / dF
       for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
         const int c = A.ci[j];
-        if (c != i && -A.v[j] >= filter_theta * std::sqrt(std::fabs(d[i] * d[c]))) add(agg[c], -w * A.v[j] / dF);
+        if (c != i && std::fabs(A.v[j]) >= filter_theta * std::sqrt(std::fabs(d[i] * d[c]))) add(agg[c], -w * A.v[j] / dF);
       }
     } else if (w != 0.0) {
       for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) add(agg[A.ci[j]], -w * A.v[j] / d[i]);

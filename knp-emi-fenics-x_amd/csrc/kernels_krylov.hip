@@ -632,11 +632,11 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     // (plain_knp marks the solver handle of a DG problem, which has made its own choices: kernels_dg.hip)
     if (h->plain_knp) {}
     else if (h->NV == 8) G.positive_conflict = true;
-    // simplices: prolongator smoothing along the strong couplings only (KnAmg::filter_theta): the operator complexity
-    // falls from 2.5-2.8 to 1.5, the iteration counts stay (995 k tets: 6.65 / 2.8 -> 6.75 / 2.85, 3.34 -> 2.37 ms per
-    // step with solves).  On stretched Q1 cells the weak entries are large positive ones and lumping them spoils the
-    // smoothing (config 2h: 7.4 -> 12.6 iterations): no filter there.
-    else G.filter_theta = 0.02;
+    // prolongator smoothing along the large couplings only (KnAmg::filter_theta): the operator complexity falls from
+    // 2.5-2.8 to 1.5 on simplices, the iteration counts stay (995 k tets: 6.65 / 2.8 -> 6.75 / 2.85, 3.34 -> 2.37 ms per
+    // step with solves).  "Large" is by magnitude: the big positive entries of stretched Q1 cells stay in the smoothing
+    // (lumping them into the diagonal cost config 2h 7.4 -> 12.6 iterations).
+    if (!h->plain_knp) G.filter_theta = 0.02;
     if (getenv("KNPEMI_AMG_APART")) G.positive_conflict = atoi(getenv("KNPEMI_AMG_APART")) != 0;
     if (const char* ft = getenv("KNPEMI_AMG_FILTER")) G.filter_theta = atof(ft);
     G.want_fused = !dist.on && use_fused();
@@ -766,11 +766,11 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     // (plain_knp marks the solver handle of a DG problem, which has made its own choices: kernels_dg.hip)
     if (h->plain_knp) {}
     else if (h->NV == 8) G.positive_conflict = true;
-    // simplices: prolongator smoothing along the strong couplings only (KnAmg::filter_theta): the operator complexity
-    // falls from 2.5-2.8 to 1.5, the iteration counts stay (995 k tets: 6.65 / 2.8 -> 6.75 / 2.85, 3.34 -> 2.37 ms per
-    // step with solves).  On stretched Q1 cells the weak entries are large positive ones and lumping them spoils the
-    // smoothing (config 2h: 7.4 -> 12.6 iterations): no filter there.
-    else G.filter_theta = 0.02;
+    // prolongator smoothing along the large couplings only (KnAmg::filter_theta): the operator complexity falls from
+    // 2.5-2.8 to 1.5 on simplices, the iteration counts stay (995 k tets: 6.65 / 2.8 -> 6.75 / 2.85, 3.34 -> 2.37 ms per
+    // step with solves).  "Large" is by magnitude: the big positive entries of stretched Q1 cells stay in the smoothing
+    // (lumping them into the diagonal cost config 2h 7.4 -> 12.6 iterations).
+    if (!h->plain_knp) G.filter_theta = 0.02;
     if (getenv("KNPEMI_AMG_APART")) G.positive_conflict = atoi(getenv("KNPEMI_AMG_APART")) != 0;
     if (const char* ft = getenv("KNPEMI_AMG_FILTER")) G.filter_theta = atof(ft);
     G.want_fused = !dist.on && use_fused();
