@@ -789,7 +789,8 @@ int kn_amg_apply(knpemi_handle* h, KnAmg& G, const double* vals, const double* d
     }
     if (l == 0 && G.block > 0) {   // x = w B^-1 r, t = r - A x
       block_apply(st, G, L.n, rl, nullptr, xl);
-      launch_spmv<M_RES>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, xl, rl, nullptr, 0.0, L.t);
+      if (h->bcols.bcol) launch_block_spmv<double>(st, h->bcols, L.n, L.A.rp, Av, xl, rl, L.t, nullptr);
+      else launch_spmv<M_RES>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, xl, rl, nullptr, 0.0, L.t);
     } else launch_spmv<M_PRE>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, nullptr, rl, dinv, L.omega, L.t, xl);
     launch_spmv<M_AX>(st, L.nc, L.r_row, L.R.rp, L.R.ci, L.R.v, L.t, nullptr, nullptr, 0.0, G.lev[l + 1].r);
   }
@@ -801,7 +802,8 @@ int kn_amg_apply(knpemi_handle* h, KnAmg& G, const double* vals, const double* d
     const double* dinv = l == 0 ? dinv0 : L.dinv;
     launch_spmv<M_ADD>(st, L.n, L.p_row, L.P.rp, L.P.ci, L.P.v, G.lev[l + 1].t, nullptr, nullptr, 0.0, xl);
     if (l == 0 && G.block > 0) {   // out = x + w B^-1 (r - A x); the level's t is free again
-      launch_spmv<M_RES>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, xl, rl, nullptr, 0.0, L.t);
+      if (h->bcols.bcol) launch_block_spmv<double>(st, h->bcols, L.n, L.A.rp, Av, xl, rl, L.t, nullptr);
+      else launch_spmv<M_RES>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, xl, rl, nullptr, 0.0, L.t);
       block_apply(st, G, L.n, L.t, xl, out);
     } else launch_spmv<M_JAC>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, xl, rl, dinv, L.omega, l == 0 ? out : L.t);
   }

@@ -1296,6 +1296,21 @@ int dg_solver(knpemi_dg* h, knpemi_handle** out) {
   s->dev.A_knp = D.A_knp; s->dev.b_knp = D.b_knp;
   s->dev.csol = h->d_csol;
   s->plain_knp = true;
+  // block columns of the systems (the cell and its facet neighbours, increasing, as the CSR pattern was built): the solver's
+  // SpMVs read these instead of one column index per entry (block_spmv.h); KNPEMI_DG_NO_BLOCK_SPMV=1 keeps the CSR kernels
+  if (!getenv("KNPEMI_DG_NO_BLOCK_SPMV")) {
+    const int NV = h->NV, nc = n / NV;
+    int nbmax = 1;
+    for (int c = 0; c < nc; ++c) nbmax = std::max(nbmax, (h->h_rowptr[(size_t)c * NV + 1] - h->h_rowptr[(size_t)c * NV]) / NV);
+    std::vector<int> bcol((size_t)nc * nbmax, -1);
+    for (int c = 0; c < nc; ++c) {
+      const int a = h->h_rowptr[(size_t)c * NV], nb = (h->h_rowptr[(size_t)c * NV + 1] - a) / NV;
+      for (int b = 0; b < nb; ++b) bcol[(size_t)c * nbmax + b] = h->h_colind[(size_t)a + (size_t)b * NV] / NV;
+    }
+    const int* d_bcol = nullptr;
+    if ((rc = dg_upload(h, bcol, &d_bcol))) return rc;
+    s->bcols.bcol = d_bcol; s->bcols.nv = NV; s->bcols.nbmax = nbmax; s->bcols.n = n;
+  }
   s->amg_emi.first_agg = h->aux_of;
   s->amg_emi.first_na = h->n_aux;
   s->amg_knp.first_agg.resize((size_t)KS * n);

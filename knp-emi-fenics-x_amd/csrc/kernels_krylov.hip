@@ -354,6 +354,10 @@ void spmv(Ctx& c, const double* x, double* y, const double* dinv, const double* 
     const KnDist& d = c.h->dist;
     if (int e = d.halo(d.ctx, const_cast<double*>(x), c.which)) c.comm_rc = c.comm_rc ? c.comm_rc : e;
   }
+  if (c.h->bcols.bcol && !dinv && !dinv_out) {   // DG systems: block columns instead of one column index per entry
+    launch_block_spmv<double>(c.h->stream, c.h->bcols, c.n, c.rowptr, c.vals, x, b, y, c.owned);
+    return;
+  }
   if (c.lpr == 4) {
     if (dinv) hipLaunchKernelGGL((spmv_kernel<true, 4>), g, dim3(256), 0, c.h->stream, c.n, c.rowptr, c.colind, c.vals, x, dinv, y,
                                  (const double*)nullptr, c.owned);

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include "block_spmv.h"
 #include <stdint.h>
 
 #include <cstring>
@@ -261,6 +262,7 @@ struct knpemi_handle {
   double* kry = nullptr; size_t kry_n = 0;           // Krylov workspace (kernels_krylov.hip)
   int kry_ones_masked = 0;                           // the workspace's `ones` vector currently holds the ownership mask
   void* kry_pinned = nullptr;                        // pinned host buffer the solvers' scalars are read through
+  KnBlockCols bcols;                 // block structure of a DG problem's systems (solver handle of knpemi_dg), else empty
   int spmv_lpr[2] = {0, 0};          // lanes per row of the Krylov SpMV of the two systems (from the average row length)
   double* fused_part = nullptr; size_t fused_part_n = 0;   // block partials of the dot products fused into the solver kernels
   double* guess_old[2] = {nullptr, nullptr};         // previous solutions (EMI, KNP) for knpemi_extrapolate_guess
