@@ -596,6 +596,7 @@ int upload_csr(KnAmg& G, const HostCsr& A, KnAmgCsr& D, hipStream_t st) {
 void kn_amg_free(KnAmg& G) {
   for (void* p : G.allocs) (void)hipFree(p);
   G.allocs.clear();
+  G.zero_sc = nullptr; G.sub_fused_ok = false;
   G.lev.clear();
   G.built = false;
 }
@@ -723,7 +724,7 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
     L.r_row = std::max(1, (int)(R.ci.size() / (size_t)R.n));
     if ((rc = upload_csr(G, P, L.P, st))) return rc;
     if ((rc = upload_csr(G, R, L.R, st))) return rc;
-    if (fused) {
+    if (fused || (G.sub_fused && l >= 1)) {
       // V(1,1) from a zero guess is  x = w D^-1 (r + t) + Pm e_c,  t = (I - w A D^-1) r,  e_c = cycle(Rm r)  with the
       // smoother folded into the transfer operators: restriction and residual, prolongation and post-smoothing become
       // one SpMV each (kernels_fused.hip)
@@ -758,6 +759,15 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
   for (auto& L : G.lev) tot += L.A.nnz;
   G.op_complexity = G.lev[0].A.nnz ? (double)tot / G.lev[0].A.nnz : 1.0;
   G.fused_ok = fused && G.lev.size() >= 2 && G.lev.back().dense_inv != nullptr;
+  G.sub_fused_ok = G.sub_fused && G.block > 0 && G.lev.size() >= 3 && G.lev.back().dense_inv != nullptr;
+  if (G.sub_fused_ok) {
+    void* z = nullptr;
+    KN_HIP(hipMalloc(&z, 32 * sizeof(double)));
+    G.allocs.push_back(z);
+    KN_HIP(hipMemsetAsync(z, 0, 32 * sizeof(double), st));
+    KN_HIP(hipStreamSynchronize(st));
+    G.zero_sc = static_cast<double*>(z);
+  }
   return KNPEMI_OK;
 }
 
@@ -770,6 +780,22 @@ int kn_amg_apply(knpemi_handle* h, KnAmg& G, const double* vals, const double* d
                  double* out) {
   hipStream_t st = h->stream;
   const int nl = (int)G.lev.size();
+  if (G.sub_fused_ok && G.block > 0) {
+    // finest level: block-Jacobi sweeps and residuals here, everything below through the merged transfer operators
+    KnAmgLevel& L = G.lev[0];
+    auto residual = [&](const double* x, double* y) {
+      if (h->bcols.bcol) launch_block_spmv<double>(st, h->bcols, L.n, L.A.rp, vals, x, r, y, nullptr);
+      else launch_spmv<M_RES>(st, L.n, L.avg_row, L.A.rp, L.A.ci, vals, x, r, nullptr, 0.0, y);
+    };
+    block_apply(st, G, L.n, r, nullptr, scratch);                       // x = w B^-1 r
+    residual(scratch, L.t);                                             // t = r - A x
+    launch_spmv<M_AX>(st, L.nc, L.r_row, L.R.rp, L.R.ci, L.R.v, L.t, nullptr, nullptr, 0.0, G.lev[1].r);
+    if (int e = kn_fused_subcycle(h, G, 1)) return e;
+    launch_spmv<M_ADD>(st, L.n, L.p_row, L.P.rp, L.P.ci, L.P.v, G.lev[1].x, nullptr, nullptr, 0.0, scratch);
+    residual(scratch, L.t);
+    block_apply(st, G, L.n, L.t, scratch, out);                         // out = x + w B^-1 (r - A x)
+    return KNPEMI_OK;
+  }
   for (int l = 0; l < nl; ++l) {
     KnAmgLevel& L = G.lev[l];
     const double* rl = l == 0 ? r : L.r;

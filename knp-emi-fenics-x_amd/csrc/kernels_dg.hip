@@ -1324,6 +1324,7 @@ int dg_solver(knpemi_dg* h, knpemi_handle** out) {
   s->amg_emi.first_tentative = s->amg_knp.first_tentative = !getenv("KNPEMI_DG_AUX_SMOOTHED");
   s->amg_emi.positive_conflict = s->amg_knp.positive_conflict = !getenv("KNPEMI_DG_PLAIN_AGGREGATION");
   s->amg_emi.filter_theta = s->amg_knp.filter_theta = 0.02;   // (as kernels_krylov.hip)
+  s->amg_emi.sub_fused = s->amg_knp.sub_fused = !getenv("KNPEMI_DG_NO_SUBCYCLE");   // merged transfer operators below the finest level
   if (const char* ft = getenv("KNPEMI_AMG_FILTER")) s->amg_emi.filter_theta = s->amg_knp.filter_theta = atof(ft);
   if (const char* th = getenv("KNPEMI_DG_THETA")) s->amg_emi.theta = s->amg_knp.theta = atof(th);
   if (getenv("KNPEMI_DG_PLAIN_AMG")) { s->amg_emi.first_na = s->amg_knp.first_na = 0; }

@@ -489,6 +489,47 @@ struct Loop {
   }
 };
 
+}  // namespace
+
+// Levels l0 .. coarsest of the cycle with the merged transfer operators (two launches per level instead of four), for a
+// hierarchy whose FINEST level is handled by the caller (the block-smoothed DG systems, kn_amg_apply): input in
+// G.lev[l0].r, result in G.lev[l0].x.  The kernels are those of the fused loops; their early-out flag reads a zeroed
+// scalar block (G.zero_sc), no dot products are involved.
+int kn_fused_subcycle(knpemi_handle* h, KnAmg& G, int l0) {
+  hipStream_t st = h->stream;
+  const Red red{G.zero_sc, nullptr};
+  const int nl = (int)G.lev.size();
+  for (int l = l0; l + 1 < nl; ++l) {
+    KnAmgLevel& L = G.lev[l];
+    DownArgs a{};
+    a.n = L.n; a.nc = L.nc;
+    a.arp = L.A.rp; a.aci = L.A.ci; a.av = L.A.v;
+    a.rrp = L.Rm.rp; a.rci = L.Rm.ci; a.rv = L.Rm.v;
+    a.dinv = L.dinv; a.omega = L.omega;
+    a.r = L.r; a.t = L.t; a.rc = G.lev[l + 1].r;
+    a.red = red;
+    const int nb = (L.n + FT / LPR - 1) / (FT / LPR) + (L.nc + FT / 64 - 1) / (FT / 64);
+    hipLaunchKernelGGL((down_kernel<IN_PLAIN>), dim3(nb), dim3(FT), 0, st, a);
+  }
+  KnAmgLevel& C = G.lev[nl - 1];
+  hipLaunchKernelGGL((dense_kernel<false>), dim3(((size_t)C.n * 64 + FT - 1) / FT), dim3(FT), 0, st, C.n, C.dense_inv, C.r, C.x, red, 0, 0);
+  for (int l = nl - 2; l >= l0; --l) {
+    KnAmgLevel& L = G.lev[l];
+    UpArgs a{};
+    a.n = L.n;
+    a.prp = L.Pm.rp; a.pci = L.Pm.ci; a.pv = L.Pm.v;
+    a.dinv = L.dinv; a.omega = L.omega;
+    a.r = L.r; a.t = L.t; a.ec = G.lev[l + 1].x; a.x = L.x;
+    a.red = red;
+    hipLaunchKernelGGL((up_kernel<false>), dim3((int)(((size_t)L.n * LPR + FT - 1) / FT)), dim3(FT), 0, st, a);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { kn_set_error(std::string("fused sub-cycle: ") + hipGetErrorString(e)); return KNPEMI_EHIP; }
+  return KNPEMI_OK;
+}
+
+namespace {
+
 // scalars + partial-sum arrays of the fused loops
 int ensure_partials(knpemi_handle* h) {
   const size_t need = (size_t)P_N * KN_PB;
