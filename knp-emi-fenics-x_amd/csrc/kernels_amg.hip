@@ -466,7 +466,8 @@ __global__ __launch_bounds__(256) void amg_spmv_kernel(int n, const int* __restr
 // stores row a of the inverse (one thread per cell read 4 or 8 rows at a stride of a row: 148 us for 124 416 cells).
 template <int BS>
 __global__ void amg_block_inv_kernel(int nb, const int* __restrict__ rowptr, const int* __restrict__ colind,
-                                     const double* __restrict__ vals, double* __restrict__ binv) {
+                                     const double* __restrict__ vals, double* __restrict__ binv,
+                                     const int* __restrict__ bcol, int nbmax, int cells_per_system) {
   constexpr int W = BS > 4 ? 8 : 4;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int c = t / W, a = t % W;
@@ -474,7 +475,14 @@ __global__ void amg_block_inv_kernel(int nb, const int* __restrict__ rowptr, con
   double mine[BS];
 #pragma unroll
   for (int bb = 0; bb < BS; ++bb) mine[bb] = 0.0;
-  if (live)
+  if (live && bcol) {      // block structure known (DG systems): the diagonal block's position from the cell's block list
+    const int cl = c % cells_per_system;
+    int pos = 0;
+    for (int b = 0; b < nbmax; ++b) if (bcol[(size_t)cl * nbmax + b] == cl) pos = b;
+    const double* v = vals + rowptr[c * BS + a] + pos * BS;
+#pragma unroll
+    for (int bb = 0; bb < BS; ++bb) mine[bb] = v[bb];
+  } else if (live)
     for (int j = rowptr[c * BS + a]; j < rowptr[c * BS + a + 1]; ++j) {
       const int b = colind[j] - c * BS;
 #pragma unroll
@@ -596,7 +604,7 @@ int upload_csr(KnAmg& G, const HostCsr& A, KnAmgCsr& D, hipStream_t st) {
 void kn_amg_free(KnAmg& G) {
   for (void* p : G.allocs) (void)hipFree(p);
   G.allocs.clear();
-  G.zero_sc = nullptr; G.sub_fused_ok = false;
+  G.zero_sc = nullptr; G.sub_fused_ok = false; G.cycle_ok = false;
   G.lev.clear();
   G.built = false;
 }
@@ -642,7 +650,10 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
   const bool verbose = getenv("KNPEMI_AMG_VERBOSE") != nullptr;
   const auto t_start = std::chrono::steady_clock::now();
   // fused cycle: one level fewer is worth more than a cheaper coarsest solve (every level costs two launches per cycle)
-  const bool fused = G.want_fused && G.block == 0 && !h_owned && G.first_na == 0;
+  const bool fused_loops = G.want_fused && G.block == 0 && !h_owned && G.first_na == 0;
+  // (want_cycle: the merged operators for kn_fused_subcycle from level 0 on a partitioned problem, where the Krylov loop
+  // itself stays the plain one)
+  const bool fused = fused_loops || (G.want_cycle && G.block == 0 && G.first_na == 0);
   const int n_dense = fused ? 1024 : 640, max_levels = 12;
   G.fused_ok = false;
   int rc;
@@ -758,9 +769,10 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
   size_t tot = 0;
   for (auto& L : G.lev) tot += L.A.nnz;
   G.op_complexity = G.lev[0].A.nnz ? (double)tot / G.lev[0].A.nnz : 1.0;
-  G.fused_ok = fused && G.lev.size() >= 2 && G.lev.back().dense_inv != nullptr;
+  G.fused_ok = fused_loops && G.lev.size() >= 2 && G.lev.back().dense_inv != nullptr;
+  G.cycle_ok = fused && !fused_loops && G.lev.size() >= 2 && G.lev.back().dense_inv != nullptr;
   G.sub_fused_ok = G.sub_fused && G.block > 0 && G.lev.size() >= 3 && G.lev.back().dense_inv != nullptr;
-  if (G.sub_fused_ok) {
+  if (G.sub_fused_ok || G.cycle_ok) {
     void* z = nullptr;
     KN_HIP(hipMalloc(&z, 32 * sizeof(double)));
     G.allocs.push_back(z);
@@ -780,6 +792,7 @@ int kn_amg_apply(knpemi_handle* h, KnAmg& G, const double* vals, const double* d
                  double* out) {
   hipStream_t st = h->stream;
   const int nl = (int)G.lev.size();
+  if (G.cycle_ok) return kn_fused_subcycle(h, G, 0, r, out);
   if (G.sub_fused_ok && G.block > 0) {
     // finest level: block-Jacobi sweeps and residuals here, everything below through the merged transfer operators
     KnAmgLevel& L = G.lev[0];
@@ -841,9 +854,12 @@ int kn_amg_refresh(knpemi_handle* h, KnAmg& G, const double* vals) {
   const KnAmgLevel& L = G.lev[0];
   const int nb = L.n / G.block;
   dim3 g(((size_t)nb * 4 + 255) / 256), g8(((size_t)nb * 8 + 255) / 256);
-  if (G.block == 3) hipLaunchKernelGGL(amg_block_inv_kernel<3>, g, dim3(256), 0, h->stream, nb, L.A.rp, L.A.ci, vals, G.binv);
-  else if (G.block == 4) hipLaunchKernelGGL(amg_block_inv_kernel<4>, g, dim3(256), 0, h->stream, nb, L.A.rp, L.A.ci, vals, G.binv);
-  else if (G.block == 8) hipLaunchKernelGGL(amg_block_inv_kernel<8>, g8, dim3(256), 0, h->stream, nb, L.A.rp, L.A.ci, vals, G.binv);
+  const KnBlockCols& B = h->bcols;
+  const int* bc = (B.bcol && B.nv == G.block) ? B.bcol : nullptr;
+  const int cps = bc ? B.n / B.nv : 1;
+  if (G.block == 3) hipLaunchKernelGGL(amg_block_inv_kernel<3>, g, dim3(256), 0, h->stream, nb, L.A.rp, L.A.ci, vals, G.binv, bc, B.nbmax, cps);
+  else if (G.block == 4) hipLaunchKernelGGL(amg_block_inv_kernel<4>, g, dim3(256), 0, h->stream, nb, L.A.rp, L.A.ci, vals, G.binv, bc, B.nbmax, cps);
+  else if (G.block == 8) hipLaunchKernelGGL(amg_block_inv_kernel<8>, g8, dim3(256), 0, h->stream, nb, L.A.rp, L.A.ci, vals, G.binv, bc, B.nbmax, cps);
   else { kn_set_error("AMG: smoother blocks of 3, 4 or 8 unknowns only"); return KNPEMI_EINVAL; }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { kn_set_error(std::string("amg_block_inv_kernel: ") + hipGetErrorString(e)); return KNPEMI_EHIP; }

@@ -494,8 +494,9 @@ struct Loop {
 // Levels l0 .. coarsest of the cycle with the merged transfer operators (two launches per level instead of four), for a
 // hierarchy whose FINEST level is handled by the caller (the block-smoothed DG systems, kn_amg_apply): input in
 // G.lev[l0].r, result in G.lev[l0].x.  The kernels are those of the fused loops; their early-out flag reads a zeroed
-// scalar block (G.zero_sc), no dot products are involved.
-int kn_fused_subcycle(knpemi_handle* h, KnAmg& G, int l0) {
+// scalar block (G.zero_sc), no dot products are involved.  l0 = 0 (the rank-local cycle of a partitioned problem): input
+// r0, result out0, the finest operator is the frozen one the hierarchy was built from.
+int kn_fused_subcycle(knpemi_handle* h, KnAmg& G, int l0, const double* r0, double* out0) {
   hipStream_t st = h->stream;
   const Red red{G.zero_sc, nullptr};
   const int nl = (int)G.lev.size();
@@ -503,10 +504,10 @@ int kn_fused_subcycle(knpemi_handle* h, KnAmg& G, int l0) {
     KnAmgLevel& L = G.lev[l];
     DownArgs a{};
     a.n = L.n; a.nc = L.nc;
-    a.arp = L.A.rp; a.aci = L.A.ci; a.av = L.A.v;
+    a.arp = L.A.rp; a.aci = L.A.ci; a.av = l == 0 ? L.frozen_v : L.A.v;
     a.rrp = L.Rm.rp; a.rci = L.Rm.ci; a.rv = L.Rm.v;
     a.dinv = L.dinv; a.omega = L.omega;
-    a.r = L.r; a.t = L.t; a.rc = G.lev[l + 1].r;
+    a.r = (l == l0 && r0) ? r0 : L.r; a.t = L.t; a.rc = G.lev[l + 1].r;
     a.red = red;
     const int nb = (L.n + FT / LPR - 1) / (FT / LPR) + (L.nc + FT / 64 - 1) / (FT / 64);
     hipLaunchKernelGGL((down_kernel<IN_PLAIN>), dim3(nb), dim3(FT), 0, st, a);
@@ -519,7 +520,7 @@ int kn_fused_subcycle(knpemi_handle* h, KnAmg& G, int l0) {
     a.n = L.n;
     a.prp = L.Pm.rp; a.pci = L.Pm.ci; a.pv = L.Pm.v;
     a.dinv = L.dinv; a.omega = L.omega;
-    a.r = L.r; a.t = L.t; a.ec = G.lev[l + 1].x; a.x = L.x;
+    a.r = (l == l0 && r0) ? r0 : L.r; a.t = L.t; a.ec = G.lev[l + 1].x; a.x = (l == l0 && out0) ? out0 : L.x;
     a.red = red;
     hipLaunchKernelGGL((up_kernel<false>), dim3((int)(((size_t)L.n * LPR + FT - 1) / FT)), dim3(FT), 0, st, a);
   }

@@ -644,6 +644,7 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     if (getenv("KNPEMI_AMG_APART")) G.positive_conflict = atoi(getenv("KNPEMI_AMG_APART")) != 0;
     if (const char* ft = getenv("KNPEMI_AMG_FILTER")) G.filter_theta = atof(ft);
     G.want_fused = !dist.on && use_fused();
+    G.want_cycle = dist.on && use_fused() && !getenv("KNPEMI_DIST_PLAIN_CYCLE");
     // the diagonal block of a rank that has ghosts has lost couplings: it is non-singular
     if ((rc = kn_amg_setup(h, G, n, D.rowptr, D.colind, D.A_emi, !has_ghosts,
                            dist.on ? dist.h_owned_emi.data() : nullptr))) return rc;
@@ -778,6 +779,7 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     if (getenv("KNPEMI_AMG_APART")) G.positive_conflict = atoi(getenv("KNPEMI_AMG_APART")) != 0;
     if (const char* ft = getenv("KNPEMI_AMG_FILTER")) G.filter_theta = atof(ft);
     G.want_fused = !dist.on && use_fused();
+    G.want_cycle = dist.on && use_fused() && !getenv("KNPEMI_DIST_PLAIN_CYCLE");
     if ((rc = kn_amg_setup(h, G, n, D.krowptr, D.kcolind, D.A_knp, false,
                            dist.on ? dist.h_owned_knp.data() : nullptr))) return rc;
     G.its_ref = -1;

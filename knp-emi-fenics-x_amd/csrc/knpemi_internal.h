@@ -167,6 +167,7 @@ struct KnAmg {
   // Block-smoothed hierarchies (DG): the levels below the finest run through the merged transfer operators of the fused
   // cycle (kn_fused_subcycle): sub_fused asks for them at set-up, sub_fused_ok says they exist (dense coarsest level)
   bool sub_fused = false, sub_fused_ok = false;
+  bool want_cycle = false, cycle_ok = false;   // point-Jacobi hierarchy of a rank's diagonal block: the whole cycle that way
   double* zero_sc = nullptr;         // 32 zeroed doubles: the "not done" flag the fused kernels look at
   double filter_theta = 0.0;         // > 0: prolongator smoothing with the filtered operator (weak entries lumped)
   bool first_tentative = false;      // the prolongator of the given aggregates is not smoothed
@@ -190,7 +191,7 @@ struct KnFusedSys {
   double* sc; double* work;   // the solver's device scalars and vector workspace (kernels_krylov.hip layout)
   size_t N;                   // stride of the workspace vectors
 };
-int kn_fused_subcycle(knpemi_handle* h, KnAmg& G, int l0);
+int kn_fused_subcycle(knpemi_handle* h, KnAmg& G, int l0, const double* r0 = nullptr, double* out0 = nullptr);
 int kn_fused_cg(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const double* b, double rtol, double atol, int maxit,
                 int* iters, double* rr, double* bb);
 int kn_fused_bicgstab(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const double* b, double rtol, double atol, int maxit,
