@@ -98,7 +98,7 @@ for f, cmd in (("bench_config2", "python bench.py --steps 20 --warmup 5"),
 
 # ---- whole DG steps with the device solves (tools/dg_solves.py) ---------------------------------------------------
 for f, cmd in (("dg_solves_config2", "python tools/dg_solves.py --workload config2 --steps 10 --warmup 2"),
-               ("dg_solves_config2_continuous_aux_space", "KNPEMI_DG_AUX_UNSPLIT=1 KNPEMI_DG_PLAIN_AGGREGATION=1 KNPEMI_DG_AUX_SMOOTHED=1 python tools/dg_solves.py --workload config2 --steps 10 --warmup 2` (the round-2 auxiliary space)"),
+               ("dg_solves_config2_continuous_aux_space", "KNPEMI_DG_AUX_UNSPLIT=1 KNPEMI_DG_PLAIN_AGGREGATION=1 KNPEMI_DG_AUX_SMOOTHED=1 python tools/dg_solves.py --workload config2 --steps 10 --warmup 2` (the continuous auxiliary space of round 2 with a smoothed prolongator; SpMV kernels, filter and sub-cycle as now)"),
                ("dg_solves_hex_r1", "python tools/dg_solves.py --workload hex_r1 --steps 10 --warmup 2"),
                ("dg_solves_config2h", "python tools/dg_solves.py --workload config2h --steps 10 --warmup 2 --solve-steps 5")):
     if not cp(os.path.join(G, "r03", f + ".json"), f"r03_{f}.json"):
