@@ -1437,7 +1437,7 @@ extern "C" int knpemi_dg_solve_emi(knpemi_dg* h, double rtol, double atol, int m
 extern "C" int knpemi_dg_set_extrapolation(knpemi_dg* h, int on) {
   if (!h) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_set_extrapolation: null handle");
   h->extrapolate = on ? 1 : 0;
-  if (h->sol) h->sol->guess_have[0] = h->sol->guess_have[1] = false;
+  if (h->sol) { h->sol->guess_have[0] = -1; h->sol->guess_have[1] = 0; }
   return KNPEMI_OK;
 }
 

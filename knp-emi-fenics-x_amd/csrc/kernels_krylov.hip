@@ -897,8 +897,12 @@ int kn_extrapolate_guess(knpemi_handle* h, int which) {
     KN_HIP(hipMalloc(&p, 2 * (size_t)n * sizeof(double)));
     h->allocs.push_back(p);
     h->guess_old[slot] = static_cast<double*>(p);
-    h->guess_have[slot] = 0;
+    h->guess_have[slot] = slot == 0 ? -1 : 0;
   }
+  // the potential a run starts with is a guess, not a solution of the system (the concentrations it starts with are the
+  // initial condition, i.e. the first point of the trajectory): no history from it -- 2 x_1 - x_0 with that x_0 cost the
+  // second and third solves of a run twice their iterations
+  if (h->guess_have[slot] < 0) { h->guess_have[slot] = 0; return KNPEMI_OK; }
   double* cur = slot == 0 ? D.VR + 7 : D.csol;
   hipLaunchKernelGGL(extrapolate_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, cur, slot == 0 ? KN_REC : 1,
                      h->guess_old[slot], order >= 2 ? h->guess_old[slot] + n : (double*)nullptr, h->guess_have[slot]);
