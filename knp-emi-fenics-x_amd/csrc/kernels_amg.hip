@@ -370,19 +370,8 @@ HostCsr smoothed_prolongator(const HostCsr& A, const std::vector<double>& d, con
 }
 
 // explicit inverse of the dense coarsest operator (+ shift * 1 1^T / n when it carries the constant null space)
-bool dense_inverse(const HostCsr& A, bool singular, std::vector<double>& inv) {
-  const int n = A.n;
-  std::vector<double> M((size_t)n * n, 0.0);
-  double tr = 0.0;
-  for (int i = 0; i < n; ++i)
-    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
-      M[(size_t)i * n + A.ci[j]] = A.v[j];
-      if (A.ci[j] == i) tr += A.v[j];
-    }
-  if (singular) {
-    const double s = tr / n / n;
-    for (auto& x : M) x += s;
-  }
+// Gauss-Jordan with partial pivoting: inv = M^-1 (M is destroyed)
+bool invert_dense(std::vector<double>& M, std::vector<double>& inv, int n) {
   inv.assign((size_t)n * n, 0.0);
   for (int i = 0; i < n; ++i) inv[(size_t)i * n + i] = 1.0;
   for (int k = 0; k < n; ++k) {
@@ -408,6 +397,55 @@ bool dense_inverse(const HostCsr& A, bool singular, std::vector<double>& inv) {
     }
   }
   return true;
+}
+
+bool dense_inverse(const HostCsr& A, bool singular, std::vector<double>& inv) {
+  const int n = A.n;
+  if (!singular) {
+    // The concentration system is K - 1 independent ion blocks and so is every coarse operator of its hierarchy: the
+    // connected components are inverted one by one (half the work of the elimination for two blocks, and the reason a
+    // 1 760-row coarsest level is affordable)
+    std::vector<int> parent(n);
+    for (int i = 0; i < n; ++i) parent[i] = i;
+    auto find = [&](int i) { while (parent[i] != i) { parent[i] = parent[parent[i]]; i = parent[i]; } return i; };
+    for (int i = 0; i < n; ++i)
+      for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+        const int a = find(i), b = find(A.ci[j]);
+        if (a != b) parent[std::max(a, b)] = std::min(a, b);
+      }
+    int ncomp = 0;
+    for (int i = 0; i < n; ++i) ncomp += find(i) == i;
+    if (ncomp > 1 && ncomp <= 8) {
+      inv.assign((size_t)n * n, 0.0);
+      std::vector<int> loc(n, -1), idx;
+      std::vector<double> M, Mi;
+      for (int root = 0; root < n; ++root) {
+        if (find(root) != root) continue;
+        idx.clear();
+        for (int i = 0; i < n; ++i) if (find(i) == root) { loc[i] = (int)idx.size(); idx.push_back(i); }
+        const int m = (int)idx.size();
+        M.assign((size_t)m * m, 0.0);
+        for (int a = 0; a < m; ++a)
+          for (int j = A.rp[idx[a]]; j < A.rp[idx[a] + 1]; ++j) M[(size_t)a * m + loc[A.ci[j]]] = A.v[j];
+        if (!invert_dense(M, Mi, m)) return false;
+        for (int a = 0; a < m; ++a)
+          for (int b = 0; b < m; ++b) inv[(size_t)idx[a] * n + idx[b]] = Mi[(size_t)a * m + b];
+      }
+      return true;
+    }
+  }
+  std::vector<double> M((size_t)n * n, 0.0);
+  double tr = 0.0;
+  for (int i = 0; i < n; ++i)
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+      M[(size_t)i * n + A.ci[j]] = A.v[j];
+      if (A.ci[j] == i) tr += A.v[j];
+    }
+  if (singular) {
+    const double s = tr / n / n;
+    for (auto& x : M) x += s;
+  }
+  return invert_dense(M, inv, n);
 }
 
 // ---- device kernels -------------------------------------------------------------------------------
@@ -654,7 +692,8 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
   // (want_cycle: the merged operators for kn_fused_subcycle from level 0 on a partitioned problem, where the Krylov loop
   // itself stays the plain one)
   const bool fused = fused_loops || (G.want_cycle && G.block == 0 && G.first_na == 0);
-  const int n_dense = fused ? 1024 : 640, max_levels = 12;
+  // (a non-singular system of several independent blocks may end on a larger dense level: dense_inverse works block by block)
+  const int n_dense = fused ? (singular ? 1024 : 2048) : 640, max_levels = 12;
   G.fused_ok = false;
   int rc;
   G.singular = singular;
@@ -713,7 +752,7 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
     if (cur.n <= n_dense || na >= cur.n * 0.9 || l == max_levels - 1) {
       // coarsening stalled on a large level (e.g. a mass-dominated operator with no strong connections):
       // that level is well conditioned for Jacobi, which then stands in for the coarsest solve
-      if (cur.n <= 1024) {
+      if (cur.n <= std::max(1024, n_dense)) {
         std::vector<double> inv;
         if (!dense_inverse(cur, singular, inv)) { kn_set_error("AMG set-up: singular coarsest operator"); return KNPEMI_ESOLVE; }
         if ((rc = upload(G, inv, &L.dense_inv, st))) return rc;
