@@ -1,0 +1,437 @@
+// Host side of the AMG set-up (kernels_amg.hip): strength graphs and aggregation, prolongators, sparse products, the dense
+// inverse of the coarsest level.  Plain C++ without any device dependency, so that the CPU tests can exercise it
+// (tests/native/amg_host_check.cpp, tests/test_amg_host.py).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <utility>
+#include <vector>
+
+namespace kn_amg_host {
+
+struct HostCsr {
+  int n = 0, m = 0;
+  std::vector<int> rp, ci;
+  std::vector<double> v;
+};
+
+// ---- host set-up ---------------------------------------------------------------------------------
+
+std::vector<double> diagonal(const HostCsr& A) {
+  std::vector<double> d(A.n, 1.0);
+  for (int i = 0; i < A.n; ++i)
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j)
+      if (A.ci[j] == i) d[i] = A.v[j];
+  return d;
+}
+
+// greedy aggregation on the strength graph (three passes: roots with free neighbourhoods, attach
+// leftovers to a neighbouring aggregate, remaining isolated points become their own aggregates)
+int aggregate(const HostCsr& A, const std::vector<double>& d, double theta, bool negative_only, std::vector<int>& agg) {
+  const int n = A.n;
+  std::vector<int> srp(n + 1, 0), sci;
+  sci.reserve(A.ci.size());
+  for (int i = 0; i < n; ++i) {
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+      const int c = A.ci[j];
+      // negative_only: classical strength (-a_ij): the positive couplings of stretched Q1 cells do not carry
+      // smooth error and must not glue aggregates together along the weak direction
+      const double a = negative_only ? -A.v[j] : std::fabs(A.v[j]);
+      if (c != i && a > 0.0 && a >= theta * std::sqrt(std::fabs(d[i] * d[c]))) sci.push_back(c);
+    }
+    srp[i + 1] = (int)sci.size();
+  }
+  agg.assign(n, -1);
+  int na = 0;
+  for (int i = 0; i < n; ++i) {
+    if (agg[i] >= 0 || srp[i] == srp[i + 1]) continue;
+    bool free_nb = true;
+    for (int j = srp[i]; j < srp[i + 1] && free_nb; ++j) free_nb = agg[sci[j]] < 0;
+    if (!free_nb) continue;
+    agg[i] = na;
+    for (int j = srp[i]; j < srp[i + 1]; ++j) agg[sci[j]] = na;
+    ++na;
+  }
+  std::vector<int> pass1(agg);
+  for (int i = 0; i < n; ++i) {
+    if (pass1[i] >= 0) continue;
+    for (int j = srp[i]; j < srp[i + 1]; ++j)
+      if (pass1[sci[j]] >= 0) { agg[i] = pass1[sci[j]]; break; }
+  }
+  for (int i = 0; i < n; ++i) {
+    if (agg[i] >= 0) continue;
+    agg[i] = na;
+    for (int j = srp[i]; j < srp[i + 1]; ++j)
+      if (agg[sci[j]] < 0) agg[sci[j]] = na;
+    ++na;
+  }
+  return na;
+}
+
+// Splits given aggregates into the connected components of the strong couplings inside them (union-find; the numbering
+// of the components follows their lowest member, so the result does not depend on the order of the unions).  Unknowns
+// that are not owned (identity rows of a rank's diagonal block) have no couplings: those of one given aggregate stay together.
+int split_aggregates(const HostCsr& A, const std::vector<double>& d, double theta, const uint8_t* owned, std::vector<int>& agg, int na) {
+  const int n = A.n;
+  std::vector<int> parent(n);
+  for (int i = 0; i < n; ++i) parent[i] = i;
+  auto find = [&](int i) {
+    while (parent[i] != i) { parent[i] = parent[parent[i]]; i = parent[i]; }
+    return i;
+  };
+  auto unite = [&](int a, int b) {
+    a = find(a); b = find(b);
+    if (a != b) parent[std::max(a, b)] = std::min(a, b);
+  };
+  std::vector<int> first_ghost(na, -1);
+  for (int i = 0; i < n; ++i) {
+    if (owned && !owned[i]) {
+      int& g = first_ghost[agg[i]];
+      if (g < 0) g = i; else unite(g, i);
+      continue;
+    }
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+      const int c = A.ci[j];
+      if (c == i || agg[c] != agg[i] || (owned && !owned[c])) continue;
+      if (-A.v[j] >= theta * std::sqrt(std::fabs(d[i] * d[c]))) unite(i, c);
+    }
+  }
+  std::vector<int> id(n, -1);
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) {
+    const int r = find(i);
+    if (id[r] < 0) id[r] = cnt++;
+    agg[i] = id[r];
+  }
+  return cnt;
+}
+
+// Aggregation that keeps strongly POSITIVELY coupled unknowns apart (KnAmg::positive_conflict).  On the first coarse level of
+// the DG systems on stretched hexahedra the two ends of a cell are coupled by +0.5 sqrt(a_ii a_jj) (the mass-like factor
+// of the long direction): the smooth error takes independent values there, but each end is negatively coupled to the
+// in-plane neighbours of the other one just above the strength threshold, and the plain greedy pass glues the two
+// cross-sections together -- every variation along the long direction is then lost to the coarse space (convergence
+// factor 0.97 of the two-level cycle on that operator).  Rule: an unknown does not join an aggregate that holds a
+// strongly positive partner of it; neighbours are taken in the order of their strength, so the in-plane ones come first.
+int aggregate_apart(const HostCsr& A, const std::vector<double>& d, double theta, double theta_pos, std::vector<int>& agg) {
+  const int n = A.n;
+  std::vector<int> srp(n + 1, 0), sci, prp(n + 1, 0), pci;
+  std::vector<std::pair<double, int>> row;
+  for (int i = 0; i < n; ++i) {
+    row.clear();
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+      const int c = A.ci[j];
+      if (c == i) continue;
+      const double s = std::sqrt(std::fabs(d[i] * d[c]));
+      if (-A.v[j] > 0.0 && -A.v[j] >= theta * s) row.emplace_back(A.v[j], c);
+      else if (A.v[j] >= theta_pos * s) pci.push_back(c);
+    }
+    std::sort(row.begin(), row.end());     // most negative first; ties by column: reproducible
+    for (auto& e : row) sci.push_back(e.second);
+    srp[i + 1] = (int)sci.size();
+    prp[i + 1] = (int)pci.size();
+  }
+  agg.assign(n, -1);
+  std::vector<std::vector<int>> members;
+  auto conflicts = [&](int k, const std::vector<int>& mem) {
+    for (int j = prp[k]; j < prp[k + 1]; ++j)
+      for (int m : mem) if (m == pci[j]) return true;
+    return false;
+  };
+  for (int i = 0; i < n; ++i) {
+    if (agg[i] >= 0 || srp[i] == srp[i + 1]) continue;
+    bool free_nb = true;
+    for (int j = srp[i]; j < srp[i + 1] && free_nb; ++j) free_nb = agg[sci[j]] < 0;
+    if (!free_nb) continue;
+    std::vector<int> mem{i};
+    for (int j = srp[i]; j < srp[i + 1]; ++j) if (!conflicts(sci[j], mem)) mem.push_back(sci[j]);
+    for (int k : mem) agg[k] = (int)members.size();
+    members.push_back(std::move(mem));
+  }
+  std::vector<int> pass1(agg);
+  for (int i = 0; i < n; ++i) {
+    if (pass1[i] >= 0) continue;
+    for (int j = srp[i]; j < srp[i + 1]; ++j) {
+      const int a = pass1[sci[j]];
+      if (a >= 0 && !conflicts(i, members[a])) { agg[i] = a; members[a].push_back(i); break; }
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    if (agg[i] >= 0) continue;
+    std::vector<int> mem{i};
+    agg[i] = (int)members.size();
+    for (int j = srp[i]; j < srp[i + 1]; ++j) {
+      const int c = sci[j];
+      if (agg[c] < 0 && !conflicts(c, mem)) { agg[c] = agg[i]; mem.push_back(c); }
+    }
+    members.push_back(std::move(mem));
+  }
+  return (int)members.size();
+}
+
+// C = A * B (Gustavson, columns of each row sorted)
+HostCsr spgemm(const HostCsr& A, const HostCsr& B) {
+  HostCsr C;
+  C.n = A.n; C.m = B.m;
+  C.rp.assign(A.n + 1, 0);
+  std::vector<int> mark(B.m, -1), cols;
+  std::vector<double> acc(B.m, 0.0);
+  for (int i = 0; i < A.n; ++i) {
+    cols.clear();
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+      const int k = A.ci[j];
+      const double a = A.v[j];
+      for (int l = B.rp[k]; l < B.rp[k + 1]; ++l) {
+        const int c = B.ci[l];
+        if (mark[c] != i) { mark[c] = i; acc[c] = 0.0; cols.push_back(c); }
+        acc[c] += a * B.v[l];
+      }
+    }
+    std::sort(cols.begin(), cols.end());
+    for (int c : cols) { C.ci.push_back(c); C.v.push_back(acc[c]); }
+    C.rp[i + 1] = (int)C.ci.size();
+  }
+  return C;
+}
+
+HostCsr transpose(const HostCsr& A) {
+  HostCsr T;
+  T.n = A.m; T.m = A.n;
+  T.rp.assign(A.m + 1, 0);
+  for (int c : A.ci) ++T.rp[c + 1];
+  for (int i = 0; i < A.m; ++i) T.rp[i + 1] += T.rp[i];
+  T.ci.resize(A.ci.size()); T.v.resize(A.v.size());
+  std::vector<int> pos(T.rp.begin(), T.rp.end() - 1);
+  for (int i = 0; i < A.n; ++i)
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+      const int p = pos[A.ci[j]]++;
+      T.ci[p] = i; T.v[p] = A.v[j];
+    }
+  return T;
+}
+
+// spectral radius of D^-1 A: 15 power iterations (x 1.1), capped by the Gershgorin bound
+double estimate_rho(const HostCsr& A, const std::vector<double>& d) {
+  double bound = 0.0;
+  for (int i = 0; i < A.n; ++i) {
+    double s = 0.0;
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) s += std::fabs(A.v[j]);
+    bound = std::max(bound, s / std::fabs(d[i]));
+  }
+  if (!(bound > 0)) return 1.0;
+  std::vector<double> v(A.n), w(A.n);
+  uint64_t state = 0x9E3779B97F4A7C15ull;   // fixed seed: the hierarchy must be reproducible
+  for (int i = 0; i < A.n; ++i) {
+    state = state * 6364136223846793005ull + 1442695040888963407ull;
+    v[i] = (double)(state >> 11) / 9007199254740992.0 - 0.5;
+  }
+  double lam = bound;
+  for (int it = 0; it < 15; ++it) {
+    double nrm = 0.0;
+    for (int i = 0; i < A.n; ++i) {
+      double s = 0.0;
+      for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) s += A.v[j] * v[A.ci[j]];
+      w[i] = s / d[i];
+      nrm += w[i] * w[i];
+    }
+    nrm = std::sqrt(nrm);
+    if (!(nrm > 0)) return bound;
+    double dot = 0.0, vv = 0.0;
+    for (int i = 0; i < A.n; ++i) { dot += w[i] * v[i]; vv += v[i] * v[i]; }
+    lam = std::fabs(dot / vv);
+    for (int i = 0; i < A.n; ++i) v[i] = w[i] / nrm;
+  }
+  return std::min(bound, 1.1 * lam);
+}
+
+// inverse of the bs x bs matrix m (row-major, destroyed); false if a pivot vanishes
+template <class T>
+bool small_inverse(T* m, T* inv, int bs) {
+  for (int i = 0; i < bs; ++i) for (int j = 0; j < bs; ++j) inv[i * bs + j] = i == j ? 1.0 : 0.0;
+  for (int k = 0; k < bs; ++k) {
+    int piv = k;
+    for (int i = k + 1; i < bs; ++i) if (fabs(m[i * bs + k]) > fabs(m[piv * bs + k])) piv = i;
+    if (m[piv * bs + k] == 0.0) return false;
+    if (piv != k)
+      for (int j = 0; j < bs; ++j) {
+        T t = m[k * bs + j]; m[k * bs + j] = m[piv * bs + j]; m[piv * bs + j] = t;
+        t = inv[k * bs + j]; inv[k * bs + j] = inv[piv * bs + j]; inv[piv * bs + j] = t;
+      }
+    const T d = 1.0 / m[k * bs + k];
+    for (int j = 0; j < bs; ++j) { m[k * bs + j] *= d; inv[k * bs + j] *= d; }
+    for (int i = 0; i < bs; ++i) {
+      if (i == k) continue;
+      const T f = m[i * bs + k];
+      for (int j = 0; j < bs; ++j) { m[i * bs + j] -= f * m[k * bs + j]; inv[i * bs + j] -= f * inv[k * bs + j]; }
+    }
+  }
+  return true;
+}
+
+// spectral radius of B^-1 A, B = the bs x bs diagonal blocks of A (power iteration, fixed seed)
+double estimate_rho_block(const HostCsr& A, int bs) {
+  const int nb = A.n / bs;
+  std::vector<double> binv((size_t)nb * bs * bs);
+  for (int c = 0; c < nb; ++c) {
+    double m[64] = {0};
+    for (int a = 0; a < bs; ++a)
+      for (int j = A.rp[c * bs + a]; j < A.rp[c * bs + a + 1]; ++j) {
+        const int b = A.ci[j] - c * bs;
+        if (b >= 0 && b < bs) m[a * bs + b] = A.v[j];
+      }
+    if (!small_inverse(m, &binv[(size_t)c * bs * bs], bs)) return -1.0;
+  }
+  std::vector<double> v(A.n), w(A.n), u(A.n);
+  uint64_t state = 0x9E3779B97F4A7C15ull;
+  for (int i = 0; i < A.n; ++i) {
+    state = state * 6364136223846793005ull + 1442695040888963407ull;
+    v[i] = (double)(state >> 11) / 9007199254740992.0 - 0.5;
+  }
+  double lam = 1.0;
+  for (int it = 0; it < 20; ++it) {
+    for (int i = 0; i < A.n; ++i) {
+      double s = 0.0;
+      for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) s += A.v[j] * v[A.ci[j]];
+      u[i] = s;
+    }
+    double nrm = 0.0;
+    for (int c = 0; c < nb; ++c)
+      for (int a = 0; a < bs; ++a) {
+        double s = 0.0;
+        for (int b = 0; b < bs; ++b) s += binv[((size_t)c * bs + a) * bs + b] * u[c * bs + b];
+        w[c * bs + a] = s;
+        nrm += s * s;
+      }
+    nrm = std::sqrt(nrm);
+    if (!(nrm > 0)) break;
+    double dot = 0.0, vv = 0.0;
+    for (int i = 0; i < A.n; ++i) { dot += w[i] * v[i]; vv += v[i] * v[i]; }
+    lam = std::fabs(dot / vv);
+    for (int i = 0; i < A.n; ++i) v[i] = w[i] / nrm;
+  }
+  return 1.1 * lam;     // the iteration approaches rho from below
+}
+
+// P = (I - w D^-1 A) T for the piecewise-constant T of `agg`.  filter_theta > 0: the smoothing uses the FILTERED operator
+// -- off-diagonal entries that are not large (|a_ij| >= filter_theta sqrt(a_ii a_jj)) are dropped and added to the
+// diagonal, so the basis functions spread along the large couplings only and the coarse stencils stay narrow (on the
+// stretched cells the small entries are the majority: 977 entries per row on the third level of the hexahedral DG
+// hierarchy without it).  By magnitude, not by sign: the big positive entries of stretched Q1 cells must stay in the
+// smoothing (lumped into the diagonal they inflate it and the smoothing is lost).
+HostCsr smoothed_prolongator(const HostCsr& A, const std::vector<double>& d, const std::vector<int>& agg, int na, double w,
+                             double filter_theta = 0.0) {
+  HostCsr P;
+  P.n = A.n; P.m = na;
+  P.rp.assign(A.n + 1, 0);
+  std::vector<int> mark(na, -1), cols;
+  std::vector<double> acc(na, 0.0);
+  for (int i = 0; i < A.n; ++i) {
+    cols.clear();
+    auto add = [&](int c, double v) {
+      if (mark[c] != i) { mark[c] = i; acc[c] = 0.0; cols.push_back(c); }
+      acc[c] += v;
+    };
+    add(agg[i], 1.0);
+    if (w != 0.0 && filter_theta > 0.0) {
+      double dF = d[i];
+      for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+        const int c = A.ci[j];
+        if (c != i && !(std::fabs(A.v[j]) >= filter_theta * std::sqrt(std::fabs(d[i] * d[c])))) dF += A.v[j];
+      }
+      if (!(dF >= 0.25 * d[i])) dF = d[i];        // (lumping must not empty the diagonal)
+      add(agg[i], -w);                             // the diagonal of the filtered row: -w dF / dF
+      for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+        const int c = A.ci[j];
+        if (c != i && std::fabs(A.v[j]) >= filter_theta * std::sqrt(std::fabs(d[i] * d[c]))) add(agg[c], -w * A.v[j] / dF);
+      }
+    } else if (w != 0.0) {
+      for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) add(agg[A.ci[j]], -w * A.v[j] / d[i]);
+    }
+    std::sort(cols.begin(), cols.end());
+    for (int c : cols) { P.ci.push_back(c); P.v.push_back(acc[c]); }
+    P.rp[i + 1] = (int)P.ci.size();
+  }
+  return P;
+}
+
+// explicit inverse of the dense coarsest operator (+ shift * 1 1^T / n when it carries the constant null space)
+// Gauss-Jordan with partial pivoting: inv = M^-1 (M is destroyed)
+bool invert_dense(std::vector<double>& M, std::vector<double>& inv, int n) {
+  inv.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) inv[(size_t)i * n + i] = 1.0;
+  for (int k = 0; k < n; ++k) {
+    int piv = k;
+    for (int i = k + 1; i < n; ++i)
+      if (std::fabs(M[(size_t)i * n + k]) > std::fabs(M[(size_t)piv * n + k])) piv = i;
+    if (M[(size_t)piv * n + k] == 0.0) return false;
+    if (piv != k)
+      for (int j = 0; j < n; ++j) {
+        std::swap(M[(size_t)k * n + j], M[(size_t)piv * n + j]);
+        std::swap(inv[(size_t)k * n + j], inv[(size_t)piv * n + j]);
+      }
+    const double ip = 1.0 / M[(size_t)k * n + k];
+    for (int j = 0; j < n; ++j) { M[(size_t)k * n + j] *= ip; inv[(size_t)k * n + j] *= ip; }
+    for (int i = 0; i < n; ++i) {
+      if (i == k) continue;
+      const double f = M[(size_t)i * n + k];
+      if (f == 0.0) continue;
+      for (int j = 0; j < n; ++j) {
+        M[(size_t)i * n + j] -= f * M[(size_t)k * n + j];
+        inv[(size_t)i * n + j] -= f * inv[(size_t)k * n + j];
+      }
+    }
+  }
+  return true;
+}
+
+bool dense_inverse(const HostCsr& A, bool singular, std::vector<double>& inv) {
+  const int n = A.n;
+  if (!singular) {
+    // The concentration system is K - 1 independent ion blocks and so is every coarse operator of its hierarchy: the
+    // connected components are inverted one by one (half the work of the elimination for two blocks, and the reason a
+    // 1 760-row coarsest level is affordable)
+    std::vector<int> parent(n);
+    for (int i = 0; i < n; ++i) parent[i] = i;
+    auto find = [&](int i) { while (parent[i] != i) { parent[i] = parent[parent[i]]; i = parent[i]; } return i; };
+    for (int i = 0; i < n; ++i)
+      for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+        const int a = find(i), b = find(A.ci[j]);
+        if (a != b) parent[std::max(a, b)] = std::min(a, b);
+      }
+    int ncomp = 0;
+    for (int i = 0; i < n; ++i) ncomp += find(i) == i;
+    if (ncomp > 1 && ncomp <= 8) {
+      inv.assign((size_t)n * n, 0.0);
+      std::vector<int> loc(n, -1), idx;
+      std::vector<double> M, Mi;
+      for (int root = 0; root < n; ++root) {
+        if (find(root) != root) continue;
+        idx.clear();
+        for (int i = 0; i < n; ++i) if (find(i) == root) { loc[i] = (int)idx.size(); idx.push_back(i); }
+        const int m = (int)idx.size();
+        M.assign((size_t)m * m, 0.0);
+        for (int a = 0; a < m; ++a)
+          for (int j = A.rp[idx[a]]; j < A.rp[idx[a] + 1]; ++j) M[(size_t)a * m + loc[A.ci[j]]] = A.v[j];
+        if (!invert_dense(M, Mi, m)) return false;
+        for (int a = 0; a < m; ++a)
+          for (int b = 0; b < m; ++b) inv[(size_t)idx[a] * n + idx[b]] = Mi[(size_t)a * m + b];
+      }
+      return true;
+    }
+  }
+  std::vector<double> M((size_t)n * n, 0.0);
+  double tr = 0.0;
+  for (int i = 0; i < n; ++i)
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+      M[(size_t)i * n + A.ci[j]] = A.v[j];
+      if (A.ci[j] == i) tr += A.v[j];
+    }
+  if (singular) {
+    const double s = tr / n / n;
+    for (auto& x : M) x += s;
+  }
+  return invert_dense(M, inv, n);
+}
+
+}  // namespace kn_amg_host
