@@ -141,11 +141,15 @@ int aggregate_apart(const HostCsr& A, const std::vector<double>& d, double theta
   };
   for (int i = 0; i < n; ++i) {
     if (agg[i] >= 0 || srp[i] == srp[i + 1]) continue;
-    bool free_nb = true;
-    for (int j = srp[i]; j < srp[i + 1] && free_nb; ++j) free_nb = agg[sci[j]] < 0;
-    if (!free_nb) continue;
+    // a root needs the neighbours it would TAKE to be free, not all its strong neighbours: the ones it leaves out (the
+    // in-plane neighbours of its positive partner) belong to the other cross-section, and waiting for them kept every
+    // vertex of the second cross-section from becoming a root (its unknowns then joined the first one's aggregates as
+    // leftovers; prototype on the r = 0 hexahedral box: 16 -> 11 CG iterations)
     std::vector<int> mem{i};
     for (int j = srp[i]; j < srp[i + 1]; ++j) if (!conflicts(sci[j], mem)) mem.push_back(sci[j]);
+    bool free_nb = true;
+    for (size_t k = 1; k < mem.size() && free_nb; ++k) free_nb = agg[mem[k]] < 0;
+    if (!free_nb) continue;
     for (int k : mem) agg[k] = (int)members.size();
     members.push_back(std::move(mem));
   }
