@@ -153,7 +153,10 @@ begin, end = "<!-- r03:begin -->", "<!-- r03:end -->"
 sec = [begin, "", "## Round 3", "",
        "Written by `tools/refresh_profiles.py` from the files beside it (collected with `tools/collect_profiles.sh`, "
        "`tools/collect_traffic.sh`, `tools/pmc_ode.sh`, `tools/pmc_rows.sh` on the MI355X box): every number below is read from "
-       "the file it stands next to.", "",
+       "the file it stands next to.  (Collected before the round's last change to the hexahedral aggregation, commit "
+       "\"aggregate_apart: a root needs the neighbours it would take to be free\": `r03_dg_solves_hex_r1.json`, "
+       "`r03_dg_solves_config2h.json` and the `with_solves` entry of `r03_bench_config2h.json` are from the build before it; "
+       "the r = 1 box measured 3.75 ms per step with 6.6 CG + 2.9 BiCGStab iterations afterwards, DESIGN section 3.7.)", "",
        "| file | command | what it shows |", "|---|---|---|"]
 sec += [f"| {a} | {b} | {c} |" for a, b, c in rows]
 sec += ["", end]
