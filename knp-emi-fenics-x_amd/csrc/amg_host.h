@@ -18,7 +18,7 @@ struct HostCsr {
 
 // ---- host set-up ---------------------------------------------------------------------------------
 
-std::vector<double> diagonal(const HostCsr& A) {
+inline std::vector<double> diagonal(const HostCsr& A) {
   std::vector<double> d(A.n, 1.0);
   for (int i = 0; i < A.n; ++i)
     for (int j = A.rp[i]; j < A.rp[i + 1]; ++j)
@@ -26,9 +26,23 @@ std::vector<double> diagonal(const HostCsr& A) {
   return d;
 }
 
+// First entry with |a_ij| > factor * sqrt(|a_ii a_jj|): for the operators this set-up sees (SPD potential systems, mass- and
+// diffusion-dominated concentration systems with a drift perturbation) every off-diagonal entry is bounded by the geometric
+// mean of its two diagonal entries up to a small factor, so an entry a thousand times beyond it is not physics but a
+// corrupted value -- finite, so the non-finite test lets it pass, and large enough to collapse the damping of a level.
+inline bool find_outlier(const HostCsr& A, const std::vector<double>& d, double factor, int* row, int* col) {
+  for (int i = 0; i < A.n; ++i)
+    for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
+      const int c = A.ci[j];
+      if (c == i || c < 0 || c >= A.n) continue;
+      if (std::fabs(A.v[j]) > factor * std::sqrt(std::fabs(d[i] * d[c]))) { *row = i; *col = c; return true; }
+    }
+  return false;
+}
+
 // greedy aggregation on the strength graph (three passes: roots with free neighbourhoods, attach
 // leftovers to a neighbouring aggregate, remaining isolated points become their own aggregates)
-int aggregate(const HostCsr& A, const std::vector<double>& d, double theta, bool negative_only, std::vector<int>& agg) {
+inline int aggregate(const HostCsr& A, const std::vector<double>& d, double theta, bool negative_only, std::vector<int>& agg) {
   const int n = A.n;
   std::vector<int> srp(n + 1, 0), sci;
   sci.reserve(A.ci.size());
@@ -72,7 +86,7 @@ int aggregate(const HostCsr& A, const std::vector<double>& d, double theta, bool
 // Splits given aggregates into the connected components of the strong couplings inside them (union-find; the numbering
 // of the components follows their lowest member, so the result does not depend on the order of the unions).  Unknowns
 // that are not owned (identity rows of a rank's diagonal block) have no couplings: those of one given aggregate stay together.
-int split_aggregates(const HostCsr& A, const std::vector<double>& d, double theta, const uint8_t* owned, std::vector<int>& agg, int na) {
+inline int split_aggregates(const HostCsr& A, const std::vector<double>& d, double theta, const uint8_t* owned, std::vector<int>& agg, int na) {
   const int n = A.n;
   std::vector<int> parent(n);
   for (int i = 0; i < n; ++i) parent[i] = i;
@@ -114,7 +128,7 @@ int split_aggregates(const HostCsr& A, const std::vector<double>& d, double thet
 // cross-sections together -- every variation along the long direction is then lost to the coarse space (convergence
 // factor 0.97 of the two-level cycle on that operator).  Rule: an unknown does not join an aggregate that holds a
 // strongly positive partner of it; neighbours are taken in the order of their strength, so the in-plane ones come first.
-int aggregate_apart(const HostCsr& A, const std::vector<double>& d, double theta, double theta_pos, std::vector<int>& agg) {
+inline int aggregate_apart(const HostCsr& A, const std::vector<double>& d, double theta, double theta_pos, std::vector<int>& agg) {
   const int n = A.n;
   std::vector<int> srp(n + 1, 0), sci, prp(n + 1, 0), pci;
   std::vector<std::pair<double, int>> row;
@@ -175,7 +189,7 @@ int aggregate_apart(const HostCsr& A, const std::vector<double>& d, double theta
 }
 
 // C = A * B (Gustavson, columns of each row sorted)
-HostCsr spgemm(const HostCsr& A, const HostCsr& B) {
+inline HostCsr spgemm(const HostCsr& A, const HostCsr& B) {
   HostCsr C;
   C.n = A.n; C.m = B.m;
   C.rp.assign(A.n + 1, 0);
@@ -199,7 +213,7 @@ HostCsr spgemm(const HostCsr& A, const HostCsr& B) {
   return C;
 }
 
-HostCsr transpose(const HostCsr& A) {
+inline HostCsr transpose(const HostCsr& A) {
   HostCsr T;
   T.n = A.m; T.m = A.n;
   T.rp.assign(A.m + 1, 0);
@@ -216,7 +230,7 @@ HostCsr transpose(const HostCsr& A) {
 }
 
 // spectral radius of D^-1 A: 15 power iterations (x 1.1), capped by the Gershgorin bound
-double estimate_rho(const HostCsr& A, const std::vector<double>& d) {
+inline double estimate_rho(const HostCsr& A, const std::vector<double>& d) {
   double bound = 0.0;
   for (int i = 0; i < A.n; ++i) {
     double s = 0.0;
@@ -274,7 +288,7 @@ bool small_inverse(T* m, T* inv, int bs) {
 }
 
 // spectral radius of B^-1 A, B = the bs x bs diagonal blocks of A (power iteration, fixed seed)
-double estimate_rho_block(const HostCsr& A, int bs) {
+inline double estimate_rho_block(const HostCsr& A, int bs) {
   const int nb = A.n / bs;
   std::vector<double> binv((size_t)nb * bs * bs);
   for (int c = 0; c < nb; ++c) {
@@ -323,7 +337,7 @@ double estimate_rho_block(const HostCsr& A, int bs) {
 // stretched cells the small entries are the majority: 977 entries per row on the third level of the hexahedral DG
 // hierarchy without it).  By magnitude, not by sign: the big positive entries of stretched Q1 cells must stay in the
 // smoothing (lumped into the diagonal they inflate it and the smoothing is lost).
-HostCsr smoothed_prolongator(const HostCsr& A, const std::vector<double>& d, const std::vector<int>& agg, int na, double w,
+inline HostCsr smoothed_prolongator(const HostCsr& A, const std::vector<double>& d, const std::vector<int>& agg, int na, double w,
                              double filter_theta = 0.0) {
   HostCsr P;
   P.n = A.n; P.m = na;
@@ -361,7 +375,7 @@ HostCsr smoothed_prolongator(const HostCsr& A, const std::vector<double>& d, con
 
 // explicit inverse of the dense coarsest operator (+ shift * 1 1^T / n when it carries the constant null space)
 // Gauss-Jordan with partial pivoting: inv = M^-1 (M is destroyed)
-bool invert_dense(std::vector<double>& M, std::vector<double>& inv, int n) {
+inline bool invert_dense(std::vector<double>& M, std::vector<double>& inv, int n) {
   inv.assign((size_t)n * n, 0.0);
   for (int i = 0; i < n; ++i) inv[(size_t)i * n + i] = 1.0;
   for (int k = 0; k < n; ++k) {
@@ -389,7 +403,7 @@ bool invert_dense(std::vector<double>& M, std::vector<double>& inv, int n) {
   return true;
 }
 
-bool dense_inverse(const HostCsr& A, bool singular, std::vector<double>& inv) {
+inline bool dense_inverse(const HostCsr& A, bool singular, std::vector<double>& inv) {
   const int n = A.n;
   if (!singular) {
     // The concentration system is K - 1 independent ion blocks and so is every coarse operator of its hierarchy: the

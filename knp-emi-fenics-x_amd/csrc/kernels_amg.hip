@@ -289,6 +289,18 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
         kn_set_error("AMG set-up: level " + std::to_string(l) + " has a zero or non-finite diagonal entry in row " + std::to_string(i));
         return KNPEMI_ESOLVE;
       }
+    if (l == 0) {   // finite but absurd: |a_ij| a thousand times beyond sqrt(a_ii a_jj) (amg_host.h: find_outlier)
+      int oi = -1, oj = -1;
+      if (find_outlier(cur, d, 1e3, &oi, &oj)) {
+        char buf[256];
+        double vij = 0.0;
+        for (int j = cur.rp[oi]; j < cur.rp[oi + 1]; ++j) if (cur.ci[j] == oj) vij = cur.v[j];
+        snprintf(buf, sizeof buf, "AMG set-up: operator entry (%d, %d) = %.6e is out of scale (a_ii = %.6e, a_jj = %.6e): "
+                 "a corrupted value, refused", oi, oj, vij, d[oi], d[oj]);
+        kn_set_error(buf);
+        return KNPEMI_EINVAL;
+      }
+    }
     const double rho = estimate_rho(cur, d);
     if (!std::isfinite(rho) || !(rho > 0.0)) {
       kn_set_error("AMG set-up: spectral radius estimate of level " + std::to_string(l) + " is not a positive finite number");

@@ -319,7 +319,9 @@ __global__ void coarse_prolong_kernel(int n, const int* __restrict__ agg_of, con
   if (i >= n) return;
   const int a = agg_of[i];
   const double w = a >= 0 ? agg_w[i] : 0.0;
-  if (mode == 0) { if (a >= 0) z[i] += (1.0 - w) * zc[a] + w * zc[a + 1]; }
+  // w == 0 (one node per rank and sub-domain, or a vertex on the lower node itself): zc[a + 1] may lie past the nl entries
+  // coarse_solve_kernel writes -- it must not be read, 0 * (stale NaN) would poison z
+  if (mode == 0) { if (a >= 0) z[i] += w > 0.0 ? (1.0 - w) * zc[a] + w * zc[a + 1] : zc[a]; }
   else z[i] = a < 0 ? 0.0 : (a == pick ? 1.0 - w : (a + 1 == pick ? w : 0.0));
 }
 
@@ -522,7 +524,9 @@ static int coarse_setup(Ctx& c, double* work_phi, double* work_y) {
   if (!d.d_coarse_inv) {
     void* p = nullptr;
     KN_HIP(hipMalloc(&p, (size_t)KN_COARSE_MAX * KN_COARSE_MAX * sizeof(double))); h->allocs.push_back(p); d.d_coarse_inv = static_cast<double*>(p);
-    KN_HIP(hipMalloc(&p, KN_COARSE_MAX * sizeof(double))); h->allocs.push_back(p); d.d_coarse_z = static_cast<double*>(p);
+    KN_HIP(hipMalloc(&p, (KN_COARSE_MAX + 1) * sizeof(double))); h->allocs.push_back(p); d.d_coarse_z = static_cast<double*>(p);
+    // (KNPEMI_DEBUG_POISON_COARSE: all-ones bytes = NaN, for the test that no entry past the nl written ones is read)
+    KN_HIP(hipMemset(d.d_coarse_z, getenv("KNPEMI_DEBUG_POISON_COARSE") ? 0xFF : 0, (KN_COARSE_MAX + 1) * sizeof(double)));
   }
   std::vector<double> Ac((size_t)nc * nc, 0.0), col(nc);
   for (int j = 0; j < nc; ++j) {

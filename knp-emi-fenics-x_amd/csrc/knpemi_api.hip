@@ -1038,6 +1038,10 @@ extern "C" int knpemi_assemble_knp(knpemi_handle* h, int flags) {
   if (!h) return fail(KNPEMI_EINVAL, "null handle");
   if (!h->have_params) return fail(KNPEMI_EINVAL, "knpemi_assemble_knp: knpemi_set_params not called");
   KN_HIP(hipSetDevice(h->device));
+  // phi_M and I_ch come from the ODE sweeps, which may run on the auxiliary streams: the assembly is ordered after them
+  // whether or not the caller has called knpemi_join (a wait on a completed or never-recorded event costs nothing)
+  KN_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  KN_HIP(hipStreamWaitEvent(h->stream, h->ev_join2, 0));
   if (flags & KNPEMI_MEMBRANE_EARLY) {   // the integrals were prepared by knpemi_assemble_knp_membrane_early
     if (h->pre_pending) {
       KN_HIP(hipStreamWaitEvent(h->stream, h->ev_pre, 0));
@@ -1057,6 +1061,7 @@ extern "C" int knpemi_solve_emi(knpemi_handle* h, double rtol, double atol, int 
   if (!(rtol >= 0) || !(atol >= 0) || maxit < 0) return fail(KNPEMI_EINVAL, "knpemi_solve_emi: bad tolerances");
   KN_HIP(hipSetDevice(h->device));
   KN_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));   // a matrix assembled on the auxiliary stream is complete
+  KN_HIP(hipStreamWaitEvent(h->stream, h->ev_join2, 0));  // ... and so is every sweep whose output the right-hand side holds
   return kn_solve_emi(h, rtol, atol, maxit, iters, relres);
 }
 
@@ -1064,6 +1069,11 @@ extern "C" int knpemi_solve_knp(knpemi_handle* h, double rtol, double atol, int 
   if (!h) return fail(KNPEMI_EINVAL, "null handle");
   if (!(rtol >= 0) || !(atol >= 0) || maxit < 0) return fail(KNPEMI_EINVAL, "knpemi_solve_knp: bad tolerances");
   KN_HIP(hipSetDevice(h->device));
+  // every writer of A_knp, b_knp and their inputs (the potential, phi_M, I_ch) is on the main stream or joined into it
+  // before the set-up's device-to-host copy and the first iteration read them (round-3 advisor finding: this entry point
+  // waited on neither join event)
+  KN_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  KN_HIP(hipStreamWaitEvent(h->stream, h->ev_join2, 0));
   return kn_solve_knp(h, rtol, atol, maxit, iters, relres);
 }
 

@@ -11,8 +11,10 @@ hand-written `RHS_HIP`.  Nothing is imported or executed: the function is parsed
 not be installed).
 
 Supported: assignments to names / tuples of names, stores into `values[...]` / `parameters[...]`, `+ - * / **`,
-unary `-`, comparisons (as 0.0 / 1.0 factors, the way `(t < 125e-3)` is used), conditional expressions, calls of
-`math.` / `np.` / `numpy.` functions with a C counterpart, numeric literals, string statements (the commented-out blocks
+unary `-`, `%` / `np.mod` (Python's sign convention: a - b floor(a / b); `math.fmod` / `np.fmod` stay C's fmod),
+comparisons (as 0.0 / 1.0 factors, the way `(t < 125e-3)` is used), conditional expressions, calls of
+`math.` / `np.` / `numpy.` functions with a C counterpart and the matching number of arguments (`math.log(x, base)` becomes
+a quotient of logarithms), numeric literals, string statements (the commented-out blocks
 Gotran modules carry) and a trailing `return`.  Anything else raises `NotImplementedError` naming the construct.
 """
 from __future__ import annotations
@@ -27,17 +29,43 @@ import textwrap
 _FUNCS = {
     "exp": "kn_exp", "log": "kn_log", "sqrt": "sqrt", "pow": "pow", "power": "pow", "fabs": "fabs", "abs": "fabs", "absolute": "fabs",
     "sin": "sin", "cos": "cos", "tan": "tan", "tanh": "tanh", "sinh": "sinh", "cosh": "cosh", "atan": "atan", "arctan": "atan",
-    "log10": "log10", "log1p": "log1p", "expm1": "expm1", "floor": "floor", "ceil": "ceil", "fmod": "fmod", "mod": "fmod",
+    "log10": "log10", "log1p": "log1p", "expm1": "expm1", "floor": "floor", "ceil": "ceil", "fmod": "fmod",
     "minimum": "fmin", "maximum": "fmax", "fmin": "fmin", "fmax": "fmax", "exp2": "exp2", "log2": "log2",
 }
+# number of arguments of each C counterpart (a call with another count is refused by name, not left to hipRTC)
+_ARITY = {name: 2 if c in ("pow", "fmod", "fmin", "fmax") else 1 for name, c in _FUNCS.items()}
+
+
+def _py_mod(a, b):
+    """Python's `%` and np.mod take the sign of the DIVISOR, C's fmod that of the dividend: a - b floor(a / b) is the
+    former (math.fmod / np.fmod are the latter and stay fmod)."""
+    return f"({a} - {b} * floor({a} / {b}))"
+
+
 _CONSTS = {"pi": "3.141592653589793", "e": "2.718281828459045"}
 _CMP = {ast.Lt: "<", ast.LtE: "<=", ast.Gt: ">", ast.GtE: ">=", ast.Eq: "==", ast.NotEq: "!="}
 _ARRAYS = ("states", "values", "parameters")
 
 
+def _const_int(e):
+    """Value of an integer literal or of `+ - *` arithmetic on integer literals (`parameters[15 + 1]`), else None."""
+    if isinstance(e, ast.Constant) and isinstance(e.value, int) and not isinstance(e.value, bool):
+        return e.value
+    if isinstance(e, ast.UnaryOp) and isinstance(e.op, (ast.USub, ast.UAdd)):
+        v = _const_int(e.operand)
+        return None if v is None else (-v if isinstance(e.op, ast.USub) else v)
+    if isinstance(e, ast.BinOp) and isinstance(e.op, (ast.Add, ast.Sub, ast.Mult)):
+        a, b = _const_int(e.left), _const_int(e.right)
+        if a is None or b is None:
+            return None
+        return a + b if isinstance(e.op, ast.Add) else a - b if isinstance(e.op, ast.Sub) else a * b
+    return None
+
+
 class _Emitter:
-    def __init__(self, argnames):
+    def __init__(self, argnames, n_states=None, n_params=None):
         self.t, self.states, self.values, self.parameters = argnames
+        self.sizes = {"states": n_states, "values": n_states, "parameters": n_params}
         self.declared = set()
         self.lines = []
 
@@ -62,10 +90,13 @@ class _Emitter:
             return f"v_{e.id}"
         if isinstance(e, ast.Subscript):
             arr = self.array(e.value.id) if isinstance(e.value, ast.Name) else None
-            idx = e.slice
-            if arr is None or not (isinstance(idx, ast.Constant) and isinstance(idx.value, int)):
+            idx = _const_int(e.slice)
+            if arr is None or idx is None:
                 raise NotImplementedError("only states[i] / values[i] / parameters[i] with a literal index are indexed")
-            return f"{arr}[{idx.value}]"
+            size = self.sizes[arr]
+            if idx < 0 or (size is not None and idx >= size):
+                raise NotImplementedError(f"index {idx} of `{arr}` is out of range" + (f" (0 .. {size - 1})" if size else ""))
+            return f"{arr}[{idx}]"
         if isinstance(e, ast.UnaryOp):
             if isinstance(e.op, ast.USub):
                 return f"(-{self.expr(e.operand)})"
@@ -85,7 +116,7 @@ class _Emitter:
             if isinstance(e.op, ast.Pow):
                 return f"pow({a}, {b})"
             if isinstance(e.op, ast.Mod):
-                return f"fmod({a}, {b})"
+                return _py_mod(a, b)
             raise NotImplementedError(f"binary operator {type(e.op).__name__}")
         if isinstance(e, ast.Compare):
             if len(e.ops) != 1 or type(e.ops[0]) not in _CMP:
@@ -104,9 +135,19 @@ class _Emitter:
                 raise NotImplementedError(f"call of `{ast.unparse(f)}`")
             if name == "float" and len(e.args) == 1:
                 return self.expr(e.args[0])
-            if name not in _FUNCS or e.keywords:
+            if e.keywords:
+                raise NotImplementedError(f"keyword arguments in the call of `{ast.unparse(f)}`")
+            args = [self.expr(a) for a in e.args]
+            if name in ("mod", "remainder") and len(args) == 2:      # np.mod / np.remainder: the sign of the divisor
+                return _py_mod(args[0], args[1])
+            if name == "log" and len(args) == 2:                      # math.log(x, base)
+                return f"(kn_log({args[0]}) / kn_log({args[1]}))"
+            if name not in _FUNCS:
                 raise NotImplementedError(f"function `{ast.unparse(f)}` has no device counterpart here")
-            return f"{_FUNCS[name]}({', '.join(self.expr(a) for a in e.args)})"
+            if len(args) != _ARITY[name]:
+                raise NotImplementedError(f"`{ast.unparse(f)}` called with {len(args)} argument(s), its device counterpart "
+                                          f"`{_FUNCS[name]}` takes {_ARITY[name]}")
+            return f"{_FUNCS[name]}({', '.join(args)})"
         raise NotImplementedError(f"expression `{ast.unparse(e)}`")
 
     # -- statements ---------------------------------------------------------------------------------------------
@@ -136,6 +177,9 @@ class _Emitter:
             tgt, val = st.targets[0], st.value
             if isinstance(tgt, (ast.Tuple, ast.List)):
                 if isinstance(val, ast.Name) and self.array(val.id):          # (a, b, c) = parameters
+                    size = self.sizes[self.array(val.id)]
+                    if size is not None and len(tgt.elts) != size:            # Python raises ValueError here
+                        raise NotImplementedError(f"{len(tgt.elts)} names unpacked from `{val.id}`, which has {size} entries")
                     for i, el in enumerate(tgt.elts):
                         self.store(el, f"{self.array(val.id)}[{i}]")
                     return
@@ -168,15 +212,17 @@ def _function_def(tree, name):
     raise ValueError(f"no function `{name}` in the given source")
 
 
-def hip_source_from_python(source, func=None):
+def hip_source_from_python(source, func=None, n_states=None, n_params=None):
     """HIP source of `rhs` from the Python source text `source` of a right-hand side with numbalsoda's signature
-    `(t, states, values, parameters)`; `func` picks the function by name (first function definition otherwise)."""
+    `(t, states, values, parameters)`; `func` picks the function by name (first function definition otherwise).
+    `n_states` / `n_params`, when known, are the lengths `(a, b, ...) = states` / `= parameters` must unpack and the bound
+    of every literal index."""
     tree = ast.parse(textwrap.dedent(source))
     fd = _function_def(tree, func)
     args = [a.arg for a in fd.args.args]
     if len(args) != 4:
         raise NotImplementedError(f"`{fd.name}` does not have the signature (t, states, values, parameters)")
-    em = _Emitter(args)
+    em = _Emitter(args, n_states, n_params)
     for st in fd.body:
         em.statement(st)
     head = (f"// generated by knpemi.rhs_codegen from the Python function `{fd.name}`\n"
@@ -196,7 +242,13 @@ def hip_source_from_module(ode):
             src = inspect.getsource(fn)
         except (OSError, TypeError):
             continue
-        return hip_source_from_python(src, getattr(fn, "__name__", None))
+        sizes = {}
+        for key, init in (("n_states", "init_state_values"), ("n_params", "init_parameter_values")):
+            try:
+                sizes[key] = len(getattr(ode, init)())
+            except Exception:      # noqa: BLE001 -- a module without the tables: no bound to check against
+                sizes[key] = None
+        return hip_source_from_python(src, getattr(fn, "__name__", None), **sizes)
     return None
 
 

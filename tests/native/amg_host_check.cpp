@@ -67,6 +67,11 @@ int amg_host_dense_inverse(int n, const int* rp, const int* ci, const double* v,
   return 1;
 }
 
+int amg_host_outlier(int n, const int* rp, const int* ci, const double* v, double factor, int* row, int* col) {
+  const HostCsr A = make(n, rp, ci, v);
+  return find_outlier(A, diagonal(A), factor, row, col) ? 1 : 0;
+}
+
 double amg_host_rho(int n, const int* rp, const int* ci, const double* v) {
   const HostCsr A = make(n, rp, ci, v);
   return estimate_rho(A, diagonal(A));

@@ -29,6 +29,7 @@ def lib():
     L.amg_host_dense_inverse.argtypes = [C.c_int, ip, ip, dp, C.c_int, dp]
     L.amg_host_rho.argtypes = [C.c_int, ip, ip, dp]
     L.amg_host_rho.restype = C.c_double
+    L.amg_host_outlier.argtypes = [C.c_int, ip, ip, dp, C.c_double, ip, ip]
     return L
 
 
@@ -103,6 +104,12 @@ def test_positively_coupled_unknowns_stay_in_different_aggregates(lib):
     # other copy's aggregate next door through its weak negative couplings): the copies mostly get aggregates of their own
     pure = lambda ag: sum(1 for g in range(ag.max() + 1) if len({int(i >= m) for i in np.flatnonzero(ag == g)}) == 1)
     assert pure(plain) == 0 and pure(apart) >= na // 2, (pure(apart), na)
+    # BOTH copies seed aggregates: a vertex becomes a root when the neighbours it would TAKE are free (the in-plane ones),
+    # not all its strong neighbours -- with the earlier rule (every strong neighbour free) the vertices of one copy waited
+    # for the other copy's in-plane neighbours, never became roots and joined the other copy's aggregates as leftovers
+    # (25 aggregates, none of them in copy 0 alone, 9 mixed; now 18 = 9 + 9, none mixed)
+    per_copy = [sum(1 for g in range(na) if {int(i >= m) for i in np.flatnonzero(apart == g)} == {c}) for c in (0, 1)]
+    assert min(per_copy) >= na // 3 and sum(per_copy) == na, (per_copy, na)
 
 
 def test_given_aggregates_split_along_their_strong_couplings(lib):
@@ -193,3 +200,23 @@ def test_dense_inverse_of_the_coarsest_level(lib):
     Z = sp.csr_matrix(np.array([[1.0, 1.0], [1.0, 1.0]]))
     n, rp, ci, v, a = _args(Z)
     assert lib.amg_host_dense_inverse(*a, 0, _p(np.zeros((2, 2)), C.c_double)) == 0
+
+
+def test_an_outlier_entry_is_found_and_named(lib):
+    """One finite but absurd entry (1e300, or merely 1e6 times its row's scale) passed the round-3 set-up, which only refused
+    non-finite values: it collapses the damping 4 / (3 rho) of the level and changes every coarser operator.  The set-up
+    now refuses |a_ij| > factor * sqrt(|a_ii a_jj|) and names the entry (kn_amg_host::find_outlier)."""
+    A = _laplace_2d(8, 8).tolil()
+    n, rp, ci, v, a = _args(A.tocsr())
+    i, j = C.c_int(-1), C.c_int(-1)
+    assert lib.amg_host_outlier(*a, 1e3, C.byref(i), C.byref(j)) == 0
+    for bad in (1e300, -4e6):
+        B = A.copy()
+        B[19, 20] = bad
+        n, rp, ci, v, a = _args(B.tocsr())
+        assert lib.amg_host_outlier(*a, 1e3, C.byref(i), C.byref(j)) == 1 and (i.value, j.value) == (19, 20)
+    # the positive couplings of stretched cells (0.48 sqrt(a_ii a_jj)) and a drift-skewed row are nowhere near the bound
+    B = A.copy()
+    B[5, 6], B[6, 5] = -3.0, 1.0
+    n, rp, ci, v, a = _args(B.tocsr())
+    assert lib.amg_host_outlier(*a, 1e3, C.byref(i), C.byref(j)) == 0

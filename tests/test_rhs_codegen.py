@@ -14,51 +14,49 @@ from knpemi.rhs_codegen import hip_source_from_module, hip_source_from_python
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# A right-hand side in the style of the Gotran-generated modules the reference ships (decorated numba cfunc, parameter
-# unpacking, math. / np. calls, a comparison used as a factor, `**` and math.pow, a commented-out block as a string
-# statement, stores into values[] and -- the side effect -- parameters[]): Hodgkin-Huxley in SI units, SURVEY appendix C.1.
-HH_PY = '''
+# A SYNTHETIC right-hand side written for this test (not any model of the reference): three states, nine parameters, and
+# every construct the Gotran-generated modules of the reference use -- a decorated numba cfunc, parameter unpacking one by
+# one, several on a line and as a tuple, math. / np. calls, a comparison used as a factor, `**` and math.pow, `%` and np.mod
+# on a possibly NEGATIVE operand, a two-argument math.log, a conditional expression, an augmented assignment, a line
+# continuation, a commented-out block as a string statement, stores into values[] and -- the side effect -- parameters[].
+SYNTH_PY = '''
 @cfunc(lsoda_sig, nopython=True)
 def rhs_numba(t, states, values, parameters):
     """
     Compute the right hand side
     """
-    g_Na_bar = parameters[0]; g_K_bar = parameters[1]
-    g_leak_Na = parameters[2]
-    g_leak_K = parameters[3]
-    m_K = parameters[4]
-    m_Na = parameters[5]
-    I_max = parameters[6]
-    Cm = parameters[7]
-    stim_amplitude = parameters[8]
-    K_e, K_i, Na_e, Na_i = parameters[9], parameters[10], parameters[11], parameters[12]
-    z_K = parameters[19]
-    psi = parameters[21]
-    E_Na = 1/psi * 1/z_K * math.log(Na_e/Na_i)
-    E_K = 1/psi * 1/z_K * math.log(K_e/K_i)
+    gain = parameters[0]; leak = parameters[1]
+    tau = parameters[2]
+    a_in, a_out, shift = parameters[3], parameters[4], parameters[5]
+    period = parameters[6]
+    (u, w, q) = states
+    rev = 1/gain * math.log(a_out/a_in)
     """
-    alpha_m = an older variant kept as a comment
+    rate = an older variant kept as a comment
     """
-    alpha_m = 0.1e3 * (25. - 1.0e3*(states[3] + 65.0e-3))/(math.exp((25. - 1.0e3*(states[3] + 65.0e-3))/10.) - 1)
-    beta_m = 4.e3*math.exp(- 1.0e3*(states[3] + 65.0e-3)/18.)
-    values[0] = (1 - states[0])*alpha_m - states[0]*beta_m
-    alpha_h = 0.07e3*math.exp(- 1.0e3*(states[3] + 65.0e-3)/20.)
-    beta_h = 1.e3/(math.exp((30.- 1.0e3*(states[3] + 65.0e-3))/10.) + 1)
-    values[1] = (1 - states[1])*alpha_h - states[1]*beta_h
-    alpha_n = 0.01e3*(10.- 1.0e3*(states[3] + 65.0e-3))/(math.exp((10.- 1.0e3*(states[3] + 65.0e-3))/10.) - 1.)
-    beta_n = 0.125e3*math.exp(- 1.0e3*(states[3] + 65.0e-3) /80.)
-    values[2] = (1 - states[2])*alpha_n - states[2]*beta_n
-    i_Stim = stim_amplitude * np.exp(-np.mod(t, 0.03)/0.002)*(t < 125e-3)
-    i_pump = I_max / ((1 + m_K / K_e) ** 2 * (1 + m_Na / Na_i) ** 3)
-    i_Na = (g_leak_Na + g_Na_bar * states[1] * math.pow(states[0], 3) + i_Stim) * \\
-           (states[3] - E_Na) + 3 * i_pump
-    i_K = (g_leak_K + g_K_bar * math.pow(states[2], 4)) * \\
-          (states[3] - E_K) - 2 * i_pump
-    parameters[15] = i_Na
-    parameters[16] = i_K
-    parameters[17] = 0.0
-    values[3] = (- i_K - i_Na) / Cm
+    rate = 0.5e2 * (3. - 2.0e1*(u + shift))/(math.exp((3. - 2.0e1*(u + shift))/4.) - 1)
+    decay = 7.e1*math.exp(- 2.0e1*(u + shift)/9.)
+    values[1] = (1 - w)*rate - w*decay
+    phase = np.mod(t - 0.4*period, period)
+    wrapped = (t - 0.4*period) % period
+    trunc = math.fmod(t - 0.4*period, period)
+    drive = parameters[7] * np.exp(-phase/0.3)*(t < 2.5) + 1e-3*(wrapped - phase) + 1e-2*trunc
+    octave = math.log(1.0 + q*q, 2.0)
+    pump = leak / ((1 + tau / a_out) ** 2 * (1 + tau / a_in) ** 3)
+    i_fast = (leak + gain * w * math.pow(u, 2) + drive) * \\
+             (u - rev) + 3 * pump
+    i_slow = (0.5*leak if u > rev else 2.0*leak) * (u - rev) - 2 * pump
+    i_slow += octave
+    parameters[7 + 1] = i_fast - i_slow
+    values[0] = (- i_slow - i_fast) / tau
+    values[2] = -q/tau + np.sqrt(np.absolute(u))
 '''
+
+
+def _synth_tables(rng):
+    s = np.array([-0.3, 0.4, 0.7]) * (1.0 + 0.05 * rng.standard_normal(3))
+    p = np.array([1.7, 0.3, 2.5, 11.0, 140.0, 0.12, 0.9, 4.0, 0.0])
+    return s, p
 
 
 def _python_function(source, name):
@@ -91,26 +89,35 @@ def _load(path, name):
 
 
 def test_gotran_style_rhs_translates_and_computes_the_same_numbers():
-    hip = hip_source_from_python(HH_PY, "rhs_numba")
+    hip = hip_source_from_python(SYNTH_PY, "rhs_numba", n_states=3, n_params=9)
     assert "__device__ inline void rhs(double t, const double* states, double* values, double* parameters)" in hip
     lib = _host_build(hip)
-    f = _python_function(HH_PY, "rhs_numba")
-    mm = _load(os.path.join(ROOT, "examples", "idealized_geometries", "mm_hh.py"), "mm_hh_tables")
+    f = _python_function(SYNTH_PY, "rhs_numba")
     rng = np.random.default_rng(1)
-    for t in (0.0, 0.0123, 0.031, 0.2):
-        s = np.asarray(mm.init_state_values(), float) * (1.0 + 0.05 * rng.standard_normal(4))
-        p = np.asarray(mm.init_parameter_values(), float)
-        p[mm.parameter_indices("Cm")] = 0.02
-        p[mm.parameter_indices("stim_amplitude")] = 10.0
-        for n_, v in (("K_e", 3.3), ("K_i", 124.0), ("Na_e", 100.7), ("Na_i", 12.8), ("z_K", 1.0), ("psi", 38.7)):
-            p[mm.parameter_indices(n_)] = v
-        v_py, p_py = np.zeros(4), p.copy()
+    dp = C.POINTER(C.c_double)
+    for t in (0.0, 0.123, 0.31, 0.37, 2.0, 3.1):          # t - 0.4 period < 0 for the first ones: the sign of `%` matters
+        s, p = _synth_tables(rng)
+        v_py, p_py = np.zeros(3), p.copy()
         f(t, s, v_py, p_py)
-        v_c, p_c = np.zeros(4), p.copy()
-        lib.call(t, s.ctypes.data_as(C.POINTER(C.c_double)), v_c.ctypes.data_as(C.POINTER(C.c_double)),
-                 p_c.ctypes.data_as(C.POINTER(C.c_double)))
-        assert np.allclose(v_c, v_py, rtol=1e-14, atol=0) and np.allclose(p_c, p_py, rtol=1e-14, atol=0)
-        assert p_c[15] != p[15] and p_c[17] == 0.0              # the side-effect currents were stored
+        v_c, p_c = np.zeros(3), p.copy()
+        lib.call(t, s.ctypes.data_as(dp), v_c.ctypes.data_as(dp), p_c.ctypes.data_as(dp))
+        assert np.allclose(v_c, v_py, rtol=1e-13, atol=0) and np.allclose(p_c, p_py, rtol=1e-13, atol=0), t
+        assert p_c[8] != p[8]                                    # the side-effect store happened
+
+
+def test_modulo_takes_the_sign_of_the_divisor_as_in_python():
+    """`%` and np.mod follow the divisor's sign, math.fmod / np.fmod the dividend's (C's fmod): a time-modulo stimulus with
+    a negative operand must not change value in translation (round-3 advisor finding: all three were emitted as fmod)."""
+    src = ("def rhs(t, states, values, parameters):\n"
+           "    values[0] = (t - 5.0) % 3.0\n    values[1] = np.mod(t - 5.0, 3.0)\n    values[2] = math.fmod(t - 5.0, 3.0)\n"
+           "    values[3] = np.fmod(t - 5.0, -3.0)\n    values[4] = (t - 5.0) % -3.0\n")
+    lib = _host_build(hip_source_from_python(src))
+    dp = C.POINTER(C.c_double)
+    for t in (0.5, 4.0, 7.25, -2.0):
+        v = np.zeros(5)
+        lib.call(t, np.zeros(1).ctypes.data_as(dp), v.ctypes.data_as(dp), np.zeros(1).ctypes.data_as(dp))
+        x = t - 5.0
+        assert np.allclose(v, [x % 3.0, np.mod(x, 3.0), math.fmod(x, 3.0), np.fmod(x, -3.0), x % -3.0], rtol=1e-15, atol=1e-15), (t, v)
 
 
 def test_module_rhs_matches_the_hand_written_device_source():
@@ -142,12 +149,22 @@ def test_unsupported_constructs_are_named():
         hip_source_from_python("def rhs(t, states, values, parameters):\n    values[0] = undefined_name\n")
     with pytest.raises(NotImplementedError, match="signature"):
         hip_source_from_python("def rhs(t, states):\n    return 0\n")
+    head = "def rhs(t, states, values, parameters):\n"
+    with pytest.raises(NotImplementedError, match=r"math.exp.*2 argument"):        # wrong arity: named, not a hipRTC error
+        hip_source_from_python(head + "    values[0] = math.exp(t, 2.0)\n")
+    with pytest.raises(NotImplementedError, match="3 names unpacked from `parameters`, which has 4"):
+        hip_source_from_python(head + "    (a, b, c) = parameters\n    values[0] = a\n", n_params=4)
+    with pytest.raises(NotImplementedError, match="out of range"):
+        hip_source_from_python(head + "    values[0] = parameters[4]\n", n_params=4)
+    with pytest.raises(NotImplementedError, match="keyword"):
+        hip_source_from_python(head + "    values[0] = np.power(t, x2=2.0)\n")
+    assert "(kn_log(t) / kn_log(10.0))" in hip_source_from_python(head + "    values[0] = math.log(t, 10)\n")
 
 
 def test_generated_source_cross_compiles_for_gfx950(hip_lib):
     log = C.create_string_buffer(1 << 16)
-    hip = hip_source_from_python(HH_PY, "rhs_numba")
-    assert hip_lib.knpemi_ode_compile_source(4, 22, hip.encode(), log, len(log)) == 0, log.value.decode()
+    hip = hip_source_from_python(SYNTH_PY, "rhs_numba", n_states=3, n_params=9)
+    assert hip_lib.knpemi_ode_compile_source(3, 9, hip.encode(), log, len(log)) == 0, log.value.decode()
 
 
 @pytest.mark.gpu

@@ -134,3 +134,28 @@ def test_every_entry_of_the_assembled_systems_is_written_by_the_assembly(hip_lib
         Ak2, bk2 = knp.assemble()
         for new, old in ((A2.data, A.data), (emi.P.data, P.data), (Ak2.data, Ak.data), (b2, b), (bk2, bk)):
             assert np.array_equal(new, old), (kind, r)
+
+
+def test_coarse_space_with_one_function_per_rank_and_sub_domain_reads_nothing_past_its_nodes(hip_lib, monkeypatch):
+    """knpemi_set_distributed_coarse with world * n_sub > 32: one node per (rank, sub-domain), k = 0, every vertex has weight
+    0 in the "upper" node -- which, for the last sub-domain, lies past the nl entries coarse_solve_kernel writes.  The
+    round-3 prolongation multiplied that entry by 0 (advisor finding: 0 * stale NaN).  Rehearsed on one process as rank 0
+    of 20 (the other ranks contribute nothing to the sums, so the system is this rank's own) with the buffer poisoned."""
+    import ctypes as C
+    import torch
+    monkeypatch.setenv("KNPEMI_DEBUG_POISON_COARSE", "1")
+    s, dp, (A, b), _ = _systems("tet", 0)
+    n = A.shape[0]
+    red = torch.zeros(8 + 64, dtype=torch.float64, device="cuda")
+    cb = (L.ALLREDUCE_FN(lambda ctx, m: 0), L.HALO_FN(lambda ctx, vec, which: 0))
+    own = np.ones(n, np.uint8)
+    L.check(dp.lib.knpemi_set_distributed(dp.h, own.ctypes.data_as(L.c_u8_p), red.data_ptr(),
+                                          C.cast(cb[0], C.c_void_p), C.cast(cb[1], C.c_void_p), None))
+    L.check(dp.lib.knpemi_set_distributed_coarse(dp.h, 0, 20))
+    dp.set_solution(L.B_EMI, np.zeros(n))
+    its, relres = dp.solve(L.B_EMI, 1e-8, 1e-40, 200)
+    x = dp.get_solution(L.B_EMI, n)
+    assert np.isfinite(x).all() and relres <= 1e-8 and its < 100, (its, relres)
+    r = b - b.mean() - A @ x
+    assert np.abs(r).max() <= 1e-6 * np.abs(b).max()
+    L.check(dp.lib.knpemi_set_distributed(dp.h, None, None, None, None, None))
