@@ -23,6 +23,7 @@ are integrated redundantly), and the recorded trajectory comes from the distribu
 (knpemi_set_distributed: halo'd SpMV, all-reduced dot products, per-GPU AMG).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...        (starts the N ranks itself, as a child `python -m torch.distributed.run`)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -865,16 +866,33 @@ def main():
                     help="assemble A_knp twice per step as the reference does (p = a, knpWeakForm.py:319)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher (the reference is started with plain `mpirun` on an unchanged script,
+        # examples/idealized_geometries/run_3D.py:27,117-121): start one rank per GPU as a CHILD process -- before torch is
+        # imported or anything touches the GPU, never by replacing this process -- and hand its exit code on.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     if os.environ.get("KNPEMI_BENCH_WATCHDOG"):   # diagnosis of a stuck rank: Python stacks of every thread after so many seconds
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["KNPEMI_BENCH_WATCHDOG"]), repeat=True, file=sys.stderr)
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("KNPEMI_BENCH_LAUNCH_PROBE"):   # test hook of the self-launch: report the rank's environment, exit with the given code
+        print(f"bench launch probe: rank {rank} of {world}, local rank {local_rank}, --gpus {args.gpus}", flush=True)
+        raise SystemExit(int(os.environ["KNPEMI_BENCH_LAUNCH_PROBE"]) if rank == world - 1 else 0)
+    import torch
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench: --gpus {args.gpus} but WORLD_SIZE = {world} (one rank per GPU; without a launcher "
+                         f"`python bench.py --gpus N` starts torch.distributed.run itself)")
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -158,3 +158,20 @@ def test_rccl_halo_transport_rehearsal_on_one_gpu():
     assert p.returncode == 0 and "ALL OK" in out, out[-3000:]
     assert out.count("library RCCL exchange") == 5 and "correct: False" not in out, out[-3000:]
     assert "distributed solves through the library's hooks" in out and "WRONG" not in out, out[-3000:]
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` without a launcher (WORLD_SIZE unset): bench.py starts torch.distributed.run itself as a
+    child process; rehearsed with both ranks on this one card and gloo as the process-group backend.  The line must carry
+    n_gpus = 2, the x-slab partition and a positive value."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(KNPEMI_BENCH_BACKEND="gloo", KNPEMI_BENCH_TRAJ_MIN="8", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--repeats", "2", "--cpu-steps", "0", "--solve-steps", "0", "--no-dg", "--no-config3"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["partition"] == "x-slabs", out["config"]

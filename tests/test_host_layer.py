@@ -96,3 +96,21 @@ def test_membrane_model_tables_and_protocol():
         mm.step_lsoda(1e-4, {})
     with pytest.raises(AssertionError):
         MembraneModel(hh, ft, 1.0, Q)
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus N` with WORLD_SIZE unset (round-3 review: it exited with "launch N > 1 with
+    torch.distributed.run"; the reference's drivers are started with plain `mpirun` on an unchanged script,
+    /root/reference/examples/idealized_geometries/run_3D.py:27,117-121): N ranks are started as a child
+    `python -m torch.distributed.run` before torch is imported, and the child's exit code is handed on."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for code in (0, 3):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4"],
+                           env=dict(env, KNPEMI_BENCH_LAUNCH_PROBE=str(code)), capture_output=True, text=True, timeout=300)
+        out = p.stdout + p.stderr
+        assert "rank 0 of 2, local rank 0, --gpus 2" in out and "rank 1 of 2, local rank 1, --gpus 2" in out, out[-2000:]
+        assert (p.returncode == 0) == (code == 0), (code, p.returncode, out[-2000:])
