@@ -48,6 +48,7 @@ SPIKE_SEARCH = 72        # trajectory steps recorded at least: contains the acti
 if os.environ.get("KNPEMI_BENCH_TRAJ_MIN"):     # rehearsals of the N > 1 code path on one GPU (gloo, ranks sharing the card)
     SPIKE_SEARCH = max(8, int(os.environ["KNPEMI_BENCH_TRAJ_MIN"]))
 WITH_SOLVES_START = 10   # trajectory step the with_solves pass starts from, whatever --steps / --warmup are
+AGREEMENT_LIMIT = 1e-6   # cpu_baseline.agreement above this ends the bench with a non-zero exit code
 
 WORKLOADS = {
     # name: (family, mesh kind, resolution factor) -- geometry of make_mesh_3D.py, 6 tets per hexahedron
@@ -237,7 +238,49 @@ def cpu_baseline(s, n_steps, threads=1, traj=None, start=0):
         if k >= start:
             t_ode += t1 - t0
             t_asm += t2 - t1
-    return (t_asm + t_ode) / n_steps, t_asm / n_steps, t_ode / n_steps, ode.nodes
+    # what the leg holds after its last step (trajectory step start + n_steps - 1): ODE tables, currents and the
+    # systems assembled in that step, for the comparison with the GPU's replay of the same steps (`agreement`)
+    import scipy.sparse as sp
+    final = {"k_end": start + n_steps, "states": st.copy(), "I_ch": Ich.copy(),
+             "A_emi": sp.csr_matrix((port.A.copy(), port.ci, port.rp), shape=(port.ntot, port.ntot)),
+             "P_emi": sp.csr_matrix((port.Pm.copy(), port.ci, port.rp), shape=(port.ntot, port.ntot)),
+             "A_knp": sp.csr_matrix((port.Ak.copy(), port.kci, port.krp), shape=(2 * port.ntot, 2 * port.ntot)),
+             "b_emi": port.b.copy(), "b_knp": port.bk.copy()}
+    return (t_asm + t_ode) / n_steps, t_asm / n_steps, t_ode / n_steps, ode.nodes, final
+
+
+def agreement(case, replay, final):
+    """GPU against the CPU port after both have replayed the same trajectory steps 0 .. k_end - 1 (same recorded solutions
+    pasted where the solves write): the membrane ODE states and side-effect currents of the last sweep and the five
+    objects assembled in the last step, max |gpu - cpu| / max |cpu| each.  The port is checker here, not product."""
+    import numpy as np
+    from knpemi import _lib as L
+    stepper = replay.stepper
+    dp = stepper.dp
+    replay.restart(final["k_end"])
+    dp.sync()
+    m = case.models[0][0]
+    st = np.ascontiguousarray(np.empty_like(m.states))
+    pa = np.ascontiguousarray(np.empty_like(m.parameters))
+    L.check(dp.lib.knpemi_ode_get_tables(dp.h, m._sub, m._model, L.dptr(st), L.dptr(pa)))
+    ix = m.ode.parameter_indices
+    Ich = np.stack([pa[:, ix(f"I_ch_{n}")] for n in ("K", "Cl", "Na")])
+
+    def rel(a, b):
+        scale = float(np.abs(b).max())
+        return float(np.abs(a - b).max() / (scale if scale > 0 else 1.0))
+
+    def crel(A, B):
+        D = (A - B).tocoo()
+        scale = float(np.abs(B.data).max())
+        return float((np.abs(D.data).max() if D.nnz else 0.0) / (scale if scale > 0 else 1.0))
+    out = {"ode_states": rel(st, final["states"]), "I_ch": rel(Ich, final["I_ch"]),
+           "A_emi": crel(dp.csr(L.A_EMI), final["A_emi"]), "P_emi": crel(dp.csr(L.P_EMI), final["P_emi"]),
+           "A_knp": crel(dp.csr(L.A_KNP), final["A_knp"]),
+           "b_emi": rel(dp.rhs(L.B_EMI), final["b_emi"]), "b_knp": rel(dp.rhs(L.B_KNP), final["b_knp"])}
+    out["max"] = max(out.values())
+    out["after_trajectory_step"] = final["k_end"] - 1
+    return out
 
 
 def device_solvers(case, its, maxit=1000):
@@ -696,6 +739,13 @@ def measure(workload, args, torch, dist, rank, world, steps, warmup, repeats, sp
                     dom_us=dom_ms / max(dom_n, 1) * 1e3, rhs=n_rhs / reps, lsoda=n_lsoda / reps)
 
     main_w = timed_windows(warmup, repeats)
+    # the same window with A_knp assembled twice per step, as the reference does it (p = a: knpWeakForm.py:319, the second
+    # assembly at pdeSolver.py:131-139; BASELINE.md section 2 and SURVEY section 8d promise both figures)
+    twice_w = None
+    if not args.knp_twice:
+        stepper.assemble_knp_twice = True
+        twice_w = timed_windows(warmup, max(3, repeats // 2))
+        stepper.assemble_knp_twice = False
     # second window: the same number of steps around the step whose ODE sweep takes longest (the action potential passes
     # the wave that integrates it: the sweep is as slow as its slowest wave).  Found with an untimed replay of the whole
     # trajectory, the sweep bracketed by events and read back after every step.
@@ -812,6 +862,13 @@ def measure(workload, args, torch, dist, rank, world, steps, warmup, repeats, sp
                     "kernel_us_per_step": per_kernel.get("ode_step_kernel"),
                     "share_of_step": per_kernel.get("ode_step_kernel", 0.0) / (med / steps * 1e6)},
         }
+        if twice_w is not None:
+            tm = twice_w["median"]
+            out["reference_faithful_knp_assembled_twice"] = {
+                "what": "the same timed window with A_knp assembled twice per step (the reference passes p = a and "
+                        "LinearProblem assembles both: knpWeakForm.py:319, pdeSolver.py:131-139)",
+                "A_knp_assemblies_per_step": 2, "value": dofs_total / (tm / steps), "unit": "dofs/s",
+                "ms_per_step": tm / steps * 1e3, "repeats_ms_per_step": [t / steps * 1e3 for t in twice_w["times"]]}
         if spike_w is not None:
             sm = spike_w["median"]
             out["spike_window"] = {
@@ -941,13 +998,15 @@ def main():
             traj = (replay.phi_t.cpu().numpy(), replay.c_t.cpu().numpy()) if replay is not None else None
             quiet = io.StringIO()
             with contextlib.redirect_stdout(quiet):
-                t_one, a_one, o_one, _ = cpu_baseline(s, n1, threads=1, traj=traj, start=args.warmup)   # before any OpenMP team exists
+                t_one, a_one, o_one, _, _ = cpu_baseline(s, n1, threads=1, traj=traj, start=args.warmup)   # before any OpenMP team exists
                 # thread count: a fully subscribed host can be slower than a partly subscribed one (spinning OpenMP
                 # team + the Python thread, CPU shares below the visible core count): probe and time the best
                 cand = sorted({min(avail, c) for c in (4, 8, 16, 32, avail)})
                 probes = {c: cpu_baseline(s, 3, threads=c)[0] for c in cand}
                 cores = min(probes, key=probes.get)
-                t_all, a_all, o_all, nrows = cpu_baseline(s, n_all, threads=cores, traj=traj, start=args.warmup)
+                agree = None
+                t_all, a_all, o_all, nrows, final = cpu_baseline(s, n_all, threads=cores, traj=traj, start=args.warmup)
+                agree = agreement(case, replay, final) if replay is not None else None
             what = ("whole steps of the C++ port (oracle/knpemi_cpu.cpp, sequential ODEPACK restatement "
                     "oracle/lsoda_seq.h) on the same mesh, replaying the same recorded trajectory from step {w} (the "
                     "window the GPU's value is timed on): EMI (A, P, b) + KNP (A, b) assembly and update {a:.1f} ms/step, "
@@ -957,6 +1016,17 @@ def main():
                 "sample": f"{n_all} " + what.format(a=a_all * 1e3, o=o_all * 1e3, n=nrows, w=args.warmup)
                           + f"; OpenMP over cells / facets / membrane dofs, {cores} threads (fastest of "
                             f"{cand} on the {avail} cores visible to this process)"}
+            if agree is not None:
+                # both legs replayed the same steps: their numbers must agree (ODE tolerances 1e-8 / 1e-10, libm against the
+                # device's exp / log / quotients; operators of identical inputs to rounding) -- a disagreement is a failed run
+                out["cpu_baseline"]["agreement"] = {
+                    "what": "max |GPU - CPU port| / max |CPU port| after both legs replayed trajectory steps 0 .. "
+                            f"{agree['after_trajectory_step']}: membrane ODE states and channel currents of the last sweep, "
+                            "the five objects assembled in the last step", **agree, "limit": AGREEMENT_LIMIT}
+                if not agree["max"] <= AGREEMENT_LIMIT:
+                    print(json.dumps(out["cpu_baseline"]["agreement"]), file=sys.stderr)
+                    raise SystemExit(f"bench: GPU and CPU port disagree by {agree['max']:.3e} (> {AGREEMENT_LIMIT:g}) on the "
+                                     f"same trajectory")
             out["cpu_baseline_1core"] = {
                 "value": dofs_total / t_one, "unit": "dofs/s", "cores": 1, "kind": "port",
                 "sample": f"{n1} " + what.format(a=a_one * 1e3, o=o_one * 1e3, n=nrows, w=args.warmup)
@@ -970,7 +1040,8 @@ def main():
         leg, _, _, _ = measure("config3", args, torch, None, 0, 1, steps=10, warmup=5, repeats=5, spike=False)
         out["config3_leg"] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "timing", "config", "roofline",
                                                    "roofline_membrane_facet_kernel", "roofline_row_kernels_alone",
-                                                   "kernels_us_per_step", "ode")}
+                                                   "kernels_us_per_step", "ode", "reference_faithful_knp_assembled_twice")
+                              if k in leg}
     if rank == 0:
         if world == 1 and not args.no_dg and tet:
             dg = run_dg(args, torch, steps=10, warmup=2, cpu=False, solves=True)

@@ -1332,9 +1332,70 @@ def test_full_size_properties(hip_lib, kind, r, label):
     assert ode.last_stats["n_failed"] == 0
 
 
-@pytest.mark.parametrize("workload", ["config5s"])
-def test_config5_synthetic_full_size(hip_lib, workload):
-    """BASELINE configs[4] stand-in at ~1e6 tetrahedra (bench.py `config5s`: ECS + neuron cells 1,3 with the HH mV/ms
+@pytest.mark.parametrize("kind,r,label", [("tet", 1, "config 2: 124 416 tetrahedra"),
+                                          ("hex", 1, "hexahedral box r = 1: 20 736 hexahedra"),
+                                          ("hex", 2, "config 2h: 165 888 hexahedra"),
+                                          ("tet", 2, "config 3 mesh: 995 328 tetrahedra")])
+def test_full_size_assembly_matches_oracle(hip_lib, kind, r, label):
+    """The oracle on the BASELINE-size meshes (round-3 review: they were only property-checked, so the paths that only
+    large meshes exercise -- the greedy chunk clustering with its tail cut, multi-slice pair lists, five row blocks per CU,
+    the XCD remap -- had never met the oracle).  All five assembled objects (A_emi, P_emi, b_emi, A_knp, b_knp) of a
+    perturbed state at 1e-10: with the splitting scheme against the numpy oracle (oracle/knpemi_oracle.py, FFCx-style
+    quadrature + COO scatter), without it against the C++ port (oracle/knpemi_cpu.cpp, itself pinned to the numpy oracle
+    by tests/test_cpu_port.py; its CSR patterns are the numpy oracle's) -- and the port against the numpy oracle on the
+    way.  Forms: /root/reference/src/knpemi/emiWeakForm.py:138-241, knpWeakForm.py:123-216."""
+    import scipy.sparse as sp
+    import cpu_port
+    from knpemi.pdeSolver import create_solver_emi, create_solver_knp
+    s = Setup(kind, r)
+    s.perturb()
+    o, P, params, ions = s.oracle()
+    c_all, phi, phiM, mm = s.oracle_fields()
+    emi = create_solver_emi(s.a_emi, s.L_emi, s.phi, s.entity_maps, s.subdomain_list, None, p=s.p_emi, direct=False)
+    knp = create_solver_knp(s.a_knp, s.L_knp, s.c, s.entity_maps, s.subdomain_list, None, p=s.p_knp)
+
+    def device(splitting):
+        for f in (s.a_emi, s.a_knp):
+            f.shared['splitting_scheme'] = splitting
+        A, b = emi.assemble()
+        Ak, bk = knp.assemble()
+        return A.copy(), emi.P.copy(), b.copy(), Ak.copy(), bk.copy()
+    # -- with the splitting scheme: the numpy oracle
+    A, Pm, b, Ak, bk = device(True)
+    Ao, Po, bo = o.assemble_emi(P, params, ions, c_all, phiM, mm, splitting_scheme=True)
+    Ako, bko = o.assemble_knp(P, params, ions, c_all, phi, phiM, mm, s.dt, splitting_scheme=True)
+    errs = dict(A_emi=csr_rel_err(A, Ao), P_emi=csr_rel_err(Pm, Po), b_emi=rel_err(b, bo),
+                A_knp=csr_rel_err(Ak, Ako), b_knp=rel_err(bk, bko))
+    assert max(errs.values()) < TOL, (label, errs)
+    # the patterns agree entry for entry (no structural zero on either side hides a missing contribution)
+    Ao, Ako = Ao.tocsr(), Ako.tocsr()
+    Ao.sort_indices()
+    Ako.sort_indices()
+    assert np.array_equal(A.indptr, Ao.indptr) and np.array_equal(A.indices, Ao.indices), label
+    assert np.array_equal(Ak.indptr, Ako.indptr) and np.array_equal(Ak.indices, Ako.indices), label
+    # -- the C++ port on the same state (the timed CPU baseline of bench.py): against the numpy oracle, then, without the
+    # splitting scheme, as the checker of the device
+    port = cpu_port.CpuPort(P, params, ions, Ao, Ako)
+    Ich = np.stack([mm[1][0]["I_ch_k"][n] for n in ("K", "Cl", "Na")])
+    a, pp, bb = port.assemble_emi(c_all, phiM, Ich, True)
+    ak, bbk = port.assemble_knp(c_all, phi, phiM, Ich, True)
+    assert rel_err(a, Ao.data) < 1e-12 and rel_err(bb, bo) < 1e-12 and rel_err(ak, Ako.data) < 1e-12 and rel_err(bbk, bko) < 1e-12
+    A, Pm, b, Ak, bk = device(False)
+    a, pp, bb = (x.copy() for x in port.assemble_emi(c_all, phiM, Ich, False))
+    ak, bbk = (x.copy() for x in port.assemble_knp(c_all, phi, phiM, Ich, False))
+    shape = Ao.shape
+    errs = dict(A_emi=csr_rel_err(A, sp.csr_matrix((a, port.ci, port.rp), shape=shape)),
+                P_emi=csr_rel_err(Pm, sp.csr_matrix((pp, port.ci, port.rp), shape=shape)), b_emi=rel_err(b, bb),
+                A_knp=csr_rel_err(Ak, sp.csr_matrix((ak, port.kci, port.krp), shape=Ako.shape)), b_knp=rel_err(bk, bbk))
+    assert max(errs.values()) < TOL, (label, "no splitting", errs)
+    assert np.abs(b - bo).max() > 0 and np.abs(bk - bko).max() > 0      # the flag does change both right-hand sides
+
+
+@pytest.mark.parametrize("workload,n_cells,n_steps", [("config5s", 995328, 6), ("config5s_r3", 7962624, 3)])
+def test_config5_synthetic_full_size(hip_lib, workload, n_cells, n_steps):
+    """BASELINE configs[4] stand-in at ~1e6 tetrahedra and at its stated size (`config5s_r3`: 7.96 M tetrahedra, 1.37 M
+    vertices, 47 k membrane dofs; the reference-side anchor is
+    /root/reference/examples/local_astrocyte_depolarization/run_stim_duration.py:150-211) (bench.py `config5s`: ECS + neuron cells 1,3 with the HH mV/ms
     model + glial cells 2,4 with the Kir4.1/pump model, pulsed ECS K+ source): properties that need no oracle --
     structure, symmetry and null space of A_emi, P = A on the ECS rows, A_knp row sums = volume / dt, identical bits on
     re-assembly, both ODE sweeps giving equal outputs for equal inputs -- and six whole device-resident time steps
@@ -1348,7 +1409,7 @@ def test_config5_synthetic_full_size(hip_lib, workload):
     case = bench.Case(workload)
     p = case.s
     assert len(p.subdomain_list) == 3 and len(case.models) == 2
-    assert sum(sd["mesh_sub"].num_cells for sd in p.subdomain_list.values()) == 995328
+    assert sum(sd["mesh_sub"].num_cells for sd in p.subdomain_list.values()) == n_cells
     emi = create_solver_emi(p.a_emi, p.L_emi, p.phi, p.entity_maps, p.subdomain_list, None, p=p.p_emi, direct=False)
     knp = create_solver_knp(p.a_knp, p.L_knp, p.c, p.entity_maps, p.subdomain_list, None, p=p.p_knp)
     A, b = emi.assemble()
@@ -1394,13 +1455,13 @@ def test_config5_synthetic_full_size(hip_lib, workload):
     st.set_source(0, case.source)
     k0 = p.c_prev[0][0].x._a.copy()
     vm0 = {t: p.phi_M_prev[t].x._a.copy() for t in (1, 2)}
-    for _ in range(6):
+    for _ in range(n_steps):
         st.step()
     st.download()           # raises if LSODA failed anywhere
     assert all(it[1] < 200 for it in st.iterations)
     k1 = p.c_prev[0][0].x._a
     inside = p.region
-    assert inside.sum() > 10 and (k1[inside] - k0[inside]).min() > 1.0          # mM, 0.6 ms of a 97 mM/ms source
+    assert inside.sum() > 10 and (k1[inside] - k0[inside]).min() > n_steps / 6.0    # mM; 0.6 ms of a 97 mM/ms source in 6 steps
     far = p.subdomain_list[0]["mesh_sub"].x[:, 0] < 4e-4
     assert np.abs(k1[far] - k0[far]).max() < 0.5
     for t in p.subdomain_list:
@@ -1411,7 +1472,7 @@ def test_config5_synthetic_full_size(hip_lib, workload):
     near = np.abs(xg[:, 0] - 16e-4) < 2e-4
     dv = p.phi_M_prev[2].x._a - case.models[1][0].ode.init_state_values()[0]
     # (the whole glial membrane relaxes by ~0.5 mV from its tabulated initial state; the source adds to that locally)
-    assert near.any() and dv[near].max() > dv[xg[:, 0] < 8e-4].max() + 0.2
+    assert near.any() and dv[near].max() > dv[xg[:, 0] < 8e-4].max() + (0.2 if n_steps >= 6 else 0.0)
     for t in (1, 2):
         v = p.phi_M_prev[t].x._a
         assert -120.0 < v.min() and v.max() < 60.0
