@@ -253,6 +253,12 @@ int knpemi_debug_ode_stamps(knpemi_handle* h, int sub, int model, uint64_t* out,
  * 1: kn_exp(a), 2: kn_powr(a, b), 3: kn_log(a).  a, b, out: n doubles each (b is ignored by ops 1 and 3). */
 int knpemi_debug_math(int op, int n, const double* a, const double* b, double* out);
 
+/* Diagnostics (no reference counterpart): `links` dependent trivial kernels on the handle's stream, `reps` times, launched
+ * one by one or replayed from a captured hipGraph; *us_per_kernel = host wall time per kernel.  kind 0: an empty one-wave
+ * kernel, 1: y = x + 1 over n doubles, 2: the one-block start kernel of the fused Krylov loops.  What a dependent launch
+ * costs inside THIS process and on THIS stream, next to tools/probes/kernel_chain.hip which measures a bare process. */
+int knpemi_debug_launch_chain(knpemi_handle* h, int kind, int n, int links, int reps, int use_graph, double* us_per_kernel);
+
 /* End-of-step update: update_pde_variables (utils.py:238-295): c_prev <- c, eliminated ion from
  * electroneutrality, phi_M_prev <- tr(phi_i) - tr(phi_e). */
 int knpemi_update_pde(knpemi_handle* h);
@@ -275,6 +281,10 @@ int knpemi_update_pde(knpemi_handle* h);
 #define KNPEMI_OPT_FUSE_MEMBRANE 2
 /* KNPEMI_OPT_PROFILE_STRIDE (n >= 1, default 1): knpemi_profile brackets every n-th launch of a selected kernel only. */
 #define KNPEMI_OPT_PROFILE_STRIDE 3
+/* KNPEMI_OPT_KNP_MIN_IT (n >= 0, default 0): knpemi_solve_knp performs at least n iterations before a residual below
+ * the target ends it (`ksp_min_it`: 5 in the reference's iterative options of the concentration solve, pdeSolver.py:101;
+ * knpemi.pdeSolver.create_solver_knp sets it).  A residual that has vanished exactly still ends the solve. */
+#define KNPEMI_OPT_KNP_MIN_IT 4
 int knpemi_set_option(knpemi_handle* h, int option, int value);
 
 /* Nodal trace of an (ECS, cell) pair of bulk functions onto Q_sub: interpolate_to_membrane

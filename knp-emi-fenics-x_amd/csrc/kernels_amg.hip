@@ -161,12 +161,18 @@ __global__ void amg_diag_inv_kernel(int n, const int* __restrict__ rowptr, const
 }
 
 // x = Minv r for the dense coarsest level: one wavefront per row
-__global__ __launch_bounds__(256) void amg_dense_kernel(int n, const double* __restrict__ Minv, const double* __restrict__ r,
-                                                        double* __restrict__ x) {
+// (the inverse is stored as dense diagonal blocks, KnAmgLevel::dense_blk)
+__global__ __launch_bounds__(256) void amg_dense_kernel(int n, const double* __restrict__ Minv, KnDenseBlocks B,
+                                                        const double* __restrict__ r, double* __restrict__ x) {
   const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
   double acc = 0.0;
-  if (row < n)
-    for (int j = l; j < n; j += 64) acc += Minv[(size_t)row * n + j] * r[j];
+  if (row < n) {
+    int b = 0;
+    for (int k = 1; k < B.nb; ++k) b = row >= B.start[k] ? k : b;
+    const double* m = Minv + (size_t)B.off[b] + (size_t)(row - B.start[b]) * B.size[b];
+    const double* rb = r + B.start[b];
+    for (int j = l; j < B.size[b]; j += 64) acc += m[j] * rb[j];
+  }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
   if (row < n && l == 0) x[row] = acc;
@@ -342,13 +348,17 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
         if (na < cur.n * 0.7) break;
       }
     }
+    // independent systems (the ion blocks of the concentration matrix) stay contiguous ranges on every level
+    if (na > 0 && !h_owned) renumber_by_component(cur, agg, na);
     if (cur.n <= n_dense || na >= cur.n * 0.9 || l == max_levels - 1) {
       // coarsening stalled on a large level (e.g. a mass-dominated operator with no strong connections):
       // that level is well conditioned for Jacobi, which then stands in for the coarsest solve
       if (cur.n <= std::max(1024, n_dense)) {
-        std::vector<double> inv;
-        if (!dense_inverse(cur, singular, inv)) { kn_set_error("AMG set-up: singular coarsest operator"); return KNPEMI_ESOLVE; }
-        if ((rc = upload(G, inv, &L.dense_inv, st))) return rc;
+        DenseInvBlocks inv;
+        if (!dense_inverse_blocks(cur, singular, inv)) { kn_set_error("AMG set-up: singular coarsest operator"); return KNPEMI_ESOLVE; }
+        if ((rc = upload(G, inv.v, &L.dense_inv, st))) return rc;
+        L.dense_blk.nb = inv.nb;
+        for (int b = 0; b < inv.nb; ++b) { L.dense_blk.start[b] = inv.start[b]; L.dense_blk.size[b] = inv.size[b]; L.dense_blk.off[b] = inv.off[b]; }
       }
       L.nc = 0;
       G.lev.push_back(L);
@@ -451,7 +461,7 @@ int kn_amg_apply(knpemi_handle* h, KnAmg& G, const double* vals, const double* d
       double* dst = nl == 1 ? out : L.t;
       if (L.dense_inv) {
         dim3 g(((size_t)L.n * 64 + 255) / 256);
-        hipLaunchKernelGGL(amg_dense_kernel, g, dim3(256), 0, st, L.n, L.dense_inv, rl, dst);
+        hipLaunchKernelGGL(amg_dense_kernel, g, dim3(256), 0, st, L.n, L.dense_inv, L.dense_blk, rl, dst);
       } else {   // Jacobi level: two damped sweeps from a zero guess
         launch_spmv<M_PRE>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, nullptr, rl, dinv, L.omega, xl == dst ? L.x : dst, xl);
         launch_spmv<M_JAC>(st, L.n, L.avg_row, L.A.rp, L.A.ci, Av, xl, rl, dinv, L.omega, dst);

@@ -811,6 +811,8 @@ extern "C" void knpemi_dg_destroy(knpemi_dg* h) {
     kn_amg_free(h->sol->amg_emi);
     kn_amg_free(h->sol->amg_knp);
     if (h->sol->kry_pinned) (void)hipHostFree(h->sol->kry_pinned);
+    if (h->sol->pub_host) (void)hipHostFree(h->sol->pub_host);
+    kn_fused_graphs_free(h->sol);
     if (h->sol->graph_emi.exec) (void)hipGraphExecDestroy(h->sol->graph_emi.exec);
     if (h->sol->graph_knp.exec) (void)hipGraphExecDestroy(h->sol->graph_knp.exec);
     for (void* p : h->sol->allocs) (void)hipFree(p);

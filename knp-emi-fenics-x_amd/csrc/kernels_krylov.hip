@@ -616,20 +616,37 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     }
     h->kry_ones_masked = dist.on ? 1 : 0;
   }
-  // x0 = current phi (ksp_initial_guess_nonzero), b = b_emi projected onto zero mean (constant null space)
-  if ((rc = kn_launch_field_gather(h, D.VR + 7, KN_REC, x, n))) return rc;
-  if (dist.on) {
-    vec(c, V_COPY, b, nullptr, D.b_emi, nullptr);
-    mask(c, b);
-    dots(c, 1, b, ones, nullptr, nullptr, nullptr, nullptr, OP_MEAN, 0, 0, 0, 1.0 / n_mean);
-    vec(c, V_SHIFT, b, nullptr, nullptr, nullptr);
-    mask(c, b);
-  } else {   // single rank: the mean of b_emi itself, then copy and shift in one pass (same arithmetic)
-    dots(c, 1, D.b_emi, ones, nullptr, nullptr, nullptr, nullptr, OP_MEAN, 0, 0, 0, 1.0 / n_mean);
-    vec(c, V_COPY_SHIFT, b, nullptr, D.b_emi, nullptr);
-  }
-  // (single rank: the inverse diagonal comes out of the first residual below)
-  if (dist.on) hipLaunchKernelGGL(diag_inv_kernel, grid1(n), dim3(256), 0, h->stream, n, c.rowptr, c.colind, c.vals, dinv);
+  // x0 = current phi (ksp_initial_guess_nonzero), b = b_emi projected onto zero mean (constant null space).  With the
+  // fused loop these launches open the captured graph of the solve's first chunk (kernels_fused.hip), hence the lambda.
+  auto pre = [&]() -> int {
+    if (int e = kn_launch_field_gather(h, D.VR + 7, KN_REC, x, n)) return e;
+    if (dist.on) {
+      vec(c, V_COPY, b, nullptr, D.b_emi, nullptr);
+      mask(c, b);
+      dots(c, 1, b, ones, nullptr, nullptr, nullptr, nullptr, OP_MEAN, 0, 0, 0, 1.0 / n_mean);
+      vec(c, V_SHIFT, b, nullptr, nullptr, nullptr);
+      mask(c, b);
+    } else {   // single rank: the mean of b_emi itself, then copy and shift in one pass (same arithmetic)
+      dots(c, 1, D.b_emi, ones, nullptr, nullptr, nullptr, nullptr, OP_MEAN, 0, 0, 0, 1.0 / n_mean);
+      vec(c, V_COPY_SHIFT, b, nullptr, D.b_emi, nullptr);
+    }
+    // (single rank: the inverse diagonal comes out of the first residual below)
+    if (dist.on) hipLaunchKernelGGL(diag_inv_kernel, grid1(n), dim3(256), 0, h->stream, n, c.rowptr, c.colind, c.vals, dinv);
+    return KNPEMI_OK;
+  };
+  // solution orthogonal to constants, then into the phi component of the vertex records (ghosts included: they take
+  // their owners' values first); idempotent
+  auto post = [&]() -> int {
+    dots(c, 1, x, ones, nullptr, nullptr, nullptr, nullptr, OP_MEAN, 0, 0, 0, 1.0 / n_mean);
+    if (dist.on) {
+      if (int e = dist.halo(dist.ctx, x, KNPEMI_B_EMI)) c.comm_rc = c.comm_rc ? c.comm_rc : e;
+      vec(c, V_SHIFT, x, nullptr, nullptr, nullptr);
+      if (int e = kn_launch_field_scatter(h, x, D.VR + 7, n, KN_REC)) return e;
+    } else if (n > 0) {
+      hipLaunchKernelGGL(scatter_shift_kernel, grid1(n), dim3(256), 0, h->stream, x, D.VR + 7, n, KN_REC, c.sc);
+    }
+    return KNPEMI_OK;
+  };
   KnAmg& G = h->amg_emi;
   const bool amg = h->pc_emi == KNPEMI_PC_AMG;
   if (amg && (!G.built || G.n != n)) {
@@ -678,8 +695,9 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   int it = 0;
   if (fused) {   // residual, target and the loop in 2 + (2 levels - 1) launches per iteration (kernels_fused.hip)
     const KnFusedSys S{n, c.rowptr, c.colind, c.vals, c.sc, h->kry, N};
-    if ((rc = kn_fused_cg(h, G, S, b, rtol, atol, maxit, &it, &sc[S_RR], &sc[S_BB]))) return rc;
+    if ((rc = kn_fused_cg(h, G, S, D.b_emi, rtol, atol, maxit, &it, &sc[S_RR], &sc[S_BB], D.VR + 7, KN_REC))) return rc;
   } else {
+    if ((rc = pre())) return rc;
     spmv(c, x, r, nullptr, b, dist.on ? nullptr : dinv);         // r = b - A x
     dots(c, 2, r, r, b, b, nullptr, nullptr, OP_START);
     if ((rc = read_scalars(c, sc, S_N))) return rc;
@@ -713,16 +731,7 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     if (debug_krylov()) fprintf(stderr, "[knpemi] emi cg it %d |r| %.3e target %.3e alpha %.3e beta %.3e\n", it, rn, target, sc[S_ALPHA], sc[S_BETA]);
     if (!std::isfinite(rn)) { kn_set_error("EMI CG broke down (non-finite residual) " + describe_scalars(sc, it)); return KNPEMI_ESOLVE; }
   }
-  // solution orthogonal to constants, then into the phi component of the vertex records (ghosts included: they
-  // take their owners' values first)
-  dots(c, 1, x, ones, nullptr, nullptr, nullptr, nullptr, OP_MEAN, 0, 0, 0, 1.0 / n_mean);
-  if (dist.on) {
-    if (int e = dist.halo(dist.ctx, x, KNPEMI_B_EMI)) c.comm_rc = c.comm_rc ? c.comm_rc : e;
-    vec(c, V_SHIFT, x, nullptr, nullptr, nullptr);
-    if ((rc = kn_launch_field_scatter(h, x, D.VR + 7, n, KN_REC))) return rc;
-  } else if (n > 0) {
-    hipLaunchKernelGGL(scatter_shift_kernel, grid1(n), dim3(256), 0, h->stream, x, D.VR + 7, n, KN_REC, c.sc);
-  }
+  if (!fused && (rc = post())) return rc;
   if (c.comm_rc) { kn_set_error("EMI solve: a communication hook failed"); return KNPEMI_EHIP; }
   if (iters) *iters = it;
   if (relres) *relres = bnorm > 0 ? rn / bnorm : rn;
@@ -756,9 +765,22 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     hipLaunchKernelGGL(ghost_identity_kernel, grid1(n), dim3(256), 0, h->stream, n, c.rowptr, c.colind, c.owned, D.A_knp);
     mask(c, D.b_knp);      // the ghost rows of the right-hand side are not assembled
   }
-  // x0 = previous concentrations in the block order [c[0][0], c[0][1], c[1][0], ...]
-  if (h->plain_knp) vec(c, V_COPY, x, nullptr, D.csol, nullptr);
-  else hipLaunchKernelGGL(knp_order_kernel, grid1(n), dim3(256), 0, h->stream, D.Ntot, KS, h->n_sub, h->d_consts, x, D.csol, 1);
+  // x0 = previous concentrations in the block order [c[0][0], c[0][1], c[1][0], ...] (first launch of the solve: with the
+  // fused loop it opens the captured graph of the first chunk)
+  auto pre = [&]() -> int {
+    if (h->plain_knp) vec(c, V_COPY, x, nullptr, D.csol, nullptr);
+    else hipLaunchKernelGGL(knp_order_kernel, grid1(n), dim3(256), 0, h->stream, D.Ntot, KS, h->n_sub, h->d_consts, x, D.csol, 1);
+    return KNPEMI_OK;
+  };
+  // the solution back into csol / the vertex records (+ the end-of-step update when it is fused); idempotent
+  auto post = [&]() -> int {
+    if (h->plain_knp) vec(c, V_COPY, D.csol, nullptr, x, nullptr);
+    else if (h->fuse_update) { if (int e = kn_launch_knp_writeback_update(h, x)) return e; }
+    else hipLaunchKernelGGL(knp_order_kernel, grid1(n), dim3(256), 0, h->stream, D.Ntot, KS, h->n_sub, h->d_consts, x, D.csol, 0);
+    return KNPEMI_OK;
+  };
+  const bool fused_planned = h->pc_knp == KNPEMI_PC_AMG && !dist.on && use_fused();
+  if (!fused_planned && (rc = pre())) return rc;
   KnAmg& G = h->amg_knp;
   const bool amg = h->pc_knp == KNPEMI_PC_AMG;
   if (dist.on) {
@@ -795,8 +817,9 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   int it = 0, restarts = 0;
   if (fused) {   // residual, target and 3 + 2 cycles launches per iteration (kernels_fused.hip)
     const KnFusedSys S{n, c.rowptr, c.colind, c.vals, c.sc, h->kry, N};
-    if ((rc = kn_fused_bicgstab(h, G, S, D.b_knp, rtol, atol, maxit, &it, &sc[S_RR], &sc[S_BB]))) return rc;
+    if ((rc = kn_fused_bicgstab(h, G, S, D.b_knp, rtol, atol, maxit, &it, &sc[S_RR], &sc[S_BB], pre, post))) return rc;
   } else {
+    if (fused_planned && (rc = pre())) return rc;      // (the hierarchy did not qualify for the fused loop after all)
     spmv(c, x, r, nullptr, D.b_knp, dist.on ? nullptr : dinv);   // r = b - A x
     vec(c, V_COPY, rhat, nullptr, r, nullptr);
     hipLaunchKernelGGL(bicg_init_kernel, grid1(std::max(n, (int)S_N)), dim3(256), 0, h->stream, n, p, v, c.sc);
@@ -833,7 +856,8 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     return rc;
   };
   const uint64_t gkey = graph_key(h, G, amg, chunk, n);
-  while (!fused && rn > target && it < maxit) {
+  const int min_it = std::max(0, std::min(h->knp_min_it, maxit));      // ksp_min_it (pdeSolver.py:101)
+  while (!fused && (rn > target || (it < min_it && rn != 0.0)) && it < maxit) {
     const int todo = std::min(chunk, maxit - it);
     if (todo == chunk) { if ((rc = run_chunk(h, h->graph_knp, gkey, chunk, iteration))) return rc; }
     else for (int k = 0; k < todo; ++k) if ((rc = iteration())) return rc;
@@ -858,9 +882,7 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   }
   if (dist.on) if (int e = dist.halo(dist.ctx, x, KNPEMI_B_KNP)) c.comm_rc = c.comm_rc ? c.comm_rc : e;
   if (c.comm_rc) { kn_set_error("KNP solve: a communication hook failed"); return KNPEMI_EHIP; }
-  if (h->plain_knp) vec(c, V_COPY, D.csol, nullptr, x, nullptr);
-  else if (h->fuse_update) { if ((rc = kn_launch_knp_writeback_update(h, x))) return rc; }
-  else hipLaunchKernelGGL(knp_order_kernel, grid1(n), dim3(256), 0, h->stream, D.Ntot, KS, h->n_sub, h->d_consts, x, D.csol, 0);
+  if (!fused && (rc = post())) return rc;
   if (iters) *iters = it;
   if (relres) *relres = bnorm > 0 ? rn / bnorm : rn;
   hipError_t e = hipGetLastError();

@@ -817,6 +817,8 @@ extern "C" void knpemi_destroy(knpemi_handle* h) {
   kn_amg_free(h->amg_emi);
   kn_amg_free(h->amg_knp);
   if (h->kry_pinned) (void)hipHostFree(h->kry_pinned);
+  if (h->pub_host) (void)hipHostFree(h->pub_host);
+  kn_fused_graphs_free(h);
   if (h->graph_emi.exec) (void)hipGraphExecDestroy(h->graph_emi.exec);
   if (h->graph_knp.exec) (void)hipGraphExecDestroy(h->graph_knp.exec);
   for (void* p : h->allocs) (void)hipFree(p);
@@ -1631,6 +1633,11 @@ extern "C" int knpemi_set_option(knpemi_handle* h, int option, int value) {
   if (option == KNPEMI_OPT_PROFILE_STRIDE) {   // the next launch of every kernel is a bracketed one
     h->prof_stride = value > 1 ? value : 1;
     for (unsigned& c : h->prof_count) c = 0;
+    return KNPEMI_OK;
+  }
+  if (option == KNPEMI_OPT_KNP_MIN_IT) {
+    if (value < 0) return fail(KNPEMI_EINVAL, "KNPEMI_OPT_KNP_MIN_IT: negative");
+    h->knp_min_it = value;
     return KNPEMI_OK;
   }
   return fail(KNPEMI_EINVAL, "knpemi_set_option: unknown option");

@@ -7,8 +7,10 @@
 #include <stdint.h>
 
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/knpemi_hip.h"
@@ -124,6 +126,10 @@ struct KnOdeModel {
   int rtc_lanes = 1;
 };
 
+// blocks of the dense coarsest-level inverse, passed to the kernels by value: block b covers the unknowns start[b] ..
+// start[b] + size[b] - 1, its row-major size[b] x size[b] inverse begins at off[b] (doubles)
+struct KnDenseBlocks { int nb = 0; int start[8] = {0}; int size[8] = {0}; int off[8] = {0}; };
+
 // Algebraic multigrid hierarchy (kernels_amg.hip)
 struct KnAmgCsr { int n = 0, m = 0, nnz = 0; int* rp = nullptr; int* ci = nullptr; double* v = nullptr; };
 struct KnAmgLevel {
@@ -137,7 +143,10 @@ struct KnAmgLevel {
   KnAmgCsr Rm, Pm;
   double* frozen_v = nullptr;
   double* dinv = nullptr;
-  double* dense_inv = nullptr;       // [n][n] explicit inverse on the coarsest level
+  // explicit inverse on the coarsest level as up to 8 dense diagonal blocks (amg_host.h: dense_inverse_blocks; the
+  // aggregates of every level are numbered component by component, so the independent ion systems are contiguous ranges)
+  double* dense_inv = nullptr;
+  KnDenseBlocks dense_blk;
   double *x = nullptr, *r = nullptr, *t = nullptr;
 };
 struct KnAmg {
@@ -192,10 +201,13 @@ struct KnFusedSys {
   size_t N;                   // stride of the workspace vectors
 };
 int kn_fused_subcycle(knpemi_handle* h, KnAmg& G, int l0, const double* r0 = nullptr, double* out0 = nullptr);
+// pre / post: what the caller has to run before the first residual / after the last iteration (both become part of the
+// captured graph of a chunk; post must be idempotent, it follows every chunk)
 int kn_fused_cg(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const double* b, double rtol, double atol, int maxit,
-                int* iters, double* rr, double* bb);
+                int* iters, double* rr, double* bb, double* phi, int phi_stride);
 int kn_fused_bicgstab(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const double* b, double rtol, double atol, int maxit,
-                      int* iters, double* rr, double* bb);
+                      int* iters, double* rr, double* bb, const std::function<int()>& pre, const std::function<int()>& post);
+void kn_fused_graphs_free(knpemi_handle* h);
 
 // Distributed solves (knpemi_set_distributed)
 struct KnDist {
@@ -268,6 +280,9 @@ struct knpemi_handle {
   double* kry = nullptr; size_t kry_n = 0;           // Krylov workspace (kernels_krylov.hip)
   int kry_ones_masked = 0;                           // the workspace's `ones` vector currently holds the ownership mask
   void* kry_pinned = nullptr;                        // pinned host buffer the solvers' scalars are read through
+  // state of the fused loops published by the device into mapped host memory (kernels_fused.hip: publish_state)
+  double* pub_host = nullptr; double* pub_host_dev = nullptr; unsigned long long* pub_count = nullptr;
+  unsigned long long pub_expected = 0;
   KnBlockCols bcols;                 // block structure of a DG problem's systems (solver handle of knpemi_dg), else empty
   int spmv_lpr[2] = {0, 0};          // lanes per row of the Krylov SpMV of the two systems (from the average row length)
   double* fused_part = nullptr; size_t fused_part_n = 0;   // block partials of the dot products fused into the solver kernels
@@ -277,8 +292,14 @@ struct knpemi_handle {
   // captured iteration bodies of the Krylov loops (kernels_krylov.hip); key = configuration they were captured for
   struct KnGraph { hipGraphExec_t exec = nullptr; uint64_t key = 0; };
   KnGraph graph_emi, graph_knp;
+  // captured chunks of the fused loops (kernels_fused.hip: run_chunk_graph), keyed by everything their kernel arguments hold
+  std::unordered_map<uint64_t, hipGraphExec_t> fused_graphs;
+  // graph replay or direct launches for the chunks of the fused loops, decided per system from timed solves (choose_mode)
+  struct FusedMode { bool decided = false, graph = true; int solves = 0; double t[2] = {0.0, 0.0}; int n[2] = {0, 0}; };
+  FusedMode fused_mode[2];
   int pc_emi = KNPEMI_PC_AMG, pc_knp = KNPEMI_PC_AMG;
   int fuse_update = 0;                 // KNPEMI_OPT_FUSE_UPDATE
+  int knp_min_it = 0;                  // KNPEMI_OPT_KNP_MIN_IT (ksp_min_it of the concentration solve, pdeSolver.py:101)
   bool plain_knp = false;              // the KNP solve's unknown order is dev.csol's own ([K-1][Ntot]; DG variant)
   int fuse_membrane = 0;               // KNPEMI_OPT_FUSE_MEMBRANE
   int prof_stride = 1;                 // KNPEMI_OPT_PROFILE_STRIDE

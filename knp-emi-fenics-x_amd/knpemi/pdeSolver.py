@@ -11,7 +11,8 @@ linear solve (adjacent to the hot path):
 * `direct=False` (the reference's CG / GMRES + hypre options, `pdeSolver.py:24-35,99-110`):
   device-resident Krylov solve on the assembled CSR (`knpemi_solve_emi`: PCG with the
   constant null space projected out; `knpemi_solve_knp`: BiCGStab; smoothed-aggregation AMG for both), same `rtol` /
-  `atol` / `ksp_max_it = 1000` semantics on the true residual, non-zero initial guess;
+  `atol` / `ksp_max_it = 1000` semantics on the true residual, non-zero initial guess, `ksp_min_it = 5` of the
+  concentration solve as three BiCGStab iterations (KNP_MIN_BICGSTAB_ITERATIONS);
 * `direct=True` (MUMPS LU, `pdeSolver.py:15-21`) and systems with Dirichlet conditions
   (MMS): sparse LU on the host with SciPy as a stand-in.
 """
@@ -23,6 +24,13 @@ import scipy.sparse.linalg as spla
 
 from . import _lib as L
 from .fem.function import Function, as_float
+
+
+# `ksp_min_it: 5` of the reference's iterative options for the concentration solve (pdeSolver.py:101) counts GMRES
+# iterations, i.e. applications of operator and preconditioner.  The device solve is BiCGStab, whose iteration applies both
+# twice: three of them are the fewest that do at least the work of five GMRES iterations.
+KSP_MIN_IT_KNP = 5
+KNP_MIN_BICGSTAB_ITERATIONS = (KSP_MIN_IT_KNP + 1) // 2
 
 
 class _KSPInfo:
@@ -195,6 +203,8 @@ class LinearProblem:
             _push_currents(dp, f)
             _push_sources(dp, f)
             dp.assemble_knp(splitting_scheme=f.splitting_scheme)
+        if self.system == "knp":
+            L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_MIN_IT, KNP_MIN_BICGSTAB_ITERATIONS))
         its, relres = dp.solve(which, self.rtol, self.atol, maxit=1000)
         self.solver.iterations, self.solver.residual_norm = its, relres
         for fn, (field, sub, idx) in zip(self.u, self._unknown_fields()):

@@ -35,6 +35,8 @@ class DeviceStepper:
             # extrapolate_guess: start each solve from 2 x_n - x_(n-1) instead of x_n (knpemi_extrapolate_guess)
             rtol_emi, rtol_knp = device_solves
             self.iterations = []
+            from .pdeSolver import KNP_MIN_BICGSTAB_ITERATIONS      # ksp_min_it of the reference's KNP options
+            L.check(a.dp.lib.knpemi_set_option(a.dp.h, L.OPT_KNP_MIN_IT, KNP_MIN_BICGSTAB_ITERATIONS))
 
             def _solve(dp, which, name, rtol, atol):
                 if extrapolate_guess:

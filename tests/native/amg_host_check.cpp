@@ -67,6 +67,29 @@ int amg_host_dense_inverse(int n, const int* rp, const int* ci, const double* v,
   return 1;
 }
 
+// the block-wise storage of the same inverse, expanded to a dense n x n array again; returns the number of stored values
+// (negative: number of blocks, when asked through nb_out)
+int amg_host_dense_inverse_blocks(int n, const int* rp, const int* ci, const double* v, int singular, double* inv_out, int* nb_out) {
+  const HostCsr A = make(n, rp, ci, v);
+  DenseInvBlocks c;
+  if (!dense_inverse_blocks(A, singular != 0, c)) return 0;
+  std::memset(inv_out, 0, sizeof(double) * (size_t)n * n);
+  for (int b = 0; b < c.nb; ++b)
+    for (int i = 0; i < c.size[b]; ++i)
+      for (int j = 0; j < c.size[b]; ++j)
+        inv_out[(size_t)(c.start[b] + i) * n + c.start[b] + j] = c.v[(size_t)c.off[b] + (size_t)i * c.size[b] + j];
+  if (nb_out) *nb_out = c.nb;
+  return (int)c.v.size();
+}
+
+// aggregates renumbered component by component (renumber_by_component)
+void amg_host_renumber(int n, const int* rp, const int* ci, const double* v, int* agg, int na) {
+  const HostCsr A = make(n, rp, ci, v);
+  std::vector<int> a(agg, agg + n);
+  renumber_by_component(A, a, na);
+  std::memcpy(agg, a.data(), sizeof(int) * n);
+}
+
 int amg_host_outlier(int n, const int* rp, const int* ci, const double* v, double factor, int* row, int* col) {
   const HostCsr A = make(n, rp, ci, v);
   return find_outlier(A, diagonal(A), factor, row, col) ? 1 : 0;

@@ -27,6 +27,8 @@ def lib():
     L.amg_host_prolongator.argtypes = [C.c_int, ip, ip, dp, ip, C.c_int, C.c_double, C.c_double, dp]
     L.amg_host_galerkin.argtypes = [C.c_int, ip, ip, dp, ip, C.c_int, C.c_double, C.c_double, dp]
     L.amg_host_dense_inverse.argtypes = [C.c_int, ip, ip, dp, C.c_int, dp]
+    L.amg_host_dense_inverse_blocks.argtypes = [C.c_int, ip, ip, dp, C.c_int, dp, ip]
+    L.amg_host_renumber.argtypes = [C.c_int, ip, ip, dp, ip, C.c_int]
     L.amg_host_rho.argtypes = [C.c_int, ip, ip, dp]
     L.amg_host_rho.restype = C.c_double
     L.amg_host_outlier.argtypes = [C.c_int, ip, ip, dp, C.c_double, ip, ip]
@@ -180,12 +182,27 @@ def test_dense_inverse_of_the_coarsest_level(lib):
     assert lib.amg_host_dense_inverse(*a, 0, _p(inv, C.c_double)) == 1
     assert np.allclose(inv @ A, np.eye(n), atol=1e-10)
     assert np.all(inv[0::2, 1::2] == 0.0) and np.all(inv[1::2, 0::2] == 0.0)      # inverted block by block
+    # interleaved components are not contiguous ranges: the block-wise storage for the device falls back to one block
+    invb, nb = np.zeros((n, n)), C.c_int()
+    assert lib.amg_host_dense_inverse_blocks(*a, 0, _p(invb, C.c_double), C.byref(nb)) == n * n and nb.value == 1
+    assert np.allclose(invb, inv, rtol=1e-12, atol=1e-14)
+    # ... the same two systems one after the other (what renumber_by_component arranges on every coarse level): two blocks,
+    # half the values, the same inverse
+    A2 = np.zeros((2 * m, 2 * m))
+    A2[:m, :m], A2[m:, m:] = B1, B2
+    n2, rp2, ci2, v2, a2 = _args(sp.csr_matrix(A2))
+    invb = np.zeros((n2, n2))
+    assert lib.amg_host_dense_inverse_blocks(*a2, 0, _p(invb, C.c_double), C.byref(nb)) == 2 * m * m and nb.value == 2
+    assert np.allclose(invb @ A2, np.eye(n2), atol=1e-10) and np.all(invb[:m, m:] == 0.0)
     # one connected non-singular system: the plain elimination
     A1 = _laplace_2d(9, 7)
     n, rp, ci, v, a = _args(A1)
     inv = np.zeros((n, n))
     assert lib.amg_host_dense_inverse(*a, 0, _p(inv, C.c_double)) == 1
     assert np.allclose(inv @ A1.toarray(), np.eye(n), atol=1e-10)
+    invb, nb = np.zeros((n, n)), C.c_int()
+    assert lib.amg_host_dense_inverse_blocks(*a, 0, _p(invb, C.c_double), C.byref(nb)) == n * n and nb.value == 1
+    assert np.array_equal(invb, inv)
     # singular (constant null space, the potential system): the inverse of A + s 1 1^T / n inverts A on the zero-mean vectors
     Tx = sp.diags([-np.ones(8), np.r_[1.0, 2 * np.ones(7), 1.0], -np.ones(8)], [-1, 0, 1])
     AN = sp.csr_matrix(sp.kron(sp.identity(6), Tx) + sp.kron(sp.diags([-np.ones(5), np.r_[1.0, 2 * np.ones(4), 1.0], -np.ones(5)], [-1, 0, 1]), sp.identity(9)))
@@ -220,3 +237,23 @@ def test_an_outlier_entry_is_found_and_named(lib):
     B[5, 6], B[6, 5] = -3.0, 1.0
     n, rp, ci, v, a = _args(B.tocsr())
     assert lib.amg_host_outlier(*a, 1e3, C.byref(i), C.byref(j)) == 0
+
+
+def test_aggregates_are_renumbered_component_by_component(lib):
+    """Two independent systems with interleaved unknowns: after renumber_by_component the aggregates of the first system
+    come first, in their old order, so the coarse operator is block diagonal with contiguous blocks."""
+    T = _laplace_2d(6, 5)
+    A = sp.lil_matrix((60, 60))
+    A[0::2, 0::2], A[1::2, 1::2] = T, 2.0 * T
+    n, rp, ci, v, a = _args(A.tocsr())
+    agg = np.zeros(n, np.int32)
+    na = lib.amg_host_aggregate(*a, 0.08, 0, _p(agg, C.c_int))
+    old = agg.copy()
+    lib.amg_host_renumber(*a, _p(agg, C.c_int), na)
+    sys_of = lambda ag: np.array([np.flatnonzero(ag == g)[0] % 2 for g in range(na)])
+    s_new = sys_of(agg)
+    assert sorted(set(agg)) == list(range(na)) and np.all(np.diff(s_new) >= 0) and 0 < s_new.sum() < na
+    for sysid in (0, 1):          # same partition, same relative order inside a system
+        members_old = [tuple(np.flatnonzero(old == g)) for g in range(na) if np.flatnonzero(old == g)[0] % 2 == sysid]
+        members_new = [tuple(np.flatnonzero(agg == g)) for g in range(na) if s_new[g] == sysid]
+        assert members_old == members_new

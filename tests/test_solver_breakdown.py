@@ -142,14 +142,15 @@ def test_coarse_space_with_one_function_per_rank_and_sub_domain_reads_nothing_pa
     round-3 prolongation multiplied that entry by 0 (advisor finding: 0 * stale NaN).  Rehearsed on one process as rank 0
     of 20 (the other ranks contribute nothing to the sums, so the system is this rank's own) with the buffer poisoned."""
     import ctypes as C
-    import torch
     monkeypatch.setenv("KNPEMI_DEBUG_POISON_COARSE", "1")
     s, dp, (A, b), _ = _systems("tet", 0)
     n = A.shape[0]
-    red = torch.zeros(8 + 64, dtype=torch.float64, device="cuda")
+    hip = C.CDLL("libamdhip64.so")          # the runtime the library already runs on: the reduction buffer (8 + 64 doubles)
+    red = C.c_void_p()
+    assert hip.hipMalloc(C.byref(red), C.c_size_t(72 * 8)) == 0 and hip.hipMemset(red, 0, C.c_size_t(72 * 8)) == 0
     cb = (L.ALLREDUCE_FN(lambda ctx, m: 0), L.HALO_FN(lambda ctx, vec, which: 0))
     own = np.ones(n, np.uint8)
-    L.check(dp.lib.knpemi_set_distributed(dp.h, own.ctypes.data_as(L.c_u8_p), red.data_ptr(),
+    L.check(dp.lib.knpemi_set_distributed(dp.h, own.ctypes.data_as(L.c_u8_p), red,
                                           C.cast(cb[0], C.c_void_p), C.cast(cb[1], C.c_void_p), None))
     L.check(dp.lib.knpemi_set_distributed_coarse(dp.h, 0, 20))
     dp.set_solution(L.B_EMI, np.zeros(n))
@@ -159,3 +160,29 @@ def test_coarse_space_with_one_function_per_rank_and_sub_domain_reads_nothing_pa
     r = b - b.mean() - A @ x
     assert np.abs(r).max() <= 1e-6 * np.abs(b).max()
     L.check(dp.lib.knpemi_set_distributed(dp.h, None, None, None, None, None))
+    dp.sync()
+    hip.hipFree(red)
+
+
+def test_minimum_iterations_of_the_concentration_solve(hip_lib):
+    """`ksp_min_it` (the reference's iterative options of the concentration solve carry ksp_min_it = 5,
+    /root/reference/src/knpemi/pdeSolver.py:101): with KNPEMI_OPT_KNP_MIN_IT = n the solve performs at least n iterations
+    although the tolerance is met earlier, and ends with a smaller residual; 0 restores the plain criterion; a start at the
+    exact solution (residual zero) still returns at once."""
+    s, dp, _, (Ak, bk) = _systems("tet", 0)
+    n = Ak.shape[0]
+    x0 = np.zeros(n)
+    out = {}
+    for min_it in (0, 5, 0):
+        L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_MIN_IT, min_it))
+        dp.set_solution(L.B_KNP, x0)
+        out[min_it] = dp.solve(L.B_KNP, 1e-3, 1e-40, 50)
+    assert 1 <= out[0][0] < 5 and out[0][1] <= 1e-3
+    assert out[5][0] == 5 and out[5][1] < 0.1 * out[0][1]
+    L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_MIN_IT, 5))
+    dp.set_solution(L.B_KNP, spla.splu(Ak.tocsc()).solve(bk))
+    its, relres = dp.solve(L.B_KNP, 1e-7, 1e-40, 50)
+    assert its <= 5 and relres < 1e-7
+    L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_MIN_IT, 0))
+    with pytest.raises(L.KnpemiError):
+        L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_MIN_IT, -1))
