@@ -285,6 +285,12 @@ int knpemi_update_pde(knpemi_handle* h);
  * the target ends it (`ksp_min_it`: 5 in the reference's iterative options of the concentration solve, pdeSolver.py:101;
  * knpemi.pdeSolver.create_solver_knp sets it).  A residual that has vanished exactly still ends the solve. */
 #define KNPEMI_OPT_KNP_MIN_IT 4
+/* KNPEMI_OPT_FOLD_MEMBRANE (0/1, default 1): the launch that writes the potential back at the end of knpemi_solve_emi
+ * (single rank, fused loop) or of knpemi_set_solution(KNPEMI_B_EMI, on_device) also forms the membrane-facet integrals of
+ * b_knp (knpWeakForm.py:168-214) for that potential, so knpemi_assemble_knp launches the row kernel only: one dependent
+ * launch fewer between the two solves.  The integrals are used only while none of their inputs has changed since; 0 keeps
+ * the facet kernel a launch of its own (what bench.py times as the facet-assembly kernel). */
+#define KNPEMI_OPT_FOLD_MEMBRANE 5
 int knpemi_set_option(knpemi_handle* h, int option, int value);
 
 /* Nodal trace of an (ECS, cell) pair of bulk functions onto Q_sub: interpolate_to_membrane

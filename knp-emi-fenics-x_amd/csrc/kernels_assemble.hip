@@ -1201,16 +1201,19 @@ struct FacetData {
   bool cell_side;
 };
 
+// phi_x != NULL: the potential is taken from that vector (one value per vertex, e.g. the solver's solution before it is
+// written into the records -- a constant shift of it cancels in the jump) instead of the records' component 7
 template <int NF>
 __device__ __forceinline__ void load_facet(const KnDev& D, const KnConsts& C, int fg, bool cell_side, int ms,
-                                           FacetData<NF>& f) {
+                                           FacetData<NF>& f, const double* __restrict__ phi_x = nullptr) {
   const int K = C.K;
   int si = 0;  // sub-domain of the cell side of this facet
 #pragma unroll
   for (int bb = 0; bb < NF; ++bb) {
-    const int vi = D.fi[(size_t)fg * NF + bb];
-    f.pe[bb] = load_rec(D.VR, D.fe[(size_t)fg * NF + bb]);
+    const int vi = D.fi[(size_t)fg * NF + bb], ve = D.fe[(size_t)fg * NF + bb];
+    f.pe[bb] = load_rec(D.VR, ve);
     f.pi[bb] = load_rec(D.VR, vi);
+    if (phi_x) { f.pe[bb].phi = phi_x[ve]; f.pi[bb].phi = phi_x[vi]; }
     const int q = D.fq[(size_t)fg * NF + bb];
     f.pm[bb] = D.phiM[q];
     const double* ich = D.Ich + (size_t)ms * KN_MAXK * D.NQtot + q;
@@ -1338,10 +1341,12 @@ __device__ __forceinline__ void facet_point_split(const FacetData<NF>& f, const 
 #ifndef KN_MEM_LQ
 #define KN_MEM_LQ 4
 #endif
+// One workgroup's share of the facet integrals; `bid` = its index among the `nb` workgroups that do this work (after the
+// XCD-aware remap: consecutive facets share vertex records, so each XCD takes one contiguous run of facets and fetches a
+// record once instead of once per XCD that meets it: 2.5 MB instead of ... of HBM-side traffic at config 2).
 template <int NF>
-__global__ __launch_bounds__(256) void knp_membrane_kernel(KnDev D, const KnConsts* __restrict__ Cp, int splitting) {
-  const KnConsts& C = *Cp;
-  extern __shared__ double qt[];
+__device__ __forceinline__ void knp_membrane_block(const KnDev& D, const KnConsts& C, int splitting, int bid,
+                                                   const double* __restrict__ phi_x, double* qt) {
   const int nq = D.nq_gamma;
   const int ntab = nq * (1 + NF + (NF == 4 ? 2 * NF : 0));
   for (int i = threadIdx.x; i < ntab; i += blockDim.x) qt[i] = D.qtab[i];
@@ -1349,7 +1354,7 @@ __global__ __launch_bounds__(256) void knp_membrane_kernel(KnDev D, const KnCons
   const double* qw = qt;
   const double* qN = qt + nq;
   const double* qdN = qt + nq * (1 + NF);
-  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gt = bid * blockDim.x + threadIdx.x;
   const int t = gt / KN_MEM_LQ, lq = gt % KN_MEM_LQ;
   // lanes past the last (facet, side) repeat the last one and drop their results: the shuffles below see whole groups
   const bool live = t < 2 * D.nftot;
@@ -1366,7 +1371,7 @@ __global__ __launch_bounds__(256) void knp_membrane_kernel(KnDev D, const KnCons
     for (int k = 0; k < KN_MAXK - 1; ++k) acc[a][k] = 0.0;
   if (ms >= 0) {
     FacetData<NF> f;
-    load_facet<NF>(D, C, fg, cell_side, ms, f);
+    load_facet<NF>(D, C, fg, cell_side, ms, f, phi_x);
     for (int q = lq; q < nq; q += KN_MEM_LQ) {
       double fk[KN_MAXK - 1];
       facet_point<NF>(f, C, q, qw, qN, qdN, splitting, fk);
@@ -1388,6 +1393,54 @@ __global__ __launch_bounds__(256) void knp_membrane_kernel(KnDev D, const KnCons
 #pragma unroll
       for (int k = 0; k < KN_MAXK - 1; ++k)
         if (k < KS) D.gam_e[(size_t)KS * pos[a] + k] = acc[a][k];
+  }
+}
+
+template <int NF>
+__global__ __launch_bounds__(256) void knp_membrane_kernel(KnDev D, const KnConsts* __restrict__ Cp, int splitting) {
+  extern __shared__ double qt[];
+  knp_membrane_block<NF>(D, *Cp, splitting, logical_block(blockIdx.x, gridDim.x), nullptr, qt);
+}
+
+// The write-back of the potential and the facet integrals of b_knp in ONE launch: the first `nbm` workgroups integrate the
+// membrane facets with the potential taken from the solution vector x itself (the mean that the write-back removes cancels
+// in the jump phi_i - phi_e), the others write phi = x - mean into the vertex records (mean = inv_n x the sum of the np
+// partial sums in `part`; np = 0: no shift, e.g. a pasted solution).  This takes the facet kernel out of the chain
+// EMI solve -> KNP assembly: knpemi_assemble_knp finds the integrals in gam_e (knpemi_handle::gam_valid).
+template <int NF>
+__global__ __launch_bounds__(256) void emi_writeback_membrane_kernel(KnDev D, const KnConsts* __restrict__ Cp, int splitting,
+                                                                     int nbm, const double* __restrict__ x, int n,
+                                                                     const double* __restrict__ part, int np, double inv_n,
+                                                                     double* __restrict__ mean_out) {
+  extern __shared__ double qt[];
+  if ((int)blockIdx.x < nbm) {
+    knp_membrane_block<NF>(D, *Cp, splitting, logical_block(blockIdx.x, nbm), x, qt);
+    return;
+  }
+  const int vb = blockIdx.x - nbm, nvb = gridDim.x - nbm;
+  int i = vb * 256 + threadIdx.x;
+  double xi = i < n ? x[i] : 0.0;
+  double mean = 0.0;
+  if (np > 0) {          // the <= 1 024 partial sums, all of a thread's loads in flight; fixed order: the same bits in every block
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    const int t = threadIdx.x;
+    if (t < np) v0 = part[t];
+    if (t + 256 < np) v1 = part[t + 256];
+    if (t + 512 < np) v2 = part[t + 512];
+    if (t + 768 < np) v3 = part[t + 768];
+    double sum = ((v0 + v1) + v2) + v3;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+    __shared__ double sh[4];
+    if ((t & 63) == 0) sh[t >> 6] = sum;
+    __syncthreads();
+    mean = ((sh[0] + sh[1]) + (sh[2] + sh[3])) * inv_n;
+    if (vb == 0 && t == 0 && mean_out) *mean_out = mean;
+  }
+  while (i < n) {
+    D.VR[(size_t)i * KN_REC + 7] = xi - mean;
+    i += nvb * 256;
+    if (i < n) xi = x[i];
   }
 }
 
@@ -1792,6 +1845,27 @@ int kn_launch_knp_membrane(knpemi_handle* h, int flags) {
   return check_launch("knp_membrane_kernel");
 }
 
+// phi <- x - mean and the membrane-facet integrals of b_knp for that potential, one launch (see the kernel).  np = 0: x is
+// written as it is.  Marks the integrals in gam_e as current.
+int kn_launch_emi_writeback_membrane(knpemi_handle* h, const double* x, const double* part, int np, double inv_n, double* mean_out) {
+  const KnDev& D = h->dev;
+  const int n = D.Ntot;
+  if (n == 0) return KNPEMI_OK;
+  const int split = (h->emi_flags & KNPEMI_NO_SPLITTING) ? 0 : 1;
+  const int NF = h->NF;
+  const size_t lds = (size_t)D.nq_gamma * (1 + NF + (NF == 4 ? 2 * NF : 0)) * sizeof(double);
+  const int nbm = (int)((2 * (size_t)D.nftot * KN_MEM_LQ + 255) / 256);
+  const int nbv = std::max(1, std::min(1024, (n + 255) / 256));
+  dim3 grid(nbm + nbv), block(256);
+  KnProfScope prof(h, KNPEMI_K_KNP_MEMBRANE);
+  if (NF == 2) hipLaunchKernelGGL((emi_writeback_membrane_kernel<2>), grid, block, lds, h->cur, D, h->d_consts, split, nbm, x, n, part, np, inv_n, mean_out);
+  else if (NF == 3) hipLaunchKernelGGL((emi_writeback_membrane_kernel<3>), grid, block, lds, h->cur, D, h->d_consts, split, nbm, x, n, part, np, inv_n, mean_out);
+  else hipLaunchKernelGGL((emi_writeback_membrane_kernel<4>), grid, block, lds, h->cur, D, h->d_consts, split, nbm, x, n, part, np, inv_n, mean_out);
+  h->gam_valid = D.nftot > 0;
+  h->gam_split = split;
+  return check_launch("emi_writeback_membrane_kernel");
+}
+
 int kn_launch_knp_membrane_pre(knpemi_handle* h, int flags) {
   const KnDev& D = h->dev;
   if (D.nftot == 0) return KNPEMI_OK;
@@ -1824,6 +1898,7 @@ int kn_launch_emi_membrane_rhs(knpemi_handle* h, int flags) {
 }
 
 int kn_launch_update_pde(knpemi_handle* h) {
+  h->gam_valid = false;      // the concentrations (and phi_M) the facet integrals were formed with change
   const KnDev& D = h->dev;
   const int n = std::max(D.Ntot, D.NQtot);
   if (n == 0) return KNPEMI_OK;
@@ -1833,6 +1908,7 @@ int kn_launch_update_pde(knpemi_handle* h) {
 }
 
 int kn_launch_knp_writeback_update(knpemi_handle* h, const double* x) {
+  h->gam_valid = false;      // the concentrations (and phi_M) the facet integrals were formed with change
   const KnDev& D = h->dev;
   const int n = std::max(D.Ntot, D.NQtot);
   if (n == 0) return KNPEMI_OK;
@@ -1842,6 +1918,7 @@ int kn_launch_knp_writeback_update(knpemi_handle* h, const double* x) {
 }
 
 int kn_launch_halo(knpemi_handle* h, int kind, int pack, const int32_t* idx, int n, double* buf) {
+  if (!pack) h->gam_valid = false;
   if (n == 0) return KNPEMI_OK;
   hipLaunchKernelGGL(halo_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->dev, kind, pack, idx, n,
                      h->moff[h->n_sub], buf);
@@ -1850,6 +1927,7 @@ int kn_launch_halo(knpemi_handle* h, int kind, int pack, const int32_t* idx, int
 
 int kn_launch_field_scatter(knpemi_handle* h, const double* src, double* dst, int n, int dst_stride) {
   if (n == 0) return KNPEMI_OK;
+  h->gam_valid = false;
   hipLaunchKernelGGL(scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, src, dst, n, dst_stride);
   return check_launch("scatter_kernel");
 }

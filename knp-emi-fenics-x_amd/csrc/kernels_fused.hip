@@ -975,6 +975,9 @@ int kn_fused_cg(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const double* b
   int np_rr = 0, np_rz = 0;
   const int nb_vec = Loop::capped((n + FT - 1) / FT);
   const double inv_n = 1.0 / (double)n;
+  // KNPEMI_OPT_FOLD_MEMBRANE: the write-back launch also integrates the membrane facets (the potential system of the CG
+  // path only: its unknowns are the vertex records' phi)
+  const bool fold = h->fold_membrane && !h->fuse_membrane && h->have_params && !h->plain_knp && phi == h->dev.VR + 7;
   auto head = [&]() -> int {
     // x0 = current phi (ksp_initial_guess_nonzero), b = b_emi projected onto zero mean (constant null space)
     hipLaunchKernelGGL(emi_pre_kernel, dim3(nb_vec), dim3(FT), 0, h->stream, n, (const double*)phi, phi_stride, x, b, L.red);
@@ -999,6 +1002,7 @@ int kn_fused_cg(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const double* b
   };
   uint64_t base = mix(mix(mix(mix(0xC6ull, (uint64_t)(uintptr_t)S.work), (uint64_t)G.builds), bits(rtol)), bits(atol));
   base = mix(mix(mix(base, (uint64_t)n), (uint64_t)(uintptr_t)b), (uint64_t)(uintptr_t)phi);
+  base = mix(mix(base, (uint64_t)(h->fold_membrane && !h->fuse_membrane)), (uint64_t)(h->emi_flags & KNPEMI_NO_SPLITTING));
   double sc[S_NF];
   int it = 0, todo = first_chunk(G.its_last, maxit);
   bool first = true;
@@ -1016,6 +1020,9 @@ int kn_fused_cg(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const double* b
       if (int e = iterations(todo)) return e;
       // the solution orthogonal to the constants, into the phi component of the vertex records (idempotent)
       hipLaunchKernelGGL(x_sum_kernel, dim3(nb_vec), dim3(FT), 0, h->stream, n, (const double*)x, L.red);
+      if (fold) {   // ... and, in the same launch, the membrane-facet integrals of b_knp for that potential
+        if (int e = kn_launch_emi_writeback_membrane(h, x, L.red.part + (size_t)P_XS * KN_PB, nb_vec, inv_n, S.sc + S_MEAN)) return e;
+      } else
       hipLaunchKernelGGL(emi_post_kernel, dim3(nb_vec), dim3(FT), 0, h->stream, n, (const double*)x, phi, phi_stride, L.red, nb_vec, inv_n);
       if (use_pub) enqueue_publish(h, pub, S.sc);
       return KNPEMI_OK;
@@ -1026,6 +1033,7 @@ int kn_fused_cg(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const double* b
       if ((todo & 1)) { std::swap(r, r2); std::swap(p, p2); }
       k += todo;
       KN_HIP(hipGraphLaunch(h->fused_graphs[key], h->stream));
+      if (fold) { h->gam_valid = h->dev.nftot > 0; h->gam_split = (h->emi_flags & KNPEMI_NO_SPLITTING) ? 0 : 1; }
     } else if ((rc = run_chunk_graph(h, key, chunk, mode.graph))) return rc;
     if (use_pub) ++h->pub_expected;
     if ((rc = read_state(h, S.sc, sc, use_pub))) return rc;

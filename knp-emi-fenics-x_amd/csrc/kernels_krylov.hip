@@ -637,6 +637,7 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   // solution orthogonal to constants, then into the phi component of the vertex records (ghosts included: they take
   // their owners' values first); idempotent
   auto post = [&]() -> int {
+    h->gam_valid = false;      // the potential changes (knpemi_handle::gam_valid)
     dots(c, 1, x, ones, nullptr, nullptr, nullptr, nullptr, OP_MEAN, 0, 0, 0, 1.0 / n_mean);
     if (dist.on) {
       if (int e = dist.halo(dist.ctx, x, KNPEMI_B_EMI)) c.comm_rc = c.comm_rc ? c.comm_rc : e;
@@ -929,6 +930,7 @@ int kn_extrapolate_guess(knpemi_handle* h, int which) {
   // initial condition, i.e. the first point of the trajectory): no history from it -- 2 x_1 - x_0 with that x_0 cost the
   // second and third solves of a run twice their iterations
   if (h->guess_have[slot] < 0) { h->guess_have[slot] = 0; return KNPEMI_OK; }
+  h->gam_valid = false;
   double* cur = slot == 0 ? D.VR + 7 : D.csol;
   hipLaunchKernelGGL(extrapolate_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, cur, slot == 0 ? KN_REC : 1,
                      h->guess_old[slot], order >= 2 ? h->guess_old[slot] + n : (double*)nullptr, h->guess_have[slot]);

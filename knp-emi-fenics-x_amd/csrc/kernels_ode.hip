@@ -14,6 +14,7 @@
 // Tables are stored transposed on the device ([column][dof]) so that neighbouring threads read
 // neighbouring addresses; the ODE work itself is latency/compute bound (fp64 exp/log, divergent
 // step control), not HBM bound.
+#include <algorithm>
 #include <cstdlib>
 
 #include "knpemi_internal.h"
@@ -27,9 +28,24 @@ OdeDev ode_dev(const knpemi_handle* h) {
   return OdeDev{D.VR, D.q2e, D.q2i, D.phiM, D.Ich};
 }
 
+// Dofs per wavefront (ode_step_body): as few as keep the sweep at one wave per SIMD (1 024 SIMDs; the stats slots of the
+// handle's sweeps are sized for that), all 64 / LANES of them otherwise.  KNPEMI_ODE_DPW forces a value (0: full waves).
+int dofs_per_wave(int nq, int lanes, int max_blocks) {
+  static const int forced = [] { const char* e = getenv("KNPEMI_ODE_DPW"); return e ? atoi(e) : -1; }();
+  const int full = ODE_BLOCK / lanes;
+  if (forced >= 0) return forced > 0 && forced < full && (nq + forced - 1) / forced <= max_blocks ? forced : 0;
+  // Measured at config 2 (2 952 dofs; round 4, bench.py): 16 dofs per wave 77.5-81 us per sweep, 8: 83.1, 4: 83.1 (spike
+  // window 106.7 / 110.8 / 104.6): fewer dofs per wave do NOT shorten the wave's stream measurably -- the trips of the 16
+  // phase machines of a wave overlap almost completely -- and four times the waves cost more than they save.  Full waves
+  // unless forced.
+  (void)max_blocks;
+  return 0;
+}
+
 template <class M, int LANES>
 void launch_model(hipStream_t st, const OdeDev& dv, const OdeArgs& a, const LsodaCoef* cf, int force_waves) {
-  dim3 grid(((size_t)a.nq * LANES + ODE_BLOCK - 1) / ODE_BLOCK), block(ODE_BLOCK);
+  const int per_wave = a.dpw > 0 ? a.dpw : ODE_BLOCK / LANES;
+  dim3 grid(((size_t)a.nq + per_wave - 1) / per_wave), block(ODE_BLOCK);
   // more waves than 1.5 x the chip's 1024 SIMDs: trade registers for a second resident wave per SIMD
   const bool dense = force_waves ? force_waves == 2 : (size_t)grid.x > 1536;
   if (a.stamps) hipLaunchKernelGGL((ode_step_kernel<M, LANES, 1, true>), grid, block, 0, st, dv, a, cf);
@@ -81,6 +97,8 @@ int kn_launch_ode_step(knpemi_handle* h, int slot, double t0, double dt, double 
   for (int i = 0; i < 8; ++i) { a.stim_idx[i] = m.stim_idx[i]; a.stim_val[i] = m.stim_val[i]; }
   a.t0 = t0; a.dt = dt; a.rtol = rtol; a.atol = atol;
   a.states = m.d_states; a.params = m.d_params; a.mask = m.d_mask; a.stats = m.d_stats;
+  a.dpw = dofs_per_wave(m.nq, m.rtc_function ? m.rtc_lanes : (m.n_states == 4 ? 4 : 1), m.n_stat_blocks - 1);
+  if (m.rtc_function) a.dpw = 0;      // (the run-time compiled sweep is launched with full waves, kernels_rtc.hip)
   // KNPEMI_ODE_STAMPS=1: diagnostic build of the sweep with s_memtime stamps between the phases (tools/ode_stamps.py)
   static const bool want_stamps = getenv("KNPEMI_ODE_STAMPS") != nullptr;
   a.stamps = nullptr;

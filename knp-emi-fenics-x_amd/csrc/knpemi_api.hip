@@ -831,6 +831,7 @@ extern "C" void knpemi_destroy(knpemi_handle* h) {
 }
 
 extern "C" int knpemi_set_params(knpemi_handle* h, const knpemi_params* p) {
+  if (h) h->gam_valid = false;
   if (!h || !p) return fail(KNPEMI_EINVAL, "knpemi_set_params: null argument");
   if (!(p->dt > 0) || !(p->C_M > 0) || p->z[h->K - 1] == 0.0)
     return fail(KNPEMI_EINVAL, "knpemi_set_params: dt, C_M must be positive and z_K non-zero");
@@ -920,6 +921,7 @@ int locate(knpemi_handle* h, int field, int sub, int idx, FieldLoc* loc) {
 }  // namespace
 
 extern "C" int knpemi_set_field(knpemi_handle* h, int field, int sub, int idx, const double* host, size_t n) {
+  if (h) h->gam_valid = false;
   if (!h || !host) return fail(KNPEMI_EINVAL, "knpemi_set_field: null argument");
   FieldLoc L;
   int rc = locate(h, field, sub, idx, &L);
@@ -987,6 +989,7 @@ extern "C" int knpemi_assemble_emi(knpemi_handle* h, int flags) {
   if (!h) return fail(KNPEMI_EINVAL, "null handle");
   if (!h->have_params) return fail(KNPEMI_EINVAL, "knpemi_assemble_emi: knpemi_set_params not called");
   KN_HIP(hipSetDevice(h->device));
+  h->emi_flags = flags;
   if (flags & KNPEMI_ON_AUX_STREAM) {
     // fork: the auxiliary stream starts after everything enqueued on the main stream so far
     KN_HIP(hipEventRecord(h->ev_fork, h->stream));
@@ -1052,8 +1055,12 @@ extern "C" int knpemi_assemble_knp(knpemi_handle* h, int flags) {
     return kn_launch_knp_rows(h, flags);
   }
   if (!h->fuse_membrane) {   // stand-alone facet kernel: partial integrals through gam_e, the row kernel adds them
-    int rc = kn_launch_knp_membrane(h, flags);
-    if (rc) return rc;
+    // ... unless the launch that wrote the potential back has formed them already, for these fields and this scheme
+    const int split = (flags & KNPEMI_NO_SPLITTING) ? 0 : 1;
+    if (!(h->gam_valid && h->gam_split == split)) {
+      int rc = kn_launch_knp_membrane(h, flags);
+      if (rc) return rc;
+    }
   }
   return kn_launch_knp_rows(h, flags);
 }
@@ -1234,7 +1241,11 @@ extern "C" int knpemi_set_solution(knpemi_handle* h, int which, const double* x,
       KN_HIP(hipMemcpyAsync(h->d_stage, x, (size_t)D.Ntot * sizeof(double), kind, h->stream));
       src = h->d_stage;
     }
-    int rc = kn_launch_field_scatter(h, src, D.VR + 7, D.Ntot, KN_REC);
+    // a solution pasted on the device stands for the write-back of knpemi_solve_emi: the same launch, facet integrals of
+    // b_knp included (KNPEMI_OPT_FOLD_MEMBRANE)
+    int rc = (on_device && h->fold_membrane && h->have_params && !h->fuse_membrane && !h->dist.on)
+                 ? kn_launch_emi_writeback_membrane(h, src, nullptr, 0, 0.0, nullptr)
+                 : kn_launch_field_scatter(h, src, D.VR + 7, D.Ntot, KN_REC);
     if (rc) return rc;
   } else if (which == KNPEMI_B_KNP) {
     const int KS = h->K - 1;
@@ -1319,7 +1330,8 @@ extern "C" int knpemi_ode_bind(knpemi_handle* h, int sub, int model, int model_i
   int rc;
   if ((rc = dev_zeros(h, (size_t)n_states * m.nq, &m.d_states))) return rc;
   if ((rc = dev_zeros(h, (size_t)n_params * m.nq, &m.d_params))) return rc;
-  m.n_stat_blocks = (int)(((size_t)m.nq * n_states + 63) / 64) + 1;   // one slot per workgroup of the sweep
+  // one slot per workgroup of the sweep (small sweeps run with fewer dofs per wave, up to one wave per SIMD: kernels_ode.hip)
+  m.n_stat_blocks = std::max((int)(((size_t)m.nq * n_states + 63) / 64), std::min(m.nq, 1024)) + 1;
   if ((rc = dev_zeros(h, 3 * (size_t)m.n_stat_blocks, &m.d_stats))) return rc;
   m.bound = 1;
   return KNPEMI_OK;
@@ -1340,7 +1352,7 @@ extern "C" int knpemi_ode_bind_source(knpemi_handle* h, int sub, int model, int 
   m.nq = h->n_q[sub];
   if ((rc = dev_zeros(h, (size_t)n_states * m.nq, &m.d_states))) return rc;
   if ((rc = dev_zeros(h, (size_t)n_params * m.nq, &m.d_params))) return rc;
-  m.n_stat_blocks = (int)(((size_t)m.nq * n_states + 63) / 64) + 1;
+  m.n_stat_blocks = std::max((int)(((size_t)m.nq * n_states + 63) / 64), std::min(m.nq, 1024)) + 1;
   if ((rc = dev_zeros(h, 3 * (size_t)m.n_stat_blocks, &m.d_stats))) return rc;
   m.bound = 1;
   return KNPEMI_OK;
@@ -1435,6 +1447,7 @@ extern "C" int knpemi_ode_step(knpemi_handle* h, int sub, int model, double t0, 
   if (!(dt > 0) || !(rtol >= 0) || !(atol >= 0) || (rtol == 0 && atol == 0))
     return fail(KNPEMI_EINVAL, "knpemi_ode_step: bad dt / tolerances");
   KN_HIP(hipSetDevice(h->device));
+  h->gam_valid = false;      // phi_M and the channel currents change
   if (flags & (KNPEMI_ODE_ON_AUX_STREAM | KNPEMI_ODE_ON_AUX2_STREAM)) {
     const bool second = (flags & KNPEMI_ODE_ON_AUX2_STREAM) != 0;
     hipStream_t side = second ? h->aux2 : h->aux;
@@ -1635,6 +1648,7 @@ extern "C" int knpemi_set_option(knpemi_handle* h, int option, int value) {
     for (unsigned& c : h->prof_count) c = 0;
     return KNPEMI_OK;
   }
+  if (option == KNPEMI_OPT_FOLD_MEMBRANE) { h->fold_membrane = value ? 1 : 0; h->gam_valid = false; return KNPEMI_OK; }
   if (option == KNPEMI_OPT_KNP_MIN_IT) {
     if (value < 0) return fail(KNPEMI_EINVAL, "KNPEMI_OPT_KNP_MIN_IT: negative");
     h->knp_min_it = value;

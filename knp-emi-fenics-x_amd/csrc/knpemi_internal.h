@@ -302,6 +302,13 @@ struct knpemi_handle {
   int knp_min_it = 0;                  // KNPEMI_OPT_KNP_MIN_IT (ksp_min_it of the concentration solve, pdeSolver.py:101)
   bool plain_knp = false;              // the KNP solve's unknown order is dev.csol's own ([K-1][Ntot]; DG variant)
   int fuse_membrane = 0;               // KNPEMI_OPT_FUSE_MEMBRANE
+  // The membrane-facet integrals of b_knp in gam_e are those of the current fields (formed by the launch that wrote the
+  // potential back, kn_launch_emi_writeback_membrane) with this splitting flag: knpemi_assemble_knp skips the facet kernel.
+  // Cleared by everything that changes an input of the integrals (concentrations, phi, phi_M, I_ch, parameters).
+  bool gam_valid = false;
+  int gam_split = 1;
+  int fold_membrane = 1;               // KNPEMI_OPT_FOLD_MEMBRANE: form them in the write-back launch of the potential
+  int emi_flags = 0;                   // flags of the last knpemi_assemble_emi (the splitting scheme the step runs with)
   int prof_stride = 1;                 // KNPEMI_OPT_PROFILE_STRIDE
   unsigned prof_count[16] = {0};
   int lds_gam_max = 0;                 // most membrane entries of one row block
@@ -365,6 +372,7 @@ int kn_launch_knp_rows(knpemi_handle* h, int flags);
 int kn_launch_knp_membrane_pre(knpemi_handle* h, int flags);
 int kn_launch_emi_membrane_rhs(knpemi_handle* h, int flags);
 int kn_launch_knp_membrane(knpemi_handle* h, int flags);
+int kn_launch_emi_writeback_membrane(knpemi_handle* h, const double* x, const double* part, int np, double inv_n, double* mean_out);
 int kn_launch_membrane_mass(knpemi_handle* h, int n_entries, const int* d_entry_row, double* d_out);
 int kn_launch_ode_step(knpemi_handle* h, int slot, double t0, double dt, double rtol, double atol,
                        int flags, const int32_t* ion_param, int v_index);

@@ -21,6 +21,7 @@ struct OdeDev {
 
 struct OdeArgs {
   int nq, q0, n_stim, flags, v_index, model_slot, NQtot, n_ions;
+  int dpw;               // membrane dofs per wavefront (<= 64 / LANES; 0 = all of them), see ode_step_body
   int ion_param[3 * KN_ODE_MAXK];
   int stim_idx[8];
   double stim_val[8];
@@ -70,11 +71,20 @@ __device__ __forceinline__ void ode_step_body(const OdeDev& D, const OdeArgs& a,
     for (int i = threadIdx.x; i < (int)(sizeof(LsodaCoef) / sizeof(double)); i += ODE_BLOCK) dst[i] = src[i];
     __syncthreads();
   }
-  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  // Dofs per wavefront.  A wave runs the UNION of the trips of its dofs' phase machines, and an instruction costs the same
+  // whatever the exec mask: with 64 / LANES dofs per wave ~10 % of the stream is other dofs' trips.  While the sweep has fewer
+  // waves than the chip has SIMDs (config 2: 185 on 1 024) the idle SIMDs buy that back: `dpw` dofs per wave, the other
+  // lanes MIRROR them (lane l integrates what lane l mod (dpw LANES) integrates and drops the result: identical control
+  // flow, no divergence added, every lane active for the wave-level sums).
+  constexpr int FULL = ODE_BLOCK / LANES;
+  const int dpw = (a.dpw > 0 && a.dpw < FULL) ? a.dpw : FULL;
+  const int lane_in = threadIdx.x % (dpw * LANES);
+  const bool primary = threadIdx.x < dpw * LANES;
+  const int qw = blockIdx.x * dpw + lane_in / LANES;
   // the lanes past the last dof repeat the last dof and drop their results: every lane of the wave stays active,
   // so the wave-level sums below see all 64 lanes
-  const bool live = gt / LANES < a.nq;
-  const int q = live ? gt / LANES : a.nq - 1, comp = gt % LANES;
+  const bool live = primary && qw < a.nq;
+  const int q = qw < a.nq ? qw : a.nq - 1, comp = threadIdx.x % LANES;
   const int qg = a.q0 + q;
   const StridedRow<0> p{a.params + q, (size_t)a.nq};   // this dof's parameter row in the transposed table
   double y[NI];

@@ -1,4 +1,5 @@
 """GPU parity tests: HIP kernels (through the C ABI and the knpemi API) against the oracle."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -356,6 +357,46 @@ def test_assembly_matches_golden_fixtures(hip_lib, kind, r):
         assert rel_err(A.diagonal(), g[f"{tag}_A_emi_diag"]) < TOL
         # structural sizes (scipy prunes exact zeros when it forms P = A + M, so P is not compared)
         assert (int(g[f"{tag}_nnz"][0]), int(g[f"{tag}_nnz"][2])) == (A.nnz, Ak.nnz)
+
+
+@pytest.mark.parametrize("kind,r", [("2d", 1), ("tet", 0), ("hex", 0)])
+def test_facet_integrals_formed_in_the_potential_write_back_launch(hip_lib, kind, r):
+    """KNPEMI_OPT_FOLD_MEMBRANE: the launch that writes a potential back (here a pasted solution, as in bench.py's timed
+    steps; knpemi_solve_emi's own write-back in the solver tests) also forms the membrane-facet integrals of b_knp
+    (knpWeakForm.py:168-214).  b_knp equals the one assembled with the facet kernel as a launch of its own bit for bit and
+    matches the oracle; the stored integrals are dropped as soon as one of their inputs changes (phi_M here)."""
+    from knpemi.pdeSolver import create_solver_emi, create_solver_knp
+    s = Setup(kind, r)
+    s.perturb()
+    o, P, params, ions = s.oracle()
+    emi = create_solver_emi(s.a_emi, s.L_emi, s.phi, s.entity_maps, s.subdomain_list, None, p=s.p_emi, direct=False)
+    knp = create_solver_knp(s.a_knp, s.L_knp, s.c, s.entity_maps, s.subdomain_list, None, p=s.p_knp)
+    emi.assemble()
+    knp.assemble()                              # pushes every field; facet kernel as its own launch
+    dp = knp.dp
+    ref = dp.rhs(L.B_KNP).copy()
+    phi_all = np.concatenate([s.phi[t].x._a for t in s.subdomain_list])
+    hip = C.CDLL("libamdhip64.so")
+    dev = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dev), C.c_size_t(phi_all.nbytes)) == 0
+    assert hip.hipMemcpy(dev, phi_all.ctypes.data_as(C.c_void_p), C.c_size_t(phi_all.nbytes), 1) == 0
+    out = {}
+    for fold in (1, 0):
+        L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_FOLD_MEMBRANE, fold))
+        dp.set_rhs(L.B_KNP, np.full(len(ref), np.nan))
+        L.check(dp.lib.knpemi_set_solution(dp.h, L.B_EMI, dev, 1))         # paste on the device
+        L.check(dp.lib.knpemi_assemble_knp(dp.h, 0))
+        out[fold] = dp.rhs(L.B_KNP).copy()
+    assert np.array_equal(out[1], out[0]) and np.array_equal(out[1], ref)
+    # an input changes after the potential was written back: the stored integrals must not be used
+    L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_FOLD_MEMBRANE, 1))
+    L.check(dp.lib.knpemi_set_solution(dp.h, L.B_EMI, dev, 1))
+    s.phi_M_prev[1].x.array[:] = s.phi_M_prev[1].x._a + 1e-3
+    _, fresh = knp.assemble()                   # pushes the new phi_M (knpemi_set_field), then assembles
+    c_all, phi, phiM, mm = s.oracle_fields()
+    _, bko = o.assemble_knp(P, params, ions, c_all, phi, phiM, mm, s.dt)
+    assert rel_err(fresh, bko) < TOL and not np.array_equal(fresh, ref)
+    hip.hipFree(dev)
 
 
 def test_device_stepper_matches_dropin_path(hip_lib):
