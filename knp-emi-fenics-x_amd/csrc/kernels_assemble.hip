@@ -222,6 +222,27 @@ __device__ __forceinline__ RecK<KS> lds_rec(const double* recs, int i) {
   return r;
 }
 
+// Staged records of a UNIFORM hexahedral mesh (every cell the same parallelepiped: the geometry is a constant of the
+// mesh, knpemi_handle::hex_geo, and no coordinates are staged): EMI 16 bytes (kappa, sigma), KNP 8 (KS + 1) bytes
+// (f_0 .. f_{KS-1}, phi) -- 40 % / 50 % of the 40- / 48-byte records, in LDS bytes staged, LDS bytes read per (row, cell)
+// pair and registers held per pair (8 records at once).
+struct Rec2 { double k, s; };
+__device__ __forceinline__ Rec2 lds_rec2(const double* recs, int i) {
+  const double2 u = *reinterpret_cast<const double2*>(recs + (size_t)i * 2);
+  return Rec2{u.x, u.y};
+}
+template <int KS>
+struct RecU { double f[KS], c; };   // c = phi
+template <int KS>
+__device__ __forceinline__ RecU<KS> lds_recu(const double* recs, int i) {
+  RecU<KS> r;
+  const double* p = recs + (size_t)i * (KS + 1);
+#pragma unroll
+  for (int k = 0; k < KS; ++k) r.f[k] = p[k];
+  r.c = p[KS];
+  return r;
+}
+
 template <int GDIM, class R>
 __device__ __forceinline__ double simplex_row0(const R (&r)[GDIM + 1], double (&d)[GDIM + 1]) {
   // gradient dot products of lambda_0 with all lambda_j, and the cell measure
@@ -325,15 +346,31 @@ __device__ __forceinline__ Rec5 lds_rec5(const double* recs, int i) {
 
 // one staged record from the 64-byte vertex record u (x y | z c3 | c0 c1 | c2 phi).  KS = 0: EMI (5 doubles),
 // KS >= 1: KNP with KS solved ions (4 + KS doubles).  fs / nvs: ECS source term (NULL when unused), v the vertex.
-template <int KS>
+template <int KS, bool UNI = false>
 __device__ __forceinline__ void write_staged(double* recs, int i, const double2 (&u)[4], double inv_dt, const double* fs0,
                                              int nvs, int v, const KnSubConst* scp) {
   if constexpr (KS == 0) {
-    double* d5 = recs + (size_t)i * 5;
     const double c0 = u[2].x, c1 = u[2].y, c2 = u[3].x, c3 = u[1].y;   // ions beyond K have kap = sig = 0 (and c = 0)
-    d5[0] = u[0].x; d5[1] = u[0].y; d5[2] = u[1].x;
-    d5[3] = scp->kap[0] * c0 + scp->kap[1] * c1 + scp->kap[2] * c2 + scp->kap[3] * c3;
-    d5[4] = scp->sig[0] * c0 + scp->sig[1] * c1 + scp->sig[2] * c2 + scp->sig[3] * c3;
+    const double kap = scp->kap[0] * c0 + scp->kap[1] * c1 + scp->kap[2] * c2 + scp->kap[3] * c3;
+    const double sig = scp->sig[0] * c0 + scp->sig[1] * c1 + scp->sig[2] * c2 + scp->sig[3] * c3;
+    if constexpr (UNI) {
+      *reinterpret_cast<double2*>(recs + (size_t)i * 2) = double2{kap, sig};
+    } else {
+      double* d5 = recs + (size_t)i * 5;
+      d5[0] = u[0].x; d5[1] = u[0].y; d5[2] = u[1].x;
+      d5[3] = kap;
+      d5[4] = sig;
+    }
+  } else if constexpr (UNI) {
+    const double cp[3] = {u[2].x, u[2].y, u[3].x};
+    double* d = recs + (size_t)i * (KS + 1);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      double f = cp[k] * inv_dt;
+      if (fs0) f += fs0[(size_t)k * nvs + v];
+      d[k] = f;
+    }
+    d[KS] = u[3].y;
   } else {
     const double cp[3] = {u[2].x, u[2].y, u[3].x};     // the solved ions live in slots 4..6
     double f[KS];
@@ -355,7 +392,7 @@ __device__ __forceinline__ void write_staged(double* recs, int i, const double2 
   }
 }
 
-template <int KS>
+template <int KS, bool UNI = false>
 __device__ __forceinline__ void stage_records(const KnDev& D, const BlkInfo& B, double* recs, uint16_t* eloc, int tid,
                                               double inv_dt, const double* fs0, int nvs,
                                               const KnSubConst* scp = nullptr) {
@@ -375,12 +412,12 @@ __device__ __forceinline__ void stage_records(const KnDev& D, const BlkInfo& B, 
     }
 #pragma unroll
   for (int k = 0; k < KN_STAGE; ++k)
-    if (vv[k] >= 0) write_staged<KS>(recs, tid + k * KN_BLOCK, u[k], inv_dt, fs0, nvs, vv[k], scp);
+    if (vv[k] >= 0) write_staged<KS, UNI>(recs, tid + k * KN_BLOCK, u[k], inv_dt, fs0, nvs, vv[k], scp);
   for (int i = tid + KN_STAGE * KN_BLOCK; i < B.nuniq; i += KN_BLOCK) {   // oversized blocks only
     const int v = D.blk_uverts[B.uoff + i];
     const double2* src = reinterpret_cast<const double2*>(D.VR + (size_t)v * KN_REC);
     const double2 uu[4] = {src[0], src[1], src[2], src[3]};
-    write_staged<KS>(recs, i, uu, inv_dt, fs0, nvs, v, scp);
+    write_staged<KS, UNI>(recs, i, uu, inv_dt, fs0, nvs, v, scp);
   }
 }
 
@@ -908,10 +945,31 @@ __device__ __forceinline__ Geo geometry(const R (&r)[8]) {
 }
 }  // namespace hexcf
 
+namespace hexcf {
+// The geometry of a cell of a uniform mesh in the frame of the row vertex: local vertex j ^ li takes position j, i.e. the
+// edge vectors of the axes whose bit is set in li change sign: g[s][t] -> d_s d_t g[s][t], |det| unchanged.
+__device__ __forceinline__ Geo reflected(const KnHexGeo& U, int li) {
+  Geo G;
+  G.det = U.det;
+  G.skew = U.skew != 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) G.g[a][b] = (a != b && (((li >> a) ^ (li >> b)) & 1)) ? -U.g[a][b] : U.g[a][b];
+  return G;
+}
+}  // namespace hexcf
+
 // Row of local vertex 0 (records in the reflected order, see above): kappa-stiffness ra, volume right-hand side.
+// BOX: the metric tensor is known to be diagonal (uniform box meshes): the mixed terms are not even compiled
+template <bool BOX = false, class R>
+__device__ __forceinline__ void hex_emi_row0_g(const R (&r)[8], const hexcf::Geo& G, double (&ra)[8], double& bvol);
 __device__ __forceinline__ void hex_emi_row0(const Rec5 (&r)[8], double (&ra)[8], double& bvol) {
+  hex_emi_row0_g(r, hexcf::geometry(r), ra, bvol);
+}
+template <bool BOX, class R>
+__device__ __forceinline__ void hex_emi_row0_g(const R (&r)[8], const hexcf::Geo& G, double (&ra)[8], double& bvol) {
   using namespace hexcf;
-  const Geo G = geometry(r);
 #pragma unroll
   for (int j = 0; j < 8; ++j) ra[j] = 0.0;
   double bv = 0.0;
@@ -932,7 +990,7 @@ __device__ __forceinline__ void hex_emi_row0(const Rec5 (&r)[8], double (&ra)[8]
     for (int j = 0; j < 8; ++j) ra[j] += (((j >> s) & 1) ? -c : c) * P[(j >> a) & 1][(j >> b) & 1];
     bv += G.g[s][s] * ds;
   }
-  if (G.skew) {
+  if (!BOX && G.skew) {
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -958,10 +1016,15 @@ __device__ __forceinline__ void hex_emi_row0(const Rec5 (&r)[8], double (&ra)[8]
 }
 
 // Row of local vertex 0 of the KNP element matrices (records in the reflected order): mass, stiffness, drift.
+template <bool BOX = false, class R8>
+__device__ __forceinline__ void hex_knp_row0_g(const R8 (&r)[8], const hexcf::Geo& G, double (&M)[8], double (&S)[8], double (&Cc)[8]);
 template <class R8>
 __device__ __forceinline__ void hex_knp_row0(const R8 (&r)[8], double (&M)[8], double (&S)[8], double (&Cc)[8]) {
+  hex_knp_row0_g(r, hexcf::geometry(r), M, S, Cc);
+}
+template <bool BOX, class R8>
+__device__ __forceinline__ void hex_knp_row0_g(const R8 (&r)[8], const hexcf::Geo& G, double (&M)[8], double (&S)[8], double (&Cc)[8]) {
   using namespace hexcf;
-  const Geo G = geometry(r);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     M[j] = G.det * (a0(j & 1) * a0((j >> 1) & 1) * a0((j >> 2) & 1));
@@ -984,7 +1047,7 @@ __device__ __forceinline__ void hex_knp_row0(const R8 (&r)[8], double (&M)[8], d
       Cc[j] -= 0.5 * g * P[(j >> a) & 1][(j >> b) & 1];
     }
   }
-  if (G.skew) {
+  if (!BOX && G.skew) {
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -1007,15 +1070,19 @@ __device__ __forceinline__ void hex_knp_row0(const R8 (&r)[8], double (&M)[8], d
   }
 }
 
-template <int LPR, bool AFFINE>
-__global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n,
-                                                            int rec_n, int want_p, int splitting) {
+// GEO: 0 general trilinear cells (2 x 2 x 2 quadrature), 1 every cell a parallelepiped (closed forms, geometry from the
+// staged coordinates), 2 every cell the SAME parallelepiped (closed forms, geometry U a constant, records without coordinates)
+template <int LPR, int GEO>
+__global__ __launch_bounds__(KN_BLOCK, GEO == 2 ? 4 : (GEO == 1 ? 3 : 2)) void emi_rows_hex_v2(
+    KnDev D, const KnConsts* __restrict__ Cp, int acc_n, int rec_n, int want_p, int splitting, KnHexGeo U) {
   constexpr int NF = 4;
+  constexpr bool AFFINE = GEO >= 1, UNI = GEO == 2;
+  constexpr int RW = UNI ? 2 : 5;
   const KnConsts& C = *Cp;
   extern __shared__ __align__(16) double lds[];
   double* accA = lds;
   double* recs = lds + (size_t)acc_n;
-  uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + 5 * (size_t)rec_n + (rec_n & 1));
+  uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + RW * (size_t)rec_n + ((RW * rec_n) & 1));
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
   const BlkInfo B = load_blk(D, b, tid >> 6);
@@ -1036,7 +1103,7 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
   const int4 ri = D.row_info[g];
   for (int i = tid; i < seglen; i += KN_BLOCK) accA[i] = 0.0;
   const KnSubConst& sc = C.sc[s];
-  stage_records<0>(D, B, recs, eloc, tid, 0.0, nullptr, 0, &sc);
+  stage_records<0, UNI>(D, B, recs, eloc, tid, 0.0, nullptr, 0, &sc);
   __syncthreads();
 
   const bool cell_side = s > 0;
@@ -1044,6 +1111,27 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
   if (valid) {
     const int rowbase = ri.x, lap = ri.y & 0xFFFF, ne = (unsigned)ri.y >> 16, rL = ri.z;
     auto do_pair = [&](int pc, uint2 sl) {
+      if constexpr (UNI) {
+        const int li = pc & 7;
+        const uint64_t s64 = ((uint64_t)sl.y << 32) | sl.x;
+        int slot[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) slot[j] = (int)((s64 >> (8 * (j ^ li))) & 255);
+        Rec2 r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = lds_rec2(recs, eloc[rL + slot[j]]);
+        double ra[8];
+        hexcf::Geo G;          // box: diagonal metric, invariant under the reflections of the row-vertex frame
+        G.det = U.det; G.skew = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b2 = 0; b2 < 3; ++b2) G.g[a][b2] = a == b2 ? U.g[a][a] : 0.0;
+        hex_emi_row0_g<true>(r, G, ra, bacc);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) unsafeAtomicAdd(&accA[lap + slot[j]], ra[j]);
+        return;
+      }
       const int li = pc & 7;
       int slot[8];
 #pragma unroll
@@ -1058,7 +1146,7 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
       for (int j = 0; j < 8; ++j) r[j] = lds_rec5(recs, eloc[rL + slot[j]]);
       double ra[8];
       if constexpr (AFFINE) hex_emi_row0(r, ra, bacc);
-      else hex_emi_row<AFFINE>(r, li, ra, bacc);
+      else hex_emi_row<false>(r, li, ra, bacc);
 #pragma unroll
       for (int j = 0; j < 8; ++j) unsafeAtomicAdd(&accA[lap + slot[j]], ra[j]);
     };
@@ -1081,14 +1169,16 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void emi_rows_hex_v2(KnDe
   });
 }
 
-template <int LPR, bool AFFINE, int KS, int MEM>
-__global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n, int rec_n,
-                                                                            int gam_n, int splitting) {
+template <int LPR, int GEO, int KS, int MEM>
+__global__ __launch_bounds__(KN_BLOCK, GEO == 2 ? 4 : (GEO == 1 ? 3 : 2)) void knp_rows_hex_v2(
+    KnDev D, const KnConsts* __restrict__ Cp, int acc_n, int rec_n, int gam_n, int splitting, KnHexGeo U) {
+  constexpr bool AFFINE = GEO >= 1, UNI = GEO == 2;
+  constexpr int RW = UNI ? KS + 1 : 4 + KS;
   const KnConsts& C = *Cp;
   extern __shared__ __align__(16) double lds[];
   double* acc = lds;
   double* recs = lds + (size_t)KS * acc_n;
-  double* gam = recs + (size_t)(4 + KS) * rec_n + (((4 + KS) * rec_n) & 1);
+  double* gam = recs + (size_t)RW * rec_n + ((RW * rec_n) & 1);
   uint16_t* eloc = reinterpret_cast<uint16_t*>(gam + (size_t)KS * gam_n);
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
@@ -1113,7 +1203,7 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDe
 #pragma unroll
     for (int k = 0; k < KS; ++k) acc[(size_t)k * acc_n + i] = 0.0;
   }
-  stage_records<KS>(D, B, recs, eloc, tid, C.inv_dt, fs0, nvs);
+  stage_records<KS, UNI>(D, B, recs, eloc, tid, C.inv_dt, fs0, nvs);
   if constexpr (MEM == 1) membrane_entries_to_lds<4, KS>(D, C, B.me0, B.mne, s > 0, splitting, tid, gam);
   __syncthreads();
 
@@ -1125,6 +1215,32 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDe
     const int rL = ri.z;
     auto do_pair = [&](int pc, uint2 sl) {
       const int li = pc & 7;
+      if constexpr (UNI) {
+        const uint64_t s64 = ((uint64_t)sl.y << 32) | sl.x;
+        int slot[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) slot[j] = (int)((s64 >> (8 * (j ^ li))) & 255);
+        RecU<KS> r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = lds_recu<KS>(recs, eloc[rL + slot[j]]);
+        double M[8], S[8], Cc[8];
+        hexcf::Geo G;
+        G.det = U.det; G.skew = false;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b2 = 0; b2 < 3; ++b2) G.g[a][b2] = a == b2 ? U.g[a][a] : 0.0;
+        hex_knp_row0_g<true>(r, G, M, S, Cc);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+          for (int k = 0; k < KS; ++k) {
+            unsafeAtomicAdd(&acc[(size_t)k * acc_n + rL + slot[j]], M[j] * C.inv_dt + sc.D[k] * S[j] + sc.zpsiD[k] * Cc[j]);
+            bk[k] += M[j] * r[j].f[k];
+          }
+        }
+        return;
+      }
       int slot[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) { slot[j] = (sl.x >> (8 * j)) & 255; slot[4 + j] = (sl.y >> (8 * j)) & 255; }
@@ -1138,7 +1254,7 @@ __global__ __launch_bounds__(KN_BLOCK, AFFINE ? 3 : 2) void knp_rows_hex_v2(KnDe
       for (int j = 0; j < 8; ++j) r[j] = lds_rec<KS>(recs, eloc[rL + slot[j]]);
       double M[8], S[8], Cc[8];
       if constexpr (AFFINE) hex_knp_row0(r, M, S, Cc);
-      else hex_knp_row<AFFINE>(r, li, M, S, Cc);
+      else hex_knp_row<false>(r, li, M, S, Cc);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
 #pragma unroll
@@ -1754,20 +1870,21 @@ static int launch_knp_v2(knpemi_handle* h, int split, int pre) {
 static int launch_emi_hex_v2(knpemi_handle* h, int want_p, int split) {
   const KnDev& D = h->dev;
   const int acc_n = (h->lds_doubles_emi + 1) & ~1, rec_n = h->lds_uniq_max;
-  const size_t lds = ((size_t)acc_n + 5 * (size_t)rec_n + 1) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
+  const int geo = h->hex_uniform ? 2 : (h->hex_affine ? 1 : 0);
+  const size_t lds = ((size_t)acc_n + (geo == 2 ? 2 : 5) * (size_t)rec_n + 1) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
   if (lds > 160 * 1024) { kn_set_error("EMI row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   dim3 grid(D.nblocks), block(KN_BLOCK);
   int rc = 0;
-#define KN_CASE2(L, AFF)                                                                            \
-    if ((rc = set_lds_limit(emi_rows_hex_v2<L, AFF>, lds))) return rc;                              \
+#define KN_CASE2(L, GEO)                                                                            \
+    if ((rc = set_lds_limit(emi_rows_hex_v2<L, GEO>, lds))) return rc;                              \
     {                                                                                               \
       KnProfScope prof(h, KNPEMI_K_EMI_ROWS);                                                       \
-      hipLaunchKernelGGL((emi_rows_hex_v2<L, AFF>), grid, block, lds, h->cur, D, h->d_consts, acc_n, \
-                         rec_n, want_p, split);                                                     \
+      hipLaunchKernelGGL((emi_rows_hex_v2<L, GEO>), grid, block, lds, h->cur, D, h->d_consts, acc_n, \
+                         rec_n, want_p, split, h->hex_geo);                                         \
     }
 #define KN_CASE(L)                                                                                  \
   case L:                                                                                           \
-    if (h->hex_affine) { KN_CASE2(L, true) } else { KN_CASE2(L, false) }                            \
+    if (geo == 2) { KN_CASE2(L, 2) } else if (geo == 1) { KN_CASE2(L, 1) } else { KN_CASE2(L, 0) }  \
     break;
   switch (h->lpr) { KN_CASE(1) KN_CASE(2) KN_CASE(4) KN_CASE(8) default: kn_set_error("bad lanes-per-row"); return KNPEMI_EINVAL; }
 #undef KN_CASE
@@ -1780,23 +1897,25 @@ static int launch_knp_hex_v2(knpemi_handle* h, int split, int pre) {
   const int acc_n = (h->lds_doubles_knp + 1) & ~1, rec_n = h->lds_uniq_max;
   const int KS = h->K - 1;
   const int gam_n = h->fuse_membrane ? std::max(1, h->lds_gam_max) : 0;
-  const size_t lds = ((size_t)KS * acc_n + (4 + KS) * (size_t)rec_n + 1 + (size_t)KS * gam_n) * sizeof(double)
+  const int geo = h->hex_uniform ? 2 : (h->hex_affine ? 1 : 0);
+  const size_t lds = ((size_t)KS * acc_n + (geo == 2 ? KS + 1 : 4 + KS) * (size_t)rec_n + 1 + (size_t)KS * gam_n) * sizeof(double)
                      + 2 * (size_t)h->lds_doubles_knp + 16;
   if (lds > 160 * 1024) { kn_set_error("KNP row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   dim3 grid(D.nblocks), block(KN_BLOCK);
   int rc = 0;
   const int mem = pre ? 2 : (gam_n > 0 ? 1 : 0);
-#define KN_CASE(L, AFF, S, M)                                                                       \
-  if (h->lpr == L && h->hex_affine == AFF && KS == S && mem == M) {                                 \
-    if ((rc = set_lds_limit(knp_rows_hex_v2<L, AFF, S, M>, lds))) return rc;                        \
+#define KN_CASE(L, GEO, S, M)                                                                       \
+  if (h->lpr == L && geo == GEO && KS == S && mem == M) {                                           \
+    if ((rc = set_lds_limit(knp_rows_hex_v2<L, GEO, S, M>, lds))) return rc;                        \
     KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                         \
-    hipLaunchKernelGGL((knp_rows_hex_v2<L, AFF, S, M>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n, gam_n, split); \
+    hipLaunchKernelGGL((knp_rows_hex_v2<L, GEO, S, M>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n, gam_n, split, h->hex_geo); \
     return check_launch("knp_rows_hex_v2");                                                         \
   }
-  KN_CASE(4, true, 2, 0) KN_CASE(4, false, 2, 0) KN_CASE(2, true, 2, 0) KN_CASE(2, false, 2, 0) KN_CASE(8, true, 2, 0) KN_CASE(8, false, 2, 0)
-  KN_CASE(1, true, 2, 0) KN_CASE(1, false, 2, 0) KN_CASE(4, true, 1, 0) KN_CASE(4, false, 1, 0) KN_CASE(4, true, 3, 0) KN_CASE(4, false, 3, 0)
-  KN_CASE(4, true, 2, 1) KN_CASE(4, false, 2, 1) KN_CASE(4, true, 1, 1) KN_CASE(4, false, 1, 1) KN_CASE(4, true, 3, 1) KN_CASE(4, false, 3, 1)
-  KN_CASE(4, true, 2, 2) KN_CASE(4, false, 2, 2) KN_CASE(4, true, 1, 2) KN_CASE(4, false, 1, 2) KN_CASE(4, true, 3, 2) KN_CASE(4, false, 3, 2)
+#define KN_GEO(L, S, M) KN_CASE(L, 2, S, M) KN_CASE(L, 1, S, M) KN_CASE(L, 0, S, M)
+  KN_GEO(4, 2, 0) KN_GEO(2, 2, 0) KN_GEO(8, 2, 0) KN_GEO(1, 2, 0) KN_GEO(4, 1, 0) KN_GEO(4, 3, 0)
+  KN_GEO(4, 2, 1) KN_GEO(4, 1, 1) KN_GEO(4, 3, 1)
+  KN_GEO(4, 2, 2) KN_GEO(4, 1, 2) KN_GEO(4, 3, 2)
+#undef KN_GEO
 #undef KN_CASE
   kn_set_error("knp_rows (hexahedra): unsupported lanes-per-row / ion-count / membrane-option combination");
   return KNPEMI_EINVAL;

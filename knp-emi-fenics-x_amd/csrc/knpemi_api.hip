@@ -285,6 +285,57 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
       affine = dev <= 1e-13 * len;
     }
     h->hex_affine = affine && getenv("KNPEMI_HEX_GENERAL") == nullptr;
+    // ... and is every cell the SAME parallelepiped (every box mesh of the reference's 3-D driver, make_mesh_3D.py:100-102:
+    // create_box with a uniform grid)?  Then the geometry is a constant of the mesh and the row kernels stage no
+    // coordinates.  The constant comes from the descriptor when the mesh generator supplies its exact cell
+    // (knpemi_problem_desc::uniform_cell: the same bits on every rank of a partitioned run), else from the first cell;
+    // every cell is checked against it.
+    if (h->hex_affine && nctot > 0 && getenv("KNPEMI_HEX_NOT_UNIFORM") == nullptr) {
+      double E[3][3];      // E[t][a]: component a of edge vector t
+      bool given = false, uniform = false;
+      for (int i = 0; i < 9; ++i) given |= d->uniform_cell[i] != 0.0;
+      // (a supplied cell that the coordinates do not bear out -- a generated mesh transformed afterwards -- is ignored)
+      for (int attempt = given ? 0 : 1; attempt < 2 && !uniform; ++attempt) {
+        for (int t = 0; t < 3; ++t)
+          for (int a = 0; a < 3; ++a)
+            E[t][a] = attempt == 0 ? d->uniform_cell[3 * t + a]
+                                   : VR[(size_t)cells[1 << t] * KN_REC + a] - VR[(size_t)cells[0] * KN_REC + a];
+        double scale = 0.0;
+        for (int t = 0; t < 3; ++t) for (int a = 0; a < 3; ++a) scale = std::max(scale, std::fabs(E[t][a]));
+        uniform = scale > 0.0;
+        for (size_t c = 0; c < (size_t)nctot && uniform; ++c) {
+          const int* cv = &cells[c * 8];
+          for (int t = 0; t < 3 && uniform; ++t)
+            for (int a = 0; a < 3; ++a) {
+              const double e = VR[(size_t)cv[1 << t] * KN_REC + a] - VR[(size_t)cv[0] * KN_REC + a];
+              if (std::fabs(e - E[t][a]) > 1e-9 * scale) { uniform = false; break; }
+            }
+        }
+      }
+      if (uniform) {
+        // the arithmetic of hexcf::geometry (kernels_assemble.hip) on the edge vectors
+        double J[3][3];
+        for (int t = 0; t < 3; ++t) for (int a = 0; a < 3; ++a) J[a][t] = E[t][a];
+        const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1], c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2],
+                     c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+        const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+        if (det != 0.0) {
+          const double inv = 1.0 / det;
+          double I[3][3];
+          I[0][0] = c00 * inv; I[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * inv; I[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * inv;
+          I[1][0] = c01 * inv; I[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * inv; I[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * inv;
+          I[2][0] = c02 * inv; I[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * inv; I[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * inv;
+          KnHexGeo& G = h->hex_geo;
+          G.det = std::fabs(det);
+          for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) G.g[a][b] = G.det * (I[a][0] * I[b][0] + I[a][1] * I[b][1] + I[a][2] * I[b][2]);
+          G.skew = (G.g[0][1] != 0.0 || G.g[0][2] != 0.0 || G.g[1][2] != 0.0) ? 1 : 0;
+          // the uniform kernels are built for BOX cells (diagonal metric: what the reference's meshes are); a uniform
+          // sheared mesh keeps the general parallelepiped kernels
+          h->hex_uniform = G.skew == 0;
+        }
+      }
+    }
   }
 
   // ---- static ICS mass of the preconditioner: P_emi = A_emi + int u v dx on the cell sub-domains ---------

@@ -130,6 +130,10 @@ struct KnOdeModel {
 // start[b] + size[b] - 1, its row-major size[b] x size[b] inverse begins at off[b] (doubles)
 struct KnDenseBlocks { int nb = 0; int start[8] = {0}; int size[8] = {0}; int off[8] = {0}; };
 
+// geometry of the cells of a uniform hexahedral mesh (edge vectors e_t = x[1 << t] - x[0] of every cell): g = |det J| J^-1 J^-T,
+// J = [e_0 e_1 e_2]; passed to the hexahedral row kernels by value
+struct KnHexGeo { double g[3][3]; double det; int skew; };
+
 // Algebraic multigrid hierarchy (kernels_amg.hip)
 struct KnAmgCsr { int n = 0, m = 0, nnz = 0; int* rp = nullptr; int* ci = nullptr; double* v = nullptr; };
 struct KnAmgLevel {
@@ -266,6 +270,8 @@ struct knpemi_handle {
   int have_params = 0;
   int lpr = 1;                         // lanes per row of the row kernels (1, 2, 4 or 8)
   bool hex_affine = false;             // every hexahedron is a parallelepiped (constant Jacobian)
+  bool hex_uniform = false;            // ... and all of them are the same one: the geometry below is a constant of the mesh
+  KnHexGeo hex_geo{};
   int lds_doubles_emi = 0, lds_doubles_knp = 0; // per-block LDS segment sizes (doubles)
   int lds_uniq_max = 0;                         // most distinct vertices touched by one row block
   std::vector<void*> allocs;  // everything hipMalloc'ed

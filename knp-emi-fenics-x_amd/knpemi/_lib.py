@@ -43,6 +43,7 @@ class ProblemDesc(C.Structure):
         ("facet_q", C.POINTER(c_int_p)), ("facet_model", C.POINTER(c_int_p)),
         ("q_to_e", C.POINTER(c_int_p)), ("q_to_i", C.POINTER(c_int_p)),
         ("n_models", c_int_p),
+        ("uniform_cell", C.c_double * 9),
     ]
 
 

@@ -143,6 +143,10 @@ class DeviceProblem:
         desc.q_to_e = _ptr_array(flat["q_to_e"], L.c_int_p)
         desc.q_to_i = _ptr_array(flat["q_to_i"], L.c_int_p)
         desc.n_models = L.iptr(self.n_models)
+        uc = getattr(mesh, "uniform_cell", None)      # edge vectors of every cell of a generated uniform box mesh
+        if uc is not None and mesh.cell_type == "hexahedron":
+            for i, v in enumerate(np.asarray(uc, np.float64).reshape(9)):
+                desc.uniform_cell[i] = float(v)
         if device is None:
             import os
             device = int(os.environ.get("LOCAL_RANK", "0")) % lib.knpemi_device_count()

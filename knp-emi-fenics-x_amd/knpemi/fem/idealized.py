@@ -85,6 +85,7 @@ def make_mesh_3D_slab(resolution_factor, cell_type, l, x_cells, comm=None):
     axes = [np.linspace(0.0, hi[d], n[d] + 1) for d in range(3)]
     axes[0] = axes[0][x_cells[0]:x_cells[1] + 1]
     mesh = create_box(comm, None, None, cell_type, axes=axes)
+    mesh.uniform_cell = np.diag(np.array(hi) / np.array(n, float))      # the global grid's cell: the same bits on every rank
     ct, ft = _tag(mesh, axon_boxes(l), [1, 1, 1, 1])
     return mesh, ct, ft
 

@@ -260,7 +260,13 @@ def create_box(comm, points, n, cell_type=CellType.hexahedron, axes=None):
         cells = hexes[:, _KUHN].reshape(-1, 4)
     else:
         raise ValueError(cell_type)
-    return Mesh(x, cells, cell_type, comm)
+    mesh = Mesh(x, cells, cell_type, comm)
+    if axes is None and points is not None:
+        # a uniform grid: every cell has the edge vectors (L_d / n_d) e_d -- known exactly here, handed to the device
+        # library so that it need not derive the cell from rounded coordinate differences (knpemi_problem_desc.uniform_cell)
+        lo, hi = np.asarray(points[0], float), np.asarray(points[1], float)
+        mesh.uniform_cell = np.diag((hi - lo) / np.array([nx, ny, nz], float))
+    return mesh
 
 
 # ---------------------------------------------------------------------------
@@ -333,6 +339,8 @@ def extract_submesh(mesh, tags, values):
     lookup[pverts] = np.arange(pverts.shape[0], dtype=np.int32)
     ctype = mesh.cell_type if tags.dim == mesh.tdim else mesh.facet_type
     sub = Mesh(mesh.x[pverts], lookup[ev], ctype, mesh.comm)
+    if tags.dim == mesh.tdim and getattr(mesh, "uniform_cell", None) is not None:
+        sub.uniform_cell = mesh.uniform_cell          # cells of a uniform grid stay cells of that grid
     sub.parent_vertices = pverts      # sub-mesh vertex -> parent vertex
     sub.parent_entities = ents        # sub-mesh cell -> parent entity (cell or facet)
     sub.parent = mesh
