@@ -1071,7 +1071,11 @@ __device__ __forceinline__ void hex_knp_row0_g(const R8 (&r)[8], const hexcf::Ge
 }
 
 // GEO: 0 general trilinear cells (2 x 2 x 2 quadrature), 1 every cell a parallelepiped (closed forms, geometry from the
-// staged coordinates), 2 every cell the SAME parallelepiped (closed forms, geometry U a constant, records without coordinates)
+// staged coordinates), 2 every cell the SAME box (closed forms, the diagonal metric U a constant of the mesh, records without
+// coordinates: 16 instead of 40 bytes).  Measured at 165 888 hexahedra (config 2h, round 4): GEO 1 -> 2 takes emi_rows from
+// 134 to 99 registers (3 -> 4 waves per SIMD) and 59.9 -> 45.0 us alone (0.29 -> 0.39 of 8 TB/s), 99 -> 64.5 us beside the
+// ODE sweep; knp_rows 168 registers + spills -> 123, 59.1 -> 46.1 us (0.285 -> 0.365).  Capping emi_rows at 96 registers
+// for a fifth wave per SIMD is slower (53.8 us): fewer registers serialise the eight record reads of a pair.
 template <int LPR, int GEO>
 __global__ __launch_bounds__(KN_BLOCK, GEO == 2 ? 4 : (GEO == 1 ? 3 : 2)) void emi_rows_hex_v2(
     KnDev D, const KnConsts* __restrict__ Cp, int acc_n, int rec_n, int want_p, int splitting, KnHexGeo U) {
