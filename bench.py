@@ -514,11 +514,13 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, wo
     def roof(which, name, us):
         by = dg_time.algorithmic_bytes(dp, which)
         # PMC counters of this build, collected in their own profiler passes (tools/collect_traffic.sh)
-        tr = load_traffic(args.workload)[1].get(name)
+        tfile, tdata = load_traffic(args.workload)
+        tr = tdata.get(name + ("_general" if os.environ.get("KNPEMI_DG_HEX_GENERAL") and kind == "hex" else ""))
         traffic = (2.0 * tr["FETCH_SIZE_KiB"] + tr["WRITE_SIZE_KiB"]) * 1024.0 if tr else None
         return {"bound": "hbm", "kernel": name, "achieved": by / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": by,
-                "avg_launch_us": us}
+                "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tfile if tr else None,
+                "frac_by_counters": traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if traffic else None,
+                "algorithmic_bytes_per_launch": by, "avg_launch_us": us}
     out = {
         "metric": "assembled dofs/s (DG volume + interior-facet SIP + membrane-facet assembly + membrane ODE sweep) per "
                   "timestep; 3D idealized mesh, fp64",
@@ -621,7 +623,7 @@ def build_problem(workload, args, rank, world):
 def load_traffic(workload):
     """HBM-side bytes per launch from the PMC passes of this build (tools/collect_traffic.sh -> profiles/rNN_traffic.json,
     collected and corrected as MI355X_MICROARCH.md prescribes); the newest round's file that has the workload."""
-    for name in ("r03_traffic.json", "r02_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", name)))[workload]
             return name, tr

@@ -1,18 +1,24 @@
 #!/bin/bash
 # Round-end evidence on the GPU box: rocprofv3 kernel statistics of the bench command, bench lines of every workload.
-# Everything lands under gpurun_out/r03/ ; tools/refresh_profiles.py copies what is to be judged into profiles/ and
+# Everything lands under gpurun_out/$ROUND/ (ROUND=r04 by default) ; tools/refresh_profiles.py copies what is to be judged into profiles/ and
 # regenerates the numbers quoted in profiles/README.md from those files.  usage: tools/collect_profiles.sh [part ...]
 # parts: stats bench bench2 (default: all; each part fits one 20-minute gpurun call)
 PARTS=${@:-stats bench bench2}
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r03
+ROUND=${ROUND:-r04}
+O=$R/gpurun_out/$ROUND
 mkdir -p $O
 for part in $PARTS; do
 if [ $part = stats ]; then
+  # one population of launches per file: the default line runs three legs (config 2, the 995 k-tet mesh, the DG variants) in
+  # one process, so each leg gets a profiler run of its own next to the driver's full command
   cd /tmp && export TMPDIR=/tmp
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_driver -- \
+      python3 $R/bench.py --steps 20 --warmup 5 > $O/stats_driver.json 2> $O/stats_driver.err
+  echo "rocprof: the driver's command done"
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_config2 -- \
-      python3 $R/bench.py --steps 20 --warmup 5 > $O/stats_config2.json 2> $O/stats_config2.err
-  echo "rocprof config2 (the driver's command) done"
+      python3 $R/bench.py --steps 20 --warmup 5 --cpu-steps 0 --no-config3 --no-dg > $O/stats_config2.json 2> $O/stats_config2.err
+  echo "rocprof config2 (this leg only) done"
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_config3 -- \
       python3 $R/bench.py --workload config3 --steps 20 --warmup 5 --cpu-steps 0 --solve-steps 0 --no-dg > $O/stats_config3.json 2> $O/stats_config3.err
   echo "rocprof config3 done"
@@ -20,8 +26,11 @@ if [ $part = stats ]; then
       python3 $R/bench.py --workload config2h --steps 20 --warmup 5 --cpu-steps 0 --solve-steps 0 --no-dg --no-overlap > $O/stats_config2h.json 2> $O/stats_config2h.err
   echo "rocprof config2h done"
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dg -- \
-      python3 $R/bench.py --variant dg --steps 50 --warmup 5 > $O/stats_dg.json 2> $O/stats_dg.err
-  echo "rocprof dg done"
+      python3 $R/bench.py --variant dg --steps 50 --warmup 5 --solve-steps 0 > $O/stats_dg.json 2> $O/stats_dg.err
+  echo "rocprof dg (tetrahedra, config 2) done"
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dg_config2h -- \
+      python3 $R/bench.py --variant dg --workload config2h --steps 20 --warmup 3 --solve-steps 0 > $O/stats_dg_config2h.json 2> $O/stats_dg_config2h.err
+  echo "rocprof dg (hexahedra, config 2h, box-mesh kernels) done"
 fi
 if [ $part = bench ]; then
   cd $R
