@@ -283,14 +283,15 @@ def agreement(case, replay, final):
     return out
 
 
-def device_solvers(case, its, maxit=1000, dp=None, min_it=None):
-    """Solve callbacks of the stepper: knpemi_solve_emi (CG + AMG) / knpemi_solve_knp (BiCGStab + AMG) at the
-    reference's tolerances, starting from the extrapolated previous solutions.  `min_it` (with `dp`): fewest BiCGStab
-    iterations of the concentration solve (KNPEMI_OPT_KNP_MIN_IT; None leaves the handle's setting alone)."""
+def device_solvers(case, its, maxit=1000, dp=None, min_it=None, method="bicgstab"):
+    """Solve callbacks of the stepper: knpemi_solve_emi (CG + AMG) / knpemi_solve_knp (BiCGStab or GMRES + AMG) at the
+    reference's tolerances, starting from the extrapolated previous solutions.  `min_it` (with `dp`): fewest iterations of
+    the concentration solve in the units of `method` (KNPEMI_OPT_KNP_MIN_IT / _METHOD; None leaves the handle's settings)."""
     from knpemi import _lib as L
     rtol_emi, rtol_knp = case.solver_rtol
     if dp is not None and min_it is not None:
-        L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_MIN_IT, int(min_it)))
+        from knpemi.pdeSolver import set_knp_solver_options
+        set_knp_solver_options(dp, method, min_it)
 
     def solver(which, key, rtol, atol):
         def run(d):
@@ -390,7 +391,7 @@ class Replay:
             self.stepper.step(self.halo)
 
 
-def with_solves(case, replay, start, n_steps, torch, min_it=0):
+def with_solves(case, replay, start, n_steps, torch, min_it=0, method="bicgstab"):
     """Whole time steps of run_3D.py:345-368 on the device, Krylov solves included: the
     same stepper with `knpemi_solve_emi` (CG + AMG) and `knpemi_solve_knp` (BiCGStab + AMG) between the assemblies.
     Starts at the FIXED trajectory step `start` (whatever --steps / --warmup are): steps start, start + 1 are untimed
@@ -402,7 +403,7 @@ def with_solves(case, replay, start, n_steps, torch, min_it=0):
     dp = stepper.dp
     replay.restart(start)
     its = {"emi": [], "knp": []}
-    stepper.solve_emi, stepper.solve_knp = device_solvers(case, its, dp=dp, min_it=min_it)
+    stepper.solve_emi, stepper.solve_knp = device_solvers(case, its, dp=dp, min_it=min_it, method=method)
     for _ in range(2):
         stepper.step(halo)
     dp.sync()
@@ -418,13 +419,15 @@ def with_solves(case, replay, start, n_steps, torch, min_it=0):
     stepper.solve_emi = stepper.solve_knp = None
     info = {k: dp.solver_info(w) for k, w in (("emi", L.B_EMI), ("knp", L.B_KNP))}
     re, rk = case.solver_rtol
-    L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_MIN_IT, 0))
+    from knpemi.pdeSolver import set_knp_solver_options
+    set_knp_solver_options(dp, "bicgstab", 0)
+    knp_name = "BiCGStab" if method == "bicgstab" else "GMRES(30), left preconditioning, preconditioned-norm test"
     return {"ms_per_step": ms, "steps": n_steps, "trajectory_steps": [start + 2, start + 2 + n_steps],
-            "knp_min_iterations": int(min_it),
+            "knp_min_iterations": int(min_it), "knp_method": method,
             "initial_guess": "3 x_n - 3 x_(n-1) + x_(n-2) (knpemi_extrapolate_guess)",
             "emi": {"solver": f"CG + SA-AMG V(1,1), rtol {re:g}", "iterations_avg": sum(its["emi"]) / n_steps,
                     "iterations_max": max(its["emi"]), **info["emi"]},
-            "knp": {"solver": f"BiCGStab + SA-AMG V(1,1), rtol {rk:g}", "iterations_avg": sum(its["knp"]) / n_steps,
+            "knp": {"solver": f"{knp_name} + SA-AMG V(1,1), rtol {rk:g}", "iterations_avg": sum(its["knp"]) / n_steps,
                     "iterations_max": max(its["knp"]), **info["knp"]}}
 
 
@@ -999,13 +1002,16 @@ def main():
                "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
                "dtype": "f64", "data": "synthetic",
                **{k: v for k, v in out.items() if k not in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")}}
-    ws = ws_min = None
+    ws = ws_min = ws_ref = None
     if args.solve_steps > 0 and replay is not None:      # collective at N > 1: every rank takes part
         ws = with_solves(case, replay, WITH_SOLVES_START, args.solve_steps, torch)
         # the same with the reference's ksp_min_it = 5 of the concentration solve (pdeSolver.py:101): five GMRES iterations
         # apply operator and preconditioner five times, three BiCGStab iterations six times
         from knpemi.pdeSolver import KNP_MIN_BICGSTAB_ITERATIONS
         ws_min = with_solves(case, replay, WITH_SOLVES_START, args.solve_steps, torch, min_it=KNP_MIN_BICGSTAB_ITERATIONS)
+        # ... and with the reference's options as PETSc runs them: GMRES(30), left preconditioning, preconditioned norm,
+        # ksp_min_it = 5 GMRES iterations (single rank: the fused loops)
+        ws_ref = with_solves(case, replay, WITH_SOLVES_START, args.solve_steps, torch, min_it=5, method="gmres") if world == 1 else None
     if rank == 0:
         if ws is not None:
             out["with_solves"] = ws
@@ -1014,6 +1020,13 @@ def main():
                         "at least three BiCGStab iterations = six applications of operator and preconditioner",
                 **{k: ws_min[k] for k in ("ms_per_step", "steps", "knp_min_iterations")},
                 "emi_iterations_avg": ws_min["emi"]["iterations_avg"], "knp_iterations_avg": ws_min["knp"]["iterations_avg"]}
+            if ws_ref is not None:
+                out["with_solves_reference_options"] = {
+                    "what": "the same steps with the concentration solve as the reference configures it (pdeSolver.py:99-110: "
+                            "ksp_type gmres, ksp_min_it 5; PETSc's defaults: restart 30, left preconditioning, classical "
+                            "Gram-Schmidt, preconditioned residual norm against |M^-1 b|)",
+                    **{k: ws_ref[k] for k in ("ms_per_step", "steps", "knp_min_iterations", "knp_method")},
+                    "emi_iterations_avg": ws_ref["emi"]["iterations_avg"], "knp_iterations_avg": ws_ref["knp"]["iterations_avg"]}
         s = case.s
         if args.cpu_steps > 0 and world == 1 and case.family == "idealized":
             avail = len(os.sched_getaffinity(0))

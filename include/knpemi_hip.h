@@ -296,6 +296,12 @@ int knpemi_update_pde(knpemi_handle* h);
  * launch fewer between the two solves.  The integrals are used only while none of their inputs has changed since; 0 keeps
  * the facet kernel a launch of its own (what bench.py times as the facet-assembly kernel). */
 #define KNPEMI_OPT_FOLD_MEMBRANE 5
+/* KNPEMI_OPT_KNP_METHOD (default 0): 0 = right-preconditioned BiCGStab, convergence on the true residual (fewest launches per
+ * V-cycle); 1 = what PETSc's defaults make of the reference's `ksp_type gmres` (pdeSolver.py:100): GMRES with restart 30, left
+ * preconditioning, classical Gram-Schmidt, convergence on the preconditioned residual norm relative to |M^-1 b|; the
+ * iteration count and KNPEMI_OPT_KNP_MIN_IT then count GMRES iterations as `ksp_min_it` / getIterationNumber() do.
+ * Single rank, AMG preconditioner (the fused loops); otherwise the option is ignored. */
+#define KNPEMI_OPT_KNP_METHOD 6
 int knpemi_set_option(knpemi_handle* h, int option, int value);
 
 /* Nodal trace of an (ECS, cell) pair of bulk functions onto Q_sub: interpolate_to_membrane

@@ -1149,6 +1149,297 @@ int kn_fused_bicgstab(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const dou
   return KNPEMI_OK;
 }
 
+// =====================================================================================================================
+// GMRES(30), left-preconditioned, classical Gram-Schmidt, convergence on the PRECONDITIONED residual norm relative to
+// |M^-1 b| -- what PETSc's defaults make of the reference's options for the concentration solve (`ksp_type gmres`,
+// pdeSolver.py:100; KSPGMRES: restart 30, left preconditioning, classical Gram-Schmidt without refinement, preconditioned
+// norm; KSPConvergedDefault with a non-zero initial guess measures against the preconditioned right-hand side).
+// KNPEMI_OPT_KNP_METHOD = 1 selects it; the default stays BiCGStab on the true residual (fewer launches per V-cycle).
+// Per Arnoldi step: normalise + SpMV (the head of that kernel applies the Givens rotations to the previous column and
+// decides convergence, every block for itself from the same numbers), the V-cycle (5 launches with three levels), the
+// j + 1 dot products as block partial sums, the orthogonalisation (its head re-sums them) = 8 launches.
+// =====================================================================================================================
+namespace {
+constexpr int GM_M = 30;                      // restart length (KSPGMRES default)
+// device scalars of a GMRES solve behind the shared ones: beta, the rotations, the rotated (upper triangular) columns
+enum { GM_BETA = 0, GM_CS = 8, GM_SN = GM_CS + GM_M, GM_R = GM_SN + GM_M, GM_H = GM_R + GM_M * GM_M, GM_N = GM_H + GM_M + 2 };
+
+struct GmState { double* gm; double* dots; };   // dots: (GM_M + 1) arrays of KN_PB partial sums
+
+// The scalar work of step j (j >= 1: column j - 1 of the Hessenberg matrix is complete once |w| = h_{j,j-1} is known): every
+// thread of every block computes it from the same inputs; block 0 records.  Returns false when the solve is over.
+__device__ __forceinline__ bool gm_column(const Red& red, const GmState& g, int j, int base, double ww, double& inv_h) {
+  double* sc = red.sc;
+  const double hj = sqrt(ww);
+  inv_h = hj != 0.0 ? 1.0 / hj : 0.0;
+  const double target2 = sc[S_TARGET2], min_it = sc[S_MINIT];
+  const bool rec = blockIdx.x == 0 && threadIdx.x == 0;
+  double res;
+  if (j == 0) {                                  // hj = beta = |M^-1 (b - A x0)|
+    res = hj;
+    if (rec) g.gm[GM_BETA] = hj;
+  } else {
+    // rotate column j - 1 by the earlier rotations, then annihilate its subdiagonal entry hj
+    const double beta = g.gm[GM_BETA];
+    double gj = beta;                            // g_{j-1} after the earlier rotations
+    double col_prev = g.gm[GM_H + 0];
+    for (int i = 0; i < j - 1; ++i) {
+      const double c = g.gm[GM_CS + i], s = g.gm[GM_SN + i];
+      const double hn = g.gm[GM_H + i + 1];
+      const double a = c * col_prev + s * hn, bnew = -s * col_prev + c * hn;
+      if (rec) g.gm[GM_R + (j - 1) * GM_M + i] = a;
+      col_prev = bnew;
+      gj = -s * gj;
+    }
+    const double d = sqrt(col_prev * col_prev + hj * hj);
+    const double c = d != 0.0 ? col_prev / d : 1.0, s = d != 0.0 ? hj / d : 0.0;
+    if (rec) { g.gm[GM_R + (j - 1) * GM_M + (j - 1)] = d; g.gm[GM_CS + j - 1] = c; g.gm[GM_SN + j - 1] = s; }
+    res = fabs(s * gj);                          // |g_j|
+  }
+  const double it = (double)(base + j);
+  const bool done = (!(res * res > target2) && it >= min_it) || hj == 0.0;
+  if (rec) {
+    sc[S_RR] = res * res; sc[S_IT] = it;
+    if (done) sc[S_DONE] = DONE_CONVERGED;
+  }
+  return !done;
+}
+
+// step j: v_j = w / |w| (stored), t = A v_j
+template <int L0>
+__global__ __launch_bounds__(FT) void gm_spmv_kernel(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                                     const double* __restrict__ av, const double* __restrict__ w,
+                                                     double* __restrict__ vj, double* __restrict__ t, Red red, GmState g, int np,
+                                                     int j, int base) {
+  const int lane = threadIdx.x % L0, stride = gridDim.x * (FT / L0);
+  int row = (blockIdx.x * FT + threadIdx.x) / L0, ra = 0, rb = 0;
+  double wr = 0.0;
+  auto fetch = [&]() { if (row < n) { ra = rp[row]; rb = rp[row + 1]; wr = w[row]; } };
+  fetch();
+  const double* const src[1] = {red.arr(P_PQ)};
+  Totals<1> T;
+  T.load(src, np);
+  if (red.sc[S_DONE] != 0.0) return;
+  double ww[1];
+  T.finish(ww);
+  double inv = 0.0;
+  if (!gm_column(red, g, j, base, ww[0], inv)) return;
+  while (row < n) {
+    const double acc = row_sum_ab<L0>(ci, av, ra, rb, lane, [&](int c) { return w[c]; });
+    if (lane == 0) { vj[row] = wr * inv; t[row] = acc * inv; }
+    row += stride;
+    fetch();
+  }
+}
+
+// end of a chunk / of a restart cycle: the scalar work of step j alone (one block)
+__global__ __launch_bounds__(FT) void gm_check_kernel(Red red, GmState g, int np, int j, int base) {
+  const double* const src[1] = {red.arr(P_PQ)};
+  Totals<1> T;
+  T.load(src, np);
+  if (red.sc[S_DONE] != 0.0) return;
+  double ww[1];
+  T.finish(ww);
+  double inv;
+  (void)gm_column(red, g, j, base, ww[0], inv);
+}
+
+// partial sums of w . v_i, i = 0 .. j (one array of partial sums per i)
+__global__ __launch_bounds__(FT) void gm_dots_kernel(int n, const double* __restrict__ w, const double* __restrict__ V, size_t ldv,
+                                                     int j, Red red, GmState g) {
+  if (red.sc[S_DONE] != 0.0) return;
+  for (int i = 0; i <= j; ++i) {
+    const double* v = V + (size_t)i * ldv;
+    double d[1] = {0.0};
+    for (int r = blockIdx.x * FT + threadIdx.x; r < n; r += gridDim.x * FT) d[0] += w[r] * v[r];
+    double* const dst[1] = {g.dots + (size_t)i * KN_PB};
+    block_partials<1>(d, dst);
+  }
+}
+
+// h_i = w . v_i from the partial sums (block 0 records column j), w -= sum_i h_i v_i, partial sums of |w|^2
+__global__ __launch_bounds__(FT) void gm_orth_kernel(int n, double* __restrict__ w, const double* __restrict__ V, size_t ldv, int j,
+                                                     Red red, GmState g, int np) {
+  if (red.sc[S_DONE] != 0.0) return;
+  __shared__ double hs[GM_M + 1];
+  for (int i = 0; i <= j; ++i) {
+    const double* const src[1] = {g.dots + (size_t)i * KN_PB};
+    Totals<1> T;
+    T.load(src, np);
+    double h[1];
+    T.finish(h);
+    if (threadIdx.x == 0) { hs[i] = h[0]; if (blockIdx.x == 0) g.gm[GM_H + i] = h[0]; }
+  }
+  __syncthreads();
+  double ww[1] = {0.0};
+  for (int r = blockIdx.x * FT + threadIdx.x; r < n; r += gridDim.x * FT) {
+    double x = w[r];
+    for (int i = 0; i <= j; ++i) x -= hs[i] * V[(size_t)i * ldv + r];
+    w[r] = x;
+    ww[0] += x * x;
+  }
+  double* const dst[1] = {red.arr(P_PQ)};
+  block_partials<1>(ww, dst);
+}
+
+// |a|^2 as block partial sums into array `which`
+__global__ __launch_bounds__(FT) void gm_sqnorm_kernel(int n, const double* __restrict__ a, Red red, int which) {
+  double d[1] = {0.0};
+  for (int r = blockIdx.x * FT + threadIdx.x; r < n; r += gridDim.x * FT) d[0] += a[r] * a[r];
+  double* const dst[1] = {red.arr(which)};
+  block_partials<1>(d, dst);
+}
+
+// loop state at the start of a restart cycle (one block): target from |M^-1 b| (first cycle only), flags
+__global__ __launch_bounds__(FT) void gm_start_kernel(Red red, int np_b, double rtol, double atol, int min_it, int first, int np_r) {
+  double* sc = red.sc;
+  double d[2], one[1];
+  {
+    const double* const src[1] = {red.arr(P_BS)};
+    Totals<1> T;
+    T.load(src, np_b);
+    T.finish(one);
+    d[0] = one[0];
+  }
+  {
+    const double* const src[1] = {red.arr(P_RR)};
+    Totals<1> T;
+    T.load(src, np_r);
+    T.finish(one);
+    d[1] = one[0];
+  }
+  if (threadIdx.x != 0) return;
+  if (first) {
+    const double bb = d[0], bnorm = sqrt(bb);
+    const double target = fmax(atol, rtol * (bnorm > 0.0 ? bnorm : 1.0));
+    sc[S_BB] = bb; sc[S_TARGET2] = target * target;
+    sc[S_IT] = 0.0; sc[S_FLAG] = 0.0; sc[S_MINIT] = (double)min_it;
+    const double rr = d[1];                      // |b - A x0|^2: only to tell non-finite input apart
+    sc[S_DONE] = !(bb - bb == 0.0) ? DONE_BAD_RHS : (!(rr - rr == 0.0) ? DONE_BAD_START : DONE_NO);
+  }
+}
+
+// x += sum_{i < k} y_i v_i, R y = g (k = columns completed in this restart cycle = S_IT - base): the triangular solve is a few
+// hundred operations, every thread does it for itself
+__global__ __launch_bounds__(FT) void gm_update_kernel(int n, double* __restrict__ x, const double* __restrict__ V, size_t ldv,
+                                                       Red red, GmState g, int base) {
+  const int k = (int)red.sc[S_IT] - base;
+  if (k <= 0) return;
+  __shared__ double ys[GM_M];
+  if (threadIdx.x == 0) {
+    double gv[GM_M];
+    double gj = g.gm[GM_BETA];
+    for (int i = 0; i < k; ++i) { const double c = g.gm[GM_CS + i], s = g.gm[GM_SN + i]; gv[i] = c * gj; gj = -s * gj; }
+    for (int i = k - 1; i >= 0; --i) {
+      double a = gv[i];
+      for (int l = i + 1; l < k; ++l) a -= g.gm[GM_R + l * GM_M + i] * ys[l];
+      ys[i] = a / g.gm[GM_R + i * GM_M + i];
+    }
+  }
+  __syncthreads();
+  for (int r = blockIdx.x * FT + threadIdx.x; r < n; r += gridDim.x * FT) {
+    double a = x[r];
+    for (int i = 0; i < k; ++i) a += ys[i] * V[(size_t)i * ldv + r];
+    x[r] = a;
+  }
+}
+
+int ensure_gmres(knpemi_handle* h, size_t n, GmState* out) {
+  const size_t need = (size_t)GM_M * n;
+  if (h->gm_n < need) {
+    void* p = nullptr;
+    KN_HIP(hipMalloc(&p, need * sizeof(double)));
+    h->allocs.push_back(p);
+    h->gm_V = static_cast<double*>(p);
+    h->gm_n = need;
+  }
+  if (!h->gm_state) {
+    void* p = nullptr;
+    const size_t doubles = GM_N + (size_t)(GM_M + 1) * KN_PB;
+    KN_HIP(hipMalloc(&p, doubles * sizeof(double)));
+    h->allocs.push_back(p);
+    KN_HIP(hipMemsetAsync(p, 0, doubles * sizeof(double), h->stream));
+    h->gm_state = static_cast<double*>(p);
+  }
+  out->gm = h->gm_state;
+  out->dots = h->gm_state + GM_N;
+  return KNPEMI_OK;
+}
+
+}  // namespace
+
+int kn_fused_gmres(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const double* b, double rtol, double atol, int maxit,
+                   int* iters, double* rr_out, double* bb_out, const std::function<int()>& pre, const std::function<int()>& post) {
+  const int n = S.n;
+  const size_t N = S.N;
+  double *x = S.work, *r = x + N, *w = r + N, *t = w + N, *tmp = t + N;
+  int rc = ensure_partials(h);
+  if (rc) return rc;
+  GmState g{};
+  if ((rc = ensure_gmres(h, (size_t)n, &g))) return rc;
+  double* V = h->gm_V;
+  const size_t ldv = (size_t)n;
+  Loop L{h, G, S, Red{S.sc, h->fused_part}, h->stream, lanes0(G)};
+  const int l0 = L.l0;
+  const int nb_row = Loop::capped(L.blocks0(n)), nb_vec = Loop::capped((n + FT - 1) / FT);
+  const int min_it = std::max(0, std::min(h->knp_min_it, maxit));
+  Publish pub{};
+  const bool use_pub = publish_usable();
+  if (use_pub && (rc = ensure_publish(h, &pub))) return rc;
+  double sc[S_NF];
+  int it = 0, base = 0;
+  bool first = true;
+  // restart length: KSPGMRES's default 30; KNPEMI_GMRES_RESTART (2 .. 30) shortens it (the restart path in the tests)
+  static const int m_restart = [] { const char* e = getenv("KNPEMI_GMRES_RESTART"); const int v = e ? atoi(e) : GM_M; return v >= 2 && v <= GM_M ? v : GM_M; }();
+  if ((rc = pre())) return rc;
+  // (the kernels of the cycle look at the early-out flag: clear what the previous solve left before the first of them runs)
+  KN_HIP(hipMemsetAsync(S.sc + S_DONE, 0, sizeof(double), h->stream));
+  for (;;) {      // restart cycles
+    // r = b - A x; w = M^-1 r; first cycle: also |M^-1 b| for the target
+    KN_LAUNCH_L0(l0, dim3(nb_row), h->stream, (residual_kernel<4, false>), (residual_kernel<16, false>), n, S.rowptr, S.colind,
+                 S.vals, (const double*)x, b, r, (double*)nullptr, L.red, 0, 0.0);
+    if (first) {
+      L.cycle<IN_PLAIN, false, false>(b, nullptr, nullptr, nullptr, nullptr, tmp, 0, 0, nullptr, nullptr);
+      hipLaunchKernelGGL(gm_sqnorm_kernel, dim3(nb_vec), dim3(FT), 0, h->stream, n, (const double*)tmp, L.red, (int)P_BS);
+    }
+    hipLaunchKernelGGL(gm_start_kernel, dim3(1), dim3(FT), 0, h->stream, L.red, nb_vec, rtol, atol, min_it, first ? 1 : 0, nb_row);
+    L.cycle<IN_PLAIN, false, false>(r, nullptr, nullptr, nullptr, nullptr, w, 0, 0, nullptr, nullptr);
+    hipLaunchKernelGGL(gm_sqnorm_kernel, dim3(nb_vec), dim3(FT), 0, h->stream, n, (const double*)w, L.red, (int)P_PQ);
+    first = false;
+    int j = 0;
+    int todo = std::max(1, std::min({std::max(first_chunk(G.its_last, maxit), min_it) - base, m_restart, maxit - base}));
+    bool done = false;
+    while (!done) {
+      for (int k = 0; k < todo && j < m_restart; ++k, ++j) {
+        KN_LAUNCH_L0(l0, dim3(nb_row), h->stream, gm_spmv_kernel<4>, gm_spmv_kernel<16>, n, S.rowptr, S.colind, S.vals,
+                     (const double*)w, V + (size_t)j * ldv, t, L.red, g, nb_vec, j, base);
+        L.cycle<IN_PLAIN, false, false>(t, nullptr, nullptr, nullptr, nullptr, w, 0, 0, nullptr, nullptr);
+        hipLaunchKernelGGL(gm_dots_kernel, dim3(nb_vec), dim3(FT), 0, h->stream, n, (const double*)w, (const double*)V, ldv, j, L.red, g);
+        hipLaunchKernelGGL(gm_orth_kernel, dim3(nb_vec), dim3(FT), 0, h->stream, n, w, (const double*)V, ldv, j, L.red, g, nb_vec);
+      }
+      hipLaunchKernelGGL(gm_check_kernel, dim3(1), dim3(FT), 0, h->stream, L.red, g, nb_vec, j, base);
+      if (use_pub) { enqueue_publish(h, pub, S.sc); ++h->pub_expected; }
+      if ((rc = read_state(h, S.sc, sc, use_pub))) return rc;
+      if ((rc = bad_input("KNP GMRES", sc))) return rc;
+      it = (int)sc[S_IT];
+      if (!std::isfinite(sc[S_RR])) { kn_set_error("KNP GMRES broke down (non-finite residual) " + describe(sc)); return KNPEMI_ESOLVE; }
+      done = sc[S_DONE] != 0.0 || it >= maxit || j >= m_restart;
+      todo = 1;
+    }
+    hipLaunchKernelGGL(gm_update_kernel, dim3(nb_vec), dim3(FT), 0, h->stream, n, x, (const double*)V, ldv, L.red, g, base);
+    if (sc[S_DONE] != 0.0 || it >= maxit) break;
+    base = it;       // restart from the updated iterate
+  }
+  if ((rc = post())) return rc;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { kn_set_error(std::string("fused GMRES: ") + hipGetErrorString(e)); return KNPEMI_EHIP; }
+  G.its_last = it;
+  *iters = it;
+  *rr_out = sc[S_RR];
+  *bb_out = sc[S_BB];
+  return KNPEMI_OK;
+}
+
 // ---- diagnostics: a chain of dependent trivial kernels on the handle's stream, timed on the host (knpemi_debug_launch_chain)
 namespace {
 __global__ void chain_empty_kernel(double* a) { if (a == nullptr) a[0] = 0.0; }

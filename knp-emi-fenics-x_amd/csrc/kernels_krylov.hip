@@ -818,6 +818,9 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   int it = 0, restarts = 0;
   if (fused) {   // residual, target and 3 + 2 cycles launches per iteration (kernels_fused.hip)
     const KnFusedSys S{n, c.rowptr, c.colind, c.vals, c.sc, h->kry, N};
+    if (h->knp_method == 1) {      // GMRES(30) as PETSc runs the reference's options (KNPEMI_OPT_KNP_METHOD)
+      if ((rc = kn_fused_gmres(h, G, S, D.b_knp, rtol, atol, maxit, &it, &sc[S_RR], &sc[S_BB], pre, post))) return rc;
+    } else
     if ((rc = kn_fused_bicgstab(h, G, S, D.b_knp, rtol, atol, maxit, &it, &sc[S_RR], &sc[S_BB], pre, post))) return rc;
   } else {
     if (fused_planned && (rc = pre())) return rc;      // (the hierarchy did not qualify for the fused loop after all)
@@ -857,7 +860,9 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
     return rc;
   };
   const uint64_t gkey = graph_key(h, G, amg, chunk, n);
-  const int min_it = std::max(0, std::min(h->knp_min_it, maxit));      // ksp_min_it (pdeSolver.py:101)
+  // ksp_min_it (pdeSolver.py:101).  With KNPEMI_OPT_KNP_METHOD = 1 it counts GMRES iterations; where this BiCGStab loop runs
+  // instead (partitioned problems, Jacobi preconditioning) an iteration applies operator and preconditioner twice
+  const int min_it = std::max(0, std::min(h->knp_method == 1 ? (h->knp_min_it + 1) / 2 : h->knp_min_it, maxit));
   while (!fused && (rn > target || (it < min_it && rn != 0.0)) && it < maxit) {
     const int todo = std::min(chunk, maxit - it);
     if (todo == chunk) { if ((rc = run_chunk(h, h->graph_knp, gkey, chunk, iteration))) return rc; }

@@ -1699,6 +1699,11 @@ extern "C" int knpemi_set_option(knpemi_handle* h, int option, int value) {
     for (unsigned& c : h->prof_count) c = 0;
     return KNPEMI_OK;
   }
+  if (option == KNPEMI_OPT_KNP_METHOD) {
+    if (value != 0 && value != 1) return fail(KNPEMI_EINVAL, "KNPEMI_OPT_KNP_METHOD: 0 (BiCGStab) or 1 (GMRES)");
+    h->knp_method = value;
+    return KNPEMI_OK;
+  }
   if (option == KNPEMI_OPT_FOLD_MEMBRANE) { h->fold_membrane = value ? 1 : 0; h->gam_valid = false; return KNPEMI_OK; }
   if (option == KNPEMI_OPT_KNP_MIN_IT) {
     if (value < 0) return fail(KNPEMI_EINVAL, "KNPEMI_OPT_KNP_MIN_IT: negative");

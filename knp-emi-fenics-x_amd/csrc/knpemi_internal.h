@@ -211,6 +211,8 @@ int kn_fused_cg(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const double* b
                 int* iters, double* rr, double* bb, double* phi, int phi_stride);
 int kn_fused_bicgstab(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const double* b, double rtol, double atol, int maxit,
                       int* iters, double* rr, double* bb, const std::function<int()>& pre, const std::function<int()>& post);
+int kn_fused_gmres(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const double* b, double rtol, double atol, int maxit,
+                   int* iters, double* rr, double* bb, const std::function<int()>& pre, const std::function<int()>& post);
 void kn_fused_graphs_free(knpemi_handle* h);
 
 // Distributed solves (knpemi_set_distributed)
@@ -306,6 +308,9 @@ struct knpemi_handle {
   int pc_emi = KNPEMI_PC_AMG, pc_knp = KNPEMI_PC_AMG;
   int fuse_update = 0;                 // KNPEMI_OPT_FUSE_UPDATE
   int knp_min_it = 0;                  // KNPEMI_OPT_KNP_MIN_IT (ksp_min_it of the concentration solve, pdeSolver.py:101)
+  int knp_method = 0;                  // KNPEMI_OPT_KNP_METHOD: 0 BiCGStab on the true residual, 1 GMRES(30) as PETSc runs it
+  double* gm_V = nullptr; size_t gm_n = 0;   // Krylov basis of the GMRES solve
+  double* gm_state = nullptr;                // its Hessenberg column, rotations, triangular factor, dot-product partial sums
   bool plain_knp = false;              // the KNP solve's unknown order is dev.csol's own ([K-1][Ntot]; DG variant)
   int fuse_membrane = 0;               // KNPEMI_OPT_FUSE_MEMBRANE
   // The membrane-facet integrals of b_knp in gam_e are those of the current fields (formed by the launch that wrote the

@@ -10,9 +10,9 @@ linear solve (adjacent to the hot path):
 
 * `direct=False` (the reference's CG / GMRES + hypre options, `pdeSolver.py:24-35,99-110`):
   device-resident Krylov solve on the assembled CSR (`knpemi_solve_emi`: PCG with the
-  constant null space projected out; `knpemi_solve_knp`: BiCGStab; smoothed-aggregation AMG for both), same `rtol` /
-  `atol` / `ksp_max_it = 1000` semantics on the true residual, non-zero initial guess, `ksp_min_it = 5` of the
-  concentration solve as three BiCGStab iterations (KNP_MIN_BICGSTAB_ITERATIONS);
+  constant null space projected out, convergence on the true residual; `knpemi_solve_knp`: GMRES(30) with left
+  preconditioning and the preconditioned-norm test as PETSc runs `ksp_type gmres`, `ksp_min_it = 5`; smoothed-aggregation
+  AMG for both), same `rtol` / `atol` / `ksp_max_it = 1000`, non-zero initial guess;
 * `direct=True` (MUMPS LU, `pdeSolver.py:15-21`) and systems with Dirichlet conditions
   (MMS): sparse LU on the host with SciPy as a stand-in.
 """
@@ -26,11 +26,26 @@ from . import _lib as L
 from .fem.function import Function, as_float
 
 
-# `ksp_min_it: 5` of the reference's iterative options for the concentration solve (pdeSolver.py:101) counts GMRES
-# iterations, i.e. applications of operator and preconditioner.  The device solve is BiCGStab, whose iteration applies both
-# twice: three of them are the fewest that do at least the work of five GMRES iterations.
+# The reference's iterative options for the concentration solve (pdeSolver.py:99-110): `ksp_type gmres`, `ksp_min_it 5`.
+# The drop-in runs them as PETSc would (KNPEMI_OPT_KNP_METHOD = 1: GMRES(30), left preconditioning, preconditioned-norm
+# test; KNPEMI_OPT_KNP_MIN_IT = 5 GMRES iterations), so `solver.getIterationNumber()` counts what the reference's does.
+# The faster device path (bench.py `with_solves`, DeviceStepper(knp_method="bicgstab")) is BiCGStab on the true residual,
+# whose iteration applies operator and preconditioner twice: three of them are the fewest that do at least the work of
+# five GMRES iterations.
 KSP_MIN_IT_KNP = 5
 KNP_MIN_BICGSTAB_ITERATIONS = (KSP_MIN_IT_KNP + 1) // 2
+
+
+def set_knp_solver_options(dp, method="gmres", min_it=None):
+    """Select the concentration solve of a device problem: "gmres" (the reference's options) or "bicgstab"; `min_it` defaults
+    to the reference's ksp_min_it in the units of the method."""
+    gm = method == "gmres"
+    if not gm and method != "bicgstab":
+        raise ValueError(f"unknown KNP method {method!r}")
+    if min_it is None:
+        min_it = KSP_MIN_IT_KNP if gm else KNP_MIN_BICGSTAB_ITERATIONS
+    L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_METHOD, 1 if gm else 0))
+    L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_MIN_IT, int(min_it)))
 
 
 class _KSPInfo:
@@ -204,7 +219,7 @@ class LinearProblem:
             _push_sources(dp, f)
             dp.assemble_knp(splitting_scheme=f.splitting_scheme)
         if self.system == "knp":
-            L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_MIN_IT, KNP_MIN_BICGSTAB_ITERATIONS))
+            set_knp_solver_options(dp, "gmres")
         its, relres = dp.solve(which, self.rtol, self.atol, maxit=1000)
         self.solver.iterations, self.solver.residual_norm = its, relres
         for fn, (field, sub, idx) in zip(self.u, self._unknown_fields()):

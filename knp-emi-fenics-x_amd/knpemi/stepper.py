@@ -24,7 +24,7 @@ from . import _lib as L
 class DeviceStepper:
     def __init__(self, forms_emi, forms_knp, c, c_prev, phi, phi_M_prev, solve_emi=None, solve_knp=None,
                  assemble_knp_twice=False, overlap=True, device_solves=None, extrapolate_guess=True,
-                 fuse_update=None, fuse_membrane=False, early_membrane=False):
+                 fuse_update=None, fuse_membrane=False, early_membrane=False, knp_method="gmres"):
         a = forms_emi[0]
         self.dp = a.dp
         self.a = a
@@ -35,8 +35,10 @@ class DeviceStepper:
             # extrapolate_guess: start each solve from 2 x_n - x_(n-1) instead of x_n (knpemi_extrapolate_guess)
             rtol_emi, rtol_knp = device_solves
             self.iterations = []
-            from .pdeSolver import KNP_MIN_BICGSTAB_ITERATIONS      # ksp_min_it of the reference's KNP options
-            L.check(a.dp.lib.knpemi_set_option(a.dp.h, L.OPT_KNP_MIN_IT, KNP_MIN_BICGSTAB_ITERATIONS))
+            # the concentration solve: "gmres" = the reference's options as PETSc runs them (pdeSolver.py:99-110),
+            # "bicgstab" = the faster device path (knpemi.pdeSolver.set_knp_solver_options)
+            from .pdeSolver import set_knp_solver_options
+            set_knp_solver_options(a.dp, knp_method)
 
             def _solve(dp, which, name, rtol, atol):
                 if extrapolate_guess:

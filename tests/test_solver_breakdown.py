@@ -186,3 +186,71 @@ def test_minimum_iterations_of_the_concentration_solve(hip_lib):
     L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_MIN_IT, 0))
     with pytest.raises(L.KnpemiError):
         L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_MIN_IT, -1))
+
+
+def test_gmres_as_the_reference_runs_it(hip_lib, monkeypatch):
+    """KNPEMI_OPT_KNP_METHOD = 1: GMRES(30) with left preconditioning and the preconditioned-norm test, what PETSc's
+    defaults make of the reference's `ksp_type gmres` (/root/reference/src/knpemi/pdeSolver.py:100).  The solution satisfies
+    the system (against SciPy's sparse LU), tighter tolerances cost more iterations, `ksp_min_it` = 5 counts GMRES
+    iterations, one BiCGStab iteration does about the work of two GMRES iterations, and a restart length of 4
+    (KNPEMI_GMRES_RESTART) reaches the same solution through the restart path."""
+    s, dp, _, (Ak, bk) = _systems("tet", 0)
+    n = Ak.shape[0]
+    x_ref = spla.splu(Ak.tocsc()).solve(bk)
+    x0 = np.zeros(n)
+    L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_METHOD, 0))
+    dp.set_solution(L.B_KNP, x0)
+    its_bi, _ = dp.solve(L.B_KNP, 1e-8, 1e-40, 100)
+    L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_METHOD, 1))
+    out = {}
+    for rtol in (1e-4, 1e-8, 1e-11):
+        dp.set_solution(L.B_KNP, x0)
+        its, relres = dp.solve(L.B_KNP, rtol, 1e-40, 100)
+        x = dp.get_solution(L.B_KNP, n)
+        out[rtol] = its
+        # (the test is on the PRECONDITIONED residual; the true one follows it within the conditioning of M^-1 A)
+        true_res = np.linalg.norm(Ak @ x - bk) / np.linalg.norm(bk)
+        assert relres <= rtol and true_res <= 1e3 * rtol, (rtol, its, relres, true_res)
+        assert rel_err(x, x_ref) <= 1e3 * rtol, (rtol, rel_err(x, x_ref))
+    assert out[1e-4] < out[1e-8] < out[1e-11] <= 40
+    assert 1.2 * its_bi <= out[1e-8] <= 3.0 * its_bi + 2, (its_bi, out)
+    L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_MIN_IT, 5))
+    dp.set_solution(L.B_KNP, x0)
+    its, relres = dp.solve(L.B_KNP, 1e-2, 1e-40, 100)
+    assert its == 5 and relres < 1e-3
+    L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_MIN_IT, 0))
+    L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_METHOD, 0))
+
+
+def test_gmres_restart_path(hip_lib):
+    """The same solve with a restart length of 4 in a fresh process (the length is read once): more iterations than the
+    unrestarted solve, the same solution."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path[:0] = [%r, %r, %r, %r]\n"
+        "import scipy.sparse.linalg as spla\n"
+        "from test_solver_breakdown import _systems\n"
+        "from knpemi import _lib as L\n"
+        "s, dp, _, (Ak, bk) = _systems('tet', 0)\n"
+        "n = Ak.shape[0]\n"
+        "L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_METHOD, 1))\n"
+        "dp.set_solution(L.B_KNP, np.zeros(n))\n"
+        "its, relres = dp.solve(L.B_KNP, 1e-10, 1e-40, 200)\n"
+        "x = dp.get_solution(L.B_KNP, n)\n"
+        "ref = spla.splu(Ak.tocsc()).solve(bk)\n"
+        "print('GMRES', its, relres, float(np.abs(x - ref).max() / np.abs(ref).max()))\n"
+    ) % tuple(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), p)
+              for p in ("knp-emi-fenics-x_amd", "oracle", "examples/idealized_geometries", "tests"))
+    res = {}
+    for m in ("30", "4"):
+        p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KNPEMI_GMRES_RESTART=m), capture_output=True,
+                           text=True, timeout=300)
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("GMRES")]
+        assert p.returncode == 0 and line, (p.stdout + p.stderr)[-2000:]
+        _, its, relres, err = line[-1].split()
+        res[m] = (int(its), float(relres), float(err))
+    assert res["30"][1] <= 1e-10 and res["4"][1] <= 1e-10 and res["30"][2] < 1e-7 and res["4"][2] < 1e-7, res
+    assert res["4"][0] >= res["30"][0] > 4, res
