@@ -18,7 +18,9 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <atomic>
 #include <numeric>
+#include <thread>
 
 #include "knpemi_internal.h"
 #include "amg_host.h"
@@ -225,6 +227,7 @@ int upload_csr(KnAmg& G, const HostCsr& A, KnAmgCsr& D, hipStream_t st) {
 }  // namespace
 
 void kn_amg_free(KnAmg& G) {
+  // (a background rebuild of this hierarchy, if any, keeps running: it owns its own KnAmg; kn_amg_async_join ends it)
   for (void* p : G.allocs) (void)hipFree(p);
   G.allocs.clear();
   G.zero_sc = nullptr; G.sub_fused_ok = false; G.cycle_ok = false;
@@ -234,11 +237,9 @@ void kn_amg_free(KnAmg& G) {
 
 // Build the hierarchy for the n x n device CSR (rowptr, colind, vals).  `singular`: the operator has the
 // constant null space (EMI).
-int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const int* d_colind, const double* d_vals,
-                 bool singular, const uint8_t* h_owned) {
-  kn_amg_free(G);
+// host copy of the device CSR, ordered after everything the handle's stream holds
+static int amg_fetch(knpemi_handle* h, int n, const int* d_rowptr, const int* d_colind, const double* d_vals, HostCsr& A) {
   hipStream_t st = h->stream;
-  HostCsr A;
   A.n = A.m = n;
   A.rp.resize(n + 1);
   KN_HIP(hipMemcpyAsync(A.rp.data(), d_rowptr, (n + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -248,6 +249,93 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
   KN_HIP(hipMemcpyAsync(A.ci.data(), d_colind, nnz * sizeof(int), hipMemcpyDeviceToHost, st));
   KN_HIP(hipMemcpyAsync(A.v.data(), d_vals, nnz * sizeof(double), hipMemcpyDeviceToHost, st));
   KN_HIP(hipStreamSynchronize(st));
+  return KNPEMI_OK;
+}
+
+static int amg_build(knpemi_handle* h, KnAmg& G, HostCsr&& A, int n, const int* d_rowptr, const int* d_colind, const double* d_vals,
+                     bool singular, const uint8_t* h_owned, bool background);
+
+void kn_amg_async_join(KnAmg& G);
+int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const int* d_colind, const double* d_vals,
+                 bool singular, const uint8_t* h_owned) {
+  kn_amg_async_join(G);       // a background rebuild of the hierarchy this call replaces ends first
+  G.rebuild_wanted = false;
+  kn_amg_free(G);
+  HostCsr A;
+  if (int rc = amg_fetch(h, n, d_rowptr, d_colind, d_vals, A)) return rc;
+  return amg_build(h, G, std::move(A), n, d_rowptr, d_colind, d_vals, singular, h_owned, false);
+}
+
+// ---- rebuild of an aged hierarchy in the background ---------------------------------------------------------------
+// The set-up is sequential host code (0.1 s at config 2, 1.4 s for the DG systems there, 14 s for the DG systems on 165 888
+// hexahedra): a rebuild in the middle of a run used to stall it for that long.  The frozen hierarchy is a preconditioner --
+// an old one costs iterations, not correctness -- so the rebuild runs on a host thread from a snapshot of the operator while
+// the solves go on with the old hierarchy, and the next solve after it has finished swaps the new one in.
+struct KnAmgAsync {
+  std::thread th;
+  std::atomic<int> state{0};      // 0 idle, 1 running, 2 ready, 3 failed
+  KnAmg next;
+  std::string error;
+};
+
+void kn_amg_async_join(KnAmg& G) {
+  if (!G.async) return;
+  if (G.async->th.joinable()) G.async->th.join();
+  if (G.async->state.load() == 2) kn_amg_free(G.async->next);
+  delete G.async;
+  G.async = nullptr;
+}
+
+// Called at the head of a solve when G.rebuild_wanted: starts the background build, or swaps a finished one in.  Returns
+// KNPEMI_OK and leaves G usable in every case.
+int kn_amg_rebuild_step(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const int* d_colind, const double* d_vals,
+                        bool singular) {
+  if (!G.async) G.async = new KnAmgAsync();
+  KnAmgAsync& a = *G.async;
+  const int st = a.state.load();
+  if (st == 0) {
+    HostCsr A;
+    if (int rc = amg_fetch(h, n, d_rowptr, d_colind, d_vals, A)) return rc;
+    // the new hierarchy takes the configuration of the old one (copy), none of its levels
+    a.next = KnAmg();
+    a.next.negative_strength = G.negative_strength; a.next.theta = G.theta; a.next.want_fused = G.want_fused;
+    a.next.first_agg = G.first_agg; a.next.first_na = G.first_na; a.next.split_first = G.split_first;
+    a.next.positive_conflict = G.positive_conflict; a.next.sub_fused = G.sub_fused; a.next.want_cycle = G.want_cycle;
+    a.next.filter_theta = G.filter_theta; a.next.first_tentative = G.first_tentative; a.next.split_theta = G.split_theta;
+    a.next.block = G.block; a.next.its_last = G.its_last; a.next.builds = G.builds;
+    a.state.store(1);
+    if (a.th.joinable()) a.th.join();
+    const int device = h->device;
+    a.th = std::thread([h, &a, device, n, d_rowptr, d_colind, d_vals, singular](HostCsr Ah) {
+      int rc = hipSetDevice(device) == hipSuccess ? KNPEMI_OK : KNPEMI_EHIP;
+      if (!rc) rc = amg_build(h, a.next, std::move(Ah), n, d_rowptr, d_colind, d_vals, singular, nullptr, true);
+      if (rc) { a.error = knpemi_last_error(); kn_amg_free(a.next); }
+      a.state.store(rc ? 3 : 2);
+    }, std::move(A));
+    return KNPEMI_OK;
+  }
+  if (st == 1) return KNPEMI_OK;                 // still building: the old hierarchy serves
+  a.th.join();
+  if (st == 2) {
+    const int builds = G.builds + 1, its_last = G.its_last;
+    KnAmgAsync* keep = G.async;
+    kn_amg_free(G);
+    G = std::move(a.next);
+    G.async = keep;
+    G.builds = builds; G.its_last = its_last; G.its_ref = -1;
+  } else if (getenv("KNPEMI_AMG_VERBOSE")) {
+    fprintf(stderr, "[knpemi amg] background rebuild failed (%s): the old hierarchy stays\n", a.error.c_str());
+  }
+  G.rebuild_wanted = false;
+  a.next = KnAmg();
+  a.state.store(0);
+  return KNPEMI_OK;
+}
+
+static int amg_build(knpemi_handle* h, KnAmg& G, HostCsr&& A_in, int n, const int* d_rowptr, const int* d_colind, const double* d_vals,
+                     bool singular, const uint8_t* h_owned, bool background) {
+  hipStream_t st = h->stream;
+  HostCsr A = std::move(A_in);
   if (h_owned) {
     // partitioned problem: the hierarchy is built for this rank's diagonal block -- couplings between owned and
     // ghost unknowns are dropped, ghost rows are identity rows (block Jacobi over the ranks; the finest level of the
@@ -405,7 +493,7 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
   G.allocs.push_back(p);
   double* w = static_cast<double*>(p);
   for (auto& L : G.lev) { L.x = w; L.r = w + L.n; L.t = w + 2 * (size_t)L.n; w += 3 * (size_t)L.n; }
-  KN_HIP(hipStreamSynchronize(st));
+  if (!background) KN_HIP(hipStreamSynchronize(st));      // (every upload of the build is a blocking copy)
   G.built = true;
   G.n = n;
   size_t tot = 0;
@@ -418,8 +506,7 @@ int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const i
     void* z = nullptr;
     KN_HIP(hipMalloc(&z, 32 * sizeof(double)));
     G.allocs.push_back(z);
-    KN_HIP(hipMemsetAsync(z, 0, 32 * sizeof(double), st));
-    KN_HIP(hipStreamSynchronize(st));
+    KN_HIP(hipMemset(z, 0, 32 * sizeof(double)));
     G.zero_sc = static_cast<double*>(z);
   }
   return KNPEMI_OK;

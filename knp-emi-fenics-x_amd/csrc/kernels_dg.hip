@@ -808,6 +808,8 @@ extern "C" void knpemi_dg_destroy(knpemi_dg* h) {
   for (void* p : h->allocs) (void)hipFree(p);
   kn_comm_free(h->comm);
   if (h->sol) {
+    kn_amg_async_join(h->sol->amg_emi);
+    kn_amg_async_join(h->sol->amg_knp);
     kn_amg_free(h->sol->amg_emi);
     kn_amg_free(h->sol->amg_knp);
     if (h->sol->kry_pinned) (void)hipHostFree(h->sol->kry_pinned);

@@ -447,6 +447,12 @@ inline bool use_fused() {
   return !off;
 }
 
+// KNPEMI_AMG_REBUILD_EVERY=k (test hook): the hierarchy is declared aged at every k-th solve of its system
+inline int rebuild_every() {
+  static const int k = getenv("KNPEMI_AMG_REBUILD_EVERY") ? atoi(getenv("KNPEMI_AMG_REBUILD_EVERY")) : 0;
+  return k;
+}
+
 inline bool debug_krylov() {
   static const bool on = getenv("KNPEMI_DEBUG_KRYLOV") != nullptr;
   return on;
@@ -672,6 +678,9 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
                            dist.on ? dist.h_owned_emi.data() : nullptr))) return rc;
     G.its_ref = -1;
     ++G.builds;
+  } else if (amg && !dist.on) {
+    if (rebuild_every() > 0 && ++G.solves % rebuild_every() == 0) G.rebuild_wanted = true;
+    if (G.rebuild_wanted && (rc = kn_amg_rebuild_step(h, G, n, D.rowptr, D.colind, D.A_emi, !has_ghosts))) return rc;
   }
   if (amg && (rc = kn_amg_refresh(h, G, D.A_emi))) return rc;
   // two-level variant on a partitioned mesh: the ranks' AMG cycles do not see each other, a coarse space of one
@@ -740,7 +749,7 @@ int kn_solve_emi(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   if (e != hipSuccess) { kn_set_error(std::string("krylov (emi): ") + hipGetErrorString(e)); return KNPEMI_EHIP; }
   if (amg) {   // frozen hierarchy: rebuild at the next solve once it has visibly aged
     if (G.its_ref < 0) G.its_ref = it;
-    else if (it > 2 * G.its_ref + 4) G.built = false;
+    else if (it > 2 * G.its_ref + 4) { if (dist.on) G.built = false; else G.rebuild_wanted = true; }
   }
   if (rn > target) { kn_set_error("EMI CG did not converge (ksp_error_if_not_converged)"); return KNPEMI_ESOLVE; }
   return KNPEMI_OK;
@@ -811,6 +820,9 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
                            dist.on ? dist.h_owned_knp.data() : nullptr))) return rc;
     G.its_ref = -1;
     ++G.builds;
+  } else if (amg && !dist.on) {
+    if (rebuild_every() > 0 && ++G.solves % rebuild_every() == 0) G.rebuild_wanted = true;
+    if (G.rebuild_wanted && (rc = kn_amg_rebuild_step(h, G, n, D.krowptr, D.kcolind, D.A_knp, false))) return rc;
   }
   if (amg && (rc = kn_amg_refresh(h, G, D.A_knp))) return rc;
   double sc[S_N];
@@ -895,7 +907,7 @@ int kn_solve_knp(knpemi_handle* h, double rtol, double atol, int maxit, int* ite
   if (e != hipSuccess) { kn_set_error(std::string("krylov (knp): ") + hipGetErrorString(e)); return KNPEMI_EHIP; }
   if (amg) {
     if (G.its_ref < 0) G.its_ref = it;
-    else if (it > 2 * G.its_ref + 4) G.built = false;
+    else if (it > 2 * G.its_ref + 4) { if (dist.on) G.built = false; else G.rebuild_wanted = true; }
   }
   if (rn > target) { kn_set_error("KNP BiCGStab did not converge (ksp_error_if_not_converged)"); return KNPEMI_ESOLVE; }
   return KNPEMI_OK;

@@ -865,6 +865,8 @@ extern "C" void knpemi_destroy(knpemi_handle* h) {
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->aux) (void)hipStreamDestroy(h->aux);
   kn_comm_destroy(h);
+  kn_amg_async_join(h->amg_emi);
+  kn_amg_async_join(h->amg_knp);
   kn_amg_free(h->amg_emi);
   kn_amg_free(h->amg_knp);
   if (h->kry_pinned) (void)hipHostFree(h->kry_pinned);

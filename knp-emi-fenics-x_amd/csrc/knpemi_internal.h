@@ -153,7 +153,11 @@ struct KnAmgLevel {
   KnDenseBlocks dense_blk;
   double *x = nullptr, *r = nullptr, *t = nullptr;
 };
+struct KnAmgAsync;     // a rebuild running on a host thread (kernels_amg.hip)
 struct KnAmg {
+  KnAmgAsync* async = nullptr;
+  bool rebuild_wanted = false;       // the hierarchy has aged (iteration count doubled): rebuild it in the background
+  int solves = 0;                    // solves with this hierarchy's system (KNPEMI_AMG_REBUILD_EVERY test hook)
   std::vector<KnAmgLevel> lev;
   std::vector<void*> allocs;
   bool built = false, singular = false;
@@ -192,9 +196,14 @@ struct KnAmg {
   double omega_block = 1.0;          // damping 4 / (3 rho(B^-1 A))
 };
 void kn_amg_free(KnAmg& G);
+void kn_amg_async_join(KnAmg& G);    // ends (waits for) a background rebuild; before the hierarchy or its handle goes away
 struct knpemi_handle;
 int kn_amg_setup(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const int* d_colind, const double* d_vals,
                  bool singular, const uint8_t* h_owned = nullptr);
+// G.rebuild_wanted: start the rebuild of an aged hierarchy on a host thread from a snapshot of the operator, or swap a
+// finished one in; G stays usable throughout
+int kn_amg_rebuild_step(knpemi_handle* h, KnAmg& G, int n, const int* d_rowptr, const int* d_colind, const double* d_vals,
+                        bool singular);
 int kn_amg_apply(knpemi_handle* h, KnAmg& G, const double* vals, const double* dinv0, const double* r, double* scratch,
                  double* out);
 int kn_amg_refresh(knpemi_handle* h, KnAmg& G, const double* vals);   // block inverses of the current finest operator

@@ -254,3 +254,46 @@ def test_gmres_restart_path(hip_lib):
         res[m] = (int(its), float(relres), float(err))
     assert res["30"][1] <= 1e-10 and res["4"][1] <= 1e-10 and res["30"][2] < 1e-7 and res["4"][2] < 1e-7, res
     assert res["4"][0] >= res["30"][0] > 4, res
+
+
+def test_aged_hierarchy_is_rebuilt_in_the_background(hip_lib):
+    """A hierarchy that has aged is rebuilt on a host thread from a snapshot of the operator while the solves go on with the old
+    one (round-3 review: a rebuild stalled the run for the 0.1-14 s of the sequential set-up); the next solve after the
+    thread has finished swaps it in.  With KNPEMI_AMG_REBUILD_EVERY=3 (test hook: every third solve declares its hierarchy
+    aged) twenty-four whole time steps rebuild both hierarchies more than once and end in the fields of the run that never
+    rebuilds, to solver tolerance."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, time, numpy as np\n"
+        "sys.path[:0] = [%r, %r, %r, %r]\n"
+        "from helpers import Setup\n"
+        "from knpemi import _lib as L\n"
+        "from knpemi.stepper import DeviceStepper\n"
+        "s = Setup('tet', 0, g_syn=10.0)\n"
+        "st = DeviceStepper((s.a_emi, s.p_emi, s.L_emi), (s.a_knp, s.p_knp, s.L_knp), s.c, s.c_prev, s.phi, s.phi_M_prev, device_solves=(1e-9, 1e-9))\n"
+        "st.add_membrane_model(s.mem_models[0]['ode'], s.stim_params['stimulus'], s.stim_params['stimulus_locator'])\n"
+        "for k in range(24):\n"
+        "    st.step()\n"
+        "    time.sleep(0.1)\n"
+        "st.download()\n"
+        "b = [st.dp.solver_info(w)['builds'] for w in (L.B_EMI, L.B_KNP)]\n"
+        "print('BUILDS', b[0], b[1], max(i[1] for i in st.iterations))\n"
+        "np.save(sys.argv[1], np.concatenate([s.phi[0].x._a, s.phi[1].x._a, s.c_prev[0][0].x._a, s.phi_M_prev[1].x._a]))\n"
+    ) % tuple(os.path.join(root, p) for p in ("knp-emi-fenics-x_amd", "oracle", "examples/idealized_geometries", "tests"))
+    import tempfile
+    d = tempfile.mkdtemp()
+    res = {}
+    for tag, env in (("plain", {}), ("rebuild", {"KNPEMI_AMG_REBUILD_EVERY": "3"})):
+        out = os.path.join(d, tag + ".npy")
+        p = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("BUILDS")]
+        assert p.returncode == 0 and line, (p.stdout + p.stderr)[-3000:]
+        res[tag] = ([int(v) for v in line[-1].split()[1:]], np.load(out))
+    assert res["plain"][0][:2] == [1, 1], res["plain"][0]
+    # (a rebuild takes 0.3-0.6 s of host time here, i.e. three to six of the 0.1 s steps, during which the old hierarchy serves)
+    assert min(res["rebuild"][0][:2]) >= 2 and res["rebuild"][0][2] < 60, res["rebuild"][0]
+    a, b = res["plain"][1], res["rebuild"][1]
+    assert np.abs(a - b).max() <= 1e-6 * np.abs(a).max()
