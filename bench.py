@@ -290,8 +290,9 @@ def device_solvers(case, its, maxit=1000, dp=None, min_it=None, method="bicgstab
     from knpemi import _lib as L
     rtol_emi, rtol_knp = case.solver_rtol
     if dp is not None and min_it is not None:
-        from knpemi.pdeSolver import set_knp_solver_options
+        from knpemi.pdeSolver import set_emi_solver_options, set_knp_solver_options
         set_knp_solver_options(dp, method, min_it)
+        set_emi_solver_options(dp, "preconditioned" if method == "gmres" else "true")
 
     def solver(which, key, rtol, atol):
         def run(d):
@@ -419,13 +420,15 @@ def with_solves(case, replay, start, n_steps, torch, min_it=0, method="bicgstab"
     stepper.solve_emi = stepper.solve_knp = None
     info = {k: dp.solver_info(w) for k, w in (("emi", L.B_EMI), ("knp", L.B_KNP))}
     re, rk = case.solver_rtol
-    from knpemi.pdeSolver import set_knp_solver_options
+    from knpemi.pdeSolver import set_emi_solver_options, set_knp_solver_options
     set_knp_solver_options(dp, "bicgstab", 0)
+    set_emi_solver_options(dp, "true")
+    emi_test = "true residual" if method == "bicgstab" else "preconditioned-norm test (KSPCG's default)"
     knp_name = "BiCGStab" if method == "bicgstab" else "GMRES(30), left preconditioning, preconditioned-norm test"
     return {"ms_per_step": ms, "steps": n_steps, "trajectory_steps": [start + 2, start + 2 + n_steps],
             "knp_min_iterations": int(min_it), "knp_method": method,
             "initial_guess": "3 x_n - 3 x_(n-1) + x_(n-2) (knpemi_extrapolate_guess)",
-            "emi": {"solver": f"CG + SA-AMG V(1,1), rtol {re:g}", "iterations_avg": sum(its["emi"]) / n_steps,
+            "emi": {"solver": f"CG + SA-AMG V(1,1), rtol {re:g}, {emi_test}", "iterations_avg": sum(its["emi"]) / n_steps,
                     "iterations_max": max(its["emi"]), **info["emi"]},
             "knp": {"solver": f"{knp_name} + SA-AMG V(1,1), rtol {rk:g}", "iterations_avg": sum(its["knp"]) / n_steps,
                     "iterations_max": max(its["knp"]), **info["knp"]}}
@@ -1022,9 +1025,11 @@ def main():
                 "emi_iterations_avg": ws_min["emi"]["iterations_avg"], "knp_iterations_avg": ws_min["knp"]["iterations_avg"]}
             if ws_ref is not None:
                 out["with_solves_reference_options"] = {
-                    "what": "the same steps with the concentration solve as the reference configures it (pdeSolver.py:99-110: "
-                            "ksp_type gmres, ksp_min_it 5; PETSc's defaults: restart 30, left preconditioning, classical "
-                            "Gram-Schmidt, preconditioned residual norm against |M^-1 b|)",
+                    "what": "the same steps with both solves as the reference configures them: the concentration solve with "
+                            "ksp_type gmres, ksp_min_it 5 (pdeSolver.py:99-110; PETSc's defaults: restart 30, left "
+                            "preconditioning, classical Gram-Schmidt, preconditioned residual norm against |M^-1 b|), the "
+                            "potential solve's CG with KSPCG's default test |M^-1 r| <= rtol |M^-1 b| (pdeSolver.py:60-72)",
+                    "emi_solver": ws_ref["emi"]["solver"],
                     **{k: ws_ref[k] for k in ("ms_per_step", "steps", "knp_min_iterations", "knp_method")},
                     "emi_iterations_avg": ws_ref["emi"]["iterations_avg"], "knp_iterations_avg": ws_ref["knp"]["iterations_avg"]}
         s = case.s

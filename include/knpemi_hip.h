@@ -302,6 +302,11 @@ int knpemi_update_pde(knpemi_handle* h);
  * iteration count and KNPEMI_OPT_KNP_MIN_IT then count GMRES iterations as `ksp_min_it` / getIterationNumber() do.
  * Single rank, AMG preconditioner (the fused loops); otherwise the option is ignored. */
 #define KNPEMI_OPT_KNP_METHOD 6
+/* KNPEMI_OPT_EMI_NORM (default 0): convergence test of the potential solve's CG: 0 = true residual |b - A x| <= max(atol,
+ * rtol |b|); 1 = what PETSc's defaults make of the reference's `ksp_type cg` (pdeSolver.py:60-72; KSPCG: left preconditioning,
+ * KSP_NORM_PRECONDITIONED): |M^-1 r| <= max(atol, rtol |M^-1 b|), the residual norm reported is that one.  Single rank,
+ * AMG preconditioner (the fused loop); otherwise the option is ignored. */
+#define KNPEMI_OPT_EMI_NORM 7
 int knpemi_set_option(knpemi_handle* h, int option, int value);
 
 /* Nodal trace of an (ECS, cell) pair of bulk functions onto Q_sub: interpolate_to_membrane

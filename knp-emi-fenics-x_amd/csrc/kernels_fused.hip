@@ -40,7 +40,7 @@ constexpr int FT = 256, LPR = 16;
 // 256 (one load): at most 1 024 partial sums, all of a thread's (<= 4) loads issued before the first is waited for.
 constexpr int KN_PB = 1024;
 // partial-sum arrays (KN_PB doubles each)
-enum { P_PQ = 0, P_RR, P_RZ, P_RV, P_TS, P_TT, P_RHR, P_BS, P_XS, P_N };     // P_BS: sum of b_emi, P_XS: sum of x (means)
+enum { P_PQ = 0, P_RR, P_RZ, P_RV, P_TS, P_TT, P_RHR, P_BS, P_XS, P_ZZ, P_N };     // P_BS: sum of b_emi, P_XS: sum of x (means)
 
 // sum_j vals[j] f(colind[j]) over row `row` with L lanes per row (all L lanes return the sum)
 template <int L, class F>
@@ -320,8 +320,9 @@ struct UpArgs {
   Red red;
 };
 
-// DOTS: CG's r.z (the finest level of the cycle)
-template <bool DOTS>
+// DOTS (the finest level of the cycle in CG): bit 0 r.z, bit 1 also z.z (the preconditioned residual norm KSPCG tests by
+// default), bit 2 the iteration ends here (count)
+template <int DOTS>
 __global__ __launch_bounds__(FT) void up_kernel(UpArgs a) {
   const int lane = threadIdx.x % LPR, stride = gridDim.x * (FT / LPR);
   int row = (blockIdx.x * FT + threadIdx.x) / LPR, ra = 0, rb = 0;
@@ -329,21 +330,29 @@ __global__ __launch_bounds__(FT) void up_kernel(UpArgs a) {
   auto fetch = [&]() { if (row < a.n) { ra = a.prp[row]; rb = a.prp[row + 1]; rrow = a.r[row]; trow = a.t[row]; drow = a.dinv[row]; } };
   fetch();
   if (a.red.sc[S_DONE] != 0.0) return;
-  double rz[1] = {0.0};
+  double rz[2] = {0.0, 0.0};
+  double it0 = 0.0;
+  if constexpr ((DOTS & 4) != 0) it0 = a.red.sc[S_IT];
   while (row < a.n) {
     const double acc = row_sum_ab<LPR>(a.pci, a.pv, ra, rb, lane, [&](int c) { return a.ec[c]; });
     if (lane == 0) {
       const double z = a.omega * drow * (rrow + trow) + acc;
       a.x[row] = z;
-      if constexpr (DOTS) rz[0] += rrow * z;
+      if constexpr ((DOTS & 1) != 0) rz[0] += rrow * z;
+      if constexpr ((DOTS & 2) != 0) rz[1] += z * z;
     }
     row += stride;
     fetch();
   }
-  if constexpr (DOTS) {
+  if constexpr ((DOTS & 2) != 0) {
+    double* const dst[2] = {a.red.arr(P_RZ), a.red.arr(P_ZZ)};
+    block_partials<2>(rz, dst);
+  } else if constexpr ((DOTS & 1) != 0) {
+    double one[1] = {rz[0]};
     double* const dst[1] = {a.red.arr(P_RZ)};
-    block_partials<1>(rz, dst);
+    block_partials<1>(one, dst);
   }
+  if constexpr ((DOTS & 4) != 0) { if (blockIdx.x == 0 && threadIdx.x == 0) a.red.sc[S_IT] = it0 + 1.0; }
 }
 
 // Coarsest level: e = Minv r, one wavefront per row; the inverse is stored as up to 8 dense diagonal blocks (the K - 1
@@ -401,7 +410,9 @@ __global__ __launch_bounds__(FT) void dense_kernel(int n, const double* __restri
 }
 
 // CG: beta = rho / rho_old, p_new = z + beta p (stored), q = A p_new, p.q
-template <int L0>
+// PRE: convergence on |z| = |M^-1 r| (the producer of z left z.z beside r.z), tested here for the iterate the previous
+// iteration produced -- at the first iteration that is the initial residual, as KSPCG tests it
+template <int L0, bool PRE>
 __global__ __launch_bounds__(FT) void cg_dir_kernel(int n, const int* __restrict__ rp, const int* __restrict__ ci,
                                                     const double* __restrict__ v, const double* __restrict__ z,
                                                     const double* __restrict__ p, double* __restrict__ pn, double* __restrict__ q,
@@ -412,13 +423,29 @@ __global__ __launch_bounds__(FT) void cg_dir_kernel(int n, const int* __restrict
   double zr = 0.0, pr = 0.0;
   auto fetch = [&]() { if (row < n) { ra = rp[row]; rb = rp[row + 1]; zr = z[row]; pr = p[row]; } };
   fetch();
-  const double* const src[1] = {red.arr(P_RZ)};
-  Totals<1> T;
-  T.load(src, np);
-  const double done = sc[S_DONE], rho_old = sc[S_RHO0 + (par ^ 1)];
-  if (done != 0.0) return;
   double rho[1];
-  T.finish(rho);
+  double done = 0.0, rho_old = 0.0;
+  if constexpr (PRE) {
+    const double* const src[2] = {red.arr(P_RZ), red.arr(P_ZZ)};
+    Totals<2> T;
+    T.load(src, np);
+    done = sc[S_DONE]; rho_old = sc[S_RHO0 + (par ^ 1)];
+    const double target2 = sc[S_TARGET2];
+    if (done != 0.0) return;
+    double d[2];
+    T.finish(d);
+    rho[0] = d[0];
+    const bool conv = !(d[1] > target2);       // also stops on a NaN: the host reports it
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc[S_RR] = d[1]; if (conv) sc[S_DONE] = DONE_CONVERGED; }
+    if (conv) return;
+  } else {
+    const double* const src[1] = {red.arr(P_RZ)};
+    Totals<1> T;
+    T.load(src, np);
+    done = sc[S_DONE]; rho_old = sc[S_RHO0 + (par ^ 1)];
+    if (done != 0.0) return;
+    T.finish(rho);
+  }
   const double beta = rho_old != 0.0 ? rho[0] / rho_old : 0.0;     // the first direction is z (whatever the buffer of p holds)
   if (blockIdx.x == 0 && threadIdx.x == 0) { sc[S_RHO0 + par] = rho[0]; sc[S_BETA] = beta; }
   double pq[1] = {0.0};
@@ -494,6 +521,60 @@ __global__ __launch_bounds__(FT) void bi_update_kernel(int n, double* __restrict
   block_partials<2>(d, dst);
 }
 
+// |a|^2 as block partial sums into array `which`
+__global__ __launch_bounds__(FT) void gm_sqnorm_kernel(int n, const double* __restrict__ a, Red red, int which) {
+  double d[1] = {0.0};
+  for (int r = blockIdx.x * FT + threadIdx.x; r < n; r += gridDim.x * FT) d[0] += a[r] * a[r];
+  double* const dst[1] = {red.arr(which)};
+  block_partials<1>(d, dst);
+}
+
+// loop state at the start of a restart cycle (one block): target from |M^-1 b| (first cycle only), flags
+__global__ __launch_bounds__(FT) void gm_start_kernel(Red red, int np_b, double rtol, double atol, int min_it, int first, int np_r) {
+  double* sc = red.sc;
+  double d[2], one[1];
+  {
+    const double* const src[1] = {red.arr(P_BS)};
+    Totals<1> T;
+    T.load(src, np_b);
+    T.finish(one);
+    d[0] = one[0];
+  }
+  {
+    const double* const src[1] = {red.arr(P_RR)};
+    Totals<1> T;
+    T.load(src, np_r);
+    T.finish(one);
+    d[1] = one[0];
+  }
+  if (threadIdx.x != 0) return;
+  if (first) {
+    const double bb = d[0], bnorm = sqrt(bb);
+    const double target = fmax(atol, rtol * (bnorm > 0.0 ? bnorm : 1.0));
+    sc[S_BB] = bb; sc[S_TARGET2] = target * target;
+    sc[S_IT] = 0.0; sc[S_FLAG] = 0.0; sc[S_MINIT] = (double)min_it;
+    sc[S_RHO0] = 0.0; sc[S_RHO1] = 0.0; sc[S_BETA] = 0.0; sc[S_ALPHA] = 0.0; sc[S_OMEGA] = 1.0;      // (CG's recurrence, when it starts here)
+    const double rr = d[1];                      // |b - A x0|^2: only to tell non-finite input apart
+    sc[S_DONE] = !(bb - bb == 0.0) ? DONE_BAD_RHS : (!(rr - rr == 0.0) ? DONE_BAD_START : DONE_NO);
+  }
+}
+
+// CG with the preconditioned-norm test, end of a chunk: the test the next iteration's first kernel would make (one block)
+__global__ __launch_bounds__(FT) void cg_check_kernel(Red red, int np) {
+  double* sc = red.sc;
+  const double* const src[1] = {red.arr(P_ZZ)};
+  Totals<1> T;
+  T.load(src, np);
+  const double done = sc[S_DONE], target2 = sc[S_TARGET2];
+  if (done != 0.0) return;
+  double zz[1];
+  T.finish(zz);
+  if (threadIdx.x == 0) {
+    sc[S_RR] = zz[0];
+    if (!(zz[0] > target2)) sc[S_DONE] = DONE_CONVERGED;
+  }
+}
+
 // BiCGStab, end of a chunk: the convergence test the next iteration's first kernel would make (one block)
 __global__ __launch_bounds__(FT) void bi_check_kernel(Red red, int np) {
   double* sc = red.sc;
@@ -523,6 +604,9 @@ __global__ __launch_bounds__(FT) void emi_pre_kernel(int n, const double* __rest
   }
   double* const dst[1] = {red.arr(P_BS)};
   block_partials<1>(bs, dst);
+  // a new solve: the cycles that run before the loop state is written (M^-1 b of the preconditioned-norm test) must not
+  // see the previous solve's flag
+  if (blockIdx.x == 0 && threadIdx.x == 0) red.sc[S_DONE] = DONE_NO;
 }
 
 // r = b - A x (and rhat = r for BiCGStab), |r|^2 and |b|^2 as block partial sums.  SHIFT (EMI): b is b_emi minus its mean
@@ -531,7 +615,8 @@ template <int L0, bool SHIFT>
 __global__ __launch_bounds__(FT) void residual_kernel(int n, const int* __restrict__ rp, const int* __restrict__ ci,
                                                       const double* __restrict__ v, const double* __restrict__ x,
                                                       const double* __restrict__ b, double* __restrict__ r,
-                                                      double* __restrict__ rhat, Red red, int np_b, double inv_n) {
+                                                      double* __restrict__ rhat, Red red, int np_b, double inv_n,
+                                                      double* __restrict__ b_out) {
   const int lane = threadIdx.x % L0, stride = gridDim.x * (FT / L0);
   int row = (blockIdx.x * FT + threadIdx.x) / L0, ra = 0, rb = 0;
   double brow = 0.0;
@@ -554,6 +639,7 @@ __global__ __launch_bounds__(FT) void residual_kernel(int n, const int* __restri
       const double bi = brow - mean, ri = bi - acc;
       r[row] = ri;
       if (rhat) rhat[row] = ri;
+      if (b_out) b_out[row] = bi;       // the projected right-hand side, for |M^-1 b|
       d[0] += ri * ri; d[1] += bi * bi;
     }
     row += stride;
@@ -652,7 +738,7 @@ struct Loop {
   // out = V-cycle(in) on the frozen hierarchy.  IN: how the finest level forms its input (down_kernel); np: partial sums
   // its scalar needs; par: parity of the iteration.  CHECK: CG's convergence test in the coarsest kernel.  Returns the
   // number of partial sums the finest kernels leave (IN_CG: r.r by the first, DOTS: r.z by the last).
-  template <int IN, bool DOTS, bool CHECK>
+  template <int IN, int DOTS, bool CHECK>
   void cycle(const double* r, const double* u, const double* w, double* formed, double* x, double* out, int np, int par,
              int* np_rr, int* np_rz) {
     const int nl = (int)G.lev.size();
@@ -693,12 +779,12 @@ struct Loop {
       a.red = red;
       if (l == 0) {
         a.r = IN == IN_PLAIN ? r : formed; a.x = out;
-        const int nb = DOTS ? capped(blocks16(L.n)) : blocks16(L.n);
+        const int nb = DOTS != 0 ? capped(blocks16(L.n)) : blocks16(L.n);
         if (np_rz) *np_rz = nb;
         hipLaunchKernelGGL((up_kernel<DOTS>), dim3(nb), dim3(FT), 0, st, a);
       } else {
         a.r = L.r; a.x = L.x;
-        hipLaunchKernelGGL((up_kernel<false>), dim3(blocks16(L.n)), dim3(FT), 0, st, a);
+        hipLaunchKernelGGL((up_kernel<0>), dim3(blocks16(L.n)), dim3(FT), 0, st, a);
       }
     }
   }
@@ -738,7 +824,7 @@ int kn_fused_subcycle(knpemi_handle* h, KnAmg& G, int l0, const double* r0, doub
     a.dinv = L.dinv; a.omega = L.omega;
     a.r = (l == l0 && r0) ? r0 : L.r; a.t = L.t; a.ec = G.lev[l + 1].x; a.x = (l == l0 && out0) ? out0 : L.x;
     a.red = red;
-    hipLaunchKernelGGL((up_kernel<false>), dim3((int)(((size_t)L.n * LPR + FT - 1) / FT)), dim3(FT), 0, st, a);
+    hipLaunchKernelGGL((up_kernel<0>), dim3((int)(((size_t)L.n * LPR + FT - 1) / FT)), dim3(FT), 0, st, a);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { kn_set_error(std::string("fused sub-cycle: ") + hipGetErrorString(e)); return KNPEMI_EHIP; }
@@ -978,31 +1064,54 @@ int kn_fused_cg(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const double* b
   // KNPEMI_OPT_FOLD_MEMBRANE: the write-back launch also integrates the membrane facets (the potential system of the CG
   // path only: its unknowns are the vertex records' phi)
   const bool fold = h->fold_membrane && !h->fuse_membrane && h->have_params && !h->plain_knp && phi == h->dev.VR + 7;
+  const bool pre_norm = h->emi_norm_pre;
   auto head = [&]() -> int {
     // x0 = current phi (ksp_initial_guess_nonzero), b = b_emi projected onto zero mean (constant null space)
     hipLaunchKernelGGL(emi_pre_kernel, dim3(nb_vec), dim3(FT), 0, h->stream, n, (const double*)phi, phi_stride, x, b, L.red);
+    if (pre_norm) {
+      // KSPCG's default test: |M^-1 r| <= max(atol, rtol |M^-1 b|).  The projected b goes to q (free until the first
+      // direction), M^-1 b to p2, its square norm replaces the sums of b in P_BS
+      KN_LAUNCH_L0(l0, dim3(nb_res), h->stream, (residual_kernel<4, true>), (residual_kernel<16, true>), n, S.rowptr, S.colind,
+                   S.vals, (const double*)x, b, r, (double*)nullptr, L.red, nb_vec, inv_n, q);
+      L.cycle<IN_PLAIN, 0, false>(q, nullptr, nullptr, nullptr, nullptr, p2, 0, 0, nullptr, nullptr);
+      hipLaunchKernelGGL(gm_sqnorm_kernel, dim3(nb_vec), dim3(FT), 0, h->stream, n, (const double*)p2, L.red, (int)P_BS);
+      hipLaunchKernelGGL(gm_start_kernel, dim3(1), dim3(FT), 0, h->stream, L.red, nb_vec, rtol, atol, 0, 1, nb_res);
+      // z_0 = M^-1 r_0 with r_0.z_0 and |z_0|^2: the first direction kernel tests the initial residual
+      L.cycle<IN_PLAIN, 3, false>(r, nullptr, nullptr, nullptr, nullptr, z, 0, 0, nullptr, &np_rz);
+      return KNPEMI_OK;
+    }
     KN_LAUNCH_L0(l0, dim3(nb_res), h->stream, (residual_kernel<4, true>), (residual_kernel<16, true>), n, S.rowptr, S.colind,
-                 S.vals, (const double*)x, b, r, (double*)nullptr, L.red, nb_vec, inv_n);
+                 S.vals, (const double*)x, b, r, (double*)nullptr, L.red, nb_vec, inv_n, (double*)nullptr);
     hipLaunchKernelGGL(start_kernel, dim3(1), dim3(FT), 0, h->stream, L.red, nb_res, rtol, atol, 0, 0, 0);
     // z_0 = M^-1 r_0, r_0.z_0 (rho_old = 0: the first direction is z_0)
-    L.cycle<IN_PLAIN, true, false>(r, nullptr, nullptr, nullptr, nullptr, z, 0, 0, nullptr, &np_rz);
+    L.cycle<IN_PLAIN, 1, false>(r, nullptr, nullptr, nullptr, nullptr, z, 0, 0, nullptr, &np_rz);
     return KNPEMI_OK;
   };
   int k = 0;     // iterations enqueued so far: their parity decides which of the alternating buffers is which
   auto iterations = [&](int count) -> int {
     for (int j = 0; j < count; ++j, ++k) {
-      KN_LAUNCH_L0(l0, dim3(nb_dir), h->stream, cg_dir_kernel<4>, cg_dir_kernel<16>, n, S.rowptr, S.colind, S.vals,
-                   (const double*)z, (const double*)p, p2, q, L.red, np_rz, k & 1);
-      // r_new = r - alpha q (stored in r2), x += alpha p_new, |r_new|^2 -> convergence; then z = M^-1 r_new, r_new.z
-      L.cycle<IN_CG, true, true>(r, q, p2, r2, x, z, nb_dir, k & 1, &np_rr, &np_rz);
+      if (pre_norm) {
+        KN_LAUNCH_L0(l0, dim3(nb_dir), h->stream, (cg_dir_kernel<4, true>), (cg_dir_kernel<16, true>), n, S.rowptr, S.colind, S.vals,
+                     (const double*)z, (const double*)p, p2, q, L.red, np_rz, k & 1);
+        // r_new = r - alpha q (stored in r2), x += alpha p_new; z = M^-1 r_new with r_new.z and |z|^2; the iteration is counted
+        L.cycle<IN_CG, 7, false>(r, q, p2, r2, x, z, nb_dir, k & 1, &np_rr, &np_rz);
+      } else {
+        KN_LAUNCH_L0(l0, dim3(nb_dir), h->stream, (cg_dir_kernel<4, false>), (cg_dir_kernel<16, false>), n, S.rowptr, S.colind, S.vals,
+                     (const double*)z, (const double*)p, p2, q, L.red, np_rz, k & 1);
+        // r_new = r - alpha q (stored in r2), x += alpha p_new, |r_new|^2 -> convergence; then z = M^-1 r_new, r_new.z
+        L.cycle<IN_CG, 1, true>(r, q, p2, r2, x, z, nb_dir, k & 1, &np_rr, &np_rz);
+      }
       std::swap(r, r2);
       std::swap(p, p2);
     }
+    // (the test the next direction kernel would make, for the host that reads the state after this chunk)
+    if (pre_norm) hipLaunchKernelGGL(cg_check_kernel, dim3(1), dim3(FT), 0, h->stream, L.red, np_rz);
     return KNPEMI_OK;
   };
   uint64_t base = mix(mix(mix(mix(0xC6ull, (uint64_t)(uintptr_t)S.work), (uint64_t)G.builds), bits(rtol)), bits(atol));
   base = mix(mix(mix(base, (uint64_t)n), (uint64_t)(uintptr_t)b), (uint64_t)(uintptr_t)phi);
   base = mix(mix(base, (uint64_t)(h->fold_membrane && !h->fuse_membrane)), (uint64_t)(h->emi_flags & KNPEMI_NO_SPLITTING));
+  base = mix(base, pre_norm ? 2 : 0);
   double sc[S_NF];
   int it = 0, todo = first_chunk(G.its_last, maxit);
   bool first = true;
@@ -1074,7 +1183,7 @@ int kn_fused_bicgstab(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const dou
   auto head = [&]() -> int {
     if (int e = pre()) return e;
     KN_LAUNCH_L0(l0, dim3(nb_res), h->stream, (residual_kernel<4, false>), (residual_kernel<16, false>), n, S.rowptr, S.colind,
-                 S.vals, (const double*)x, b, r, rhat, L.red, 0, 0.0);
+                 S.vals, (const double*)x, b, r, rhat, L.red, 0, 0.0, (double*)nullptr);
     hipLaunchKernelGGL(start_kernel, dim3(1), dim3(FT), 0, h->stream, L.red, nb_res, rtol, atol, 1, nb_update, min_it);
     return KNPEMI_OK;
   };
@@ -1083,11 +1192,11 @@ int kn_fused_bicgstab(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const dou
     for (int j = 0; j < count; ++j, ++k) {
       // p = r + beta (p - omega v) is formed by the finest down kernel, which reads p and v at neighbouring rows while
       // it stores its own: the new direction goes to the buffer of t (free until the second SpMV) and the two names swap
-      L.cycle<IN_BI_P, false, false>(r, p, v, t, nullptr, phat, nb_update, k & 1, nullptr, nullptr);
+      L.cycle<IN_BI_P, 0, false>(r, p, v, t, nullptr, phat, nb_update, k & 1, nullptr, nullptr);
       std::swap(p, t);
       KN_LAUNCH_L0(l0, dim3(nb_spmv), h->stream, (bi_spmv_kernel<0, 4>), (bi_spmv_kernel<0, 16>), n, S.rowptr, S.colind, S.vals,
                    (const double*)phat, v, (const double*)rhat, L.red);
-      L.cycle<IN_BI_S, false, false>(r, v, nullptr, s, nullptr, shat, nb_spmv, k & 1, nullptr, nullptr);
+      L.cycle<IN_BI_S, 0, false>(r, v, nullptr, s, nullptr, shat, nb_spmv, k & 1, nullptr, nullptr);
       KN_LAUNCH_L0(l0, dim3(nb_spmv), h->stream, (bi_spmv_kernel<1, 4>), (bi_spmv_kernel<1, 16>), n, S.rowptr, S.colind, S.vals,
                    (const double*)shat, t, (const double*)s, L.red);
       hipLaunchKernelGGL(bi_update_kernel, dim3(nb_update), dim3(FT), 0, h->stream, n, x, r, (const double*)phat,
@@ -1282,43 +1391,6 @@ __global__ __launch_bounds__(FT) void gm_orth_kernel(int n, double* __restrict__
   block_partials<1>(ww, dst);
 }
 
-// |a|^2 as block partial sums into array `which`
-__global__ __launch_bounds__(FT) void gm_sqnorm_kernel(int n, const double* __restrict__ a, Red red, int which) {
-  double d[1] = {0.0};
-  for (int r = blockIdx.x * FT + threadIdx.x; r < n; r += gridDim.x * FT) d[0] += a[r] * a[r];
-  double* const dst[1] = {red.arr(which)};
-  block_partials<1>(d, dst);
-}
-
-// loop state at the start of a restart cycle (one block): target from |M^-1 b| (first cycle only), flags
-__global__ __launch_bounds__(FT) void gm_start_kernel(Red red, int np_b, double rtol, double atol, int min_it, int first, int np_r) {
-  double* sc = red.sc;
-  double d[2], one[1];
-  {
-    const double* const src[1] = {red.arr(P_BS)};
-    Totals<1> T;
-    T.load(src, np_b);
-    T.finish(one);
-    d[0] = one[0];
-  }
-  {
-    const double* const src[1] = {red.arr(P_RR)};
-    Totals<1> T;
-    T.load(src, np_r);
-    T.finish(one);
-    d[1] = one[0];
-  }
-  if (threadIdx.x != 0) return;
-  if (first) {
-    const double bb = d[0], bnorm = sqrt(bb);
-    const double target = fmax(atol, rtol * (bnorm > 0.0 ? bnorm : 1.0));
-    sc[S_BB] = bb; sc[S_TARGET2] = target * target;
-    sc[S_IT] = 0.0; sc[S_FLAG] = 0.0; sc[S_MINIT] = (double)min_it;
-    const double rr = d[1];                      // |b - A x0|^2: only to tell non-finite input apart
-    sc[S_DONE] = !(bb - bb == 0.0) ? DONE_BAD_RHS : (!(rr - rr == 0.0) ? DONE_BAD_START : DONE_NO);
-  }
-}
-
 // x += sum_{i < k} y_i v_i, R y = g (k = columns completed in this restart cycle = S_IT - base): the triangular solve is a few
 // hundred operations, every thread does it for itself
 __global__ __launch_bounds__(FT) void gm_update_kernel(int n, double* __restrict__ x, const double* __restrict__ V, size_t ldv,
@@ -1397,13 +1469,13 @@ int kn_fused_gmres(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const double
   for (;;) {      // restart cycles
     // r = b - A x; w = M^-1 r; first cycle: also |M^-1 b| for the target
     KN_LAUNCH_L0(l0, dim3(nb_row), h->stream, (residual_kernel<4, false>), (residual_kernel<16, false>), n, S.rowptr, S.colind,
-                 S.vals, (const double*)x, b, r, (double*)nullptr, L.red, 0, 0.0);
+                 S.vals, (const double*)x, b, r, (double*)nullptr, L.red, 0, 0.0, (double*)nullptr);
     if (first) {
-      L.cycle<IN_PLAIN, false, false>(b, nullptr, nullptr, nullptr, nullptr, tmp, 0, 0, nullptr, nullptr);
+      L.cycle<IN_PLAIN, 0, false>(b, nullptr, nullptr, nullptr, nullptr, tmp, 0, 0, nullptr, nullptr);
       hipLaunchKernelGGL(gm_sqnorm_kernel, dim3(nb_vec), dim3(FT), 0, h->stream, n, (const double*)tmp, L.red, (int)P_BS);
     }
     hipLaunchKernelGGL(gm_start_kernel, dim3(1), dim3(FT), 0, h->stream, L.red, nb_vec, rtol, atol, min_it, first ? 1 : 0, nb_row);
-    L.cycle<IN_PLAIN, false, false>(r, nullptr, nullptr, nullptr, nullptr, w, 0, 0, nullptr, nullptr);
+    L.cycle<IN_PLAIN, 0, false>(r, nullptr, nullptr, nullptr, nullptr, w, 0, 0, nullptr, nullptr);
     hipLaunchKernelGGL(gm_sqnorm_kernel, dim3(nb_vec), dim3(FT), 0, h->stream, n, (const double*)w, L.red, (int)P_PQ);
     first = false;
     int j = 0;
@@ -1413,7 +1485,7 @@ int kn_fused_gmres(knpemi_handle* h, KnAmg& G, const KnFusedSys& S, const double
       for (int k = 0; k < todo && j < m_restart; ++k, ++j) {
         KN_LAUNCH_L0(l0, dim3(nb_row), h->stream, gm_spmv_kernel<4>, gm_spmv_kernel<16>, n, S.rowptr, S.colind, S.vals,
                      (const double*)w, V + (size_t)j * ldv, t, L.red, g, nb_vec, j, base);
-        L.cycle<IN_PLAIN, false, false>(t, nullptr, nullptr, nullptr, nullptr, w, 0, 0, nullptr, nullptr);
+        L.cycle<IN_PLAIN, 0, false>(t, nullptr, nullptr, nullptr, nullptr, w, 0, 0, nullptr, nullptr);
         hipLaunchKernelGGL(gm_dots_kernel, dim3(nb_vec), dim3(FT), 0, h->stream, n, (const double*)w, (const double*)V, ldv, j, L.red, g);
         hipLaunchKernelGGL(gm_orth_kernel, dim3(nb_vec), dim3(FT), 0, h->stream, n, w, (const double*)V, ldv, j, L.red, g, nb_vec);
       }

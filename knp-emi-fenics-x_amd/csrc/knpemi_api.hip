@@ -1706,6 +1706,11 @@ extern "C" int knpemi_set_option(knpemi_handle* h, int option, int value) {
     h->knp_method = value;
     return KNPEMI_OK;
   }
+  if (option == KNPEMI_OPT_EMI_NORM) {
+    if (value != 0 && value != 1) return fail(KNPEMI_EINVAL, "KNPEMI_OPT_EMI_NORM: 0 (true residual) or 1 (preconditioned)");
+    h->emi_norm_pre = value;
+    return KNPEMI_OK;
+  }
   if (option == KNPEMI_OPT_FOLD_MEMBRANE) { h->fold_membrane = value ? 1 : 0; h->gam_valid = false; return KNPEMI_OK; }
   if (option == KNPEMI_OPT_KNP_MIN_IT) {
     if (value < 0) return fail(KNPEMI_EINVAL, "KNPEMI_OPT_KNP_MIN_IT: negative");

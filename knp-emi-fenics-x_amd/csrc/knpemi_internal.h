@@ -317,6 +317,7 @@ struct knpemi_handle {
   int pc_emi = KNPEMI_PC_AMG, pc_knp = KNPEMI_PC_AMG;
   int fuse_update = 0;                 // KNPEMI_OPT_FUSE_UPDATE
   int knp_min_it = 0;                  // KNPEMI_OPT_KNP_MIN_IT (ksp_min_it of the concentration solve, pdeSolver.py:101)
+  int emi_norm_pre = 0;                // KNPEMI_OPT_EMI_NORM: 1 = CG tests the preconditioned residual norm (KSPCG's default)
   int knp_method = 0;                  // KNPEMI_OPT_KNP_METHOD: 0 BiCGStab on the true residual, 1 GMRES(30) as PETSc runs it
   double* gm_V = nullptr; size_t gm_n = 0;   // Krylov basis of the GMRES solve
   double* gm_state = nullptr;                // its Hessenberg column, rotations, triangular factor, dot-product partial sums

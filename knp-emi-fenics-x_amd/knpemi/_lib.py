@@ -24,6 +24,7 @@ B_EMI, B_KNP = 0, 1
 WANT_P, NO_SPLITTING, SKIP_MEMBRANE_RHS, ON_AUX_STREAM, MEMBRANE_EARLY = 1, 2, 4, 8, 16
 ODE_SET_V, ODE_SET_TRACES, ODE_ON_AUX, ODE_ON_AUX2 = 1, 2, 4, 8
 OPT_FUSE_UPDATE, OPT_FUSE_MEMBRANE, OPT_PROFILE_STRIDE, OPT_KNP_MIN_IT, OPT_FOLD_MEMBRANE, OPT_KNP_METHOD = 1, 2, 3, 4, 5, 6
+OPT_EMI_NORM = 7
 K_ODE, K_EMI_ROWS, K_KNP_ROWS, K_KNP_MEMBRANE, K_UPDATE, K_EMI_MEMBRANE = range(6)
 KERNEL_NAMES = ["ode_step_kernel", "emi_rows_kernel", "knp_rows_kernel", "knp_membrane_kernel", "update_pde_kernel",
                 "emi_membrane_rhs_kernel"]

@@ -48,6 +48,15 @@ def set_knp_solver_options(dp, method="gmres", min_it=None):
     L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_MIN_IT, int(min_it)))
 
 
+def set_emi_solver_options(dp, norm="preconditioned"):
+    """Convergence test of the potential solve's CG: "preconditioned" = what PETSc's KSPCG defaults make of the reference's
+    options (pdeSolver.py:60-72: |M^-1 r| against |M^-1 b|), "true" = the true residual (the faster device path's choice:
+    its norm comes for free with the residual update)."""
+    if norm not in ("preconditioned", "true"):
+        raise ValueError(f"unknown norm {norm!r}")
+    L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_EMI_NORM, 1 if norm == "preconditioned" else 0))
+
+
 class _KSPInfo:
     """`problem.solver` stand-in: only what the drivers query."""
 
@@ -220,6 +229,8 @@ class LinearProblem:
             dp.assemble_knp(splitting_scheme=f.splitting_scheme)
         if self.system == "knp":
             set_knp_solver_options(dp, "gmres")
+        else:
+            set_emi_solver_options(dp, "preconditioned")
         its, relres = dp.solve(which, self.rtol, self.atol, maxit=1000)
         self.solver.iterations, self.solver.residual_norm = its, relres
         for fn, (field, sub, idx) in zip(self.u, self._unknown_fields()):

@@ -37,8 +37,9 @@ class DeviceStepper:
             self.iterations = []
             # the concentration solve: "gmres" = the reference's options as PETSc runs them (pdeSolver.py:99-110),
             # "bicgstab" = the faster device path (knpemi.pdeSolver.set_knp_solver_options)
-            from .pdeSolver import set_knp_solver_options
+            from .pdeSolver import set_emi_solver_options, set_knp_solver_options
             set_knp_solver_options(a.dp, knp_method)
+            set_emi_solver_options(a.dp, "preconditioned" if knp_method == "gmres" else "true")
 
             def _solve(dp, which, name, rtol, atol):
                 if extrapolate_guess:

@@ -222,6 +222,40 @@ def test_gmres_as_the_reference_runs_it(hip_lib, monkeypatch):
     L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_KNP_METHOD, 0))
 
 
+def test_cg_with_the_preconditioned_norm_test(hip_lib):
+    """KNPEMI_OPT_EMI_NORM = 1: the potential solve's CG tests |M^-1 r| against |M^-1 b|, what PETSc's KSPCG defaults make of
+    the reference's `ksp_type cg` (/root/reference/src/knpemi/pdeSolver.py:60-72).  Same iterates as the true-residual test
+    (the recurrence is the same), so the solutions of the two agree to the tolerance; tighter tolerances cost more
+    iterations; started at the solution the solve returns without iterating."""
+    import driver
+    s, dp, (A, b), _ = _systems("tet", 0)
+    n = A.shape[0]
+    x_ref = driver.solve_singular(A, b)
+    x_ref -= x_ref.mean()
+    bp = b - b.mean()
+    x0 = np.zeros(n)
+    dp.set_solution(L.B_EMI, x0)
+    its_true, _ = dp.solve(L.B_EMI, 1e-8, 1e-40, 200)
+    L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_EMI_NORM, 1))
+    out = {}
+    for rtol in (1e-4, 1e-8, 1e-11):
+        dp.set_solution(L.B_EMI, x0)
+        its, relres = dp.solve(L.B_EMI, rtol, 1e-40, 200)
+        x = dp.get_solution(L.B_EMI, n)
+        out[rtol] = its
+        true_res = np.linalg.norm(A @ x - bp) / np.linalg.norm(bp)
+        assert relres <= rtol and true_res <= 1e3 * rtol, (rtol, its, relres, true_res)
+        assert rel_err(x - x.mean(), x_ref) <= 1e3 * rtol, (rtol, rel_err(x - x.mean(), x_ref))
+    assert out[1e-4] < out[1e-8] < out[1e-11] <= 80
+    assert abs(out[1e-8] - its_true) <= 4, (out, its_true)
+    dp.set_solution(L.B_EMI, x_ref)
+    its, relres = dp.solve(L.B_EMI, 1e-6, 1e-40, 50)
+    assert its == 0 and relres < 1e-6
+    with pytest.raises(L.KnpemiError):
+        L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_EMI_NORM, 2))
+    L.check(dp.lib.knpemi_set_option(dp.h, L.OPT_EMI_NORM, 0))
+
+
 def test_gmres_restart_path(hip_lib):
     """The same solve with a restart length of 4 in a fresh process (the length is read once): more iterations than the
     unrestarted solve, the same solution."""
