@@ -36,6 +36,7 @@ struct DgDev {
   const int* nbr;
   const unsigned* finfo;
   const int* mfid;                   // [n_cell][nv] membrane facet of local facet f (-1)
+  const double* box_h;               // box meshes of hexahedra: [n_cell][3] edge lengths along the local axes, else NULL
   const unsigned char* cell_sub;
   const int* rowptr;
   double* A_emi;

@@ -14,6 +14,11 @@
 //   update       : src/knpemi/utils.py:238-295
 #include "knpemi_internal.h"
 
+// The operators leave the row kernels as streaming stores: they are read next by another kernel and would only push the vertex
+// records, which neighbouring row blocks re-read, out of the L2 (round 4, A/B on one box: 2-4 % per row kernel at 995 k tets and
+// on the 166 k-hexahedron mesh).
+#define KN_ROW_STORE(v, p) __builtin_nontemporal_store((v), (p))
+
 namespace {
 
 __device__ __forceinline__ int logical_block(int bid, int nb) {
@@ -519,8 +524,8 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
   __syncthreads();
   rows.for_each_entry(tid, 0, [&](int i, int64_t gp) {
     const double a = accA[i];
-    D.A_emi[gp] = a;
-    if (want_p) D.P_emi[gp] = cell_side ? a + D.P_mass[gp - D.pmass0] : a;
+    KN_ROW_STORE(a, &D.A_emi[gp]);
+    if (want_p) KN_ROW_STORE(cell_side ? a + D.P_mass[gp - D.pmass0] : a, &D.P_emi[gp]);
   });
 }
 
@@ -666,7 +671,7 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
   double* out0 = D.A_knp + (size_t)KS * subnnz0 - subnnz0;
   rows.for_each_entry(tid, 1, [&](int i, int64_t gp) {
 #pragma unroll
-    for (int k = 0; k < KS; ++k) out0[(size_t)k * subnnz + gp] = acc[(size_t)k * acc_n + i];
+    for (int k = 0; k < KS; ++k) KN_ROW_STORE(acc[(size_t)k * acc_n + i], &out0[(size_t)k * subnnz + gp]);
   });
 }
 
@@ -1168,8 +1173,8 @@ __global__ __launch_bounds__(KN_BLOCK, GEO == 2 ? 4 : (GEO == 1 ? 3 : 2)) void e
   __syncthreads();
   rows.for_each_entry(tid, 0, [&](int i, int64_t gp) {
     const double a = accA[i];
-    D.A_emi[gp] = a;
-    if (want_p) D.P_emi[gp] = cell_side ? a + D.P_mass[gp - D.pmass0] : a;
+    KN_ROW_STORE(a, &D.A_emi[gp]);
+    if (want_p) KN_ROW_STORE(cell_side ? a + D.P_mass[gp - D.pmass0] : a, &D.P_emi[gp]);
   });
 }
 
@@ -1300,7 +1305,7 @@ __global__ __launch_bounds__(KN_BLOCK, GEO == 2 ? 4 : (GEO == 1 ? 3 : 2)) void k
   double* out0 = D.A_knp + (size_t)KS * subnnz0 - subnnz0;
   rows.for_each_entry(tid, 1, [&](int i, int64_t gp) {
 #pragma unroll
-    for (int k = 0; k < KS; ++k) out0[(size_t)k * subnnz + gp] = acc[(size_t)k * acc_n + i];
+    for (int k = 0; k < KS; ++k) KN_ROW_STORE(acc[(size_t)k * acc_n + i], &out0[(size_t)k * subnnz + gp]);
   });
 }
 

@@ -135,6 +135,8 @@ struct ImgRow {
 template <int NV>
 __device__ __forceinline__ void copy_out(double* __restrict__ dst, const double* img, int span, int tid) {
   constexpr int PQ = dg_padq<NV>();
+  // (plain stores: the whole-line streaming stores that help the hexahedral kernels -- kernels_dg_hex.hip, hx_flush -- cost these
+  // contiguous spans 6-8 % at 995 k tetrahedra and gain 3-4 % at 124 k; round 4, A/B on one box)
   if constexpr (NV == 4) {
     double2* d2 = reinterpret_cast<double2*>(dst);
     for (int e = tid; e < span / 2; e += DG_BLOCK)
@@ -862,6 +864,7 @@ extern "C" int knpemi_dg_create(const knpemi_dg_desc* d, int device, knpemi_dg**
   KN_HIP(hipEventCreate(&h->ev1));
 
   const int nc = (int)d->n_cells, nmf = (int)d->n_mem_facets, n = nc * NV;
+  std::vector<double> box_h;      // hexahedral box meshes: the cells' edge lengths along their local axes
   for (int c = 0; c < nc; ++c)
     if (d->cell_sub[c] < 0 || d->cell_sub[c] >= d->n_sub) return dg_fail(KNPEMI_EINVAL, "knpemi_dg_create: cell_sub out of range");
   if (hex) {
@@ -892,6 +895,7 @@ extern "C" int knpemi_dg_create(const knpemi_dg_desc* d, int device, knpemi_dg**
     // 1e-12 of their size -- the kernels then use constant facet frames (kernels_dg_hex.hip); KNPEMI_DG_HEX_GENERAL=1
     // keeps the general kernels (tests run both on the same mesh)
     bool box = getenv("KNPEMI_DG_HEX_GENERAL") == nullptr;
+    box_h.assign((size_t)nc * 3, 0.0);
     for (int c = 0; c < nc && box; ++c) {
       const int32_t* cv = d->cells + (size_t)c * 8;
       const double* x0 = d->x + (size_t)cv[0] * 3;
@@ -901,6 +905,7 @@ extern "C" int knpemi_dg_create(const knpemi_dg_desc* d, int device, knpemi_dg**
         for (int k = 0; k < 3; ++k) e[t][k] = xt[k] - x0[k];
         len[t] = std::sqrt(e[t][0] * e[t][0] + e[t][1] * e[t][1] + e[t][2] * e[t][2]);
       }
+      for (int t = 0; t < 3; ++t) box_h[(size_t)c * 3 + t] = len[t];
       const double size = std::max(len[0], std::max(len[1], len[2]));
       for (int a = 0; a < 3 && box; ++a)
         for (int b = a + 1; b < 3; ++b)
@@ -1054,6 +1059,8 @@ extern "C" int knpemi_dg_create(const knpemi_dg_desc* d, int device, knpemi_dg**
   if ((rc = dg_upload(h, nbr, &D.nbr))) return rc;
   if ((rc = dg_upload(h, finfo, &D.finfo))) return rc;
   if ((rc = dg_upload(h, mfid, &D.mfid))) return rc;
+  D.box_h = nullptr;
+  if (h->hex_box && (rc = dg_upload(h, box_h, &D.box_h))) return rc;
   if ((rc = dg_upload(h, csub, &D.cell_sub))) return rc;
   if ((rc = dg_upload(h, h->h_rowptr, &D.rowptr))) return rc;
   if ((rc = dg_upload(h, h->h_q2e, &D.q2e))) return rc;

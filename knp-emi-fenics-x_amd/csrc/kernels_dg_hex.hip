@@ -31,8 +31,10 @@
 //      Every block of a row is one 64-byte line: the lanes put their blocks (a neighbour block in the neighbour's local
 //      column order) into LDS scratch lines and four lanes store one line together, 16 whole lines per instruction.
 // Box meshes (all cells orthogonal parallelepipeds) take the kernels at the end of this file.
+#include <algorithm>
 #include <string>
 #include <type_traits>
+#include <vector>
 
 #include "dg_internal.h"
 
@@ -196,8 +198,13 @@ __device__ __forceinline__ void hx_flush(const double* scrs, int* dsts, int tid,
   for (int k = 0; k < 4; ++k) {
     const int r = 16 * k + (tid >> 2), part = tid & 3;
     const int d = dsts[r];
-    if (d >= 0)
-      *reinterpret_cast<double2*>(base + d + 2 * part) = *reinterpret_cast<const double2*>(scrs + r * HX_SCR + 2 * part);
+    if (d >= 0) {
+      // written once, read by a later kernel: a streaming store, so that the value arrays (600 MB per system at 166 k cells)
+      // do not push the records the neighbours are about to read out of the L2
+      typedef double hx_d2 __attribute__((ext_vector_type(2)));
+      const hx_d2 v = *reinterpret_cast<const hx_d2*>(scrs + r * HX_SCR + 2 * part);
+      __builtin_nontemporal_store(v, reinterpret_cast<hx_d2*>(base + d + 2 * part));
+    }
   }
   hx_lds_sync();
 }
@@ -767,9 +774,82 @@ __device__ __forceinline__ void hx_fold(const double (&e)[4], double (&acc)[4]) 
     }
 }
 
+// The workgroup's own records (64 rows x 64 bytes, contiguous) into LDS: lane l of pass k moves bytes 16 (64 k + l) .. + 16,
+// 16 whole lines per instruction (a lane reading its own record alone touches 64 lines per instruction).
+__device__ __forceinline__ void hx_stage_own(double* lrec, const double* __restrict__ rec, int cell0, int ncell, int tid) {
+  const double2* blk = reinterpret_cast<const double2*>(rec + (size_t)cell0 * HX_NV * KN_REC);
+  double2 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = k * DG_BLOCK + tid;
+    v[k] = make_double2(0.0, 0.0);
+    if ((e >> 2) < ncell * HX_NV) v[k] = blk[e];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = k * DG_BLOCK + tid;
+    *reinterpret_cast<double2*>(lrec + (e >> 2) * DG_RPITCH + 2 * (e & 3)) = v[k];
+  }
+}
+
+// The neighbour cells of the workgroup's (cell, facet) tasks, read WHOLE.  A task needs the four vertices of the
+// neighbour on the facet and the four behind them -- the neighbour's eight records, 512 contiguous bytes.  One
+// instruction reads the neighbours of two tasks (32 lanes x 16 bytes each, 16 whole lines); a task lane gathering the
+// same values for itself issues ~70 instructions of 48 lines each, and the CU's address unit, not HBM, is what the phase
+// waited for (s_memtime stamps, round 4: 37 % of the kernel).  Tasks 2 b and 2 b + 1 belong to cell b / 3 of the
+// workgroup.  `tgo`: on lane t < 48 the neighbour cell of task t, or -1.  consume(cell, task, record, part, v, sub):
+// v = doubles 2 part, 2 part + 1 of the record; called by all 64 lanes (zeros for an absent neighbour), `sub` = the
+// cell's sub-domain, a scalar.
+template <int GROUPS, class F>
+__device__ __forceinline__ void hx_neighbour_cells(const double* __restrict__ rec, int tgo, int tsub, int tid, F&& consume) {
+  constexpr int NB = HX_TASKS / 2, PER = NB / GROUPS;      // instructions in flight together: 4 registers each
+  static_assert(NB % GROUPS == 0, "groups of equal size");
+  const int half = tid >> 5, within = tid & 31;
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g) {
+    double2 v[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int b = PER * g + u;
+      const int cA = __builtin_amdgcn_readlane(tgo, 2 * b), cB = __builtin_amdgcn_readlane(tgo, 2 * b + 1);
+      const int c = half ? cB : cA;
+      v[u] = make_double2(0.0, 0.0);
+      if (c >= 0) v[u] = reinterpret_cast<const double2*>(rec + (size_t)c * (HX_NV * KN_REC))[within];
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int b = PER * g + u;
+      const int sub = __builtin_amdgcn_readlane(tsub, 6 * (b / 3));
+      consume(2 * b + half, within >> 2, within & 3, v[u], sub);
+    }
+  }
+}
+
+// lane p of every quad of lanes gets x of the quad's lane SRC
+template <int SRC>
+__device__ __forceinline__ double hx_quad_bcast(double x) {
+  constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);     // quad_perm:[SRC, SRC, SRC, SRC]
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Diagnostic build (make CXXFLAGS+=-DKN_HX_STAMPS): the box kernels add up s_memtime differences between their phases
+// (one atomic per phase and wave); the launcher prints the averages every 32 launches.
+#ifdef KN_HX_STAMPS
+__device__ unsigned long long hx_stamp_acc[1024 * 32];     // [slot = workgroup % 1024][phase]
+#define HX_STAMP_BEGIN unsigned long long hx_t_ = __builtin_amdgcn_s_memtime();
+#define HX_STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+                         if (threadIdx.x == 0) atomicAdd(&hx_stamp_acc[(blockIdx.x & 1023) * 32 + (i)], n_ - hx_t_); hx_t_ = n_; } while (0)
+#else
+#define HX_STAMP_BEGIN
+#define HX_STAMP(i) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(DG_BLOCK, 3) void dg_emi_hex_box_kernel(DgDev D, const DgConsts* __restrict__ Cp, int chunk, int splitting) {
   __shared__ double lrec[DG_BLOCK * DG_RPITCH];   // the records; after the second barrier the scratch lines of the block stores
-  __shared__ double fsum[HX_TASKS * HX_FS_BOX_EMI];
+  __shared__ __attribute__((aligned(16))) double fsum[HX_TASKS * HX_FS_BOX_EMI];   // first: (kappa, sigma) sums of the neighbours' vertices
   __shared__ int dsts[DG_BLOCK];
   double* const scrs = lrec;                      // (HX_SCR == DG_RPITCH; the rows are done with the records by then)
   const DgConsts& C = *Cp;
@@ -777,23 +857,20 @@ __global__ __launch_bounds__(DG_BLOCK, 3) void dg_emi_hex_box_kernel(DgDev D, co
   if (cell0 >= D.n_cell) return;
   const int ncell = min(HX_CELLS, D.n_cell - cell0);
   const int tid = threadIdx.x;
+  HX_STAMP_BEGIN
   const int lc = tid >> 3, i = tid & 7, T = cell0 + lc, row = T * HX_NV + i;
   const bool valid = lc < ncell;
   const int tc = tid / HX_NFC, tf = tid - tc * HX_NFC;
   const bool task = tid < HX_TASKS && tc < ncell;
-  int tnb = -1, tmf = -1;
+  int tnb = -1, tmf = -1, tsub = 0;
   unsigned tfi = 0;
-  if (valid) {
-    const double2* p = reinterpret_cast<const double2*>(D.rec + (size_t)row * KN_REC);
-    double2* q = reinterpret_cast<double2*>(lrec + tid * DG_RPITCH);
-    const double2 a = p[0], b = p[1], c = p[2], d = p[3];
-    q[0] = a; q[1] = b; q[2] = c; q[3] = d;
-  }
   if (task) {
     tnb = D.nbr[(cell0 + tc) * HX_NFC + tf];
     tfi = D.finfo[(cell0 + tc) * HX_NFC + tf];
     tmf = D.mfid[(cell0 + tc) * HX_NFC + tf];
+    tsub = D.cell_sub[cell0 + tc];
   }
+  hx_stage_own(lrec, D.rec, cell0, ncell, tid);
   int nb[HX_NFC] = {-1, -1, -1, -1, -1, -1};
   unsigned fi[HX_NFC] = {0, 0, 0, 0, 0, 0};
   int s = 0, rp = 0;
@@ -803,12 +880,39 @@ __global__ __launch_bounds__(DG_BLOCK, 3) void dg_emi_hex_box_kernel(DgDev D, co
 #pragma unroll
     for (int f = 0; f < HX_NFC; ++f) { nb[f] = D.nbr[T * HX_NFC + f]; fi[f] = D.finfo[T * HX_NFC + f]; }
   }
+  HX_STAMP(0);      // own records, topology
+  // interior facets: kappa- and sigma-weighted concentration sums of the neighbour's eight vertices, summed in the order the
+  // rows of the neighbour sum their own (ion 0, 1, 2, 3: doubles 4, 5, 6, 3 of the record, i.e. lanes 2, 2, 3, 1 of the
+  // record's quad); lane 1 of the quad ends up with both and stores them
+  const bool interior = task && tnb >= 0 && (tfi & 3) == 1;
+  double hN = 1.0;
+  if (interior) hN = D.box_h[(size_t)tnb * 3 + (((tfi >> 2) & 7) >> 1)];
+  hx_neighbour_cells<1>(D.rec, interior ? tnb : -1, tsub, tid, [&](int t, int j, int part, double2 v, int sub) {
+    const double* kp = C.kap[sub];
+    const double* sp = C.sig[sub];
+    double ks = fma(kp[1], v.y, kp[0] * v.x), gs = fma(sp[1], v.y, sp[0] * v.x);      // lane 2: ions 0, 1
+    ks = fma(kp[2], v.x, hx_quad_bcast<2>(ks)); gs = fma(sp[2], v.x, hx_quad_bcast<2>(gs));      // lane 3: + ion 2
+    ks = fma(kp[3], v.y, hx_quad_bcast<3>(ks)); gs = fma(sp[3], v.y, hx_quad_bcast<3>(gs));      // lane 1: + ion 3
+    if (part == 1) *reinterpret_cast<double2*>(fsum + (t * HX_NV + j) * 2) = make_double2(ks, gs);
+  });
   __syncthreads();
-  if (task && tnb >= 0) {
-    const int a = tf >> 1, b = tf & 1, kind = tfi & 3, ts_ = D.cell_sub[cell0 + tc];
+  HX_STAMP(1);      // neighbour cells
+  double kN[4] = {0, 0, 0, 0}, dsN[4] = {0, 0, 0, 0};
+  if (interior) {
     const int ao = ((tfi >> 2) & 7) >> 1;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int jn = (tfi >> (5 + 3 * m)) & 7, jt = jn ^ (1 << ao);
+      const double2 n0 = *reinterpret_cast<const double2*>(fsum + (tid * HX_NV + jn) * 2);
+      kN[m] = n0.x;
+      dsN[m] = fsum[(tid * HX_NV + jt) * 2 + 1] - n0.y;
+    }
+  }
+  hx_lds_sync();     // (the sums are in registers before the summaries overwrite them)
+  if (task && tnb >= 0) {
+    const int a = tf >> 1, b = tf & 1, kind = tfi & 3, ts_ = tsub;
     const double* r0[4];
-    double kT[4], kN[4], dsT[4], dsN[4];
+    double kT[4], dsT[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int jv = hx_facet_vertex(a, b, m), jo = jv ^ (1 << a);
@@ -819,27 +923,13 @@ __global__ __launch_bounds__(DG_BLOCK, 3) void dg_emi_hex_box_kernel(DgDev D, co
       for (int q = 0; q < KN_MAXK; ++q) {
         k0 += C.kap[ts_][q] * r0[m][KN_CSLOT(q)]; g0 += C.sig[ts_][q] * r0[m][KN_CSLOT(q)]; g1 += C.sig[ts_][q] * r1[KN_CSLOT(q)];
       }
-      kT[m] = k0; dsT[m] = g1 - g0; kN[m] = 0.0; dsN[m] = 0.0;
+      kT[m] = k0; dsT[m] = g1 - g0;
     }
     const double* cb = lrec + tc * HX_NV * DG_RPITCH;
     const double hT = hx_edge_len(cb, cb + (1 << a) * DG_RPITCH);
     const double A = hx_edge_len(cb, cb + (1 << hx_ax1(a)) * DG_RPITCH) * hx_edge_len(cb, cb + (1 << hx_ax2(a)) * DG_RPITCH);
     double* my = fsum + tid * HX_FS_BOX_EMI;
     if (kind == 1) {
-      double hN = 1.0;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int jn = (tfi >> (5 + 3 * m)) & 7, jt = jn ^ (1 << ao);
-        const double* n0 = D.rec + ((size_t)tnb * HX_NV + jn) * KN_REC;
-        const double* n1 = D.rec + ((size_t)tnb * HX_NV + jt) * KN_REC;
-        double k0 = 0.0, g0 = 0.0, g1 = 0.0;
-#pragma unroll
-        for (int q = 0; q < KN_MAXK; ++q) {
-          k0 += C.kap[ts_][q] * n0[KN_CSLOT(q)]; g0 += C.sig[ts_][q] * n0[KN_CSLOT(q)]; g1 += C.sig[ts_][q] * n1[KN_CSLOT(q)];
-        }
-        kN[m] = k0; dsN[m] = g1 - g0;
-        if (m == 0) hN = hx_edge_len(n0, n1);
-      }
       const double cT = -fast_rcp(hT), cN = fast_rcp(hN);
       my[0] = 0.25 * A; my[1] = 0.5 * (cN - cT); my[2] = cT; my[3] = cN;
 #pragma unroll
@@ -873,6 +963,7 @@ __global__ __launch_bounds__(DG_BLOCK, 3) void dg_emi_hex_box_kernel(DgDev D, co
       }
     }
   }
+  HX_STAMP(2);      // facet summaries
   double kap[8], sg[8];
   BoxCell Bc{};
   if (valid) {
@@ -888,6 +979,7 @@ __global__ __launch_bounds__(DG_BLOCK, 3) void dg_emi_hex_box_kernel(DgDev D, co
     Bc = hx_box_cell(cb, cb + DG_RPITCH, cb + 2 * DG_RPITCH, cb + 4 * DG_RPITCH);
   }
   __syncthreads();
+  HX_STAMP(17);     // coefficients, barrier
   double A[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   double rhs = 0.0;
   auto point = [&](auto P_) {
@@ -917,6 +1009,7 @@ __global__ __launch_bounds__(DG_BLOCK, 3) void dg_emi_hex_box_kernel(DgDev D, co
   point(std::integral_constant<int, 2>{}); point(std::integral_constant<int, 3>{});
   point(std::integral_constant<int, 4>{}); point(std::integral_constant<int, 5>{});
   point(std::integral_constant<int, 6>{}); point(std::integral_constant<int, 7>{});
+  HX_STAMP(3);      // volume terms
   int slot_self, slot[HX_NFC];
   hx_slots(T, nb, slot_self, slot);
   double* scr = scrs + tid * HX_SCR;
@@ -969,8 +1062,10 @@ __global__ __launch_bounds__(DG_BLOCK, 3) void dg_emi_hex_box_kernel(DgDev D, co
       }
       rhs += kind == 3 ? g : -g;
     }
+    HX_STAMP(4 + 2 * f);      // facet f: arithmetic
     if (have) hx_put_nbr(scr, fi[f], B0, B1);
     hx_flush(scrs, dsts, tid, have, rp + slot[f] * HX_NV, D.A_emi);
+    HX_STAMP(5 + 2 * f);      // facet f: exchange + stores issued
   };
   facet(std::integral_constant<int, 0>{}); facet(std::integral_constant<int, 1>{});
   facet(std::integral_constant<int, 2>{}); facet(std::integral_constant<int, 3>{});
@@ -978,13 +1073,14 @@ __global__ __launch_bounds__(DG_BLOCK, 3) void dg_emi_hex_box_kernel(DgDev D, co
   if (valid) hx_put_own(scr, A);
   hx_flush(scrs, dsts, tid, valid, rp + slot_self * HX_NV, D.A_emi);
   if (valid) D.b_emi[row] = rhs;
+  HX_STAMP(16);     // own block
 }
 
 template <int KS>
 __global__ __launch_bounds__(DG_BLOCK, 2) void dg_knp_hex_box_kernel(DgDev D, const DgConsts* __restrict__ Cp, int chunk, int splitting) {
   constexpr int FS = HX_FS_BOX_KNP;
   __shared__ double lrec[DG_BLOCK * DG_RPITCH];
-  __shared__ double fsum[HX_TASKS * FS];
+  __shared__ __attribute__((aligned(16))) double fsum[HX_TASKS * FS];   // first: the potentials of the neighbours' vertices
   __shared__ double scrs[DG_BLOCK * HX_SCR];
   __shared__ int dsts[DG_BLOCK];
   const DgConsts& C = *Cp;
@@ -996,19 +1092,15 @@ __global__ __launch_bounds__(DG_BLOCK, 2) void dg_knp_hex_box_kernel(DgDev D, co
   const bool valid = lc < ncell;
   const int tc = tid / HX_NFC, tf = tid - tc * HX_NFC;
   const bool task = tid < HX_TASKS && tc < ncell;
-  int tnb = -1, tmf = -1;
+  int tnb = -1, tmf = -1, tsub = 0;
   unsigned tfi = 0;
-  if (valid) {
-    const double2* p = reinterpret_cast<const double2*>(D.rec + (size_t)row * KN_REC);
-    double2* q = reinterpret_cast<double2*>(lrec + tid * DG_RPITCH);
-    const double2 a = p[0], b = p[1], c = p[2], d = p[3];
-    q[0] = a; q[1] = b; q[2] = c; q[3] = d;
-  }
   if (task) {
     tnb = D.nbr[(cell0 + tc) * HX_NFC + tf];
     tfi = D.finfo[(cell0 + tc) * HX_NFC + tf];
     tmf = D.mfid[(cell0 + tc) * HX_NFC + tf];
+    tsub = D.cell_sub[cell0 + tc];
   }
+  hx_stage_own(lrec, D.rec, cell0, ncell, tid);
   int nb[HX_NFC] = {-1, -1, -1, -1, -1, -1};
   unsigned fi[HX_NFC] = {0, 0, 0, 0, 0, 0};
   int s = 0, rp = 0;
@@ -1018,13 +1110,29 @@ __global__ __launch_bounds__(DG_BLOCK, 2) void dg_knp_hex_box_kernel(DgDev D, co
 #pragma unroll
     for (int f = 0; f < HX_NFC; ++f) { nb[f] = D.nbr[T * HX_NFC + f]; fi[f] = D.finfo[T * HX_NFC + f]; }
   }
+  // the potential at the eight vertices of every task's neighbour (hx_neighbour_cells): double 7 of a record sits in lane 3 of
+  // the record's quad
+  double hN = 1.0;
+  if (task && tnb >= 0 && (tfi & 3) == 1) hN = D.box_h[(size_t)tnb * 3 + (((tfi >> 2) & 7) >> 1)];
+  hx_neighbour_cells<1>(D.rec, task ? tnb : -1, tsub, tid, [&](int t, int j, int part, double2 v, int) {
+    if (part == 3) fsum[t * HX_NV + j] = v.y;
+  });
   __syncthreads();
+  double pN0[4] = {0, 0, 0, 0}, dpN[4] = {0, 0, 0, 0};
   if (task && tnb >= 0) {
-    const int a = tf >> 1, b = tf & 1, kind = tfi & 3, ts_ = D.cell_sub[cell0 + tc];
     const int ao = ((tfi >> 2) & 7) >> 1;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int jn = (tfi >> (5 + 3 * m)) & 7, jt = jn ^ (1 << ao);
+      pN0[m] = fsum[tid * HX_NV + jn];
+      if ((tfi & 3) == 1) dpN[m] = fsum[tid * HX_NV + jt] - pN0[m];
+    }
+  }
+  hx_lds_sync();     // (the potentials are in registers before the summaries overwrite them)
+  if (task && tnb >= 0) {
+    const int a = tf >> 1, b = tf & 1, kind = tfi & 3, ts_ = tsub;
     const double* rT[4];
-    double pT0[4], pN0[4], dpT[4], dpN[4];
-    double hN = 1.0;
+    double pT0[4], dpT[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int jv = hx_facet_vertex(a, b, m), jo = jv ^ (1 << a);
@@ -1032,15 +1140,6 @@ __global__ __launch_bounds__(DG_BLOCK, 2) void dg_knp_hex_box_kernel(DgDev D, co
       const double* r1 = lrec + (tc * HX_NV + jo) * DG_RPITCH;
       pT0[m] = rT[m][7];
       dpT[m] = r1[7] - rT[m][7];
-      const int jn = (tfi >> (5 + 3 * m)) & 7, jt = jn ^ (1 << ao);
-      const double* n0 = D.rec + ((size_t)tnb * HX_NV + jn) * KN_REC;
-      pN0[m] = n0[7];
-      dpN[m] = 0.0;
-      if (kind == 1) {
-        const double* n1 = D.rec + ((size_t)tnb * HX_NV + jt) * KN_REC;
-        dpN[m] = n1[7] - n0[7];
-        if (m == 0) hN = hx_edge_len(n0, n1);
-      }
     }
     const double* cb = lrec + tc * HX_NV * DG_RPITCH;
     const double hT = hx_edge_len(cb, cb + (1 << a) * DG_RPITCH);
@@ -1257,6 +1356,22 @@ int kn_dg_hex_launch_emi(hipStream_t st, const kn_dg::DgDev& D, const kn_dg::DgC
   const int nblocks = (D.n_cell + HX_CELLS - 1) / HX_CELLS, chunk = (nblocks + 7) / 8;
   if (box) hipLaunchKernelGGL(dg_emi_hex_box_kernel, dim3(8 * chunk), dim3(DG_BLOCK), 0, st, D, d_consts, chunk, splitting);
   else hipLaunchKernelGGL(dg_emi_hex_kernel, dim3(8 * chunk), dim3(DG_BLOCK), 0, st, D, d_consts, chunk, splitting);
+#ifdef KN_HX_STAMPS
+  static int launches = 0;
+  if (box && ++launches % 8 == 0) {
+    static std::vector<unsigned long long> acc(1024 * 32);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(acc.data(), HIP_SYMBOL(hx_stamp_acc), acc.size() * sizeof(unsigned long long));
+    const double waves = 8.0 * nblocks;
+    double ph[18] = {0}, total = 0.0;
+    for (int sl = 0; sl < 1024; ++sl) for (int i = 0; i < 18; ++i) ph[i] += (double)acc[sl * 32 + i];
+    for (int i = 0; i < 18; ++i) total += ph[i];
+    fprintf(stderr, "[hx stamps] dg_emi_hex_box_kernel, s_memtime ticks (100 MHz) per wave, 8 launches of %d waves: total %.1f\n", nblocks, total / waves);
+    for (int i = 0; i < 18; ++i) fprintf(stderr, "[hx stamps]   phase %2d: %8.1f\n", i, ph[i] / waves);
+    std::fill(acc.begin(), acc.end(), 0ull);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(hx_stamp_acc), acc.data(), acc.size() * sizeof(unsigned long long));
+  }
+#endif
   return hx_check("dg_emi_hex_kernel");
 }
 
