@@ -150,6 +150,18 @@ template <int NV> constexpr int dg_fs_emi() { return (6 + 2 * NV) | 1; }   // n[
 // n[3] area inv_h gphiNn | interior facet: gNn[nv]; membrane facet: G[facet vertex][k], the membrane integrals
 template <int NV, int KS> constexpr int dg_fs_knp() { return (6 + ((NV - 1) * KS > NV ? (NV - 1) * KS : NV)) | 1; }
 
+// Diagnostic build (make CXXFLAGS+=-DKN_DG_STAMPS): dg_emi_kernel adds up s_memtime differences between its phases (one
+// atomic per phase and wave, spread over 1024 slots); the launcher prints the averages every 8 launches.
+#ifdef KN_DG_STAMPS
+__device__ unsigned long long dg_stamp_acc[1024 * 16];
+#define DG_STAMP_BEGIN unsigned long long dg_t_ = __builtin_amdgcn_s_memtime();
+#define DG_STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+                         if (threadIdx.x == 0) atomicAdd(&dg_stamp_acc[(blockIdx.x & 1023) * 16 + (i)], n_ - dg_t_); dg_t_ = n_; } while (0)
+#else
+#define DG_STAMP_BEGIN
+#define DG_STAMP(i) do {} while (0)
+#endif
+
 template <int NV>
 __global__ __launch_bounds__(DG_BLOCK) void dg_emi_kernel(DgDev D, const DgConsts* __restrict__ Cp, int chunk, int splitting) {
   constexpr int GD = NV - 1, NF = NV - 1;
@@ -163,8 +175,12 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_emi_kernel(DgDev D, const DgConst
   if (row0 >= D.n_dof) return;
   const int nrows = min(RPB, D.n_dof - row0);
   const int tid = threadIdx.x;
+  DG_STAMP_BEGIN
   const bool valid = tid < nrows;
   const int base = D.rowptr[row0];
+  // (the end of the workgroup's span of the value array: needed only when the rows leave, requested with everything else --
+  // loaded there it was one more round trip to memory per wave, an eighth of its life; s_memtime stamps, round 4)
+  const int span_end = D.rowptr[row0 + nrows];
   const int row = row0 + tid, T = row / NV, i = row - T * NV;
   int p[NV], nb[NV];
   unsigned fi[NV];
@@ -187,6 +203,7 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_emi_kernel(DgDev D, const DgConst
     }
   }
   __syncthreads();
+  DG_STAMP(0);      // own records and topology
   if (valid) {
     double sg[NV];
 #pragma unroll
@@ -266,6 +283,7 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_emi_kernel(DgDev D, const DgConst
     }
   }
   __syncthreads();
+  DG_STAMP(1);      // geometry, the facet opposite my vertex (neighbour gather)
   double self[NV], nbv[NV][NV];   // nbv[f][b]: column of the neighbour's dof at my vertex b; b == f: its far vertex
   if (valid) {
     double kbar = 0.0;
@@ -339,6 +357,7 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_emi_kernel(DgDev D, const DgConst
     }
     D.b_emi[row] = rhs;
   }
+  DG_STAMP(2);      // rows
   // The rows go out through an LDS image of DG_ROUND rows at a time, laid out as they sit in the CSR value array: the
   // wave that owns them fills it, the whole workgroup copies it out linearly.  (One image for all rows of the
   // workgroup would cost 2.5 x the LDS and a third of the resident waves.)
@@ -346,7 +365,7 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_emi_kernel(DgDev D, const DgConst
   if (valid) block_slots<NV>(T, nb, slot_self, slot);
   for (int r0 = 0; r0 < nrows; r0 += DG_ROUND) {
     const int r1 = min(r0 + DG_ROUND, nrows);
-    const int wbase = D.rowptr[row0 + r0] - base, wspan = D.rowptr[row0 + r1] - base - wbase;
+    const int wbase = r0 == 0 ? 0 : D.rowptr[row0 + r0] - base, wspan = (r1 == nrows ? span_end : D.rowptr[row0 + r1]) - base - wbase;
     if (tid >= r0 && tid < r1) {
       const ImgRow<NV> out(img, rowoff - wbase);
 #pragma unroll
@@ -362,8 +381,10 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_emi_kernel(DgDev D, const DgConst
       }
     }
     __syncthreads();
+    DG_STAMP(3);    // row image filled
     copy_out<NV>(D.A_emi + base + wbase, img, wspan, tid);
     if (r1 < nrows) __syncthreads();
+    DG_STAMP(4);    // copied out
   }
 }
 
@@ -386,6 +407,9 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_knp_kernel(DgDev D, const DgConst
   const int tid = threadIdx.x;
   const bool valid = tid < nrows;
   const int base = D.rowptr[row0];
+  // (the end of the workgroup's span of the value array: needed only when the rows leave, requested with everything else --
+  // loaded there it was one more round trip to memory per wave, an eighth of its life; s_memtime stamps, round 4)
+  const int span_end = D.rowptr[row0 + nrows];
   const int row = row0 + tid, T = row / NV, i = row - T * NV;
   int p[NV], nb[NV];
   unsigned fi[NV];
@@ -599,7 +623,7 @@ __global__ __launch_bounds__(DG_BLOCK) void dg_knp_kernel(DgDev D, const DgConst
     const double Dk = C.D[s][k], zpD = C.z[k] * C.psi * Dk;
     for (int r0 = 0; r0 < nrows; r0 += DG_ROUND) {
       const int r1 = min(r0 + DG_ROUND, nrows);
-      const int wbase = D.rowptr[row0 + r0] - base, wspan = D.rowptr[row0 + r1] - base - wbase;
+      const int wbase = r0 == 0 ? 0 : D.rowptr[row0 + r0] - base, wspan = (r1 == nrows ? span_end : D.rowptr[row0 + r1]) - base - wbase;
       if (k > 0 || r0 > 0) __syncthreads();   // the previous image has been copied out
       if (tid >= r0 && tid < r1) {
         const ImgRow<NV> out(img, off - wbase);
@@ -777,6 +801,22 @@ int launch_emi(knpemi_dg* h, int flags) {
   const int split = !(flags & KNPEMI_NO_SPLITTING);
   if (NV == 3) hipLaunchKernelGGL(dg_emi_kernel<3>, dim3(8 * chunk), dim3(DG_BLOCK), lds, h->stream, h->dev, h->d_consts, chunk, split);
   else hipLaunchKernelGGL(dg_emi_kernel<4>, dim3(8 * chunk), dim3(DG_BLOCK), lds, h->stream, h->dev, h->d_consts, chunk, split);
+#ifdef KN_DG_STAMPS
+  static int launches = 0;
+  if (++launches % 8 == 0) {
+    static std::vector<unsigned long long> acc(1024 * 16);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(acc.data(), HIP_SYMBOL(dg_stamp_acc), acc.size() * sizeof(unsigned long long));
+    const double waves = 8.0 * nblocks;
+    double ph[5] = {0}, total = 0.0;
+    for (int sl = 0; sl < 1024; ++sl) for (int i = 0; i < 5; ++i) ph[i] += (double)acc[sl * 16 + i];
+    for (int i = 0; i < 5; ++i) total += ph[i];
+    fprintf(stderr, "[dg stamps] dg_emi_kernel, cycles per wave, 8 launches of %d waves: total %.1f\n", nblocks, total / waves);
+    for (int i = 0; i < 5; ++i) fprintf(stderr, "[dg stamps]   phase %d: %8.1f\n", i, ph[i] / waves);
+    std::fill(acc.begin(), acc.end(), 0ull);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(dg_stamp_acc), acc.data(), acc.size() * sizeof(unsigned long long));
+  }
+#endif
   return dg_check_launch("dg_emi_kernel");
 }
 
