@@ -427,6 +427,18 @@ __device__ __forceinline__ void stage_records(const KnDev& D, const BlkInfo& B, 
   }
 }
 
+// Diagnostic build (make CXXFLAGS+=-DKN_ROW_STAMPS): emi_rows_v2 adds up s_memtime differences between its phases (first wave
+// of every workgroup); the launcher prints the averages every 16 launches.
+#ifdef KN_ROW_STAMPS
+__device__ unsigned long long row_stamp_acc[1024 * 8];
+#define ROW_STAMP_BEGIN unsigned long long row_t_ = __builtin_amdgcn_s_memtime();
+#define ROW_STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+                          if (threadIdx.x == 0) atomicAdd(&row_stamp_acc[(blockIdx.x & 1023) * 8 + (i)], n_ - row_t_); row_t_ = n_; } while (0)
+#else
+#define ROW_STAMP_BEGIN
+#define ROW_STAMP(i) do {} while (0)
+#endif
+
 template <int GDIM, int LPR>
 __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n,
                                                         int rec_n, int want_p, int splitting) {
@@ -437,6 +449,7 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
   double* recs = lds + (size_t)acc_n;
   uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + 5 * (size_t)rec_n + (rec_n & 1));
   const int tid = threadIdx.x;
+  ROW_STAMP_BEGIN
   const int b = logical_block(blockIdx.x, D.nblocks);
   const BlkInfo B = load_blk(D, b, tid >> 6);
   const int s = B.sub, seglen = B.seglen;
@@ -456,7 +469,9 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
   for (int i = tid; i < seglen; i += KN_BLOCK) accA[i] = 0.0;
   const KnSubConst& sc = C.sc[s];
   stage_records<0>(D, B, recs, eloc, tid, 0.0, nullptr, 0, &sc);
+  ROW_STAMP(0);     // descriptors -> vertex ids -> records -> LDS
   __syncthreads();
+  ROW_STAMP(1);     // barrier
 
   const bool cell_side = s > 0;
   double bacc = 0.0, gam = 0.0;   // volume part / membrane Robin part of b_emi
@@ -522,12 +537,15 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
 #pragma unroll
   for (int m = 1; m < LPR; m <<= 1) { bacc += __shfl_xor(bacc, m); gam += __shfl_xor(gam, m); }
   if (valid && sub == 0) D.b_emi[g] = bacc + gam;
+  ROW_STAMP(2);     // pair loop
   __syncthreads();
+  ROW_STAMP(3);     // barrier
   rows.for_each_entry(tid, 0, [&](int i, int64_t gp) {
     const double a = accA[i];
     KN_ROW_STORE(a, &D.A_emi[gp]);
     if (want_p) KN_ROW_STORE(cell_side ? a + D.P_mass[gp - D.pmass0] : a, &D.P_emi[gp]);
   });
+  ROW_STAMP(4);     // write-out issued
 }
 
 // MEM: where the membrane integrals of b_knp come from -- 0: the partial integrals knp_membrane_kernel left in gam_e
@@ -1845,6 +1863,22 @@ static int launch_emi_v2(knpemi_handle* h, int want_p, int split) {
     break;
   switch (h->lpr) { KN_CASE(1) KN_CASE(2) KN_CASE(4) KN_CASE(8) default: kn_set_error("bad lanes-per-row"); return KNPEMI_EINVAL; }
 #undef KN_CASE
+#ifdef KN_ROW_STAMPS
+  static int launches = 0;
+  if (++launches % 16 == 0) {
+    static std::vector<unsigned long long> acc(1024 * 8);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(acc.data(), HIP_SYMBOL(row_stamp_acc), acc.size() * sizeof(unsigned long long));
+    const double blocks = 16.0 * D.nblocks;
+    double ph[5] = {0}, total = 0.0;
+    for (int sl = 0; sl < 1024; ++sl) for (int i = 0; i < 5; ++i) ph[i] += (double)acc[sl * 8 + i];
+    for (int i = 0; i < 5; ++i) total += ph[i];
+    fprintf(stderr, "[row stamps] emi_rows_v2, cycles per workgroup, 16 launches of %d workgroups: total %.1f\n", D.nblocks, total / blocks);
+    for (int i = 0; i < 5; ++i) fprintf(stderr, "[row stamps]   phase %d: %8.1f\n", i, ph[i] / blocks);
+    std::fill(acc.begin(), acc.end(), 0ull);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(row_stamp_acc), acc.data(), acc.size() * sizeof(unsigned long long));
+  }
+#endif
   return check_launch("emi_rows_v2");
 }
 
