@@ -31,6 +31,7 @@ if [ $part = stats ]; then
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dg_config2h -- \
       python3 $R/bench.py --variant dg --workload config2h --steps 20 --warmup 3 --solve-steps 0 > $O/stats_dg_config2h.json 2> $O/stats_dg_config2h.err
   echo "rocprof dg (hexahedra, config 2h, box-mesh kernels) done"
+  find $O -name "*_kernel_trace.csv" -delete      # (the statistics are what is kept; the traces are 7 MB each)
 fi
 if [ $part = bench ]; then
   cd $R

@@ -24,3 +24,5 @@ for c in FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum; do
   echo "pass $c done"
 done
 python3 $R/tools/traffic_summary.py $OUT $W $TAG
+# (the per-launch averages are in $OUT.json; the raw passes are tens of MB)
+rm -rf $OUT

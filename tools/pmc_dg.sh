@@ -15,3 +15,5 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES S
   echo "pass $i ($grp) done"
 done
 python3 $R/tools/pmc_summary.py $R/gpurun_out/$OUT
+# the summary is what is kept: the per-pass traces are tens of MB and gpurun merges at most 64 MiB back
+rm -rf $R/gpurun_out/$OUT/p[0-9]*
