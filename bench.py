@@ -526,7 +526,9 @@ def run_dg(args, torch, steps=None, warmup=None, cpu=True, dist=None, rank=0, wo
         return {"bound": "hbm", "kernel": name, "achieved": by / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tfile if tr else None,
                 "frac_by_counters": traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if traffic else None,
-                "algorithmic_bytes_per_launch": by, "avg_launch_us": us}
+                "algorithmic_bytes_per_launch": by, "avg_launch_us": us,
+                "kernel_trace": load_kernel_trace(args.workload, name, "dg")
+                if not (os.environ.get("KNPEMI_DG_HEX_GENERAL") and kind == "hex") else None}
     out = {
         "metric": "assembled dofs/s (DG volume + interior-facet SIP + membrane-facet assembly + membrane ODE sweep) per "
                   "timestep; 3D idealized mesh, fp64",
@@ -636,6 +638,30 @@ def load_traffic(workload):
         except (OSError, KeyError, ValueError):
             continue
     return None, {}
+
+
+def load_kernel_trace(workload, kernel, variant="cg"):
+    """Average duration of `kernel` in the committed rocprofv3 kernel statistics of this build for that leg alone
+    (profiles/rNN_<leg>_kernel_stats.csv, one population of launches per row).  The HIP events `avg_launch_us` comes from
+    bracket the launch on its stream and so include the dispatch (~2-3 us) that a kernel trace leaves out: for the
+    10-15 us kernels of config 2 the two differ by that much, for the long kernels by a few per cent."""
+    import csv
+    leg = {("cg", "config2"): "config2", ("cg", "config3"): "config3", ("cg", "config2h"): "config2h",
+           ("dg", "config2"): "dg", ("dg", "config2h"): "dg_config2h"}.get((variant, workload))
+    stem = {"emi_rows_kernel": "emi_rows", "knp_rows_kernel": "knp_rows", "dg_emi_hex_kernel": "dg_emi_hex",
+            "dg_knp_hex_kernel": "dg_knp_hex", "dg_emi_kernel": "dg_emi_kernel", "dg_knp_kernel": "dg_knp_kernel"}.get(kernel)
+    if leg is None or stem is None:
+        return None
+    for rnd in ("r04", "r03"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{leg}_kernel_stats.csv")
+        try:
+            for r in csv.DictReader(open(path)):
+                if stem in r["Name"]:
+                    return {"avg_us": float(r["AverageNs"]) / 1e3, "launches": int(r["Calls"]), "source": os.path.basename(path),
+                            "note": "kernel trace (excludes the dispatch the HIP events of avg_launch_us include)"}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def measure(workload, args, torch, dist, rank, world, steps, warmup, repeats, spike=True, traj_min=0):
@@ -843,6 +869,7 @@ def measure(workload, args, torch, dist, rank, world, steps, warmup, repeats, sp
                     # the same launch priced with the bytes the PMC counters saw instead of the SURVEY accounting
                     "frac_by_counters": by_counters / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if by_counters else None,
                     "algorithmic_bytes_per_launch": survey_b[kernel], "avg_launch_us": us,
+                    "kernel_trace": load_kernel_trace(workload, kernel) if world == 1 else None,
                     "bytes_this_design_touches": design_b[kernel],
                     "frac_of_design_bytes": design_b[kernel] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                     # a launch cannot be shorter than the launch floor: the fraction of peak a perfect kernel would
