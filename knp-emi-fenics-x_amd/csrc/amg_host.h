@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -15,6 +17,88 @@ struct HostCsr {
   std::vector<int> rp, ci;
   std::vector<double> v;
 };
+
+// ---- row-parallel loops ---------------------------------------------------------------------------
+// The products and row-wise constructions below treat every row independently, so they run on the host's threads
+// (KNPEMI_AMG_THREADS, default: the hardware's, at most 16; small inputs stay on the calling thread).  Results do not depend
+// on the number of threads: rows are computed exactly as the sequential loop computes them, and sums over rows are taken
+// over KN_SUM_CHUNKS fixed row ranges in range order (a hierarchy must be reproducible from one machine to the next).
+constexpr int KN_SUM_CHUNKS = 64;
+constexpr int KN_PAR_MIN_ROWS = 20000;
+
+inline int host_threads() {
+  static const int n = [] {
+    const char* e = getenv("KNPEMI_AMG_THREADS");
+    int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    return std::max(1, std::min(t, 16));
+  }();
+  return n;
+}
+
+// fn(chunk, begin, end) for `chunks` contiguous ranges of [0, n), dealt to the threads round robin
+template <class F>
+void for_chunks(int n, int chunks, F&& fn) {
+  chunks = std::max(1, std::min(chunks, n));
+  auto range = [&](int c, int& b, int& e) { b = (int)((int64_t)n * c / chunks); e = (int)((int64_t)n * (c + 1) / chunks); };
+  const int nt = n >= KN_PAR_MIN_ROWS ? std::min(host_threads(), chunks) : 1;
+  if (nt <= 1) {
+    for (int c = 0; c < chunks; ++c) { int b, e; range(c, b, e); fn(c, b, e); }
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&, t] { for (int c = t; c < chunks; c += nt) { int b, e; range(c, b, e); fn(c, b, e); } });
+  for (auto& x : th) x.join();
+}
+
+// A matrix whose rows are produced independently: row(i, scratch, cols, vals) appends row i's sorted columns and values; every
+// thread owns one Scratch (constructed by make_scratch()).  The pieces are stitched together in row order.
+template <class MakeScratch, class Row>
+HostCsr build_rows(int n, int m, MakeScratch&& make_scratch, Row&& row) {
+  HostCsr C;
+  C.n = n; C.m = m;
+  C.rp.assign(n + 1, 0);
+  const int chunks = n >= KN_PAR_MIN_ROWS ? 4 * host_threads() : 1;
+  std::vector<std::vector<int>> pc(chunks);
+  std::vector<std::vector<double>> pv(chunks);
+  for_chunks(n, chunks, [&](int c, int b, int e) {
+    auto scratch = make_scratch();
+    for (int i = b; i < e; ++i) {
+      row(i, scratch, pc[c], pv[c]);
+      C.rp[i + 1] = (int)pc[c].size();       // (within the chunk; shifted below)
+    }
+  });
+  // (chunk c covers rows [n c / chunks, n (c + 1) / chunks): same ranges as for_chunks dealt out)
+  const int used = std::max(1, std::min(chunks, n));
+  size_t off = 0;
+  for (int c = 0; c < used; ++c) {
+    const int b = (int)((int64_t)n * c / used), e = (int)((int64_t)n * (c + 1) / used);
+    for (int i = b; i < e; ++i) C.rp[i + 1] += (int)off;
+    off += pc[c].size();
+  }
+  C.ci.resize(off); C.v.resize(off);
+  for_chunks(used, used, [&](int c, int, int) {
+    const int b = (int)((int64_t)n * c / used);
+    const size_t at = (size_t)C.rp[b];
+    std::copy(pc[c].begin(), pc[c].end(), C.ci.begin() + at);
+    std::copy(pv[c].begin(), pv[c].end(), C.v.begin() + at);
+  });
+  return C;
+}
+
+// sum over rows of f(i), in KN_SUM_CHUNKS fixed ranges added up in range order
+template <class F>
+double sum_rows(int n, F&& f) {
+  double part[KN_SUM_CHUNKS] = {0.0};
+  for_chunks(n, KN_SUM_CHUNKS, [&](int c, int b, int e) {
+    double s = 0.0;
+    for (int i = b; i < e; ++i) s += f(i);
+    part[c] = s;
+  });
+  double s = 0.0;
+  for (int c = 0; c < KN_SUM_CHUNKS; ++c) s += part[c];
+  return s;
+}
 
 // ---- host set-up ---------------------------------------------------------------------------------
 
@@ -189,28 +273,28 @@ inline int aggregate_apart(const HostCsr& A, const std::vector<double>& d, doubl
 }
 
 // C = A * B (Gustavson, columns of each row sorted)
+struct GustavsonScratch {
+  std::vector<int> mark, cols;
+  std::vector<double> acc;
+  explicit GustavsonScratch(int m) : mark(m, -1), acc(m, 0.0) {}
+};
+
 inline HostCsr spgemm(const HostCsr& A, const HostCsr& B) {
-  HostCsr C;
-  C.n = A.n; C.m = B.m;
-  C.rp.assign(A.n + 1, 0);
-  std::vector<int> mark(B.m, -1), cols;
-  std::vector<double> acc(B.m, 0.0);
-  for (int i = 0; i < A.n; ++i) {
-    cols.clear();
+  return build_rows(A.n, B.m, [&] { return GustavsonScratch(B.m); },
+                    [&](int i, GustavsonScratch& S, std::vector<int>& ci, std::vector<double>& v) {
+    S.cols.clear();
     for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) {
       const int k = A.ci[j];
       const double a = A.v[j];
       for (int l = B.rp[k]; l < B.rp[k + 1]; ++l) {
         const int c = B.ci[l];
-        if (mark[c] != i) { mark[c] = i; acc[c] = 0.0; cols.push_back(c); }
-        acc[c] += a * B.v[l];
+        if (S.mark[c] != i) { S.mark[c] = i; S.acc[c] = 0.0; S.cols.push_back(c); }
+        S.acc[c] += a * B.v[l];
       }
     }
-    std::sort(cols.begin(), cols.end());
-    for (int c : cols) { C.ci.push_back(c); C.v.push_back(acc[c]); }
-    C.rp[i + 1] = (int)C.ci.size();
-  }
-  return C;
+    std::sort(S.cols.begin(), S.cols.end());
+    for (int c : S.cols) { ci.push_back(c); v.push_back(S.acc[c]); }
+  });
 }
 
 inline HostCsr transpose(const HostCsr& A) {
@@ -246,17 +330,15 @@ inline double estimate_rho(const HostCsr& A, const std::vector<double>& d) {
   }
   double lam = bound;
   for (int it = 0; it < 15; ++it) {
-    double nrm = 0.0;
-    for (int i = 0; i < A.n; ++i) {
+    double nrm = sum_rows(A.n, [&](int i) {
       double s = 0.0;
       for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) s += A.v[j] * v[A.ci[j]];
       w[i] = s / d[i];
-      nrm += w[i] * w[i];
-    }
+      return w[i] * w[i];
+    });
     nrm = std::sqrt(nrm);
     if (!(nrm > 0)) return bound;
-    double dot = 0.0, vv = 0.0;
-    for (int i = 0; i < A.n; ++i) { dot += w[i] * v[i]; vv += v[i] * v[i]; }
+    const double dot = sum_rows(A.n, [&](int i) { return w[i] * v[i]; }), vv = sum_rows(A.n, [&](int i) { return v[i] * v[i]; });
     lam = std::fabs(dot / vv);
     for (int i = 0; i < A.n; ++i) v[i] = w[i] / nrm;
   }
@@ -308,23 +390,26 @@ inline double estimate_rho_block(const HostCsr& A, int bs) {
   }
   double lam = 1.0;
   for (int it = 0; it < 20; ++it) {
-    for (int i = 0; i < A.n; ++i) {
-      double s = 0.0;
-      for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) s += A.v[j] * v[A.ci[j]];
-      u[i] = s;
-    }
-    double nrm = 0.0;
-    for (int c = 0; c < nb; ++c)
+    for_chunks(A.n, 4 * host_threads(), [&](int, int r0, int r1) {
+      for (int i = r0; i < r1; ++i) {
+        double s = 0.0;
+        for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) s += A.v[j] * v[A.ci[j]];
+        u[i] = s;
+      }
+    });
+    double nrm = sum_rows(nb, [&](int c) {
+      double q = 0.0;
       for (int a = 0; a < bs; ++a) {
         double s = 0.0;
         for (int b = 0; b < bs; ++b) s += binv[((size_t)c * bs + a) * bs + b] * u[c * bs + b];
         w[c * bs + a] = s;
-        nrm += s * s;
+        q += s * s;
       }
+      return q;
+    });
     nrm = std::sqrt(nrm);
     if (!(nrm > 0)) break;
-    double dot = 0.0, vv = 0.0;
-    for (int i = 0; i < A.n; ++i) { dot += w[i] * v[i]; vv += v[i] * v[i]; }
+    const double dot = sum_rows(A.n, [&](int i) { return w[i] * v[i]; }), vv = sum_rows(A.n, [&](int i) { return v[i] * v[i]; });
     lam = std::fabs(dot / vv);
     for (int i = 0; i < A.n; ++i) v[i] = w[i] / nrm;
   }
@@ -339,16 +424,12 @@ inline double estimate_rho_block(const HostCsr& A, int bs) {
 // smoothing (lumped into the diagonal they inflate it and the smoothing is lost).
 inline HostCsr smoothed_prolongator(const HostCsr& A, const std::vector<double>& d, const std::vector<int>& agg, int na, double w,
                              double filter_theta = 0.0) {
-  HostCsr P;
-  P.n = A.n; P.m = na;
-  P.rp.assign(A.n + 1, 0);
-  std::vector<int> mark(na, -1), cols;
-  std::vector<double> acc(na, 0.0);
-  for (int i = 0; i < A.n; ++i) {
-    cols.clear();
-    auto add = [&](int c, double v) {
-      if (mark[c] != i) { mark[c] = i; acc[c] = 0.0; cols.push_back(c); }
-      acc[c] += v;
+  return build_rows(A.n, na, [&] { return GustavsonScratch(na); },
+                    [&](int i, GustavsonScratch& S, std::vector<int>& ci, std::vector<double>& v) {
+    S.cols.clear();
+    auto add = [&](int c, double x) {
+      if (S.mark[c] != i) { S.mark[c] = i; S.acc[c] = 0.0; S.cols.push_back(c); }
+      S.acc[c] += x;
     };
     add(agg[i], 1.0);
     if (w != 0.0 && filter_theta > 0.0) {
@@ -366,11 +447,9 @@ inline HostCsr smoothed_prolongator(const HostCsr& A, const std::vector<double>&
     } else if (w != 0.0) {
       for (int j = A.rp[i]; j < A.rp[i + 1]; ++j) add(agg[A.ci[j]], -w * A.v[j] / d[i]);
     }
-    std::sort(cols.begin(), cols.end());
-    for (int c : cols) { P.ci.push_back(c); P.v.push_back(acc[c]); }
-    P.rp[i + 1] = (int)P.ci.size();
-  }
-  return P;
+    std::sort(S.cols.begin(), S.cols.end());
+    for (int c : S.cols) { ci.push_back(c); v.push_back(S.acc[c]); }
+  });
 }
 
 // explicit inverse of the dense coarsest operator (+ shift * 1 1^T / n when it carries the constant null space)

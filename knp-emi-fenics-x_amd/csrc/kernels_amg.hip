@@ -470,12 +470,14 @@ static int amg_build(knpemi_handle* h, KnAmg& G, HostCsr&& A_in, int n, const in
       // smoother folded into the transfer operators: restriction and residual, prolongation and post-smoothing become
       // one SpMV each (kernels_fused.hip)
       HostCsr Sl = cur, Sr = cur;     // I - w D^-1 A (rows scaled), I - w A D^-1 (columns scaled)
-      for (int i = 0; i < cur.n; ++i)
-        for (int j = cur.rp[i]; j < cur.rp[i + 1]; ++j) {
-          const int c = cur.ci[j];
-          Sl.v[j] = (c == i ? 1.0 : 0.0) - L.omega * cur.v[j] / d[i];
-          Sr.v[j] = (c == i ? 1.0 : 0.0) - L.omega * cur.v[j] / d[c];
-        }
+      for_chunks(cur.n, 4 * host_threads(), [&](int, int r0, int r1) {
+        for (int i = r0; i < r1; ++i)
+          for (int j = cur.rp[i]; j < cur.rp[i + 1]; ++j) {
+            const int c = cur.ci[j];
+            Sl.v[j] = (c == i ? 1.0 : 0.0) - L.omega * cur.v[j] / d[i];
+            Sr.v[j] = (c == i ? 1.0 : 0.0) - L.omega * cur.v[j] / d[c];
+          }
+      });
       const HostCsr Pm = spgemm(Sl, P), Rm = spgemm(R, Sr);
       if ((rc = upload_csr(G, Pm, L.Pm, st))) return rc;
       if ((rc = upload_csr(G, Rm, L.Rm, st))) return rc;

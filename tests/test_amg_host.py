@@ -19,7 +19,7 @@ def lib():
     so = os.path.join(HERE, "native", "_build", "libamg_host.so")
     src = os.path.join(HERE, "native", "amg_host_check.cpp")
     os.makedirs(os.path.dirname(so), exist_ok=True)
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-shared", "-fPIC", "-o", so, src])
     L = C.CDLL(so)
     ip, dp, bp = C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_ubyte)
     L.amg_host_aggregate.argtypes = [C.c_int, ip, ip, dp, C.c_double, C.c_int, ip]
@@ -257,3 +257,19 @@ def test_aggregates_are_renumbered_component_by_component(lib):
         members_old = [tuple(np.flatnonzero(old == g)) for g in range(na) if np.flatnonzero(old == g)[0] % 2 == sysid]
         members_new = [tuple(np.flatnonzero(agg == g)) for g in range(na) if s_new[g] == sysid]
         assert members_old == members_new
+
+
+def test_row_parallel_set_up_does_not_depend_on_the_number_of_threads(tmp_path):
+    """The sparse products, the prolongator and the power iteration of the set-up run on the host's threads above 20 000
+    rows (csrc/amg_host.h: build_rows, sum_rows); a hierarchy must be reproducible from one machine to the next, so the
+    results are the same BITS with one thread and with several (tools/probes/amg_host_bench.cpp runs both and prints
+    digests of P and of the Galerkin operator)."""
+    exe = str(tmp_path / "amg_host_bench")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(os.path.dirname(HERE), "knp-emi-fenics-x_amd", "csrc"),
+                           os.path.join(os.path.dirname(HERE), "tools", "probes", "amg_host_bench.cpp"), "-o", exe])
+    env = dict(os.environ, KNPEMI_AMG_THREADS="4")
+    out = subprocess.run([exe, "30"], env=env, capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    assert len(out) == 2, out
+    tails = [line.split("| rho")[1] for line in out]          # rho to 17 digits and the two digests
+    threads = sorted(int(line.split("threads")[1].split("|")[0]) for line in out)
+    assert threads == [1, 4] and tails[0] == tails[1], out
