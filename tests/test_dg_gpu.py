@@ -560,3 +560,84 @@ def test_dg_full_size_properties(hip_lib, r, label):
     assert np.array_equal(dp.matrix(0).data, A.data)
     for k in range(2):
         assert np.array_equal(dp.matrix(1 + k).data, datas[k])
+
+
+def test_dg_q1_assembly_matches_oracle_on_20k_hexahedra(hip_lib):
+    """The box-mesh kernels on the reference's 3-D geometry at r = 1 (20 736 hexahedra, 2 592 workgroups: the XCD-aware
+    workgroup order with 324 workgroups per XCD, neighbours in other workgroups and other XCD ranges, the streaming block
+    stores and the wave-wide neighbour reads of round 4) against the restatement, SI parameters, 1e-10 of the largest entry.
+    The parity tests above stop at 216 cells; the restatement needs ~30 s here."""
+    from knpemi.dg import DGProblem
+    from knpemi.fem.idealized import make_mesh_3D
+    import knpemi_dg_oracle as dg
+    mesh, ct, ft = make_mesh_3D(1, "hexahedron")
+    dp = DGProblem(mesh, ct, ft, [0, 1], [1])
+    assert dp.n_cells == 20736
+    o = dg.make_dg_oracle(mesh.x, mesh.cells, mesh.cell_type, dp.cell_sub, dp.mem_facets, dp.mem_tags)
+    ions = [dict(name="Na", z=1.0, D=[1.33e-9] * 2), dict(name="K", z=1.0, D=[1.96e-9] * 2), dict(name="Cl", z=-1.0, D=[2.03e-9] * 2)]
+    params = dict(dt=1e-4, F=96485.0, psi=96485.0 / (8.314 * 300.0), C_M=0.02)
+    ins = (dp.cell_sub > 0)[:, None] * np.ones((1, dp.nv), bool)
+    w = np.sin(2e5 * dp.X[:, :, 0]) * np.cos(2e6 * dp.X[:, :, 1])
+    c_all = [np.where(ins, i, e) * (1.0 + 1e-2 * w * (1 + k)) for k, (e, i) in enumerate(((100.0, 12.0), (4.0, 125.0), (104.0, 137.0)))]
+    phi = np.where(ins, -0.0744, 0.0) + 1e-3 * w
+    rng = np.random.default_rng(7)
+    phi_M = -0.0744 + 1e-3 * rng.standard_normal((dp.nmf, dp.nf))
+    I_ch = [1e-2 * rng.standard_normal((dp.nmf, dp.nf)) for _ in range(3)]
+    _push(dp, params, ions, c_all, phi, phi_M, I_ch)
+    dp.assemble_emi(True)
+    dp.assemble_knp(True)
+    A, b = o.assemble_emi(params, ions, c_all, phi_M, I_ch, splitting_scheme=True)
+    assert csr_rel_err(dp.matrix(0), A) < TOL and rel_err(dp.rhs(0), b) < TOL
+    As, bs = o.assemble_knp(params, ions, c_all, phi, phi_M, I_ch, splitting_scheme=True)
+    for k in range(2):
+        assert csr_rel_err(dp.matrix(1 + k), As[k]) < TOL and rel_err(dp.rhs(1 + k), bs[k]) < TOL, k
+
+
+def test_dg_q1_full_size_properties(hip_lib, monkeypatch):
+    """config 2h (165 888 hexahedra, the reference's own 3-D cell type at r = 2) through what needs no oracle, as
+    test_dg_full_size_properties does for tetrahedra: symmetric potential matrix with the constants in its kernel, a
+    compatible right-hand side, every column of A_k - M / dt summing to zero, sorted rows of one 8-wide block per cell and
+    neighbour, a second assembly reproducing every bit -- and the general kernels (KNPEMI_DG_HEX_GENERAL=1) agreeing with
+    the box-mesh kernels to rounding on the whole mesh."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import dg_time
+    dp = dg_time.build(2, cell="hexahedron")
+    n = dp.n
+    assert dp.n_cells == 165888 and dp.nv == 8
+    dp.assemble_emi()
+    dp.assemble_knp()
+    A = dp.matrix(0)
+    scale = abs(A.data).max()
+    assert abs(A - A.T).max() < 1e-12 * scale
+    assert np.abs(A @ np.ones(n)).max() < 1e-10 * scale
+    b = dp.rhs(0)
+    assert abs(b.sum()) < 1e-9 * np.abs(b).sum()
+    assert np.all(np.diff(dp.indptr) % 8 == 0) and int(np.diff(dp.indptr).max()) == 8 * 7
+    for i in np.random.default_rng(0).integers(0, n, 2000):
+        cols = dp.indices[dp.indptr[i]:dp.indptr[i + 1]]
+        assert np.all(np.diff(cols) > 0) and i in cols
+    X = dp.X                                                   # box cells: volume = product of the three edges at vertex 0
+    vol = np.prod([np.linalg.norm(X[:, 1 << t] - X[:, 0], axis=1) for t in range(3)], axis=0)
+    mass_col = np.repeat(vol / 8.0, 8) / 1e-4
+    datas, rhs = [A.data.copy()], [b.copy()]
+    for k in range(2):
+        Ak = dp.matrix(1 + k)
+        col = np.asarray(Ak.sum(axis=0)).ravel()
+        assert np.abs(col - mass_col).max() < 1e-9 * abs(Ak.data).max(), k
+        datas.append(Ak.data.copy())
+        rhs.append(dp.rhs(1 + k).copy())
+        del Ak
+    dp.assemble_emi()
+    dp.assemble_knp()
+    for w in range(3):
+        assert np.array_equal(dp.matrix(w).data, datas[w]), w
+    del dp, A
+    monkeypatch.setenv("KNPEMI_DG_HEX_GENERAL", "1")
+    dg2 = dg_time.build(2, cell="hexahedron")
+    dg2.assemble_emi()
+    dg2.assemble_knp()
+    for w in range(3):
+        d = dg2.matrix(w).data
+        assert np.abs(d - datas[w]).max() < 1e-11 * np.abs(datas[w]).max(), w
+        assert np.abs(dg2.rhs(w) - rhs[w]).max() < 1e-11 * np.abs(rhs[w]).max(), w
