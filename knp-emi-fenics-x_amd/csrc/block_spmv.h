@@ -2,7 +2,9 @@
 // bcol[c * nbmax ..] (the cell itself and its facet neighbours, increasing), so the column of entry idx of a row is
 // bcol[idx / NV] * NV + idx % NV -- 4 bytes of index per BLOCK instead of per entry (a third of the bytes of the CSR
 // kernel on broken P1).  (An fp32 copy of the values for the preconditioner's residuals was measured too: 5.58 against 5.57 ms
-// per DG step at config 2 -- the kernel is not bound by its bytes; not kept.  VT stays a template parameter.)
+// per DG step at config 2 -- the kernel is not bound by its bytes; not kept.  Measured again in round 4 with the cell-wise
+// kernel below and the copy refreshed once per solve: 25.4 against 25.2 ms on 166 k hexahedra, 5.74 against 5.46 ms at
+// config 2, same iteration counts -- still not kept.  VT stays a template parameter.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
