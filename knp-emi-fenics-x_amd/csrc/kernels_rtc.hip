@@ -63,8 +63,10 @@ int compile(int ns, int np, const std::string& user, std::vector<char>* code, st
     return KNPEMI_EHIP;
   }
   // the integrator keeps its state in registers: same flag as csrc/Makefile uses for kernels_ode.hip
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-simplifycfg-sink-common=false"};
-  const hiprtcResult res = hiprtcCompileProgram(prog, 5, opts);
+  // (the same code generation options as kernels_ode.o, Makefile: no common-code sinking, instruction scheduling for ILP)
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-simplifycfg-sink-common=false",
+                        "-mllvm", "-amdgpu-sched-strategy=max-ilp"};
+  const hiprtcResult res = hiprtcCompileProgram(prog, 7, opts);
   size_t n = 0;
   if (hiprtcGetProgramLogSize(prog, &n) == HIPRTC_SUCCESS && n > 1) {
     log->assign(n, '\0');
