@@ -264,6 +264,11 @@ int knpemi_debug_math(int op, int n, const double* a, const double* b, double* o
  * costs inside THIS process and on THIS stream, next to tools/probes/kernel_chain.hip which measures a bare process. */
 int knpemi_debug_launch_chain(knpemi_handle* h, int kind, int n, int links, int reps, int use_graph, double* us_per_kernel);
 
+/* Diagnostics (no reference counterpart): which geometry specialisations knpemi_create selected for the row kernels.
+ * *flags: bit 0 = lattice tetrahedra of a uniform grid (shape table, no coordinates staged), bit 1 = hexahedra that are all
+ * parallelepipeds, bit 2 = ... and all the same box (uniform hexahedral kernels). */
+int knpemi_debug_geometry(knpemi_handle* h, int* flags);
+
 /* End-of-step update: update_pde_variables (utils.py:238-295): c_prev <- c, eliminated ion from
  * electroneutrality, phi_M_prev <- tr(phi_i) - tr(phi_e). */
 int knpemi_update_pde(knpemi_handle* h);

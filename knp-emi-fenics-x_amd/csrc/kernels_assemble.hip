@@ -427,6 +427,21 @@ __device__ __forceinline__ void stage_records(const KnDev& D, const BlkInfo& B, 
   }
 }
 
+// Lattice tetrahedra of a uniform grid (knpemi_create, KnDev::tet_tab): a cell is one of at most eight shapes whose gradient
+// dot products and volume are constants of the mesh, so the row kernels stage no coordinates and do no geometry: the pair
+// entry names the shape and the canonical number of each of its vertices, the 4 + 1 numbers come from a 136-double table in
+// LDS.  KN_TET_TAB doubles: [shape][a][b] g_a . g_b, then [shape] |T|.
+constexpr int KN_TET_TAB = 8 * 16 + 8;
+template <int NV>
+__device__ __forceinline__ double tet_table_row0(const double* tab, uint32_t sl, double (&d)[NV]) {
+  static_assert(NV == 4, "lattice tetrahedra");
+  const int shape = (sl >> 5) & 7;
+  const int c1 = (sl >> 13) & 3, c2 = (sl >> 21) & 3, c3 = (sl >> 29) & 3, c0 = 6 - c1 - c2 - c3;
+  const double* row = tab + (shape * 4 + c0) * 4;
+  d[0] = row[c0]; d[1] = row[c1]; d[2] = row[c2]; d[3] = row[c3];
+  return tab[128 + shape];
+}
+
 // Diagnostic build (make CXXFLAGS+=-DKN_ROW_STAMPS): emi_rows_v2 adds up s_memtime differences between its phases (first wave
 // of every workgroup); the launcher prints the averages every 16 launches.
 #ifdef KN_ROW_STAMPS
@@ -439,15 +454,20 @@ __device__ unsigned long long row_stamp_acc[1024 * 8];
 #define ROW_STAMP(i) do {} while (0)
 #endif
 
-template <int GDIM, int LPR>
+// UT: lattice tetrahedra of a uniform grid (tet_table_row0)
+template <int GDIM, int LPR, bool UT = false>
 __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n,
                                                         int rec_n, int want_p, int splitting) {
   constexpr int NV = GDIM + 1, NF = GDIM;
   const KnConsts& C = *Cp;
   extern __shared__ __align__(16) double lds[];
+  constexpr int RD = UT ? 2 : 5;                       // doubles per staged record
+  constexpr int SM = UT ? 31 : 255;                    // slot mask of a pair-entry byte (= the "no slot" value)
+  using RecT = std::conditional_t<UT, Rec2, Rec5>;
   double* accA = lds;
-  double* recs = lds + (size_t)acc_n;
-  uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + 5 * (size_t)rec_n + (rec_n & 1));
+  double* tab = lds + (size_t)acc_n;                   // UT: the shape table
+  double* recs = tab + (UT ? KN_TET_TAB : 0);
+  uint16_t* eloc = reinterpret_cast<uint16_t*>(recs + RD * (size_t)rec_n + ((RD * rec_n) & 1));
   const int tid = threadIdx.x;
   ROW_STAMP_BEGIN
   const int b = logical_block(blockIdx.x, D.nblocks);
@@ -468,7 +488,8 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
   // phase A: zero accumulators, stage the records of the block's Laplacian entries
   for (int i = tid; i < seglen; i += KN_BLOCK) accA[i] = 0.0;
   const KnSubConst& sc = C.sc[s];
-  stage_records<0>(D, B, recs, eloc, tid, 0.0, nullptr, 0, &sc);
+  if constexpr (UT) { if (tid < KN_TET_TAB) tab[tid] = D.tet_tab[tid]; }
+  stage_records<0, UT>(D, B, recs, eloc, tid, 0.0, nullptr, 0, &sc);
   ROW_STAMP(0);     // descriptors -> vertex ids -> records -> LDS
   __syncthreads();
   ROW_STAMP(1);     // barrier
@@ -480,23 +501,26 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
     // The diagonal entry receives a term from every pair: keep it in registers and add it once.
     int diag = -1;
     double dA = 0.0;
-    Rec5 r[NV];
-    uint32_t have = 0xFFFFFFFFu;     // slots whose contributions pend[1..] currently hold (255: none)
+    RecT r[NV];
+    auto rec = [&](int i) { if constexpr (UT) return lds_rec2(recs, i); else return lds_rec5(recs, i); };
+    uint32_t have = 0xFFFFFFFFu;     // slots whose contributions pend[1..] currently hold (SM: none)
     double pend[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) pend[j] = 0.0;
     auto do_pair = [&](uint32_t sl) {
       int slot[NV];
 #pragma unroll
-      for (int j = 0; j < NV; ++j) slot[j] = (sl >> (8 * j)) & 255;
-      if (diag < 0) { diag = slot[0]; r[0] = lds_rec5(recs, eloc[rL + diag]); }   // the row's own vertex, once
+      for (int j = 0; j < NV; ++j) slot[j] = (sl >> (8 * j)) & SM;
+      if (diag < 0) { diag = slot[0]; r[0] = rec(eloc[rL + diag]); }   // the row's own vertex, once
       // (The host orders a lane's pairs in strips that share all but one vertex; knp_rows_v2 keeps the shared records
       // in registers.  Here that costs the fifth block per CU -- 104 instead of 84 registers -- and the LDS pipe is
       // less loaded, 36 % against 51 %: measured 49.4 against 47.7 us at 995 k tets, so every record is read again.)
 #pragma unroll
-      for (int j = 1; j < NV; ++j) r[j] = lds_rec5(recs, eloc[rL + slot[j]]);
+      for (int j = 1; j < NV; ++j) r[j] = rec(eloc[rL + slot[j]]);
       double d[NV];
-      const double vol = simplex_row0<GDIM>(r, d);
+      double vol;
+      if constexpr (UT) vol = tet_table_row0<NV>(tab, sl, d);
+      else vol = simplex_row0<GDIM>(r, d);
       double ksum = 0, sd = 0;
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
@@ -510,9 +534,9 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
       // contributions are summed in a register and go to LDS when another vertex takes the position.
 #pragma unroll
       for (int j = 1; j < NV; ++j) {
-        const int hs = (int)((have >> (8 * j)) & 255);
+        const int hs = (int)((have >> (8 * j)) & SM);
         if (slot[j] != hs) {
-          if (hs != 255) unsafeAtomicAdd(&accA[lap + hs], pend[j]);
+          if (hs != SM) unsafeAtomicAdd(&accA[lap + hs], pend[j]);
           pend[j] = 0.0;
         }
         pend[j] += vol * kbar * d[j];
@@ -528,8 +552,8 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
     }
 #pragma unroll
     for (int j = 1; j < NV; ++j) {
-      const int hs = (int)((have >> (8 * j)) & 255);
-      if (hs != 255) unsafeAtomicAdd(&accA[lap + hs], pend[j]);
+      const int hs = (int)((have >> (8 * j)) & SM);
+      if (hs != SM) unsafeAtomicAdd(&accA[lap + hs], pend[j]);
     }
     if (diag >= 0) unsafeAtomicAdd(&accA[lap + diag], dA);
     if (ne > 0) emi_membrane_row<NF>(D, C, ri.w, ne, sub, LPR, cell_side, rowbase, accA, splitting, gam);
@@ -552,15 +576,19 @@ __global__ __launch_bounds__(KN_BLOCK) void emi_rows_v2(KnDev D, const KnConsts*
 // (default), 1: evaluated here into LDS (KNPEMI_OPT_FUSE_MEMBRANE), 2: the early form (KNPEMI_MEMBRANE_EARLY).  A
 // template parameter, not a run-time switch: the two optional paths cost the default one 46 registers per lane
 // (140 instead of 94: three instead of five waves per SIMD).
-template <int GDIM, int LPR, int KS, int MEM>
+template <int GDIM, int LPR, int KS, int MEM, bool UT = false>
 __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts* __restrict__ Cp, int acc_n, int rec_n,
                                                         int gam_n, int splitting) {
   constexpr int NV = GDIM + 1;
   const KnConsts& C = *Cp;
   extern __shared__ __align__(16) double lds[];
+  constexpr int RD = UT ? KS + 1 : 4 + KS;             // doubles per staged record
+  constexpr int SM = UT ? 31 : 255;                    // slot mask of a pair-entry byte (= the "no slot" value)
+  using RecT = std::conditional_t<UT, RecU<KS>, RecK<KS>>;
   double* acc = lds;                                   // KS accumulator arrays of acc_n doubles, one per solved ion
-  double* recs = lds + (size_t)KS * acc_n;
-  double* gam = recs + (size_t)(4 + KS) * rec_n + (((4 + KS) * rec_n) & 1);   // gam_n > 0: fused membrane integrals
+  double* tab = lds + (size_t)KS * acc_n;              // UT: the shape table of the lattice tetrahedra
+  double* recs = tab + (UT ? KN_TET_TAB : 0);
+  double* gam = recs + (size_t)RD * rec_n + ((RD * rec_n) & 1);   // gam_n > 0: fused membrane integrals
   uint16_t* eloc = reinterpret_cast<uint16_t*>(gam + (size_t)KS * gam_n);
   const int tid = threadIdx.x;
   const int b = logical_block(blockIdx.x, D.nblocks);
@@ -583,7 +611,8 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
 #pragma unroll
     for (int k = 0; k < KS; ++k) acc[(size_t)k * acc_n + i] = 0.0;
   }
-  stage_records<KS>(D, B, recs, eloc, tid, C.inv_dt, fs0, nvs);
+  if constexpr (UT) { if (tid < KN_TET_TAB) tab[tid] = D.tet_tab[tid]; }
+  stage_records<KS, UT>(D, B, recs, eloc, tid, C.inv_dt, fs0, nvs);
   if constexpr (MEM == 1) membrane_entries_to_lds<GDIM, KS>(D, C, B.me0, B.mne, s > 0, splitting, tid, gam);
   __syncthreads();
 
@@ -597,7 +626,8 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
     double dk[KS];   // diagonal entries of the ion blocks, added once after the loop
 #pragma unroll
     for (int k = 0; k < KS; ++k) dk[k] = 0.0;
-    RecK<KS> r[NV];
+    RecT r[NV];
+    auto rec = [&](int i) { if constexpr (UT) return lds_recu<KS>(recs, i); else return lds_rec<KS>(recs, i); };
     // The host orders a lane's pairs in strips: consecutive cells share all but one vertex, at the same byte positions
     // of the pair entry.  The records of the shared vertices stay in registers; only a slot that changed is read from
     // LDS again (one 48-byte record per pair instead of three: knp_rows 53.6 -> 46.9 us at 995 k tets, with four
@@ -611,13 +641,15 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
     auto do_pair = [&](uint32_t sl) {
       int slot[NV];
 #pragma unroll
-      for (int j = 0; j < NV; ++j) slot[j] = (sl >> (8 * j)) & 255;
-      if (diag < 0) { diag = slot[0]; r[0] = lds_rec<KS>(recs, eloc[rL + diag]); }
+      for (int j = 0; j < NV; ++j) slot[j] = (sl >> (8 * j)) & SM;
+      if (diag < 0) { diag = slot[0]; r[0] = rec(eloc[rL + diag]); }
 #pragma unroll
       for (int j = 1; j < NV; ++j)
-        if (slot[j] != (int)((have >> (8 * j)) & 255)) r[j] = lds_rec<KS>(recs, eloc[rL + slot[j]]);
+        if (slot[j] != (int)((have >> (8 * j)) & SM)) r[j] = rec(eloc[rL + slot[j]]);
       double d[NV];
-      const double vol = simplex_row0<GDIM>(r, d);
+      double vol;
+      if constexpr (UT) vol = tet_table_row0<NV>(tab, sl, d);
+      else vol = simplex_row0<GDIM>(r, d);
       double gp = 0;
 #pragma unroll
       for (int j = 0; j < NV; ++j) gp += r[j].c * d[j];
@@ -631,12 +663,12 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
       // off-diagonal entries: summed in registers while a vertex keeps its position, to LDS when it leaves (emi_rows_v2)
 #pragma unroll
       for (int j = 1; j < NV; ++j) {
-        const int hs = (int)((have >> (8 * j)) & 255);
+        const int hs = (int)((have >> (8 * j)) & SM);
         const bool moved = slot[j] != hs;
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
           if (moved) {
-            if (hs != 255) unsafeAtomicAdd(&acc[(size_t)k * acc_n + rL + hs], pend[j][k]);
+            if (hs != SM) unsafeAtomicAdd(&acc[(size_t)k * acc_n + rL + hs], pend[j][k]);
             pend[j][k] = 0.0;
           }
           pend[j][k] += m * C.inv_dt + sc.D[k] * vol * d[j] + sc.zpsiD[k] * drift;
@@ -654,10 +686,10 @@ __global__ __launch_bounds__(KN_BLOCK) void knp_rows_v2(KnDev D, const KnConsts*
     }
 #pragma unroll
     for (int j = 1; j < NV; ++j) {
-      const int hs = (int)((have >> (8 * j)) & 255);
+      const int hs = (int)((have >> (8 * j)) & SM);
 #pragma unroll
       for (int k = 0; k < KS; ++k)
-        if (hs != 255) unsafeAtomicAdd(&acc[(size_t)k * acc_n + rL + hs], pend[j][k]);
+        if (hs != SM) unsafeAtomicAdd(&acc[(size_t)k * acc_n + rL + hs], pend[j][k]);
     }
     if (diag >= 0) {
 #pragma unroll
@@ -1848,21 +1880,26 @@ template <int GDIM>
 static int launch_emi_v2(knpemi_handle* h, int want_p, int split) {
   const KnDev& D = h->dev;
   const int acc_n = (h->lds_doubles_emi + 1) & ~1, rec_n = h->lds_uniq_max;
-  const size_t lds = ((size_t)acc_n + 5 * (size_t)rec_n + 1) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
+  const bool ut = GDIM == 3 && h->tet_uniform && D.tet_tab;
+  const size_t lds = ((size_t)acc_n + (ut ? 2 : 5) * (size_t)rec_n + 1 + (ut ? KN_TET_TAB : 0)) * sizeof(double) + 2 * (size_t)h->lds_doubles_knp + 16;
   if (lds > 160 * 1024) { kn_set_error("EMI row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   dim3 grid(D.nblocks), block(KN_BLOCK);
   int rc = 0;
-#define KN_CASE(L)                                                                                  \
-  case L:                                                                                           \
-    if ((rc = set_lds_limit(emi_rows_v2<GDIM, L>, lds))) return rc;                                 \
+#define KN_CASE2(L, U)                                                                              \
+    if ((rc = set_lds_limit(emi_rows_v2<GDIM, L, U>, lds))) return rc;                              \
     {                                                                                               \
       KnProfScope prof(h, KNPEMI_K_EMI_ROWS);                                                       \
-      hipLaunchKernelGGL((emi_rows_v2<GDIM, L>), grid, block, lds, h->cur, D, h->d_consts, acc_n, \
-                         rec_n, want_p, split);                                                            \
-    }                                                                                               \
+      hipLaunchKernelGGL((emi_rows_v2<GDIM, L, U>), grid, block, lds, h->cur, D, h->d_consts, acc_n, \
+                         rec_n, want_p, split);                                                     \
+    }
+#define KN_CASE(L)                                                                                  \
+  case L:                                                                                           \
+    if constexpr (GDIM == 3) { if (ut) { KN_CASE2(L, true) } else { KN_CASE2(L, false) } }          \
+    else { KN_CASE2(L, false) }                                                                     \
     break;
   switch (h->lpr) { KN_CASE(1) KN_CASE(2) KN_CASE(4) KN_CASE(8) default: kn_set_error("bad lanes-per-row"); return KNPEMI_EINVAL; }
 #undef KN_CASE
+#undef KN_CASE2
 #ifdef KN_ROW_STAMPS
   static int launches = 0;
   if (++launches % 16 == 0) {
@@ -1888,18 +1925,22 @@ static int launch_knp_v2(knpemi_handle* h, int split, int pre) {
   const int acc_n = (h->lds_doubles_knp + 1) & ~1, rec_n = h->lds_uniq_max;
   const int KS = h->K - 1;
   const int gam_n = h->fuse_membrane ? std::max(1, h->lds_gam_max) : 0;
-  const size_t lds = ((size_t)KS * acc_n + (4 + KS) * (size_t)rec_n + 1 + (size_t)KS * gam_n) * sizeof(double)
+  const bool ut = GDIM == 3 && h->tet_uniform && D.tet_tab;
+  const size_t lds = ((size_t)KS * acc_n + (ut ? KS + 1 : 4 + KS) * (size_t)rec_n + 1 + (ut ? KN_TET_TAB : 0) + (size_t)KS * gam_n) * sizeof(double)
                      + 2 * (size_t)h->lds_doubles_knp + 16;
   if (lds > 160 * 1024) { kn_set_error("KNP row block does not fit in 160 KiB of LDS"); return KNPEMI_EINVAL; }
   dim3 grid(D.nblocks), block(KN_BLOCK);
   int rc = 0;
   const int mem = pre ? 2 : (gam_n > 0 ? 1 : 0);
+#define KN_CASE2(L, S, M, U)                                                                        \
+    if ((rc = set_lds_limit(knp_rows_v2<GDIM, L, S, M, U>, lds))) return rc;                        \
+    KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                         \
+    hipLaunchKernelGGL((knp_rows_v2<GDIM, L, S, M, U>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n, gam_n, split); \
+    return check_launch("knp_rows_v2");
 #define KN_CASE(L, S, M)                                                                            \
   if (h->lpr == L && KS == S && mem == M) {                                                         \
-    if ((rc = set_lds_limit(knp_rows_v2<GDIM, L, S, M>, lds))) return rc;                           \
-    KnProfScope prof(h, KNPEMI_K_KNP_ROWS);                                                         \
-    hipLaunchKernelGGL((knp_rows_v2<GDIM, L, S, M>), grid, block, lds, h->cur, D, h->d_consts, acc_n, rec_n, gam_n, split); \
-    return check_launch("knp_rows_v2");                                                             \
+    if constexpr (GDIM == 3) { if (ut) { KN_CASE2(L, S, M, true) } else { KN_CASE2(L, S, M, false) } } \
+    else { KN_CASE2(L, S, M, false) }                                                               \
   }
   // lanes per row: 2 (triangles) or 4 by default, KNPEMI_LPR for experiments; K - 1 = 1..3 solved ions; the optional
   // membrane paths (fused, early) for the default lanes-per-row only
@@ -1907,6 +1948,7 @@ static int launch_knp_v2(knpemi_handle* h, int split, int pre) {
   KN_CASE(2, 2, 1) KN_CASE(4, 2, 1) KN_CASE(2, 1, 1) KN_CASE(4, 1, 1) KN_CASE(2, 3, 1) KN_CASE(4, 3, 1)
   KN_CASE(2, 2, 2) KN_CASE(4, 2, 2) KN_CASE(2, 1, 2) KN_CASE(4, 1, 2) KN_CASE(2, 3, 2) KN_CASE(4, 3, 2)
 #undef KN_CASE
+#undef KN_CASE2
   kn_set_error("knp_rows: unsupported lanes-per-row / ion-count / membrane-option combination");
   return KNPEMI_EINVAL;
 }

@@ -528,6 +528,97 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
       sl_ptr[(size_t)b * SPB + w + 1] = sl_ptr[(size_t)b * SPB + w] + mx * KN_SLICE;
     }
   const bool simplex = NV != 8;
+  // ---- tetrahedra: is every cell a lattice tetrahedron of a uniform grid? ------------------------------------------
+  // (the box meshes of the reference's 3-D driver split into tetrahedra, knpemi_problem_desc::uniform_cell: the vertices of a
+  // cell are corners of ONE grid cell.)  Then a cell is one of a handful of shapes -- six for the Kuhn split -- whose gradient
+  // dot products and volume follow from the grid's edge vectors alone: the same bits on every rank, no coordinates staged,
+  // no geometry in the row kernels (kernels_assemble.hip: tet_table_row0).  The pair entries carry the shape (3 bits) and
+  // the canonical number of each vertex (its rank among the cell's corner codes, 2 bits), which leaves 5 bits per slot.
+  std::vector<uint8_t> tet_shape, tet_canon;      // per cell: shape; canonical numbers of the four vertices, 2 bits each
+  std::vector<double> tet_tab;
+  if (NV == 4 && d->gdim == 3 && nctot > 0 && getenv("KNPEMI_TET_NOT_UNIFORM") == nullptr) {
+    bool ok = false;
+    for (int i = 0; i < 9; ++i) ok |= d->uniform_cell[i] != 0.0;
+    int longest = 0;
+    for (int g = 0; g < Ntot; ++g) longest = std::max(longest, rowptrL[g + 1] - rowptrL[g]);
+    ok = ok && longest <= 31;
+    double E[3][3], Ei[3][3], scale = 0.0;      // E[t][a]: component a of grid edge t; Ei: x = sum_t l_t E[t]  =>  l = Ei (x)
+    for (int t = 0; t < 3; ++t) for (int a = 0; a < 3; ++a) { E[t][a] = d->uniform_cell[3 * t + a]; scale = std::max(scale, std::fabs(E[t][a])); }
+    if (ok) {
+      const double det = E[0][0] * (E[1][1] * E[2][2] - E[1][2] * E[2][1]) - E[0][1] * (E[1][0] * E[2][2] - E[1][2] * E[2][0]) +
+                         E[0][2] * (E[1][0] * E[2][1] - E[1][1] * E[2][0]);
+      ok = det != 0.0;
+      if (ok) {
+        // rows of the inverse of the matrix whose COLUMNS are the edges
+        const double c[3][3] = {{E[1][1] * E[2][2] - E[1][2] * E[2][1], E[1][2] * E[2][0] - E[1][0] * E[2][2], E[1][0] * E[2][1] - E[1][1] * E[2][0]},
+                                {E[2][1] * E[0][2] - E[2][2] * E[0][1], E[2][2] * E[0][0] - E[2][0] * E[0][2], E[2][0] * E[0][1] - E[2][1] * E[0][0]},
+                                {E[0][1] * E[1][2] - E[0][2] * E[1][1], E[0][2] * E[1][0] - E[0][0] * E[1][2], E[0][0] * E[1][1] - E[0][1] * E[1][0]}};
+        for (int t = 0; t < 3; ++t) for (int a = 0; a < 3; ++a) Ei[t][a] = c[t][a] / det;
+      }
+    }
+    std::vector<int> keys;                      // shape -> sorted corner codes, 3 bits each
+    if (ok) {
+      tet_shape.assign((size_t)nctot, 0);
+      tet_canon.assign((size_t)nctot, 0);
+      for (size_t cc = 0; cc < (size_t)nctot && ok; ++cc) {
+        const int* cv = &cells[cc * 4];
+        int l[4][3], code[4];
+        for (int i = 0; i < 4 && ok; ++i)
+          for (int t = 0; t < 3; ++t) {
+            double x = 0.0;
+            for (int a = 0; a < 3; ++a) x += Ei[t][a] * (VR[(size_t)cv[i] * KN_REC + a] - VR[(size_t)cv[0] * KN_REC + a]);
+            const double r = std::nearbyint(x);
+            if (std::fabs(x - r) > 1e-6 || std::fabs(r) > 1.0) { ok = false; break; }
+            l[i][t] = (int)r;
+          }
+        if (!ok) break;
+        for (int t = 0; t < 3; ++t) {
+          int m = 0;
+          for (int i = 0; i < 4; ++i) m = std::min(m, l[i][t]);
+          for (int i = 0; i < 4; ++i) { l[i][t] -= m; if (l[i][t] > 1) ok = false; }
+        }
+        if (!ok) break;
+        for (int i = 0; i < 4; ++i) code[i] = l[i][0] | (l[i][1] << 1) | (l[i][2] << 2);
+        int key = 0, canon = 0, sorted[4] = {code[0], code[1], code[2], code[3]};
+        std::sort(sorted, sorted + 4);
+        for (int i = 0; i < 3; ++i) if (sorted[i] == sorted[i + 1]) ok = false;
+        if (!ok) break;
+        for (int i = 0; i < 4; ++i) {
+          key |= sorted[i] << (3 * i);
+          canon |= (int)(std::lower_bound(sorted, sorted + 4, code[i]) - sorted) << (2 * i);
+        }
+        int sh = (int)(std::find(keys.begin(), keys.end(), key) - keys.begin());
+        if (sh == (int)keys.size()) { keys.push_back(key); if (keys.size() > 8) { ok = false; break; } }
+        tet_shape[cc] = (uint8_t)sh;
+        tet_canon[cc] = (uint8_t)canon;
+      }
+    }
+    if (ok) {
+      tet_tab.assign(8 * 16 + 8, 0.0);
+      for (size_t sh = 0; sh < keys.size() && ok; ++sh) {
+        double P[4][3], e[3][3];
+        for (int i = 0; i < 4; ++i) {
+          const int code = (keys[sh] >> (3 * i)) & 7;
+          for (int a = 0; a < 3; ++a) P[i][a] = ((code & 1) ? E[0][a] : 0.0) + ((code & 2) ? E[1][a] : 0.0) + ((code & 4) ? E[2][a] : 0.0);
+        }
+        for (int j = 0; j < 3; ++j) for (int a = 0; a < 3; ++a) e[j][a] = P[j + 1][a] - P[0][a];
+        auto cross = [](const double* u, const double* v, double* w) {
+          w[0] = u[1] * v[2] - u[2] * v[1]; w[1] = u[2] * v[0] - u[0] * v[2]; w[2] = u[0] * v[1] - u[1] * v[0];
+        };
+        double g[4][3];
+        cross(e[1], e[2], g[1]); cross(e[2], e[0], g[2]); cross(e[0], e[1], g[3]);
+        const double det = e[0][0] * g[1][0] + e[0][1] * g[1][1] + e[0][2] * g[1][2];
+        if (det == 0.0) { ok = false; break; }
+        for (int j = 1; j < 4; ++j) for (int a = 0; a < 3; ++a) g[j][a] /= det;
+        for (int a = 0; a < 3; ++a) g[0][a] = -(g[1][a] + g[2][a] + g[3][a]);
+        for (int i = 0; i < 4; ++i)
+          for (int j = 0; j < 4; ++j) tet_tab[(sh * 4 + i) * 4 + j] = g[i][0] * g[j][0] + g[i][1] * g[j][1] + g[i][2] * g[j][2];
+        tet_tab[128 + sh] = std::fabs(det) * (1.0 / 6.0);
+      }
+    }
+    h->tet_uniform = ok;
+    if (!ok) { tet_shape.clear(); tet_canon.clear(); tet_tab.clear(); }
+  }
   std::vector<int> pair_cell(simplex ? 0 : (size_t)sl_ptr.back(), -1);
   std::vector<uint32_t> pair_slots(simplex ? 0 : (size_t)sl_ptr.back() * SW, 0);
   std::vector<uint32_t> pair_sl(simplex ? (size_t)sl_ptr.back() : 0, 0xFFFFFFFFu);
@@ -583,6 +674,16 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
             }
             uint32_t slots = (uint32_t)(std::lower_bound(rb, re, g) - rb);
             for (int j = 1; j < NV; ++j) slots |= (uint32_t)(std::lower_bound(rb, re, cur[j - 1]) - rb) << (8 * j);
+            if (h->tet_uniform) {   // lattice tetrahedra: the cell's shape and the canonical numbers of the vertices in bytes 1-3
+              const size_t cc = (size_t)(v2c[v2c_ptr[g] + pick] >> 3);
+              const int* cv = &cells[cc * NV];
+              slots |= (uint32_t)tet_shape[cc] << 5;
+              for (int j = 1; j < NV; ++j) {
+                int li = 0;
+                while (li < NV && cv[li] != cur[j - 1]) ++li;
+                slots |= (uint32_t)((tet_canon[cc] >> (2 * li)) & 3) << (8 * j + 5);
+              }
+            }
             const size_t ent = (size_t)sl_ptr[(size_t)b * SPB + w] + (size_t)len * KN_SLICE + (rs * LPR + sub);
             pair_sl[ent] = slots;
             used[pick] = 1;
@@ -772,6 +873,8 @@ extern "C" int knpemi_create(const knpemi_problem_desc* d, int device, knpemi_ha
   }
   if ((rc = dev_upload(h, sl_ptr, &D.sl_ptr))) return rc;
   if ((rc = dev_upload(h, pair_sl, &D.pair_sl))) return rc;
+  D.tet_tab = nullptr;
+  if (h->tet_uniform && (rc = dev_upload(h, tet_tab, &D.tet_tab))) return rc;
   if ((rc = dev_upload(h, pair_cell, &D.pair_cell))) return rc;
   if ((rc = dev_upload(h, pair_slots, &D.pair_slots))) return rc;
   if ((rc = dev_upload(h, rowptr, &D.rowptr))) return rc;
@@ -1780,5 +1883,11 @@ extern "C" int knpemi_timer_stop_ms(knpemi_handle* h, double* ms) {
   float f = 0.f;
   KN_HIP(hipEventElapsedTime(&f, h->ev0, h->ev1));
   *ms = f;
+  return KNPEMI_OK;
+}
+
+extern "C" int knpemi_debug_geometry(knpemi_handle* h, int* flags) {
+  if (!h || !flags) return fail(KNPEMI_EINVAL, "knpemi_debug_geometry: null argument");
+  *flags = (h->tet_uniform ? 1 : 0) | (h->hex_affine ? 2 : 0) | (h->hex_uniform ? 4 : 0);
   return KNPEMI_OK;
 }

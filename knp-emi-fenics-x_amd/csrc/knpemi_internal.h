@@ -74,7 +74,11 @@ struct KnDev {
                               // holds the 64/lpr rows blk_row0[b] + (64/lpr)*w .. of block b; lane
                               // r*lpr + j of step p reads pair p*lpr + j of row r of the slice
   const uint32_t* pair_sl;    // simplices: NV x uint8 slots of the cell's vertices in the row's Laplacian
-                              // segment (byte 0 = the row's own vertex); 0xFFFFFFFF marks padding
+                              // segment (byte 0 = the row's own vertex); 0xFFFFFFFF marks padding.  Lattice tetrahedra
+                              // (tet_tab != NULL): slots are 5 bits, bits 5-7 of byte 0 hold the cell's shape, bits
+                              // 5-6 of bytes 1-3 the canonical vertex number of the vertex in that byte
+  const double* tet_tab;      // lattice tetrahedra of a uniform grid (knpemi_create): [8 shapes][4][4] gradient dot
+                              // products of the canonical vertices, then [8] cell volumes; NULL otherwise
   const int* pair_cell;       // hexahedra: cell*8 + local index, -1 = padding
   const uint32_t* pair_slots; // hexahedra: 8 x uint8 slots in two consecutive words per entry
   // EMI CSR (monolithic) and Laplacian-pattern CSR (KNP blocks share it per sub-domain)
@@ -281,6 +285,7 @@ struct knpemi_handle {
   int have_params = 0;
   int lpr = 1;                         // lanes per row of the row kernels (1, 2, 4 or 8)
   bool hex_affine = false;             // every hexahedron is a parallelepiped (constant Jacobian)
+  bool tet_uniform = false;            // tetrahedra: every cell a lattice tetrahedron of a uniform grid (dev.tet_tab)
   bool hex_uniform = false;            // ... and all of them are the same one: the geometry below is a constant of the mesh
   KnHexGeo hex_geo{};
   int lds_doubles_emi = 0, lds_doubles_knp = 0; // per-block LDS segment sizes (doubles)

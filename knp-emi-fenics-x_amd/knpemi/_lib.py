@@ -135,6 +135,7 @@ SIGNATURES = {
     "knpemi_debug_ode_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_int]),
     "knpemi_debug_math": (C.c_int, [C.c_int, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p]),
     "knpemi_debug_launch_chain": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_dbl_p]),
+    "knpemi_debug_geometry": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "knpemi_update_pde": (C.c_int, [C.c_void_p]),
     "knpemi_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "knpemi_trace": (C.c_int, [C.c_void_p, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, c_dbl_p]),

@@ -144,7 +144,7 @@ class DeviceProblem:
         desc.q_to_i = _ptr_array(flat["q_to_i"], L.c_int_p)
         desc.n_models = L.iptr(self.n_models)
         uc = getattr(mesh, "uniform_cell", None)      # edge vectors of every cell of a generated uniform box mesh
-        if uc is not None and mesh.cell_type == "hexahedron":
+        if uc is not None and mesh.cell_type in ("hexahedron", "tetrahedron"):     # (tetrahedra: the grid they were split from)
             for i, v in enumerate(np.asarray(uc, np.float64).reshape(9)):
                 desc.uniform_cell[i] = float(v)
         if device is None:

@@ -1599,3 +1599,45 @@ def test_ion_counts_other_than_three_match_oracle(hip_lib, kind, r, n_ions):
                 assert np.array_equal(c_prev[t][k].x._a, cnew[t][k])
             el = -(1.0 / zs[-1]) * (-1 * float(rho[t]) + sum(z * ck for z, ck in zip(zs[:-1], cnew[t])))
             assert rel_err(ions[-1][f'c_{t}'].x._a, el) < 1e-14
+
+
+@pytest.mark.parametrize("r", [0, 1])
+def test_lattice_tetrahedra_agree_with_the_general_tetrahedron_kernels(hip_lib, r, monkeypatch):
+    """The box meshes of the reference's 3-D driver split into tetrahedra (make_mesh_3D.py:100-102): knpemi_create finds every
+    cell to be a lattice tetrahedron of the uniform grid and the row kernels take gradient dot products and volumes from the
+    shape table instead of staging coordinates (kernels_assemble.hip: tet_table_row0); KNPEMI_TET_NOT_UNIFORM=1 keeps the
+    general kernels.  Both against the numpy oracle at 1e-10 and against each other to rounding, all five assembled objects,
+    both splitting modes; the lattice path must actually have been taken (six shapes of the Kuhn split)."""
+    from knpemi.pdeSolver import create_solver_emi, create_solver_knp
+    out = {}
+    for name in ("lattice", "general"):
+        if name == "general":
+            monkeypatch.setenv("KNPEMI_TET_NOT_UNIFORM", "1")
+        else:
+            monkeypatch.delenv("KNPEMI_TET_NOT_UNIFORM", raising=False)
+        s = Setup("tet", r)
+        s.perturb()
+        emi = create_solver_emi(s.a_emi, s.L_emi, s.phi, s.entity_maps, s.subdomain_list, None, p=s.p_emi, direct=False)
+        knp = create_solver_knp(s.a_knp, s.L_knp, s.c, s.entity_maps, s.subdomain_list, None, p=s.p_knp)
+        o, P, params, ions = s.oracle()
+        c_all, phi, phiM, mm = s.oracle_fields()
+        for splitting in (True, False):
+            for f in (s.a_emi, s.a_knp):
+                f.shared['splitting_scheme'] = splitting
+            A, b = emi.assemble()
+            Ak, bk = knp.assemble()
+            got = (A.copy(), emi.P.copy(), b.copy(), Ak.copy(), bk.copy())
+            Ao, Po, bo = o.assemble_emi(P, params, ions, c_all, phiM, mm, splitting_scheme=splitting)
+            Ako, bko = o.assemble_knp(P, params, ions, c_all, phi, phiM, mm, s.dt, splitting_scheme=splitting)
+            errs = dict(A_emi=csr_rel_err(got[0], Ao), P_emi=csr_rel_err(got[1], Po), b_emi=rel_err(got[2], bo),
+                        A_knp=csr_rel_err(got[3], Ako), b_knp=rel_err(got[4], bko))
+            assert max(errs.values()) < TOL, (name, splitting, errs)
+            out[name, splitting] = got
+        import ctypes
+        flags = ctypes.c_int(-1)
+        L.check(emi.dp.lib.knpemi_debug_geometry(emi.dp.h, ctypes.byref(flags)))
+        assert bool(flags.value & 1) == (name == "lattice"), (name, flags.value)
+    for splitting in (True, False):
+        for a, b in zip(out["lattice", splitting], out["general", splitting]):
+            da, db = (a.data, b.data) if hasattr(a, "data") and hasattr(a, "indptr") else (a, b)
+            assert np.abs(da - db).max() <= 1e-12 * np.abs(db).max()
