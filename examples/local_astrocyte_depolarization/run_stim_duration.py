@@ -81,6 +81,8 @@ def read_mesh(cfg):
     mesh, ct, ft = make_mesh_3D(int(m["resolution_factor"]), m["cell_type"], l=int(m["length"]),
                                 axon_tags=(1, 2, 1, 2))
     mesh.x[:] = mesh.x * 100.0   # metres -> centimetres (the units of this example)
+    if getattr(mesh, "uniform_cell", None) is not None:
+        mesh.uniform_cell = mesh.uniform_cell * 100.0      # the grid cell the generator handed on, in the same units
     return mesh, ct, ft
 
 

@@ -73,6 +73,8 @@ class LocalPart:
         marker = MeshTags(mesh, mesh.tdim, local_cells, np.ones(len(local_cells), np.int32))
         sub, emap, vmap, _, _ = extract_submesh(mesh, marker, 1)
         self.mesh = sub
+        if getattr(mesh, "uniform_cell", None) is not None:
+            sub.uniform_cell = mesh.uniform_cell          # cells of a uniform grid stay cells of that grid: the same bits on every rank
         self.rank, self.world = rank, world
         self.cell_global = local_cells
         self.vert_global = vmap.sub_to_parent.astype(np.int64)     # ascending
