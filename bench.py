@@ -658,6 +658,7 @@ def load_kernel_trace(workload, kernel, variant="cg"):
             for r in csv.DictReader(open(path)):
                 if stem in r["Name"]:
                     return {"avg_us": float(r["AverageNs"]) / 1e3, "launches": int(r["Calls"]), "source": os.path.basename(path),
+                            "kernel": r["Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0],
                             "note": "kernel trace (excludes the dispatch the HIP events of avg_launch_us include)"}
         except (OSError, KeyError, ValueError):
             continue
