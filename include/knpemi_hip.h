@@ -109,10 +109,15 @@ typedef struct {
   const int32_t* const* q_to_e;      /* [n_sub] -> n_q ECS vertex of each Q dof (utils.py:150-207) */
   const int32_t* const* q_to_i;      /* [n_sub] -> n_q cell vertex of each Q dof */
   const int32_t* n_models;           /* [n_sub] membrane models of the cell (len(mem_models)) */
-  /* Optional (hexahedra): the three edge vectors e_t = x[1 << t] - x[0] (row t) shared by EVERY cell of a uniform box mesh
+  /* Optional.  Hexahedra: the three edge vectors e_t = x[1 << t] - x[0] (row t) shared by EVERY cell of a uniform box mesh
    * as its generator knows them (make_mesh_3D.py:100-102: dolfinx.mesh.create_box on a uniform grid), all zero = unknown.
    * When every cell matches it (or, unknown, the first cell) to 1e-9 the row kernels use it as the geometry of every cell
-   * and stage no coordinates; a generator that supplies it gives every rank of a partitioned run the same bits. */
+   * and stage no coordinates; a generator that supplies it gives every rank of a partitioned run the same bits.
+   * Tetrahedra: the edge vectors of the uniform GRID the mesh was split from (BASELINE configs 2, 3, 5: six Kuhn tetrahedra
+   * per grid cell).  When the vertices of every cell are corners of one grid cell (lattice coordinates within 1e-6 of
+   * integers) and no Laplacian row is longer than 31, the row kernels take gradient products and volumes from a table of
+   * the (at most eight) cell shapes and stage no coordinates; there is no fall-back to the first cell: all zero, or a cell
+   * that does not fit, keeps the general kernels. */
   double uniform_cell[9];
 } knpemi_problem_desc;
 
