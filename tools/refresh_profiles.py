@@ -86,6 +86,14 @@ for f, cmd in (("bench_config2", "python bench.py --steps 20 --warmup 5"),
     wm = d.get("with_solves_reference_ksp_min_it")
     if wm:
         bits.append(f"with ksp_min_it honoured {wm['ms_per_step']:.3f} ms/step ({wm['knp_iterations_avg']:.2f} BiCGStab)")
+    wr = d.get("with_solves_reference_options")
+    if wr:
+        bits.append(f"with the reference's Krylov options {wr['ms_per_step']:.3f} ms/step ({wr['emi_iterations_avg']:.2f} CG on the "
+                    f"preconditioned norm + {wr['knp_iterations_avg']:.2f} GMRES)")
+    wx = d.get("with_solves_reference_tests_fastest_methods")
+    if wx:
+        bits.append(f"with the reference's stopping rules and BiCGStab {wx['ms_per_step']:.3f} ms/step "
+                    f"({wx['emi_iterations_avg']:.2f} CG + {wx['knp_iterations_avg']:.2f} BiCGStab)")
     tw = d.get("reference_faithful_knp_assembled_twice")
     if tw:
         bits.append(f"A_knp assembled twice {tw['ms_per_step']:.4f} ms/step, {tw['value']:.3e} dofs/s")
