@@ -58,7 +58,8 @@ class DeviceStepper:
         # kernels after the join follow the longer one on the same stream without a cross-stream signal (~15 us).
         # Decided from their measured durations at the first step (None = not yet known).
         self.ode_on_aux = None
-        self.overlap_threshold_ms = 0.025
+        import os
+        self.overlap_threshold_ms = float(os.environ.get("KNPEMI_OVERLAP_THRESHOLD_MS", "0.025"))     # (0: always side by side)
         self.k = 0
         self.models = []   # MembraneModel objects, in registration order
         self._model_setup = []   # (MembraneModel, stimulus, locator, initial time) for reset()
